@@ -1,0 +1,112 @@
+"""Deterministic synthetic inputs for the DIINN decode path.
+
+Counter-based generator keyed by ``(seed, tensor_name, flat_index)`` so that
+the golden-fixture script (which runs next to the reference), the CPU oracle
+tests and the GPU parity tests all regenerate *bit-identical* fp32 weights and
+encoder features without shipping megabytes of tensors.  Only integer hashing
+and exactly-representable float arithmetic are used (no libm calls), so the
+values do not depend on the host CPU or the numpy build.
+
+Distributions follow SURVEY.md §8(d2):
+  * weights / biases ~ U(-1/sqrt(fan_in), +1/sqrt(fan_in))  -- what
+    ``ImplicitDecoder(mode=3)`` produces with PyTorch's default Conv2d init
+    (reference: src/models/components/diinn.py:73-80,92);
+  * encoder features ~ approximately N(0,1) (Irwin-Hall, 12 uniforms - 6).
+
+Parameter names and shapes are the reference's state_dict entries
+(SURVEY.md App. A.1).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+IN_CHANNELS = 64
+HIDDEN = 256
+N_LAYERS = 4
+UNFOLD = IN_CHANNELS * 9  # 576
+
+
+def _mix(z: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on a uint64 array (wrapping arithmetic)."""
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def _name_key(seed: int, name: str) -> np.uint64:
+    h = 0xCBF29CE484222325  # FNV-1a 64
+    for ch in name.encode("utf-8"):
+        h = ((h ^ ch) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    h ^= (seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    return _mix(np.array([h], dtype=np.uint64))[0]
+
+
+def _bits24(seed: int, name: str, n: int, stream: int = 0) -> np.ndarray:
+    """n integers in [0, 2^24), one per flat index."""
+    key = _name_key(seed, f"{name}#{stream}")
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64) * _GOLDEN + key
+    return (_mix(idx) >> np.uint64(40)).astype(np.int64)
+
+
+def uniform(seed: int, name: str, shape, bound: float) -> np.ndarray:
+    """fp32 array ~ U(-bound, bound); value = fp32((2u-1)*bound), u = k/2^24."""
+    n = int(np.prod(shape))
+    k = _bits24(seed, name, n)
+    u = (2.0 * k.astype(np.float64) + 1.0) / float(1 << 24) - 1.0  # exact in f64
+    return (u * float(bound)).astype(np.float32).reshape(shape)
+
+
+def normalish(seed: int, name: str, shape) -> np.ndarray:
+    """fp32 array, approx N(0,1): sum of 12 uniforms - 6 (exact f64 arithmetic)."""
+    n = int(np.prod(shape))
+    acc = np.zeros(n, dtype=np.float64)
+    for s in range(12):
+        acc += _bits24(seed, name, n, stream=s + 1).astype(np.float64)
+    acc = acc / float(1 << 24) - 6.0
+    return acc.astype(np.float32).reshape(shape)
+
+
+def decoder_param_shapes() -> "OrderedDict[str, tuple]":
+    """Reference ``ImplicitDecoder(mode=3, init_q=False).state_dict()`` layout
+    (diinn.py:53-92)."""
+    shapes: "OrderedDict[str, tuple]" = OrderedDict()
+    for i in range(N_LAYERS):
+        kin = UNFOLD if i == 0 else HIDDEN + UNFOLD
+        qin = 3 if i == 0 else HIDDEN
+        shapes[f"K.{i}.0.weight"] = (HIDDEN, kin, 1, 1)
+        shapes[f"K.{i}.0.bias"] = (HIDDEN,)
+        shapes[f"Q.{i}.0.weight"] = (HIDDEN, qin, 1, 1)
+        shapes[f"Q.{i}.0.bias"] = (HIDDEN,)
+    shapes["last_layer.weight"] = (3, HIDDEN, 1, 1)
+    shapes["last_layer.bias"] = (3,)
+    return shapes
+
+
+def decoder_state_dict(seed: int = 123, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """Synthetic decoder weights in the reference's state_dict naming.
+
+    ``gain`` scales every tensor (gain=3 is the SURVEY §8(d2) stress set:
+    larger sine arguments and output magnitude)."""
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, shape in decoder_param_shapes().items():
+        layer = name.rsplit(".", 1)[0] + ".weight"
+        wshape = decoder_param_shapes()[layer]
+        fan_in = wshape[1] * wshape[2] * wshape[3]
+        bound = 1.0 / math.sqrt(fan_in)
+        sd[name] = (uniform(seed, name, shape, bound) * np.float32(gain)).astype(np.float32)
+    return sd
+
+
+def encoder_features(seed: int, b: int, h: int, w: int, tag: str = "feat") -> np.ndarray:
+    """Synthetic LR encoder feature map [B,64,H,W] fp32 (stands in for RDN output)."""
+    return normalish(seed, f"{tag}:{b}x{h}x{w}", (b, IN_CHANNELS, h, w))
