@@ -1,0 +1,93 @@
+"""ctypes binding of libdiinn_hip.so (the C ABI in include/diinn_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a symbol
+cannot be resolved, importing/using this module raises.  The HIP path is the
+product; nothing here ever routes to a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libdiinn_hip.so")
+
+DIINN_OK = 0
+SIN_ACCURATE = 0
+SIN_HW = 1
+ABI_VERSION = 1
+
+_f = C.POINTER(C.c_float)
+_i32 = C.POINTER(C.c_int32)
+_ip = C.POINTER(C.c_int)
+_f3 = _f * 3
+
+# name -> (restype, argtypes): every symbol include/diinn_hip.h declares
+SIGNATURES = {
+    "diinn_abi_version": (C.c_int, []),
+    "diinn_status_string": (C.c_char_p, [C.c_int]),
+    "diinn_last_hip_error": (C.c_int, []),
+    "diinn_packed_weight_floats": (C.c_size_t, []),
+    "diinn_pack_weights": (C.c_int, [_f, _f, _f3, _f3, _f, _f, _f3, _f3, _f, _f, _f]),
+    "diinn_make_axis_tables": (C.c_int, [C.c_int, C.c_int, C.c_int, _i32, _f]),
+    "diinn_uses_small_output_kernel": (C.c_int, [C.c_int, C.c_int]),
+    "diinn_make_axis_tables_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "diinn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "diinn_lr_rows_for_band": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip]),
+    "diinn_precompute_P": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "diinn_decode_band": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "diinn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "diinn_decode_launch_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class DiinnNativeError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the library (once) and bind every declared symbol; raise if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise DiinnNativeError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` or "
+                f"`python -c 'import diinn_amd.build as b; b.build()'` (needs hipcc). "
+                f"There is no CPU fallback for the DIINN decode path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise DiinnNativeError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        ver = lib.diinn_abi_version()
+        if ver != ABI_VERSION:
+            raise DiinnNativeError(f"ABI version mismatch: library {ver}, binding {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != DIINN_OK:
+        lib = load()
+        msg = lib.diinn_status_string(status).decode()
+        extra = f" (hipError_t {lib.diinn_last_hip_error()})" if status == 3 else ""
+        raise DiinnNativeError(f"{what} failed: {msg}{extra}")
+
+
+def fptr(arr):
+    """float* of a contiguous float32 numpy array."""
+    return arr.ctypes.data_as(_f)

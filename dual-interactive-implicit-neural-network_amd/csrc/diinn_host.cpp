@@ -1,0 +1,133 @@
+// diinn_host.cpp -- host-only half of the C ABI (include/diinn_hip.h):
+// weight repacking, coordinate/index tables, size queries.  No HIP calls here.
+// Build with -ffp-contract=off (axis_eval must round every fp32 op separately).
+#include <cmath>
+#include <cstring>
+#include <cstdint>
+
+#include "../../include/diinn_hip.h"
+#include "diinn_layout.h"
+
+using namespace diinn;
+
+extern "C" {
+
+int diinn_abi_version(void) { return DIINN_ABI_VERSION; }
+
+const char* diinn_status_string(int status) {
+    switch (status) {
+        case DIINN_OK: return "ok";
+        case DIINN_ERR_INVALID_ARG: return "invalid argument";
+        case DIINN_ERR_UNSUPPORTED: return "unsupported decoder variant";
+        case DIINN_ERR_HIP: return "HIP runtime error";
+        case DIINN_ERR_TOO_LARGE: return "extent too large for 32-bit indexing";
+        default: return "unknown status";
+    }
+}
+
+size_t diinn_packed_weight_floats(void) { return PACKED_FLOATS; }
+
+// Reference layouts:
+//   K.i weight [256, 832]: input channel 0..255 = q, 256..831 = unfolded feature c*9+ky*3+kx
+//   (torch.cat([q, x]) at diinn.py:136; unfold order at diinn.py:168)
+int diinn_pack_weights(const float* K0w, const float* K0b,
+                       const float* const Kw[3], const float* const Kb[3],
+                       const float* Q0w, const float* Q0b,
+                       const float* const Qw[3], const float* const Qb[3],
+                       const float* Lw, const float* Lb,
+                       float* packed) {
+    if (!K0w || !K0b || !Kw || !Kb || !Q0w || !Q0b || !Qw || !Qb || !Lw || !Lb || !packed)
+        return DIINN_ERR_INVALID_ARG;
+    for (int i = 0; i < 3; ++i)
+        if (!Kw[i] || !Kb[i] || !Qw[i] || !Qb[i]) return DIINN_ERR_INVALID_ARG;
+
+    // WL: [layer][m][kg][part][lane][e]
+    for (int i = 0; i < 3; ++i) {
+        const float* wk = Kw[i];   // [256][832], q half = columns 0..255
+        const float* wq = Qw[i];   // [256][256]
+        for (int m = 0; m < 8; ++m)
+            for (int kg = 0; kg < WL_KG; ++kg)
+                for (int part = 0; part < 2; ++part) {
+                    float* dst = packed + OFF_WL + (size_t)i * WL_LAYER +
+                                 (((size_t)m * WL_KG + kg) * 2 + part) * WL_PIECE;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int out = 32 * m + (lane & 31);
+                        const int h = lane >> 5;
+                        for (int e = 0; e < 4; ++e) {
+                            const int in = chan_of(4 * kg + e, h);
+                            dst[lane * 4 + e] = part == 0 ? wk[(size_t)out * (HID + UNF) + in]
+                                                          : wq[(size_t)out * HID + in];
+                        }
+                    }
+                }
+    }
+    // WP: [mo][kg][lane][e];  Wx_i[ch][c*9 + t] = feature half of K.i
+    for (int mo = 0; mo < 32; ++mo) {
+        const int i = mo >> 3;
+        const float* w = (i == 0) ? K0w : Kw[i - 1];
+        const size_t ld = (i == 0) ? (size_t)UNF : (size_t)(HID + UNF);
+        const size_t col0 = (i == 0) ? 0 : (size_t)HID;
+        for (int kg = 0; kg < WP_KG; ++kg) {
+            float* dst = packed + OFF_WP + ((size_t)mo * WP_KG + kg) * WL_PIECE;
+            for (int lane = 0; lane < 64; ++lane) {
+                const int ch = 32 * (mo & 7) + (lane & 31);
+                const int h = lane >> 5;
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = 4 * kg + e;
+                    const int t = kk >> 5;                 // tap ky*3+kx
+                    const int c = 2 * (kk & 31) + h;       // feature channel
+                    dst[lane * 4 + e] = w[(size_t)ch * ld + col0 + (size_t)c * 9 + t];
+                }
+            }
+        }
+    }
+    // small tables
+    float* bk = packed + OFF_BK;
+    std::memcpy(bk, K0b, HID * sizeof(float));
+    for (int i = 0; i < 3; ++i) std::memcpy(bk + (i + 1) * HID, Kb[i], HID * sizeof(float));
+    float* q0 = packed + OFF_Q0;
+    for (int ch = 0; ch < HID; ++ch) {
+        q0[0 * HID + ch] = Q0w[ch * 3 + 0];   // rel_h
+        q0[1 * HID + ch] = Q0w[ch * 3 + 1];   // rel_w
+        q0[2 * HID + ch] = Q0w[ch * 3 + 2];   // ratio
+        q0[3 * HID + ch] = Q0b[ch];
+    }
+    for (int i = 0; i < 3; ++i) std::memcpy(packed + OFF_BQ + i * HID, Qb[i], HID * sizeof(float));
+    std::memcpy(packed + OFF_L, Lw, 3 * HID * sizeof(float));
+    float* bl = packed + OFF_BL;
+    bl[0] = Lb[0]; bl[1] = Lb[1]; bl[2] = Lb[2]; bl[3] = 0.0f;
+    return DIINN_OK;
+}
+
+int diinn_uses_small_output_kernel(int Hu, int Wu) { return (Hu + Wu) <= 128 ? 1 : 0; }
+
+int diinn_make_axis_tables(int n_in, int n_out, int small_output, int32_t* idx, float* rel) {
+    if (n_in <= 0 || n_out <= 0) return DIINN_ERR_INVALID_ARG;
+    const Axis a = make_axis(n_in, n_out, small_output ? 1 : 0);
+    for (int j = 0; j < n_out; ++j) {
+        int id; float r;
+        axis_eval(a, j, id, r);
+        if (idx) idx[j] = id;
+        if (rel) rel[j] = r;
+    }
+    return DIINN_OK;
+}
+
+size_t diinn_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * H * W * PCH * sizeof(float);
+}
+
+int diinn_lr_rows_for_band(int H, int Hu, int Wu, int y0, int y1, int* r0, int* r1) {
+    if (H <= 0 || Hu <= 0 || Wu <= 0 || y0 < 0 || y1 > Hu || y0 >= y1 || !r0 || !r1)
+        return DIINN_ERR_INVALID_ARG;
+    const Axis a = make_axis(H, Hu, diinn_uses_small_output_kernel(Hu, Wu));
+    int lo, hi; float rel;
+    axis_eval(a, y0, lo, rel);       // idx is monotone non-decreasing in j
+    axis_eval(a, y1 - 1, hi, rel);
+    *r0 = lo;
+    *r1 = hi + 1;
+    return DIINN_OK;
+}
+
+}  // extern "C"

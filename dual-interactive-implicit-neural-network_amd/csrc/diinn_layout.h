@@ -1,0 +1,102 @@
+// diinn_layout.h -- packed-weight image layout and the coordinate formulas shared
+// by the host packer (diinn_host.cpp) and the gfx950 kernels (diinn_kernels.hip).
+//
+// The decode kernel keeps the 256-channel activation q of 32 HR pixels in the
+// registers of one wave, in the accumulator layout of v_mfma_f32_32x32x2_f32:
+//   lane l = 32*h + j   holds pixel j, and for M-tile m (32 channels) register r
+//   holds channel  32*m + (r&3) + 8*(r>>2) + 4*h                      [chan_of()]
+// so an accumulator register is directly the B operand (k = h) of the next
+// layer's MFMA.  All weight images are pre-permuted on the host to that order.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define DIINN_HD __host__ __device__ __forceinline__
+#else
+#define DIINN_HD inline
+#endif
+
+namespace diinn {
+
+constexpr int C_IN   = 64;    // encoder feature channels   (diinn.py:40 in_channels)
+constexpr int HID    = 256;   // hidden width               (diinn.py:40 hidden_dims)
+constexpr int NLAYER = 4;
+constexpr int UNF    = C_IN * 9;          // 576 unfolded channels (diinn.py:168)
+constexpr int PCH    = NLAYER * HID;      // 1024 floats of P per LR cell
+constexpr int NOUT   = 3;
+
+// ---- packed image sections (offsets in floats) --------------------------------
+// WL: stacked per-pixel layers i=1..3.  [layer 3][m 8][kg 32][part 2][lane 64][e 4]
+//     part 0 = q-half of K[i] (modulation), part 1 = Q[i] (synthesis);
+//     value = W_part[ out = 32m + (lane&31) ][ in = chan_of(kk = 4kg+e, lane>>5) ]
+constexpr int    WL_KG      = HID / 2 / 4;                 // 32 groups of 4 k-steps
+constexpr size_t WL_PIECE   = 64 * 4;                      // floats per (lane,e) piece = 1 KiB
+constexpr size_t WL_LAYER   = (size_t)8 * WL_KG * 2 * WL_PIECE;
+constexpr size_t OFF_WL     = 0;
+constexpr size_t SZ_WL      = 3 * WL_LAYER;                // 393,216 floats = 1.5 MiB
+// WP: the hoisted 3x3 conv 64 -> 1024.  [mo 32][kg 72][lane 64][e 4]
+//     k-step kk = 4kg+e: tap t = kk/32 (= ky*3+kx), channel c = 2*(kk%32) + (lane>>5);
+//     value = Wx[ o = 32mo + (lane&31) ][ c ][ ky ][ kx ],  o = i*256 + ch
+constexpr int    WP_KSTEPS  = UNF / 2;                     // 288
+constexpr int    WP_KG      = WP_KSTEPS / 4;               // 72
+constexpr size_t OFF_WP     = OFF_WL + SZ_WL;
+constexpr size_t SZ_WP      = (size_t)32 * WP_KG * WL_PIECE;   // 589,824 floats = 2.25 MiB
+// small tables, natural channel order
+constexpr size_t OFF_BK     = OFF_WP + SZ_WP;              // bK[4][256]
+constexpr size_t OFF_Q0     = OFF_BK + 4 * HID;            // Q0h[256] Q0w[256] Q0r[256] bQ0[256]
+constexpr size_t OFF_BQ     = OFF_Q0 + 4 * HID;            // bQ[1..3][256]
+constexpr size_t OFF_L      = OFF_BQ + 3 * HID;            // L[3][256]
+constexpr size_t OFF_BL     = OFF_L + 3 * HID;             // bL[3] + pad
+constexpr size_t PACKED_FLOATS = OFF_BL + 4;               // 986,628
+
+// channel held by activation register (m, r) of lane-half h
+DIINN_HD int chan_of(int kk /* = 16*m + r */, int h) {
+    const int m = kk >> 4, r = kk & 15;
+    return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+
+// ---- coordinates (reference: diinn.py:94-110, ATen nearest-exact)
+struct Axis {
+    float c0_in, c1_in;     // fp32(-1 + 1/n_in), fp32(2/n_in)      (python doubles -> fp32)
+    float c0_out, c1_out;   // same for n_out
+    float n_in_f;           // fp32(n_in)
+    float scale;            // fp32(n_in) / fp32(n_out)
+    int   n_in;
+    int   small_output;     // ATen small-output kernel rounding (Hu + Wu <= 128)
+};
+
+inline Axis make_axis(int n_in, int n_out, int small_output) {
+    Axis a;
+    a.c0_in  = (float)(-1.0 + 1.0 / (double)n_in);
+    a.c1_in  = (float)(2.0 / (double)n_in);
+    a.c0_out = (float)(-1.0 + 1.0 / (double)n_out);
+    a.c1_out = (float)(2.0 / (double)n_out);
+    a.n_in_f = (float)n_in;
+    a.scale  = (float)n_in / (float)n_out;
+    a.n_in = n_in;
+    a.small_output = small_output;
+    return a;
+}
+
+// Index of the LR sample and relative coordinate of HR sample j along one axis.
+// Every operation is an individually rounded fp32 (or fp64) op in the reference's
+// order; translation units including this header are built with -ffp-contract=off.
+DIINN_HD void axis_eval(const Axis& a, int j, int& idx, float& rel) {
+    const float jf = (float)j;
+    int id;
+    if (a.small_output) {
+        const double p = ((double)j + 0.5) * (double)a.scale;
+        id = (int)__builtin_floorf((float)p);
+    } else {
+        float r = __builtin_fmaf(a.scale, jf + 0.5f, -0.5f);   // single rounding (ATen builds with FMA)
+        r = r < 0.0f ? 0.0f : r;
+        id = (int)__builtin_floorf((float)((double)r + 0.5));
+    }
+    id = id < a.n_in - 1 ? id : a.n_in - 1;
+    const float g_out = a.c1_out * jf + a.c0_out;               // mul, then add (not contracted)
+    const float g_in  = a.c1_in * (float)id + a.c0_in;
+    idx = id;
+    rel = (g_out - g_in) * a.n_in_f;
+}
+
+}  // namespace diinn

@@ -1,0 +1,225 @@
+"""Host side of the MI355X DIINN decode path: the reference's ``ImplicitDecoder``
+interface, executed by the gfx950 kernels in libdiinn_hip.so.
+
+Mirrors /root/reference/src/models/components/diinn.py:
+  * ``ImplicitDecoder(in_channels=64, hidden_dims=[256]*4, mode=1, init_q=False)``
+    registers parameters under the same names and shapes as diinn.py:40-92
+    (``K.{i}.0.weight`` ..., ``Q.{i}.0.*``, ``last_layer.*``) so reference
+    checkpoints ``load_state_dict`` unchanged;
+  * ``forward(x, size, bsize=None)`` has the argument meaning of diinn.py:163-173.
+
+The compute is the HIP path and only the HIP path: CPU tensors, missing
+library, autograd or decoder variants the kernels do not cover raise instead of
+silently falling back.  PyTorch is used for device memory and the stream only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _native
+
+IN_CHANNELS = 64
+HIDDEN = 256
+P_CHANNELS = 1024
+
+
+class SineAct(nn.Module):
+    """sin activation of the synthesis branch (reference: diinn.py:21-26)."""
+
+    def forward(self, x):
+        return torch.sin(x)
+
+
+# ---------------------------------------------------------------------------
+# packed weights
+# ---------------------------------------------------------------------------
+def pack_state_dict(sd, prefix: str = "") -> torch.Tensor:
+    """Reference-named decoder tensors -> packed host image (1-D fp32 CPU tensor).
+
+    ``sd`` maps ``{prefix}K.0.0.weight`` ... to tensors/arrays in the layouts of
+    SURVEY.md App. A.1 (mode 3, init_q=False).  Calls the C ABI
+    ``diinn_pack_weights`` (include/diinn_hip.h)."""
+    lib = _native.load()
+
+    def get(name, shape):
+        t = sd[prefix + name]
+        a = t.detach().to("cpu", torch.float32).numpy() if isinstance(t, torch.Tensor) else np.asarray(t, np.float32)
+        a = np.ascontiguousarray(a.reshape(shape), dtype=np.float32)
+        return a
+
+    k0w = get("K.0.0.weight", (HIDDEN, 576)); k0b = get("K.0.0.bias", (HIDDEN,))
+    kw = [get(f"K.{i}.0.weight", (HIDDEN, HIDDEN + 576)) for i in (1, 2, 3)]
+    kb = [get(f"K.{i}.0.bias", (HIDDEN,)) for i in (1, 2, 3)]
+    q0w = get("Q.0.0.weight", (HIDDEN, 3)); q0b = get("Q.0.0.bias", (HIDDEN,))
+    qw = [get(f"Q.{i}.0.weight", (HIDDEN, HIDDEN)) for i in (1, 2, 3)]
+    qb = [get(f"Q.{i}.0.bias", (HIDDEN,)) for i in (1, 2, 3)]
+    lw = get("last_layer.weight", (3, HIDDEN)); lb = get("last_layer.bias", (3,))
+
+    packed = np.empty(lib.diinn_packed_weight_floats(), dtype=np.float32)
+    f3 = _native._f3
+    st = lib.diinn_pack_weights(
+        _native.fptr(k0w), _native.fptr(k0b),
+        f3(*[_native.fptr(a) for a in kw]), f3(*[_native.fptr(a) for a in kb]),
+        _native.fptr(q0w), _native.fptr(q0b),
+        f3(*[_native.fptr(a) for a in qw]), f3(*[_native.fptr(a) for a in qb]),
+        _native.fptr(lw), _native.fptr(lb), _native.fptr(packed))
+    _native.check(st, "diinn_pack_weights")
+    return torch.from_numpy(packed)
+
+
+def axis_tables(n_in: int, n_out: int, small_output: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """Host tables (idx int32, rel fp32) from the C ABI ``diinn_make_axis_tables``."""
+    lib = _native.load()
+    idx = np.empty(n_out, np.int32)
+    rel = np.empty(n_out, np.float32)
+    st = lib.diinn_make_axis_tables(n_in, n_out, int(small_output),
+                                    idx.ctypes.data_as(_native._i32), _native.fptr(rel))
+    _native.check(st, "diinn_make_axis_tables")
+    return idx, rel
+
+
+def lr_rows_for_band(h: int, hu: int, wu: int, y0: int, y1: int) -> Tuple[int, int]:
+    """LR rows [r0,r1) whose cells HR rows [y0,y1) read (C ABI ``diinn_lr_rows_for_band``)."""
+    lib = _native.load()
+    r0, r1 = C.c_int(), C.c_int()
+    _native.check(lib.diinn_lr_rows_for_band(h, hu, wu, y0, y1, C.byref(r0), C.byref(r1)),
+                  "diinn_lr_rows_for_band")
+    return r0.value, r1.value
+
+
+# ---------------------------------------------------------------------------
+# functional entry: features -> RGB on the current HIP stream
+# ---------------------------------------------------------------------------
+def _require_cuda(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"diinn_amd: {what} must live on a ROCm GPU (got device {t.device}); the MI355X decode "
+            f"path has no CPU implementation")
+
+
+def decode_features(feat: torch.Tensor, packed: torch.Tensor, size: Sequence[int],
+                    out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
+                    rows: Optional[Tuple[int, int]] = None, sin_mode: int = _native.SIN_ACCURATE
+                    ) -> torch.Tensor:
+    """Decode encoder features ``feat`` [B,64,H,W] to RGB [B,3,Hu,Wu].
+
+    ``rows=(y0,y1)`` computes only that HR row band (tile sharding across GPUs);
+    the rest of ``out`` is left untouched.  ``workspace`` is the P image
+    [B,H,W,1024] fp32 (allocated if None).  Enqueues two kernels on the current
+    stream; never synchronises."""
+    lib = _native.load()
+    _require_cuda(feat, "feat")
+    _require_cuda(packed, "packed weights")
+    if feat.dtype != torch.float32 or feat.dim() != 4 or feat.shape[1] != IN_CHANNELS:
+        raise ValueError(f"feat must be fp32 [B,{IN_CHANNELS},H,W], got {feat.dtype} {tuple(feat.shape)}")
+    hu, wu = size  # same unpack as the reference (diinn.py:96): raises unless len(size) == 2
+    hu, wu = int(hu), int(wu)
+    feat = feat.contiguous()
+    b, _, h, w = feat.shape
+    y0, y1 = (0, hu) if rows is None else (int(rows[0]), int(rows[1]))
+    if out is None:
+        out = torch.empty((b, 3, hu, wu), dtype=torch.float32, device=feat.device)
+    else:
+        if out.shape != (b, 3, hu, wu) or out.dtype != torch.float32 or not out.is_contiguous() \
+                or out.device != feat.device:
+            raise ValueError("out must be a contiguous fp32 [B,3,Hu,Wu] tensor on feat's device")
+    need = lib.diinn_workspace_bytes(b, h, w)
+    if workspace is None:
+        workspace = torch.empty(need // 4, dtype=torch.float32, device=feat.device)
+    elif workspace.numel() * workspace.element_size() < need or not workspace.is_contiguous() \
+            or workspace.device != feat.device:
+        raise ValueError(f"workspace must be a contiguous buffer of >= {need} bytes on feat's device")
+    with torch.cuda.device(feat.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        st = lib.diinn_decode(C.c_void_p(stream), C.c_void_p(feat.data_ptr()), C.c_void_p(packed.data_ptr()),
+                              C.c_void_p(workspace.data_ptr()), C.c_void_p(out.data_ptr()),
+                              b, h, w, hu, wu, y0, y1, int(sin_mode))
+    _native.check(st, "diinn_decode")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# nn.Module mirror of the reference class
+# ---------------------------------------------------------------------------
+class ImplicitDecoder(nn.Module):
+    """Drop-in for the reference ``ImplicitDecoder`` (diinn.py:39-173).
+
+    Every mode registers the reference's parameters (so any reference checkpoint
+    loads); the MI355X kernels implement the paper's final variant, ``mode=3,
+    init_q=False`` (README.md:111-112 of the reference).  Other variants raise
+    ``NotImplementedError`` in ``forward``."""
+
+    def __init__(self, in_channels: int = 64, hidden_dims=(256, 256, 256, 256), mode: int = 1,
+                 init_q: bool = False, sin_mode: int = _native.SIN_ACCURATE):
+        super().__init__()
+        self.mode = mode
+        self.init_q = init_q
+        self.in_channels = in_channels
+        self.hidden_dims = list(hidden_dims)
+        self.sin_mode = sin_mode
+        unfolded = in_channels * 9
+        if init_q:
+            self.first_layer = nn.Sequential(nn.Conv2d(3, unfolded, 1), SineAct())
+        self.K = nn.ModuleList()
+        self.Q = nn.ModuleList()
+        k_in, q_in = unfolded, (unfolded if init_q else 3)
+        for width in self.hidden_dims:
+            self.K.append(nn.Sequential(nn.Conv2d(k_in, width, 1), nn.ReLU()))
+            self.Q.append(nn.Sequential(nn.Conv2d(q_in, width, 1), SineAct()))
+            # mode 1 chains k -> K[i]; modes 2-4 feed [k or q ; unfolded features] (diinn.py:53-88)
+            k_in = width if mode == 1 else width + unfolded
+            q_in = width
+        if mode == 4:
+            self.last_layer = nn.Conv2d(self.hidden_dims[-1], 3, 3, padding=1, padding_mode="reflect")
+        else:
+            self.last_layer = nn.Conv2d(self.hidden_dims[-1], 3, 1)
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_key = None
+        self._workspace: Optional[torch.Tensor] = None
+
+    # -- packed-weight cache ---------------------------------------------------
+    def _weights_key(self, device):
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def packed_weights(self, device) -> torch.Tensor:
+        key = self._weights_key(device)
+        if self._packed is None or self._packed_key != key:
+            self._packed = pack_state_dict(self.state_dict()).to(device)
+            self._packed_key = key
+        return self._packed
+
+    def _check_supported(self):
+        if self.mode != 3 or self.init_q:
+            raise NotImplementedError(
+                f"diinn_amd HIP decode path implements mode=3, init_q=False (the reference's final model); "
+                f"got mode={self.mode}, init_q={self.init_q}")
+        if self.in_channels != IN_CHANNELS or self.hidden_dims != [HIDDEN] * 4:
+            raise NotImplementedError("diinn_amd HIP decode path is built for in_channels=64, hidden_dims=[256]*4")
+
+    def forward(self, x: torch.Tensor, size, bsize: Optional[int] = None) -> torch.Tensor:
+        """x [B,64,H,W] fp32 encoder features, size=(H_up, W_up) -> [B,3,H_up,W_up].
+
+        ``bsize`` is the reference's column-strip size (diinn.py:149-160), a
+        memory knob there.  The fused kernels keep every per-pixel intermediate
+        in registers, so it is accepted and ignored (results are identical for
+        any value; the reference's hang for bsize < H_up cannot occur)."""
+        self._check_supported()
+        _require_cuda(x, "x")
+        if bsize is None and torch.is_grad_enabled() and (
+                x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # reference: bsize=None runs step() under autograd (training, sr_module.py:128)
+            raise RuntimeError(
+                "diinn_amd: autograd through the HIP decode path is not implemented; call under "
+                "torch.no_grad()/inference_mode (or pass bsize, which the reference also runs without grad)")
+        b, c, h, w = x.shape
+        need = b * h * w * P_CHANNELS
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != x.device:
+            self._workspace = torch.empty(need, dtype=torch.float32, device=x.device)
+        with torch.no_grad():
+            return decode_features(x, self.packed_weights(x.device), size, workspace=self._workspace,
+                                   sin_mode=self.sin_mode)

@@ -1,0 +1,127 @@
+/*
+ * diinn_hip.h -- C ABI of the MI355X (gfx950) DIINN implicit-decoder library
+ * (libdiinn_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of the reference
+ * (robotic-vision-lab/Dual-Interactive-Implicit-Neural-Network):
+ *     ImplicitDecoder.forward(x, size, bsize)   mode=3, init_q=False
+ *     src/models/components/diinn.py:163-173   (helpers :94-110, :132-139, :149-160)
+ * The reference is pure Python/ATen and has no FFI of its own; the entry points
+ * below are what a ctypes binding inside that forward() would call
+ * (INTEGRATION.md shows the stub).  Plain pointers and sizes only: no torch
+ * types, no exceptions, no hidden allocation, no global mutable state.
+ *
+ * Conventions
+ *   - every function returns a DIINN_* status (0 = ok), except the size queries;
+ *   - "host" pointers are ordinary CPU memory, "dev" pointers are HIP device
+ *     memory on the device that is current for the calling thread;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *     Launch functions only enqueue work: they never synchronise, allocate or
+ *     copy, so they can be captured into a hipGraph;
+ *   - device buffers are borrowed for the lifetime of the enqueued work only;
+ *   - all arithmetic is fp32 ("f32"); indices are int32.
+ */
+#ifndef DIINN_HIP_H
+#define DIINN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIINN_ABI_VERSION 1
+
+/* status codes */
+#define DIINN_OK                 0
+#define DIINN_ERR_INVALID_ARG    1   /* null pointer, non-positive size, bad range   */
+#define DIINN_ERR_UNSUPPORTED    2   /* decoder variant the HIP path does not cover  */
+#define DIINN_ERR_HIP            3   /* a HIP runtime call failed (see diinn_last_hip_error) */
+#define DIINN_ERR_TOO_LARGE      4   /* an extent overflows the kernels' 32-bit indexing */
+
+/* decoder geometry fixed by the reference's defaults (diinn.py:40): in_channels=64,
+ * hidden_dims=[256]*4, 3x3 unfold -> 576, RGB head. */
+#define DIINN_IN_CHANNELS 64
+#define DIINN_HIDDEN      256
+#define DIINN_LAYERS      4
+#define DIINN_OUT         3
+#define DIINN_P_CHANNELS  (DIINN_LAYERS * DIINN_HIDDEN)   /* 1024 floats per LR cell */
+
+/* sine evaluation used by the synthesis branch (reference: torch.sin, diinn.py:25-26) */
+#define DIINN_SIN_ACCURATE 0   /* Cody-Waite reduction + polynomial, <= ~3 ulp        */
+#define DIINN_SIN_HW       1   /* v_sin_f32 after fract(x/2pi); parity still <= 1e-4 */
+
+int         diinn_abi_version(void);
+const char* diinn_status_string(int status);
+/* hipError_t of the most recent failing HIP call made by this thread (0 if none). */
+int         diinn_last_hip_error(void);
+
+/* ---- weights: reference state_dict -> packed device image ------------------
+ * Replaces: the 18 parameter tensors ImplicitDecoder.__init__ registers
+ * (diinn.py:73-80,92; names/shapes in SURVEY.md App. A.1).
+ * Inputs are HOST pointers to contiguous fp32 tensors in the reference's own
+ * layouts:
+ *   K0w [256,576]        K0b [256]          (K.0.0.weight / .bias)
+ *   Kw[i] [256,832]      Kb[i] [256]   i=0..2 -> K.1..K.3 (first 256 input
+ *                                        channels multiply q, last 576 the unfolded features, diinn.py:136)
+ *   Q0w [256,3]          Q0b [256]          (Q.0.0: inputs rel_h, rel_w, ratio)
+ *   Qw[i] [256,256]      Qb[i] [256]   i=0..2 -> Q.1..Q.3
+ *   Lw [3,256]           Lb [3]             (last_layer)
+ * Output: `packed` HOST buffer of diinn_packed_weight_floats() floats, to be
+ * copied verbatim to the device by the caller.  Pure host function. */
+size_t diinn_packed_weight_floats(void);
+int    diinn_pack_weights(const float* K0w, const float* K0b,
+                          const float* const Kw[3], const float* const Kb[3],
+                          const float* Q0w, const float* Q0b,
+                          const float* const Qw[3], const float* const Qb[3],
+                          const float* Lw, const float* Lb,
+                          float* packed);
+
+/* ---- coordinates / nearest-exact indices (host, bit-exact) ------------------
+ * Replaces: ImplicitDecoder._make_pos_encoding (diinn.py:94-110) and the index
+ * map of F.interpolate(mode='nearest-exact') (diinn.py:106,168) for ONE axis.
+ * idx[n_out] = source LR index of every HR sample, rel[n_out] = (up - in[idx]) * n_in
+ * in the reference's fp32 operation order.  `small_output` != 0 selects ATen's
+ * small-output CPU kernel rounding, which the reference hits when Hu + Wu <= 128
+ * (see diinn_uses_small_output_kernel).  Either output pointer may be NULL. */
+int diinn_make_axis_tables(int n_in, int n_out, int small_output, int32_t* idx, float* rel);
+int diinn_uses_small_output_kernel(int Hu, int Wu);
+/* Same tables evaluated by the device code the decode kernel uses (for tests).
+ * idx_dev/rel_dev: DEVICE buffers of n_out elements. */
+int diinn_make_axis_tables_device(void* stream, int n_in, int n_out, int small_output,
+                                  int32_t* idx_dev, float* rel_dev);
+
+/* ---- workspace ---------------------------------------------------------------
+ * The per-cell modulation image P[B,H,W,1024] fp32 is the
+ * only workspace.  rows [r0,r1) of the LR map are needed to decode HR rows
+ * [y0,y1): diinn_lr_rows_for_band reports them (no halo: the 3x3 halo is read
+ * from `feat` directly). */
+size_t diinn_workspace_bytes(int B, int H, int W);
+int    diinn_lr_rows_for_band(int H, int Hu, int Wu, int y0, int y1, int* r0, int* r1);
+
+/* ---- kernels -------------------------------------------------------------------
+ * diinn_precompute_P  (replaces: F.unfold(x,3,padding=1) + the feature half of
+ *   K[0..3], diinn.py:168,133,136): P[b,y,x,i*256+ch] = Wx_i . unfold(feat)[b,:,y,x] + bK_i
+ *   for LR rows [r0,r1).  feat_dev [B,64,H,W] contiguous NCHW; P_dev [B,H,W,1024].
+ * diinn_decode_band   (replaces: nearest-exact replication + step() mode 3 +
+ *   batched_step, diinn.py:168,132-139,149-160): writes out_dev[b, :, y0:y1, :]
+ *   of a contiguous [B,3,Hu,Wu] tensor.  Needs P rows for the band.
+ * diinn_decode        = precompute_P on the rows the band needs, then decode_band. */
+int diinn_precompute_P(void* stream, const float* feat_dev, const float* packed_dev,
+                       float* P_dev, int B, int H, int W, int r0, int r1);
+int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
+                      float* out_dev, int B, int H, int W, int Hu, int Wu,
+                      int y0, int y1, int sin_mode);
+int diinn_decode(void* stream, const float* feat_dev, const float* packed_dev,
+                 float* workspace_dev, float* out_dev,
+                 int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode);
+
+/* Dominant-kernel launch geometry, for benchmarks/roofline accounting. */
+int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,
+                             int* grid_x, int* grid_y, int* grid_z, int* block);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIINN_HIP_H */

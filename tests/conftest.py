@@ -1,0 +1,33 @@
+"""pytest configuration: ``-m gpu`` tests need a real MI355X; everything else runs on CPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a ROCm GPU (MI355X); run with -m gpu")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    """Outputs/tables produced by the real reference decoder (tests/golden/make_golden.py)."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "diinn_golden.npz"))
+
+
+def golden_cases(g):
+    out = []
+    for k in g.files:
+        if k.startswith("meta/"):
+            name = k[5:]
+            b, h, w, hu, wu, gain, bs = g[k]
+            out.append((name, int(b), int(h), int(w), int(hu), int(wu), float(gain)))
+    return out
