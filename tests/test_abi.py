@@ -1,0 +1,127 @@
+"""CPU: the C-ABI shared library loads, exports every symbol include/diinn_hip.h declares, and its
+host-only functions (packing, tables, size queries) are right.  No kernel launches here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import diinn_amd.synth as synth
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "diinn_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import diinn_amd.build as b
+    b.build()                     # no-op when libdiinn_hip.so is current
+    import diinn_amd._native as N
+    return N.load()
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(diinn_[A-Za-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    import diinn_amd._native as N
+    names = declared_symbols()
+    assert len(names) >= 13
+    raw = C.CDLL(N.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/diinn_hip.h but not exported"
+        assert n in N.SIGNATURES, f"{n} has no ctypes signature in _native.py"
+    assert sorted(N.SIGNATURES) == names
+
+
+def test_abi_version_and_status_strings(lib):
+    assert lib.diinn_abi_version() == 1
+    assert lib.diinn_status_string(0) == b"ok"
+    assert b"invalid" in lib.diinn_status_string(1)
+
+
+def test_host_axis_tables_bit_exact_vs_reference(lib, golden):
+    import diinn_amd.decoder as D
+    for k in golden.files:
+        if not k.startswith("idx/"):
+            continue
+        _, path, pair = k.split("/")
+        n_in, n_out = map(int, pair.split("_"))
+        idx, rel = D.axis_tables(n_in, n_out, path == "small")
+        assert np.array_equal(idx, golden[k]), k
+        assert np.array_equal(rel.view(np.uint32), golden[f"rel/{path}/{pair}"].view(np.uint32)), k
+
+
+def test_invalid_arguments_return_status_not_crash(lib):
+    assert lib.diinn_make_axis_tables(0, 5, 0, None, None) == 1
+    assert lib.diinn_workspace_bytes(1, 0, 3) == 0
+    r0, r1 = C.c_int(), C.c_int()
+    assert lib.diinn_lr_rows_for_band(8, 16, 16, 5, 5, C.byref(r0), C.byref(r1)) == 1
+    assert lib.diinn_decode_band(None, None, None, None, 1, 8, 8, 16, 16, 0, 16, 0) == 1
+    assert lib.diinn_precompute_P(None, None, None, None, 1, 8, 8, 0, 8) == 1
+
+
+def test_workspace_and_band_rows(lib):
+    import diinn_amd.decoder as D
+    assert lib.diinn_workspace_bytes(2, 48, 40) == 2 * 48 * 40 * 1024 * 4
+    assert D.lr_rows_for_band(256, 1024, 1024, 0, 1024) == (0, 256)
+    assert D.lr_rows_for_band(256, 1024, 1024, 512, 768) == (128, 192)
+    import diinn_oracle as orc
+    idx, _ = orc.axis_tables(37, 120)
+    for (y0, y1) in [(0, 1), (5, 77), (119, 120)]:
+        assert D.lr_rows_for_band(37, 120, 171, y0, y1) == (int(idx[y0]), int(idx[y1 - 1]) + 1)
+
+
+def _chan_of(kk, h):
+    m, r = kk >> 4, kk & 15
+    return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def test_packed_image_layout(lib):
+    """Independent numpy restatement of the layout in csrc/diinn_layout.h."""
+    import diinn_amd.decoder as D
+    sd = synth.decoder_state_dict(11)
+    packed = D.pack_state_dict(sd).numpy()
+    assert packed.size == lib.diinn_packed_weight_floats() == 986_628
+    lane = np.arange(64)
+    out_l, h_l = lane & 31, lane >> 5
+    # WL section
+    WL = packed[:3 * 8 * 32 * 2 * 256].reshape(3, 8, 32, 2, 64, 4)
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        i, m, kg, part, l, e = (int(rng.integers(n)) for n in (3, 8, 32, 2, 64, 4))
+        o, cin = 32 * m + (l & 31), _chan_of(4 * kg + e, l >> 5)
+        w = sd[f"K.{i + 1}.0.weight"][o, cin, 0, 0] if part == 0 else sd[f"Q.{i + 1}.0.weight"][o, cin, 0, 0]
+        assert WL[i, m, kg, part, l, e] == w
+    # WP section: [mo][kg][lane][e] = Wx[o][c][ky][kx]
+    off = WL.size
+    WP = packed[off:off + 32 * 72 * 256].reshape(32, 72, 64, 4)
+    for _ in range(200):
+        mo, kg, l, e = (int(rng.integers(n)) for n in (32, 72, 64, 4))
+        i, ch = mo >> 3, 32 * (mo & 7) + (l & 31)
+        kk = 4 * kg + e
+        t, c = kk >> 5, 2 * (kk & 31) + (l >> 5)
+        col = c * 9 + t + (0 if i == 0 else 256)
+        assert WP[mo, kg, l, e] == sd[f"K.{i}.0.weight"][ch, col, 0, 0]
+    off += WP.size
+    for i in range(4):
+        assert np.array_equal(packed[off + 256 * i: off + 256 * (i + 1)], sd[f"K.{i}.0.bias"])
+    off += 1024
+    q0 = sd["Q.0.0.weight"][:, :, 0, 0]
+    for j in range(3):
+        assert np.array_equal(packed[off + 256 * j: off + 256 * (j + 1)], q0[:, j])
+    assert np.array_equal(packed[off + 768: off + 1024], sd["Q.0.0.bias"])
+    off += 1024
+    for i in range(3):
+        assert np.array_equal(packed[off + 256 * i: off + 256 * (i + 1)], sd[f"Q.{i + 1}.0.bias"])
+    off += 768
+    assert np.array_equal(packed[off: off + 768].reshape(3, 256), sd["last_layer.weight"][:, :, 0, 0])
+    off += 768
+    assert np.array_equal(packed[off: off + 3], sd["last_layer.bias"])
+    # every channel appears exactly once per lane-half in the activation register order
+    seen = sorted(_chan_of(kk, h) for kk in range(128) for h in range(2))
+    assert seen == list(range(256))
