@@ -11,7 +11,8 @@ import os
 import threading
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libdiinn_hip.so")
+# DIINN_HIP_LIB lets kernel experiments load an alternative build of the same ABI
+LIB_PATH = os.environ.get("DIINN_HIP_LIB") or os.path.join(PKG_DIR, "libdiinn_hip.so")
 
 DIINN_OK = 0
 SIN_ACCURATE = 0

@@ -61,14 +61,14 @@ int diinn_pack_weights(const float* K0w, const float* K0b,
                     }
                 }
     }
-    // WP: [mo][kg][lane][e];  Wx_i[ch][c*9 + t] = feature half of K.i
+    // WP: [mp][kg][t][lane][e], mo = 2mp+t;  Wx_i[ch][c*9 + tap] = feature half of K.i
     for (int mo = 0; mo < 32; ++mo) {
         const int i = mo >> 3;
         const float* w = (i == 0) ? K0w : Kw[i - 1];
         const size_t ld = (i == 0) ? (size_t)UNF : (size_t)(HID + UNF);
         const size_t col0 = (i == 0) ? 0 : (size_t)HID;
         for (int kg = 0; kg < WP_KG; ++kg) {
-            float* dst = packed + OFF_WP + ((size_t)mo * WP_KG + kg) * WL_PIECE;
+            float* dst = packed + OFF_WP + ((((size_t)(mo >> 1) * WP_KG + kg) * 2) + (mo & 1)) * WL_PIECE;
             for (int lane = 0; lane < 64; ++lane) {
                 const int ch = 32 * (mo & 7) + (lane & 31);
                 const int h = lane >> 5;

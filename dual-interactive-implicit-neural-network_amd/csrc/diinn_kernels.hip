@@ -70,6 +70,29 @@ struct DecodeParams {
 };
 
 constexpr int TILE_W = 8, TILE_H = 4;           // one wave: 8x4 HR pixels
+// timing-ablation hooks (wrong results when defined; never in the shipped build)
+#ifdef ABL_WSTREAM
+#define ABL_STEP(x) ((x) & 3)
+#else
+#define ABL_STEP(x) (x)
+#endif
+#ifdef ABL_NOSIN
+#define ABL_SIN(x) (x)
+#else
+#define ABL_SIN(x) dsin<SIN_MODE>(x)
+#endif
+#ifndef DECODE_RUN_LAYERS
+#define DECODE_RUN_LAYERS 3                     // < 3 only in timing-ablation builds (wrong results)
+#endif
+#ifndef P_PREFETCH
+#define P_PREFETCH 4
+#endif
+#ifndef DECODE_PREFETCH
+#define DECODE_PREFETCH 4                       // weight ring depth, in steps of 8 MFMAs
+#endif
+
+// relu without the canonicalising v_max that fmaxf(x, 0) emits for an MFMA result
+__device__ __forceinline__ float relu0(float x) { return x > 0.0f ? x : 0.0f; }
 constexpr int WG_TILES_X = 2, WG_TILES_Y = 2;   // 4 waves -> 16x8 HR pixels per workgroup
 
 template <int SIN_MODE>
@@ -114,48 +137,85 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
                     float a = __builtin_fmaf(wr[e], p.ratio, bq[e]);
                     a = __builtin_fmaf(ww[e], relw, a);
                     a = __builtin_fmaf(wh[e], relh, a);
-                    q[16 * m + 4 * g + e] = __builtin_fmaxf(pv[e], 0.0f) * dsin<SIN_MODE>(a);
+                    q[16 * m + 4 * g + e] = relu0(pv[e]) * dsin<SIN_MODE>(a);
                 }
             }
         }
     }
 
     // ---- layers 1..3: [k;s] = [Wq_i;Qw_i] . q + [P_i[cell]; bQ_i];  q = relu(k) * sin(s)   (diinn.py:135-137)
+    // Software pipeline, spelled out in program order (the loops below are fully unrolled):
+    //   * weight pieces are fetched PF steps (8 MFMAs = 512 cycles each) ahead into a register ring
+    //     that is carried across tiles and layers (the packed image is contiguous in step order);
+    //   * the accumulator seeds of tile m+1 (P_i[cell], bQ_i) are fetched during tile m;
+    //   * the VALU epilogue (relu * sin) of tile m-1 is spread over the MFMA stream of tile m.
+    constexpr int PF = DECODE_PREFETCH;
+    static_assert(WL_KG % PF == 0, "ring index must be static");
+    const float* __restrict__ wp = Wt + OFF_WL + lane * 4;       // advances one layer per iteration
+    f32x4 rk[PF], rq[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        rk[d] = *(const f32x4*)(wp + (size_t)(2 * d + 0) * WL_PIECE);
+        rq[d] = *(const f32x4*)(wp + (size_t)(2 * d + 1) * WL_PIECE);
+    }
+    f32x4 sk[4], sq[4];                                          // seeds of the next tile
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        sk[g] = *(const f32x4*)(Pc + HID + 8 * g);
+        sq[g] = *(const f32x4*)(Wt + OFF_BQ + 4 * h + 8 * g);
+    }
 #pragma unroll 1
-    for (int layer = 0; layer < 3; ++layer) {
-        const float* __restrict__ Wl = Wt + OFF_WL + (size_t)layer * WL_LAYER + lane * 4;
+    for (int layer = 0; layer < DECODE_RUN_LAYERS; ++layer) {
+        const int nl = layer < 2 ? layer + 1 : 2;                // seeds of the next layer's tile 0 (clamped)
         const float* __restrict__ Pl = Pc + (layer + 1) * HID;
         const float* __restrict__ Bq = Wt + OFF_BQ + layer * HID + 4 * h;
+        const float* __restrict__ Pn = Pc + (nl + 1) * HID;
+        const float* __restrict__ Bn = Wt + OFF_BQ + nl * HID + 4 * h;
         float qn[128];
+        f32x16 pk, ps;                                           // finished accumulators of the previous tile
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             f32x16 ak, as;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 pv = *(const f32x4*)(Pl + 32 * m + 8 * g);
-                const f32x4 bv = *(const f32x4*)(Bq + 32 * m + 8 * g);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    ak[4 * g + e] = pv[e];
-                    as[4 * g + e] = bv[e];
+                    ak[4 * g + e] = sk[g][e];
+                    as[4 * g + e] = sq[g][e];
                 }
             }
 #pragma unroll
             for (int kg = 0; kg < WL_KG; ++kg) {
-                const f32x4 wk = *(const f32x4*)(Wl + ((size_t)(m * WL_KG + kg) * 2 + 0) * WL_PIECE);
-                const f32x4 wq = *(const f32x4*)(Wl + ((size_t)(m * WL_KG + kg) * 2 + 1) * WL_PIECE);
+                const int s = m * WL_KG + kg;
+                const f32x4 wk = rk[s % PF], wq = rq[s % PF];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     ak = MFMA32(wk[e], q[4 * kg + e], ak);
                     as = MFMA32(wq[e], q[4 * kg + e], as);
                 }
-            }
+                // refill the ring slot just consumed with the piece PF steps ahead
+                rk[s % PF] = *(const f32x4*)(wp + (size_t)(2 * ABL_STEP(s + PF) + 0) * WL_PIECE);
+                rq[s % PF] = *(const f32x4*)(wp + (size_t)(2 * ABL_STEP(s + PF) + 1) * WL_PIECE);
+                if (kg == 4) {                                    // seeds for the next tile
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                qn[16 * m + r] = __builtin_fmaxf(ak[r], 0.0f) * dsin<SIN_MODE>(as[r]);
+                    for (int g = 0; g < 4; ++g) {
+                        sk[g] = *(const f32x4*)((m < 7 ? Pl + 32 * (m + 1) : Pn) + 8 * g);
+                        sq[g] = *(const f32x4*)((m < 7 ? Bq + 32 * (m + 1) : Bn) + 8 * g);
+                    }
+                }
+                if (m > 0 && (kg & 1) == 0) {                     // one epilogue element of tile m-1 every 16 MFMAs
+                    const int r = kg >> 1;
+                    qn[16 * (m - 1) + r] = relu0(pk[r]) * ABL_SIN(ps[r]);
+                }
+            }
+            pk = ak;
+            ps = as;
         }
 #pragma unroll
+        for (int r = 0; r < 16; ++r) qn[16 * 7 + r] = relu0(pk[r]) * dsin<SIN_MODE>(ps[r]);
+#pragma unroll
         for (int i = 0; i < 128; ++i) q[i] = qn[i];
+        wp += WL_LAYER;
     }
 
     // ---- head: out = L . q3 + bL   (diinn.py:138)
@@ -195,7 +255,12 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
 // ---------------------------------------------------------------------------------
 // P kernel: P[b,y,x, i*256+ch] = sum_{c,ky,kx} Wx_i[ch,c,ky,kx] * feat[b,c,y+ky-1,x+kx-1] + bK_i[ch]
 // (zero padding; diinn.py:168 unfold + the feature columns of K[i], diinn.py:133,136)
-// Workgroup = 4 waves on the same 32 LR cells of one row; wave i produces P_i.
+// An implicit-im2col GEMM [cells x 576] . [576 x 1024] on v_mfma_f32_32x32x2_f32.
+// Workgroup = 4 waves = a 4-row x 32-column block of LR cells; its 6 x 34 x 64 feature halo
+// tile is staged once in LDS (zero padded), and each wave (one row of 32 cells) streams the
+// whole packed WP image past it two M-tiles at a time: A operands from the packed image
+// (identical for the 4 waves -> one L1 fill), B operands by ds_read_b32 at an immediate
+// offset per (tap, channel).  Few registers -> 2 workgroups per CU hide each other's waits.
 // ---------------------------------------------------------------------------------
 struct PParams {
     const float* feat;   // [B,64,H,W]
@@ -204,60 +269,84 @@ struct PParams {
     int B, H, W, r0, r1;
 };
 
-__global__ __launch_bounds__(256, 1) void precompute_P_kernel(const PParams p) {
+constexpr int PT_ROWS = 4, PT_COLS = 32;                 // cells per workgroup: 4 x 32
+constexpr int PT_LR = PT_ROWS + 2, PT_LC = PT_COLS + 2;  // with the 3x3 halo: 6 x 34
+constexpr int PT_CH = PT_LR * PT_LC;                     // 204 floats per channel
+constexpr int PT_LDS_FLOATS = C_IN * PT_CH;              // 13,056 floats = 52,224 B
+
+__global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
+    __shared__ __attribute__((aligned(16))) float tile[PT_LDS_FLOATS];
     const int lane = threadIdx.x & 63;
-    const int i = threadIdx.x >> 6;          // which P_i this wave produces
+    const int wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
-    const int x = blockIdx.x * 32 + j;
-    const int y = p.r0 + blockIdx.y;
     const int b = blockIdx.z;
+    const int x0 = blockIdx.x * PT_COLS;
+    const int y0 = p.r0 + blockIdx.y * PT_ROWS;
 
-    // B operands: the 3x3 neighbourhood of this lane's cell, all 64 channels.
-    // k-step kk = 32*t + cp: tap t, channel 2*cp + h.
-    float fb[WP_KSTEPS];
-    const float* __restrict__ fbase = p.feat + ((size_t)b * C_IN + h) * p.H * p.W;
-    const size_t cstride = (size_t)2 * p.H * p.W;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    // stage feat[b, :, y0-1 .. y0+4, x0-1 .. x0+32] (zeros outside the map)
+    const float* __restrict__ fb = p.feat + (size_t)b * C_IN * p.H * p.W;
+    for (int idx = threadIdx.x; idx < PT_LDS_FLOATS; idx += 256) {
+        const int c = idx / PT_CH;
+        const int rem = idx - c * PT_CH;
+        const int ly = rem / PT_LC, lx = rem - ly * PT_LC;
+        const int yy = y0 + ly - 1, xx = x0 + lx - 1;
         const bool ok = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
-        const size_t off = ok ? ((size_t)yy * p.W + xx) : 0;
-#pragma unroll
-        for (int cp = 0; cp < 32; ++cp) {
-            const float v = fbase[cp * cstride + off];
-            fb[32 * t + cp] = ok ? v : 0.0f;
-        }
+        tile[idx] = ok ? fb[((size_t)c * p.H + yy) * p.W + xx] : 0.0f;
     }
+    __syncthreads();
 
-    const float* __restrict__ Wp = p.Wt + OFF_WP + lane * 4;
-    const float* __restrict__ Bk = p.Wt + OFF_BK + i * HID + 4 * h;
-    float* __restrict__ Pout = p.P + (((size_t)b * p.H + y) * p.W + x) * PCH + i * HID + 4 * h;
-    const bool store = x < p.W;
+    const int x = x0 + j, y = y0 + wave;
+    const bool store = (x < p.W) && (y < p.r1);
+    // a wave whose row is past the band still runs (cheap at the band edge) -- no barrier follows,
+    // so it may simply leave.
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(store) == 0ull))) return;
 
+    // B operand of k-step kk = 32*t + cp (tap t = ky*3+kx, channel 2*cp + h):
+    //   tile[(2cp + h) * PT_CH + (wave + ky) * PT_LC + j + kx]
+    const int tb_off = h * PT_CH + wave * PT_LC + j;
+
+    constexpr int PF = P_PREFETCH;
+    static_assert(WP_KG % PF == 0, "ring index must be static");
+    const float* __restrict__ wp = p.Wt + OFF_WP + lane * 4;    // advances one M-tile pair per iteration
+    const float* __restrict__ Bk = p.Wt + OFF_BK + 4 * h;
+    float* __restrict__ Pout = p.P + (((size_t)b * p.H + (y < p.H ? y : p.H - 1)) * p.W + (x < p.W ? x : p.W - 1)) * PCH + 4 * h;
+    f32x4 r0v[PF], r1v[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        r0v[d] = *(const f32x4*)(wp + (size_t)(2 * d + 0) * WL_PIECE);
+        r1v[d] = *(const f32x4*)(wp + (size_t)(2 * d + 1) * WL_PIECE);
+    }
 #pragma unroll 1
-    for (int m = 0; m < 8; m += 2) {
+    for (int mp = 0; mp < 16; ++mp) {
+        // the B operands do not depend on mp: hide the base from LICM, or all 288 LDS reads are
+        // hoisted out of this loop and live (spilled) across it
+        int off = tb_off;
+        asm volatile("" : "+v"(off));
+        const float* tbm = tile + off;          // still an LDS (ds_read) address
         f32x16 a0, a1;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 b0 = *(const f32x4*)(Bk + 32 * m + 8 * g);
-            const f32x4 b1 = *(const f32x4*)(Bk + 32 * (m + 1) + 8 * g);
+            const f32x4 s0 = *(const f32x4*)(Bk + 64 * mp + 8 * g);
+            const f32x4 s1 = *(const f32x4*)(Bk + 64 * mp + 32 + 8 * g);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                a0[4 * g + e] = b0[e];
-                a1[4 * g + e] = b1[e];
+                a0[4 * g + e] = s0[e];
+                a1[4 * g + e] = s1[e];
             }
         }
-        const float* __restrict__ w0 = Wp + (size_t)(i * 8 + m) * WP_KG * WL_PIECE;
-        const float* __restrict__ w1 = w0 + (size_t)WP_KG * WL_PIECE;
 #pragma unroll
         for (int kg = 0; kg < WP_KG; ++kg) {
-            const f32x4 u0 = *(const f32x4*)(w0 + (size_t)kg * WL_PIECE);
-            const f32x4 u1 = *(const f32x4*)(w1 + (size_t)kg * WL_PIECE);
+            const f32x4 u0 = r0v[kg % PF], u1 = r1v[kg % PF];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                a0 = MFMA32(u0[e], fb[4 * kg + e], a0);
-                a1 = MFMA32(u1[e], fb[4 * kg + e], a1);
+                const int kk = 4 * kg + e;
+                const int t = kk >> 5, cp = kk & 31;
+                const float bv = tbm[(2 * cp) * PT_CH + (t / 3) * PT_LC + (t % 3)];
+                a0 = MFMA32(u0[e], bv, a0);
+                a1 = MFMA32(u1[e], bv, a1);
             }
+            r0v[kg % PF] = *(const f32x4*)(wp + (size_t)(2 * (kg + PF) + 0) * WL_PIECE);
+            r1v[kg % PF] = *(const f32x4*)(wp + (size_t)(2 * (kg + PF) + 1) * WL_PIECE);
         }
         if (store) {
 #pragma unroll
@@ -268,10 +357,11 @@ __global__ __launch_bounds__(256, 1) void precompute_P_kernel(const PParams p) {
                     v0[e] = a0[4 * g + e];
                     v1[e] = a1[4 * g + e];
                 }
-                *(f32x4*)(Pout + 32 * m + 8 * g) = v0;
-                *(f32x4*)(Pout + 32 * (m + 1) + 8 * g) = v1;
+                *(f32x4*)(Pout + 64 * mp + 8 * g) = v0;
+                *(f32x4*)(Pout + 64 * mp + 32 + 8 * g) = v1;
             }
         }
+        wp += (size_t)WP_KG * 2 * WL_PIECE;
     }
 }
 
@@ -325,7 +415,7 @@ int diinn_precompute_P(void* stream, const float* feat_dev, const float* packed_
     if (st) return st;
     if (r0 < 0 || r1 > H || r0 >= r1) return DIINN_ERR_INVALID_ARG;
     PParams p{feat_dev, packed_dev, P_dev, B, H, W, r0, r1};
-    const dim3 grid((W + 31) / 32, r1 - r0, B);
+    const dim3 grid((W + PT_COLS - 1) / PT_COLS, (r1 - r0 + PT_ROWS - 1) / PT_ROWS, B);
     hipLaunchKernelGGL(precompute_P_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }

@@ -34,8 +34,9 @@ constexpr size_t WL_PIECE   = 64 * 4;                      // floats per (lane,e
 constexpr size_t WL_LAYER   = (size_t)8 * WL_KG * 2 * WL_PIECE;
 constexpr size_t OFF_WL     = 0;
 constexpr size_t SZ_WL      = 3 * WL_LAYER;                // 393,216 floats = 1.5 MiB
-// WP: the hoisted 3x3 conv 64 -> 1024.  [mo 32][kg 72][lane 64][e 4]
-//     k-step kk = 4kg+e: tap t = kk/32 (= ky*3+kx), channel c = 2*(kk%32) + (lane>>5);
+// WP: the hoisted 3x3 conv 64 -> 1024.  [mp 16][kg 72][t 2][lane 64][e 4], M-tile mo = 2mp+t
+//     (step order of the P kernel: two M-tiles advance together through K)
+//     k-step kk = 4kg+e: tap = kk/32 (= ky*3+kx), channel c = 2*(kk%32) + (lane>>5);
 //     value = Wx[ o = 32mo + (lane&31) ][ c ][ ky ][ kx ],  o = i*256 + ch
 constexpr int    WP_KSTEPS  = UNF / 2;                     // 288
 constexpr int    WP_KG      = WP_KSTEPS / 4;               // 72

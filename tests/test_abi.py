@@ -97,16 +97,16 @@ def test_packed_image_layout(lib):
         o, cin = 32 * m + (l & 31), _chan_of(4 * kg + e, l >> 5)
         w = sd[f"K.{i + 1}.0.weight"][o, cin, 0, 0] if part == 0 else sd[f"Q.{i + 1}.0.weight"][o, cin, 0, 0]
         assert WL[i, m, kg, part, l, e] == w
-    # WP section: [mo][kg][lane][e] = Wx[o][c][ky][kx]
+    # WP section: [mp][kg][t][lane][e] = Wx[o][c][ky][kx], M-tile mo = 2mp+t
     off = WL.size
-    WP = packed[off:off + 32 * 72 * 256].reshape(32, 72, 64, 4)
+    WP = packed[off:off + 32 * 72 * 256].reshape(16, 72, 2, 64, 4)
     for _ in range(200):
         mo, kg, l, e = (int(rng.integers(n)) for n in (32, 72, 64, 4))
         i, ch = mo >> 3, 32 * (mo & 7) + (l & 31)
         kk = 4 * kg + e
         t, c = kk >> 5, 2 * (kk & 31) + (l >> 5)
         col = c * 9 + t + (0 if i == 0 else 256)
-        assert WP[mo, kg, l, e] == sd[f"K.{i}.0.weight"][ch, col, 0, 0]
+        assert WP[mo >> 1, kg, mo & 1, l, e] == sd[f"K.{i}.0.weight"][ch, col, 0, 0]
     off += WP.size
     for i in range(4):
         assert np.array_equal(packed[off + 256 * i: off + 256 * (i + 1)], sd[f"K.{i}.0.bias"])
