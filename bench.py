@@ -51,15 +51,28 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(sd, feat_np, size):
-    """Reference-faithful CPU decode (oracle/) timed on this host, bounded sample of the same workload."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import diinn_oracle as orc
+def effective_cores() -> int:
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box exposes 256 logical CPUs but limits the container to a quota of 16)."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
+def cpu_baseline(sd, feat_np, size):
+    """Reference-faithful CPU decode (oracle/) timed on this host, bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import diinn_oracle as orc
+    cores = effective_cores()
     torch.set_num_threads(cores)
     hu, wu = size
     # probe: 64 HR rows; then the reported sample is sized for roughly 10-20 s of CPU work

@@ -1,0 +1,168 @@
+"""The callers' side of the boundary: the reference's module
+surface around the decoder, so its workflows run on the MI355X path unchanged.
+
+  RDN / make_rdn     encoder, plain PyTorch-ROCm (north_star: "the encoder stays PyTorch-ROCm");
+                     parameter names follow reference src/models/components/rdn.py:37-105 so
+                     checkpoints load
+  DIINN              reference diinn.py:8-19: encoder -> ImplicitDecoder (HIP kernels)
+  make_net           reference sr_module.py:42-50
+  SRLitModule        reference sr_module.py:62-194, the parts the inference callers use:
+                     ctor hparams, ``net``, ``sub``/``div`` buffers, forward, step,
+                     load_from_checkpoint.  pytorch_lightning is not required (it is absent from
+                     the target image); training hooks, losses' optimisers and metrics are out of
+                     scope for this tier.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .decoder import ImplicitDecoder
+
+
+# ---------------------------------------------------------------------------
+# RDN encoder (config 'B': 16 blocks x 8 convs, growth 64), features only
+# ---------------------------------------------------------------------------
+class RDB_Conv(nn.Module):
+    """3x3 conv + ReLU whose output is concatenated to its input (dense connection)."""
+
+    def __init__(self, inChannels: int, growRate: int, kSize: int = 3):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(inChannels, growRate, kSize, padding=(kSize - 1) // 2), nn.ReLU())
+
+    def forward(self, x):
+        return torch.cat((x, self.conv(x)), 1)
+
+
+class RDB(nn.Module):
+    """Residual dense block: C dense convs, 1x1 local feature fusion, residual add."""
+
+    def __init__(self, growRate0: int, growRate: int, nConvLayers: int, kSize: int = 3):
+        super().__init__()
+        self.convs = nn.Sequential(*[RDB_Conv(growRate0 + c * growRate, growRate, kSize) for c in range(nConvLayers)])
+        self.LFF = nn.Conv2d(growRate0 + nConvLayers * growRate, growRate0, 1)
+
+    def forward(self, x):
+        return self.LFF(self.convs(x)) + x
+
+
+class RDN(nn.Module):
+    _CONFIGS = {"A": (20, 6, 32), "B": (16, 8, 64)}
+
+    def __init__(self, G0: int = 64, RDNkSize: int = 3, RDNconfig: str = "B", n_colors: int = 3):
+        super().__init__()
+        self.D, C, G = self._CONFIGS[RDNconfig]
+        pad = (RDNkSize - 1) // 2
+        self.SFENet1 = nn.Conv2d(n_colors, G0, RDNkSize, padding=pad)
+        self.SFENet2 = nn.Conv2d(G0, G0, RDNkSize, padding=pad)
+        self.RDBs = nn.ModuleList([RDB(G0, G, C) for _ in range(self.D)])
+        self.GFF = nn.Sequential(nn.Conv2d(self.D * G0, G0, 1), nn.Conv2d(G0, G0, RDNkSize, padding=pad))
+        self.out_dim = G0
+        self.args = SimpleNamespace(G0=G0, RDNkSize=RDNkSize, RDNconfig=RDNconfig, scale=[2],
+                                    no_upsampling=True, n_colors=n_colors)
+
+    def forward(self, x):
+        shallow = self.SFENet1(x)
+        x = self.SFENet2(shallow)
+        blocks = []
+        for rdb in self.RDBs:
+            x = rdb(x)
+            blocks.append(x)
+        return self.GFF(torch.cat(blocks, 1)) + shallow
+
+
+def make_rdn(G0=64, RDNkSize=3, RDNconfig="B", scale=2, no_upsampling=True):
+    if not no_upsampling:
+        raise NotImplementedError("DIINN uses RDN as a feature encoder only (no_upsampling=True)")
+    return RDN(G0=G0, RDNkSize=RDNkSize, RDNconfig=RDNconfig)
+
+
+# ---------------------------------------------------------------------------
+# model assemblies
+# ---------------------------------------------------------------------------
+class DIINN(nn.Module):
+    """Reference diinn.py:8-19: ``decoder(encoder(x), size, bsize)``."""
+
+    def __init__(self, mode, init_q):
+        super().__init__()
+        self.encoder = make_rdn()
+        self.decoder = ImplicitDecoder(mode=mode, init_q=init_q)
+
+    def forward(self, x, size, bsize=None):
+        return self.decoder(self.encoder(x), size, bsize)
+
+
+class BICUBIC_NET(nn.Module):
+    """Antialiased bicubic resize baseline (reference sr_module.py:53-60 via torchvision.Resize,
+    which lowers to this interpolate call)."""
+
+    def forward(self, x, size, eval_bsize=None):
+        return F.interpolate(x, size=tuple(int(s) for s in size), mode="bicubic", align_corners=False, antialias=True)
+
+
+def make_net(arch, mode, init_q):
+    if arch == "diinn":
+        return DIINN(mode=mode, init_q=init_q)
+    if arch == "bicubic":
+        return BICUBIC_NET()
+    if arch in ("liif", "metasr"):
+        raise NotImplementedError(f"arch={arch!r}: comparison baselines of the reference are outside this build "
+                                  f"(SURVEY.md §2 rows 7-8)")
+    return None   # the reference's make_net falls through to None for unknown names
+
+
+class SRLitModule(nn.Module):
+    """Inference surface of the reference LightningModule (sr_module.py:62-125)."""
+
+    def __init__(self, arch: str, mode: int = 1, init_q: bool = False, lr: float = 1e-4, lr_gamma: float = 0.5,
+                 lr_step: int = 10, eval_bsize: int = 30000):
+        super().__init__()
+        self.hparams = SimpleNamespace(arch=arch, mode=mode, init_q=init_q, lr=lr, lr_gamma=lr_gamma,
+                                       lr_step=lr_step, eval_bsize=eval_bsize)
+        self.net = make_net(arch, mode, init_q)
+        self.register_buffer("sub", torch.FloatTensor([0.5]).view(1, -1, 1, 1))
+        self.register_buffer("div", torch.FloatTensor([0.5]).view(1, -1, 1, 1))
+        self.criterion = nn.L1Loss()
+
+    def forward(self, x: torch.Tensor, size, eval_bsize=None):
+        return self.net(x, size, eval_bsize)
+
+    def step(self, batch: Any, eval_bsize=None):
+        """sr_module.py:113-125: ``batch`` maps scale -> (lr, hr, name); normalise, decode, L1, de-normalise."""
+        loss = 0
+        pred_hrs: Dict[Any, torch.Tensor] = {}
+        for scale in batch:
+            lr, hr, _ = batch[scale]
+            lr = (lr - self.sub) / self.div
+            hr = (hr - self.sub) / self.div
+            pred_hr = self.forward(lr, hr.shape[-2:], eval_bsize)
+            loss += self.criterion(pred_hr, hr)
+            pred_hrs[scale] = (pred_hr * self.div + self.sub).clamp_(0, 1)
+        return loss / len(batch), pred_hrs
+
+    @torch.no_grad()
+    def test_step(self, batch: Any, batch_idx: int = 0, dataloader_idx: Optional[int] = None):
+        """Decode with the checkpoint's eval_bsize and report PSNR per scale (torchmetrics' definition,
+        data_range=1; SSIM / LR-PSNR of sr_module.py:167-175 need torchmetrics/torchvision)."""
+        _, pred_hrs = self.step(batch, self.hparams.eval_bsize)
+        res = {}
+        for scale in batch:
+            mse = torch.mean((pred_hrs[scale] - batch[scale][1]) ** 2)
+            res[scale] = {"psnr_res": 10.0 * torch.log10(1.0 / mse)}
+        return res
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path: str, map_location=None, strict: bool = True, **overrides):
+        """Lightning checkpoint dict: ``hyper_parameters`` (ctor kwargs saved by save_hyperparameters,
+        sr_module.py:91) and ``state_dict`` (keys ``net.encoder.*``, ``net.decoder.*``, ``sub``, ``div``)."""
+        ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+        hp = dict(ckpt.get("hyper_parameters", {}))
+        hp.update(overrides)
+        known = ("arch", "mode", "init_q", "lr", "lr_gamma", "lr_step", "eval_bsize")
+        model = cls(**{k: v for k, v in hp.items() if k in known})
+        model.load_state_dict(ckpt["state_dict"], strict=strict)
+        return model.eval()

@@ -110,3 +110,16 @@ def decoder_state_dict(seed: int = 123, gain: float = 1.0) -> "OrderedDict[str, 
 def encoder_features(seed: int, b: int, h: int, w: int, tag: str = "feat") -> np.ndarray:
     """Synthetic LR encoder feature map [B,64,H,W] fp32 (stands in for RDN output)."""
     return normalish(seed, f"{tag}:{b}x{h}x{w}", (b, IN_CHANNELS, h, w))
+
+
+def state_dict_for(shapes, seed: int = 123, prefix: str = "") -> "OrderedDict[str, np.ndarray]":
+    """Synthetic tensors for any conv-style module given ``{name: shape}`` (names ending in
+    ``.weight``/``.bias``): U(+-1/sqrt(fan_in)) with fan_in taken from the sibling weight."""
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, shape in shapes.items():
+        shape = tuple(int(x) for x in shape)
+        wname = name.rsplit(".", 1)[0] + ".weight"
+        wshape = tuple(int(x) for x in shapes.get(wname, shape))
+        fan_in = int(np.prod(wshape[1:])) if len(wshape) > 1 else 1
+        out[name] = uniform(seed, prefix + name, shape, 1.0 / math.sqrt(max(fan_in, 1)))
+    return out

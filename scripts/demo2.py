@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""demo2 on the MI355X path: given an LR image, super-resolve it to the desired resolution.
+
+Same command line as the reference's demo2.py (reference demo2.py:12-19):
+    python scripts/demo2.py --lr_path img.png --output_size 512 768 --ckpt_path last.ckpt \
+        [--model_name default_model] [--file_ext .png]
+Behaviour kept from the reference (demo2.py:29-41): no (x-0.5)/0.5 normalisation, the output
+goes to <dir(lr_path)>/<model_name>/<model_name>_<file>_<H>x<W>.png.  Differences: the model and
+the image are moved to the GPU (the reference leaves them on the CPU), and image I/O uses PIL
+because torchvision is not part of the target image.
+"""
+import os
+import sys
+from argparse import ArgumentParser
+from pathlib import Path
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from PIL import Image  # noqa: E402
+
+from diinn_amd.modules import SRLitModule  # noqa: E402
+
+
+def read_rgb(path):
+    img = np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / 255.0
+    return torch.from_numpy(img).permute(2, 0, 1).unsqueeze(0).contiguous()
+
+
+def save_rgb(t, path):
+    arr = (t[0].clamp(0, 1).mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy())
+    Image.fromarray(arr).save(path)
+
+
+@torch.no_grad()
+def demo2(args):
+    dev = torch.device("cuda:0")
+    if args.model_name == "bicubic":
+        model = SRLitModule(arch="bicubic")
+    else:
+        model = SRLitModule.load_from_checkpoint(args.ckpt_path)
+    model = model.to(dev).eval()
+    print(args.lr_path)
+    filename, _ = os.path.splitext(os.path.basename(args.lr_path))
+    lr = read_rgb(args.lr_path).to(dev)
+    out_dir = os.path.join(os.path.dirname(args.lr_path) or ".", args.model_name)
+    Path(out_dir).mkdir(parents=True, exist_ok=True)
+    sr = model(lr, args.output_size)
+    save_rgb(sr, os.path.join(out_dir, "{}_{}_{}x{}.png".format(args.model_name, filename,
+                                                               args.output_size[0], args.output_size[1])))
+
+
+if __name__ == "__main__":
+    parser = ArgumentParser()
+    parser.add_argument("--lr_path", type=str, required=True)
+    parser.add_argument("--output_size", type=int, nargs="+", required=True)
+    parser.add_argument("--ckpt_path", type=str, required=True)
+    parser.add_argument("--model_name", type=str, default="default_model")
+    parser.add_argument("--file_ext", type=str, default=".png")
+    demo2(parser.parse_args())

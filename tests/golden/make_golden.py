@@ -103,6 +103,22 @@ def main():
         for (h, w, hu, wu) in [(48, 48, 96, 96), (40, 56, 132, 185), (720, 1280, 2376, 4224), (1024, 1024, 8192, 8192)]:
             r = torch.zeros(1).new_tensor([(h * w) / (hu * wu)]).numpy()
             out[f"ratio/{h}_{w}_{hu}_{wu}"] = r.astype(np.float32)
+        # callers' side: RDN encoder key names/shapes and a DIINN end-to-end output
+        import json
+        from src.models.components.diinn import DIINN as RefDIINN
+        from src.models.components.rdn import make_rdn as ref_make_rdn
+        enc = ref_make_rdn()
+        shapes = {k: list(v.shape) for k, v in enc.state_dict().items()}
+        out["rdn/shapes_json"] = np.array(json.dumps(shapes))
+        enc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_for(shapes, 123, "enc.").items()})
+        img = torch.from_numpy(synth.uniform(123, "img:1x3x12x10", (1, 3, 12, 10), 0.5) + np.float32(0.5))
+        out["rdn/out_1x3x12x10"] = enc.eval()(img).numpy()
+        net = RefDIINN(mode=3, init_q=False).eval()
+        full = {k: list(v.shape) for k, v in net.state_dict().items()}
+        out["diinn/shapes_json"] = np.array(json.dumps(full))
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_for(full, 123, "diinn.").items()})
+        out["diinn/out_1x3x12x10_to_31x27"] = net(img, [31, 27], 30000).numpy()
+        print("rdn + diinn e2e captured", len(shapes), len(full))
     np.savez(os.path.join(HERE, "diinn_golden.npz"), **out)
     print("wrote", os.path.join(HERE, "diinn_golden.npz"))
 

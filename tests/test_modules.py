@@ -1,0 +1,95 @@
+"""The callers' side of the boundary: DIINN / SRLitModule / RDN mirror."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import diinn_amd.synth as synth
+
+
+def _shapes(golden, key):
+    return json.loads(str(golden[key]))
+
+
+def test_rdn_state_dict_matches_reference_and_output(golden):
+    """Encoder stays PyTorch: same keys/shapes as reference rdn.py and the same output on CPU."""
+    import diinn_amd.modules as M
+    ref_shapes = _shapes(golden, "rdn/shapes_json")
+    enc = M.make_rdn()
+    assert {k: list(v.shape) for k, v in enc.state_dict().items()} == ref_shapes
+    assert sum(p.numel() for p in enc.parameters()) == 21_973_952
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_for(ref_shapes, 123, "enc.").items()})
+    img = torch.from_numpy(synth.uniform(123, "img:1x3x12x10", (1, 3, 12, 10), 0.5) + np.float32(0.5))
+    with torch.no_grad():
+        out = enc.eval()(img).numpy()
+    ref = golden["rdn/out_1x3x12x10"]
+    assert float(np.abs(out - ref).max()) <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_diinn_and_lit_module_key_names(golden):
+    import diinn_amd.modules as M
+    full = _shapes(golden, "diinn/shapes_json")
+    net = M.DIINN(mode=3, init_q=False)
+    assert {k: list(v.shape) for k, v in net.state_dict().items()} == full
+    lit = M.SRLitModule(arch="diinn", mode=3, init_q=False)
+    keys = set(lit.state_dict())
+    assert {"net." + k for k in full} | {"sub", "div"} == keys          # sr_module.py:93-97
+    assert lit.hparams.eval_bsize == 30000 and float(lit.sub) == 0.5
+
+
+def test_load_from_checkpoint_roundtrip(tmp_path, golden):
+    """A Lightning-style checkpoint dict (hyper_parameters + state_dict) loads by name."""
+    import diinn_amd.modules as M
+    full = _shapes(golden, "diinn/shapes_json")
+    sd = {"net." + k: torch.from_numpy(v) for k, v in synth.state_dict_for(full, 123, "diinn.").items()}
+    sd["sub"] = torch.full((1, 1, 1, 1), 0.5)
+    sd["div"] = torch.full((1, 1, 1, 1), 0.5)
+    path = tmp_path / "last.ckpt"
+    torch.save({"state_dict": sd, "hyper_parameters": {"arch": "diinn", "mode": 3, "init_q": False, "lr": 1e-4,
+                                                       "lr_gamma": 0.5, "lr_step": 10, "eval_bsize": 30000}}, path)
+    lit = M.SRLitModule.load_from_checkpoint(str(path))
+    assert lit.hparams.mode == 3 and not lit.training
+    assert torch.equal(lit.net.decoder.K[1][0].weight, sd["net.decoder.K.1.0.weight"])
+
+
+def test_bicubic_and_unknown_arch():
+    import diinn_amd.modules as M
+    y = M.SRLitModule(arch="bicubic")(torch.rand(1, 3, 8, 8), (16, 12))
+    assert y.shape == (1, 3, 16, 12)
+    with pytest.raises(NotImplementedError):
+        M.make_net("liif", 1, False)
+
+
+@pytest.mark.gpu
+def test_diinn_end_to_end_on_gpu_matches_reference(golden):
+    """Encoder (PyTorch-ROCm) + HIP decoder vs the reference DIINN run on the CPU.  The encoder's
+    GPU convolutions differ from the CPU's at ~1e-6; the tolerance is the decoder's 1e-4."""
+    import diinn_amd.modules as M
+    full = _shapes(golden, "diinn/shapes_json")
+    dev = torch.device("cuda:0")
+    net = M.DIINN(mode=3, init_q=False)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_for(full, 123, "diinn.").items()})
+    net = net.to(dev).eval()
+    img = torch.from_numpy(synth.uniform(123, "img:1x3x12x10", (1, 3, 12, 10), 0.5) + np.float32(0.5)).to(dev)
+    with torch.no_grad():
+        out = net(img, [31, 27], 30000).cpu().numpy()
+    ref = golden["diinn/out_1x3x12x10_to_31x27"]
+    assert out.shape == ref.shape
+    assert float(np.abs(out - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.gpu
+def test_lit_module_step_normalisation(golden):
+    """SRLitModule.step: (x-.5)/.5 -> forward(.., hr.shape[-2:], eval_bsize) -> *.5+.5, clamp (sr_module.py:113-125)."""
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    lit = M.SRLitModule(arch="diinn", mode=3, init_q=False).to(dev).eval()
+    lr = torch.rand(1, 3, 10, 9, device=dev)
+    hr = torch.rand(1, 3, 25, 22, device=dev)
+    with torch.no_grad():
+        loss, preds = lit.step({2.5: (lr, hr, "x")}, 30000)
+        direct = lit((lr - 0.5) / 0.5, hr.shape[-2:], 30000)
+    assert preds[2.5].shape == hr.shape and float(preds[2.5].min()) >= 0 and float(preds[2.5].max()) <= 1
+    assert torch.allclose(preds[2.5], (direct * 0.5 + 0.5).clamp(0, 1))
+    assert torch.isfinite(loss)
