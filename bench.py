@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--sin", choices=["accurate", "hw"], default=os.environ.get("DIINN_SIN", "accurate"))
+    ap.add_argument("--sin", choices=["accurate", "hw", "hw_reduced"], default=os.environ.get("DIINN_SIN", "default"),
+                    help="sine evaluation of the synthesis branch (default: the library default, hw_reduced)")
     ap.add_argument("--dist-mode", choices=["halo", "bcast"], default="halo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -127,7 +128,9 @@ def main():
     import diinn_amd.synth as synth
 
     lib = N.load()
-    sin_mode = N.SIN_HW if args.sin == "hw" else N.SIN_ACCURATE
+    sin_mode = {"accurate": N.SIN_ACCURATE, "hw": N.SIN_HW, "hw_reduced": N.SIN_HW_REDUCED,
+                "default": N.SIN_DEFAULT}[args.sin]
+    sin_name = {N.SIN_ACCURATE: "accurate", N.SIN_HW: "hw", N.SIN_HW_REDUCED: "hw_reduced"}[sin_mode]
     sd = synth.decoder_state_dict(123)
     packed = D.pack_state_dict(sd).to(dev)
 
@@ -205,7 +208,7 @@ def main():
             "config": {
                 "workload": f"c2: {LR}x{LR} LR encoder features per GPU, x{SCALE} decode -> "
                             f"{HU}x{WU} HR total ({world} row band(s) of {LR * SCALE}x{WU}), B=1, mode=3",
-                "lr": [H, W], "hr": [HU, WU], "sin": args.sin,
+                "lr": [H, W], "hr": [HU, WU], "sin": sin_name,
                 "parallelism": f"hr-row-bands x{world}" + (f" ({args.dist_mode} feature hand-off)" if world > 1 else ""),
                 "step": "feature hand-off (N>1) + precompute_P + decode_kernel",
             },

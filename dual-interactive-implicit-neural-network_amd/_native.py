@@ -17,6 +17,10 @@ LIB_PATH = os.environ.get("DIINN_HIP_LIB") or os.path.join(PKG_DIR, "libdiinn_hi
 DIINN_OK = 0
 SIN_ACCURATE = 0
 SIN_HW = 1
+SIN_HW_REDUCED = 2
+# default: 2-term Cody-Waite reduction + v_sin_f32 (max abs error 4e-7 for |x| <= 1e4, measured in
+# tests/test_gpu_parity.py::test_device_sine_accuracy); SIN_ACCURATE (1e-7) costs ~4 % more time
+SIN_DEFAULT = SIN_HW_REDUCED
 ABI_VERSION = 1
 
 _f = C.POINTER(C.c_float)
@@ -34,6 +38,7 @@ SIGNATURES = {
     "diinn_make_axis_tables": (C.c_int, [C.c_int, C.c_int, C.c_int, _i32, _f]),
     "diinn_uses_small_output_kernel": (C.c_int, [C.c_int, C.c_int]),
     "diinn_make_axis_tables_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "diinn_eval_sin_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "diinn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "diinn_lr_rows_for_band": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip]),
     "diinn_precompute_P": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -52,9 +52,21 @@ __device__ __forceinline__ float dsin<DIINN_SIN_ACCURATE>(float x) {
 }
 
 // v_sin_f32 takes revolutions; fract keeps it inside the instruction's valid domain.
+// The product x/(2 pi) is rounded to fp32 before the reduction, so the absolute error grows
+// like |x| * 6e-8: fine for O(1)..O(100) arguments, the fastest form (3 VALU ops).
 template <>
 __device__ __forceinline__ float dsin<DIINN_SIN_HW>(float x) {
     return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.15915494309189533577f));
+}
+
+// Cody-Waite reduction by multiples of 2 pi (exact to ~1e-7 for |x| <= 1e5), then v_sin_f32 on
+// the reduced argument: 6 VALU ops, error independent of |x|.
+template <>
+__device__ __forceinline__ float dsin<DIINN_SIN_HW_REDUCED>(float x) {
+    const float k = __builtin_rintf(x * 0.15915494309189533577f);
+    float r = __builtin_fmaf(k, -6.28318548202514648438f, x);       // 2 pi, fp32 head
+    r = __builtin_fmaf(k, 1.74845553146951715461e-07f, r);           // -(2 pi - head)
+    return __builtin_amdgcn_sinf(r * 0.15915494309189533577f);
 }
 
 // ---------------------------------------------------------------------------------
@@ -84,6 +96,16 @@ constexpr int TILE_W = 8, TILE_H = 4;           // one wave: 8x4 HR pixels
 #ifndef DECODE_RUN_LAYERS
 #define DECODE_RUN_LAYERS 3                     // < 3 only in timing-ablation builds (wrong results)
 #endif
+#ifndef WSTREAM_AUX
+#define WSTREAM_AUX 0                           // cache-policy bits of the weight-stream loads (sc0=1, nt=2, sc1=16)
+#endif
+#ifndef DECODE_WLDS
+#define DECODE_WLDS 0                           // 1: stage the weight stream through an LDS ring shared by the 4 waves
+#endif
+#if DECODE_WLDS
+constexpr int WLDS_NSLOT = 4;
+constexpr int WLDS_SLOT_FLOATS = 16 * 256;      // 8 steps x 2 parts x 1 KiB
+#endif
 #ifndef P_PREFETCH
 #define P_PREFETCH 4
 #endif
@@ -92,13 +114,27 @@ constexpr int TILE_W = 8, TILE_H = 4;           // one wave: 8x4 HR pixels
 #endif
 
 // relu without the canonicalising v_max that fmaxf(x, 0) emits for an MFMA result
-__device__ __forceinline__ float relu0(float x) { return x > 0.0f ? x : 0.0f; }
+__device__ __forceinline__ float relu0(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));     // one VALU op (fmaxf adds a canonicalising v_max)
+    return r;
+}
+
+// Weight-stream loads go through a buffer descriptor: address = SGPR descriptor base + SGPR byte
+// offset (scalar unit) + one constant per-lane VGPR offset, so the stream costs no VALU address
+// arithmetic.  That matters here: on gfx950 the fp32 MFMA shares its issue/datapath with the VALU
+// (tools/ubench/mfma_rate.hip: every VALU op between MFMAs costs ~3.2 cycles of MFMA time).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld_piece(__amdgpu_buffer_rsrc_t rsrc, int lane_off, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, WSTREAM_AUX));
+}
+constexpr int PIECE_BYTES = (int)(WL_PIECE * sizeof(float));
 constexpr int WG_TILES_X = 2, WG_TILES_Y = 2;   // 4 waves -> 16x8 HR pixels per workgroup
 
 template <int SIN_MODE>
 __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform (scalar offsets)
     const int h = lane >> 5, j = lane & 31;
 
     const int x = blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
@@ -106,7 +142,11 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     const int b = blockIdx.z;
     const bool valid = (x < p.Wu) && (y < p.y1);
     // whole wave outside the band/image: nothing to do (wave-uniform, no barriers in this kernel)
+#if !DECODE_WLDS
     if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
+#endif
+    // (with the LDS weight ring every wave of the workgroup must reach every barrier: waves outside
+    //  the image run on clamped coordinates and simply do not store)
     const int xc = x < p.Wu ? x : p.Wu - 1;
     const int yc = y < p.y1 ? y : p.y1 - 1;
 
@@ -151,13 +191,39 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     //   * the VALU epilogue (relu * sin) of tile m-1 is spread over the MFMA stream of tile m.
     constexpr int PF = DECODE_PREFETCH;
     static_assert(WL_KG % PF == 0, "ring index must be static");
-    const float* __restrict__ wp = Wt + OFF_WL + lane * 4;       // advances one layer per iteration
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);   // reads past the end return 0
+    const int lane_off = lane * 16;
+    int wp = (int)(OFF_WL * sizeof(float));                      // byte offset; advances one layer per iteration
+#if DECODE_WLDS
+    // LDS weight ring: slot = 8 steps = 16 KiB (16 pieces); wave w fetches pieces 4w..4w+3 of every
+    // slot (each weight byte leaves L2 once per CU), two slots ahead of the readers, through 4
+    // staging registers: global -> VGPR during slot b-1, VGPR -> LDS at the start of slot b
+    // (for slot b+2), one workgroup barrier per slot.  NSLOT = 4 so that the slot being written
+    // is never one that a slower wave can still be reading.
+    __shared__ __attribute__((aligned(16))) float wlds[WLDS_NSLOT * WLDS_SLOT_FLOATS];
+    float* const wl_w = wlds + (wave * 4) * WL_PIECE + lane * 4;      // where this wave stages its pieces
+    const float* const wl_r = wlds + lane * 4;                          // where every wave reads
+    f32x4 stg[4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *(f32x4*)(wl_w + b * WLDS_SLOT_FLOATS + i * WL_PIECE) =
+                ld_piece(wrs, lane_off, wp + (b * 16 + wave * 4 + i) * PIECE_BYTES);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stg[i] = ld_piece(wrs, lane_off, wp + (2 * 16 + wave * 4 + i) * PIECE_BYTES);
+    __syncthreads();
+    f32x4 nk = *(const f32x4*)(wl_r), nq = *(const f32x4*)(wl_r + WL_PIECE);   // operands of step 0
+#else
     f32x4 rk[PF], rq[PF];
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
-        rk[d] = *(const f32x4*)(wp + (size_t)(2 * d + 0) * WL_PIECE);
-        rq[d] = *(const f32x4*)(wp + (size_t)(2 * d + 1) * WL_PIECE);
+        rk[d] = ld_piece(wrs, lane_off, wp + (2 * d + 0) * PIECE_BYTES);
+        rq[d] = ld_piece(wrs, lane_off, wp + (2 * d + 1) * PIECE_BYTES);
     }
+#endif
     f32x4 sk[4], sq[4];                                          // seeds of the next tile
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -187,6 +253,33 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
 #pragma unroll
             for (int kg = 0; kg < WL_KG; ++kg) {
                 const int s = m * WL_KG + kg;
+#ifdef DECODE_LOCKSTEP
+                if (s % DECODE_LOCKSTEP == 0) __builtin_amdgcn_s_barrier();   // keep the 4 waves on the same weight lines
+#endif
+#if DECODE_WLDS
+                if ((s & 7) == 0) {                               // slot boundary (static: unrolled)
+                    const int b = s >> 3;                         // slot within the layer; 32 slots/layer, 32 % NSLOT == 0
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)                   // staged pieces of slot b+2 -> LDS
+                        *(f32x4*)(wl_w + ((b + 2) % WLDS_NSLOT) * WLDS_SLOT_FLOATS + i * WL_PIECE) = stg[i];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)                   // fetch this wave's pieces of slot b+3
+                        stg[i] = ld_piece(wrs, lane_off, wp + ((b + 3) * 16 + wave * 4 + i) * PIECE_BYTES);
+                    __syncthreads();
+                }
+                const f32x4 wk = nk, wq = nq;
+                {   // operands of step s+1 (its slot was published at least one barrier ago)
+                    const int s1 = s + 1;
+                    const float* slot = wl_r + ((s1 >> 3) % WLDS_NSLOT) * WLDS_SLOT_FLOATS + (s1 & 7) * 2 * WL_PIECE;
+                    nk = *(const f32x4*)(slot);
+                    nq = *(const f32x4*)(slot + WL_PIECE);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ak = MFMA32(wk[e], q[4 * kg + e], ak);
+                    as = MFMA32(wq[e], q[4 * kg + e], as);
+                }
+#else
                 const f32x4 wk = rk[s % PF], wq = rq[s % PF];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -194,8 +287,9 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
                     as = MFMA32(wq[e], q[4 * kg + e], as);
                 }
                 // refill the ring slot just consumed with the piece PF steps ahead
-                rk[s % PF] = *(const f32x4*)(wp + (size_t)(2 * ABL_STEP(s + PF) + 0) * WL_PIECE);
-                rq[s % PF] = *(const f32x4*)(wp + (size_t)(2 * ABL_STEP(s + PF) + 1) * WL_PIECE);
+                rk[s % PF] = ld_piece(wrs, lane_off, wp + (2 * ABL_STEP(s + PF) + 0) * PIECE_BYTES);
+                rq[s % PF] = ld_piece(wrs, lane_off, wp + (2 * ABL_STEP(s + PF) + 1) * PIECE_BYTES);
+#endif
                 if (kg == 4) {                                    // seeds for the next tile
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -215,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
         for (int r = 0; r < 16; ++r) qn[16 * 7 + r] = relu0(pk[r]) * dsin<SIN_MODE>(ps[r]);
 #pragma unroll
         for (int i = 0; i < 128; ++i) q[i] = qn[i];
-        wp += WL_LAYER;
+        wp += (int)(WL_LAYER * sizeof(float));
     }
 
     // ---- head: out = L . q3 + bL   (diinn.py:138)
@@ -366,6 +460,15 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
 }
 
 // ---------------------------------------------------------------------------------
+// sine kernel (tests): the device sine of each mode, elementwise
+// ---------------------------------------------------------------------------------
+template <int MODE>
+__global__ void sin_kernel(const float* x, float* y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = dsin<MODE>(x[i]);
+}
+
+// ---------------------------------------------------------------------------------
 // tables kernel (tests): the device evaluation of axis_eval
 // ---------------------------------------------------------------------------------
 __global__ void axis_tables_kernel(Axis a, int n_out, int32_t* idx, float* rel) {
@@ -399,6 +502,18 @@ int diinn_make_axis_tables_device(void* stream, int n_in, int n_out, int small_o
     const Axis a = make_axis(n_in, n_out, small_output ? 1 : 0);
     hipLaunchKernelGGL(axis_tables_kernel, dim3((n_out + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, a, n_out, idx_dev, rel_dev);
+    return hip_status(hipGetLastError());
+}
+
+int diinn_eval_sin_device(void* stream, int sin_mode, const float* x_dev, float* y_dev, int n) {
+    if (!x_dev || !y_dev || n <= 0) return DIINN_ERR_INVALID_ARG;
+    const dim3 grid((n + 255) / 256), blk(256);
+    switch (sin_mode) {
+        case DIINN_SIN_ACCURATE: hipLaunchKernelGGL(sin_kernel<DIINN_SIN_ACCURATE>, grid, blk, 0, (hipStream_t)stream, x_dev, y_dev, n); break;
+        case DIINN_SIN_HW: hipLaunchKernelGGL(sin_kernel<DIINN_SIN_HW>, grid, blk, 0, (hipStream_t)stream, x_dev, y_dev, n); break;
+        case DIINN_SIN_HW_REDUCED: hipLaunchKernelGGL(sin_kernel<DIINN_SIN_HW_REDUCED>, grid, blk, 0, (hipStream_t)stream, x_dev, y_dev, n); break;
+        default: return DIINN_ERR_UNSUPPORTED;
+    }
     return hip_status(hipGetLastError());
 }
 
@@ -438,7 +553,7 @@ int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
     if (st) return st;
     if (Hu <= 0 || Wu <= 0 || y0 < 0 || y1 > Hu || y0 >= y1) return DIINN_ERR_INVALID_ARG;
     if ((double)Hu * Wu >= 2.0e9) return DIINN_ERR_TOO_LARGE;
-    if (sin_mode != DIINN_SIN_ACCURATE && sin_mode != DIINN_SIN_HW) return DIINN_ERR_UNSUPPORTED;
+    if (sin_mode < DIINN_SIN_ACCURATE || sin_mode > DIINN_SIN_HW_REDUCED) return DIINN_ERR_UNSUPPORTED;
     int gx, gy, gz, blk;
     diinn_decode_launch_info(B, Hu, Wu, y0, y1, &gx, &gy, &gz, &blk);
     if (gy > 65535 * 16) return DIINN_ERR_TOO_LARGE;
@@ -452,6 +567,8 @@ int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
     const dim3 grid(gx, gy, gz);
     if (sin_mode == DIINN_SIN_HW)
         hipLaunchKernelGGL(decode_kernel<DIINN_SIN_HW>, grid, dim3(blk), 0, (hipStream_t)stream, p);
+    else if (sin_mode == DIINN_SIN_HW_REDUCED)
+        hipLaunchKernelGGL(decode_kernel<DIINN_SIN_HW_REDUCED>, grid, dim3(blk), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(decode_kernel<DIINN_SIN_ACCURATE>, grid, dim3(blk), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());

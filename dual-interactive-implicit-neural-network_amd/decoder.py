@@ -104,7 +104,7 @@ def _require_cuda(t: torch.Tensor, what: str) -> None:
 
 def decode_features(feat: torch.Tensor, packed: torch.Tensor, size: Sequence[int],
                     out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
-                    rows: Optional[Tuple[int, int]] = None, sin_mode: int = _native.SIN_ACCURATE
+                    rows: Optional[Tuple[int, int]] = None, sin_mode: int = _native.SIN_DEFAULT
                     ) -> torch.Tensor:
     """Decode encoder features ``feat`` [B,64,H,W] to RGB [B,3,Hu,Wu].
 
@@ -155,7 +155,7 @@ class ImplicitDecoder(nn.Module):
     ``NotImplementedError`` in ``forward``."""
 
     def __init__(self, in_channels: int = 64, hidden_dims=(256, 256, 256, 256), mode: int = 1,
-                 init_q: bool = False, sin_mode: int = _native.SIN_ACCURATE):
+                 init_q: bool = False, sin_mode: int = _native.SIN_DEFAULT):
         super().__init__()
         self.mode = mode
         self.init_q = init_q

@@ -98,7 +98,7 @@ def distribute_features(feat: Optional[torch.Tensor], shape: Tuple[int, int, int
 def decode_sharded(feat: Optional[torch.Tensor], shape: Tuple[int, int, int, int], packed: torch.Tensor,
                    size, src: int = 0, group=None, mode: str = "halo",
                    out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
-                   feat_buf: Optional[torch.Tensor] = None, sin_mode: int = 0):
+                   feat_buf: Optional[torch.Tensor] = None, sin_mode: Optional[int] = None):
     """One sharded decode: distribute features from ``src``, then each rank decodes its HR band
     with the HIP kernels.  Returns (out, (y0, y1)); only out[:, :, y0:y1, :] is valid on this rank."""
     from . import decoder as D
@@ -109,13 +109,17 @@ def decode_sharded(feat: Optional[torch.Tensor], shape: Tuple[int, int, int, int
     bands = all_bands(hu, world)
     need = []
     for (y0, y1) in bands:
-        need.append(feature_rows_for_band(h, D.lr_rows_for_band(h, hu, wu, y0, y1)))
+        # an empty band (more ranks than HR rows) still takes part in the exchange with one row
+        need.append(feature_rows_for_band(h, D.lr_rows_for_band(h, hu, wu, y0, y1)) if y1 > y0 else (0, 1))
     if world > 1:
         local = distribute_features(feat, shape, need, src=src, group=group, mode=mode,
                                     device=packed.device, buf=feat_buf)
     else:
         local = feat
     y0, y1 = bands[rank]
+    if y1 <= y0:                     # more ranks than HR rows: nothing to decode here
+        return out, (y0, y1)
+    from . import _native
     out = D.decode_features(local, packed, (hu, wu), out=out, workspace=workspace, rows=(y0, y1),
-                            sin_mode=sin_mode)
+                            sin_mode=_native.SIN_DEFAULT if sin_mode is None else sin_mode)
     return out, (y0, y1)

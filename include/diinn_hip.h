@@ -50,7 +50,8 @@ extern "C" {
 
 /* sine evaluation used by the synthesis branch (reference: torch.sin, diinn.py:25-26) */
 #define DIINN_SIN_ACCURATE 0   /* Cody-Waite reduction + polynomial, <= ~3 ulp        */
-#define DIINN_SIN_HW       1   /* v_sin_f32 after fract(x/2pi); parity still <= 1e-4 */
+#define DIINN_SIN_HW       1   /* v_sin_f32 after fract(x/2pi): abs error ~ |x|*6e-8, 3 VALU ops */
+#define DIINN_SIN_HW_REDUCED 2 /* Cody-Waite reduction by 2pi, then v_sin_f32: error independent of |x| */
 
 int         diinn_abi_version(void);
 const char* diinn_status_string(int status);
@@ -91,6 +92,10 @@ int diinn_uses_small_output_kernel(int Hu, int Wu);
  * idx_dev/rel_dev: DEVICE buffers of n_out elements. */
 int diinn_make_axis_tables_device(void* stream, int n_in, int n_out, int small_output,
                                   int32_t* idx_dev, float* rel_dev);
+
+/* The device sine of `sin_mode`, elementwise over n floats (tests: accuracy of the synthesis
+ * branch's activation, reference torch.sin, diinn.py:25-26). */
+int diinn_eval_sin_device(void* stream, int sin_mode, const float* x_dev, float* y_dev, int n);
 
 /* ---- workspace ---------------------------------------------------------------
  * The per-cell modulation image P[B,H,W,1024] fp32 is the
