@@ -79,7 +79,25 @@ struct DecodeParams {
     int B, H, W, Hu, Wu, y0, y1;
     float ratio;           // fp32(H*W / (Hu*Wu))   (diinn.py:166)
     Axis ah, aw;
+#ifdef DIINN_STAMPS
+    unsigned long long* stamps;   // diagnostic build only: 8 x u64 per wave (never in the shipped library)
+#endif
 };
+
+#ifdef DIINN_STAMPS
+// In-kernel stamps (cdna_hip_programming.md section 7): one asm statement, fenced, values go to a
+// buffer nothing else reads.  STAMP(i) records s_memtime; slot 7 records s_memrealtime (100 MHz).
+#define STAMP(i)                                                                              \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (p.stamps && lane == 0) p.stamps[stamp_base + (i)] = t_;                           \
+    } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 
 constexpr int TILE_W = 8, TILE_H = 4;           // one wave: 8x4 HR pixels
 // timing-ablation hooks (wrong results when defined; never in the shipped build)
@@ -98,13 +116,6 @@ constexpr int TILE_W = 8, TILE_H = 4;           // one wave: 8x4 HR pixels
 #endif
 #ifndef WSTREAM_AUX
 #define WSTREAM_AUX 0                           // cache-policy bits of the weight-stream loads (sc0=1, nt=2, sc1=16)
-#endif
-#ifndef DECODE_WLDS
-#define DECODE_WLDS 0                           // 1: stage the weight stream through an LDS ring shared by the 4 waves
-#endif
-#if DECODE_WLDS
-constexpr int WLDS_NSLOT = 4;
-constexpr int WLDS_SLOT_FLOATS = 16 * 256;      // 8 steps x 2 parts x 1 KiB
 #endif
 #ifndef P_PREFETCH
 #define P_PREFETCH 4
@@ -142,11 +153,7 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     const int b = blockIdx.z;
     const bool valid = (x < p.Wu) && (y < p.y1);
     // whole wave outside the band/image: nothing to do (wave-uniform, no barriers in this kernel)
-#if !DECODE_WLDS
     if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
-#endif
-    // (with the LDS weight ring every wave of the workgroup must reach every barrier: waves outside
-    //  the image run on clamped coordinates and simply do not store)
     const int xc = x < p.Wu ? x : p.Wu - 1;
     const int yc = y < p.y1 ? y : p.y1 - 1;
 
@@ -155,6 +162,15 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     axis_eval(p.ah, yc, iy, relh);
     axis_eval(p.aw, xc, ix, relw);
 
+#ifdef DIINN_STAMPS
+    const size_t stamp_base = ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    if (p.stamps && lane == 0) {
+        unsigned long long rt;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+        p.stamps[stamp_base + 7] = rt;
+    }
+#endif
+    STAMP(0);
     const float* __restrict__ Wt = p.Wt;
     const float* __restrict__ Pc = p.P + (((size_t)b * p.H + iy) * p.W + ix) * PCH + 4 * h;
 
@@ -183,6 +199,7 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
         }
     }
 
+    STAMP(1);
     // ---- layers 1..3: [k;s] = [Wq_i;Qw_i] . q + [P_i[cell]; bQ_i];  q = relu(k) * sin(s)   (diinn.py:135-137)
     // Software pipeline, spelled out in program order (the loops below are fully unrolled):
     //   * weight pieces are fetched PF steps (8 MFMAs = 512 cycles each) ahead into a register ring
@@ -195,35 +212,12 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
         (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);   // reads past the end return 0
     const int lane_off = lane * 16;
     int wp = (int)(OFF_WL * sizeof(float));                      // byte offset; advances one layer per iteration
-#if DECODE_WLDS
-    // LDS weight ring: slot = 8 steps = 16 KiB (16 pieces); wave w fetches pieces 4w..4w+3 of every
-    // slot (each weight byte leaves L2 once per CU), two slots ahead of the readers, through 4
-    // staging registers: global -> VGPR during slot b-1, VGPR -> LDS at the start of slot b
-    // (for slot b+2), one workgroup barrier per slot.  NSLOT = 4 so that the slot being written
-    // is never one that a slower wave can still be reading.
-    __shared__ __attribute__((aligned(16))) float wlds[WLDS_NSLOT * WLDS_SLOT_FLOATS];
-    float* const wl_w = wlds + (wave * 4) * WL_PIECE + lane * 4;      // where this wave stages its pieces
-    const float* const wl_r = wlds + lane * 4;                          // where every wave reads
-    f32x4 stg[4];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *(f32x4*)(wl_w + b * WLDS_SLOT_FLOATS + i * WL_PIECE) =
-                ld_piece(wrs, lane_off, wp + (b * 16 + wave * 4 + i) * PIECE_BYTES);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) stg[i] = ld_piece(wrs, lane_off, wp + (2 * 16 + wave * 4 + i) * PIECE_BYTES);
-    __syncthreads();
-    f32x4 nk = *(const f32x4*)(wl_r), nq = *(const f32x4*)(wl_r + WL_PIECE);   // operands of step 0
-#else
     f32x4 rk[PF], rq[PF];
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
         rk[d] = ld_piece(wrs, lane_off, wp + (2 * d + 0) * PIECE_BYTES);
         rq[d] = ld_piece(wrs, lane_off, wp + (2 * d + 1) * PIECE_BYTES);
     }
-#endif
     f32x4 sk[4], sq[4];                                          // seeds of the next tile
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -253,33 +247,6 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
 #pragma unroll
             for (int kg = 0; kg < WL_KG; ++kg) {
                 const int s = m * WL_KG + kg;
-#ifdef DECODE_LOCKSTEP
-                if (s % DECODE_LOCKSTEP == 0) __builtin_amdgcn_s_barrier();   // keep the 4 waves on the same weight lines
-#endif
-#if DECODE_WLDS
-                if ((s & 7) == 0) {                               // slot boundary (static: unrolled)
-                    const int b = s >> 3;                         // slot within the layer; 32 slots/layer, 32 % NSLOT == 0
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)                   // staged pieces of slot b+2 -> LDS
-                        *(f32x4*)(wl_w + ((b + 2) % WLDS_NSLOT) * WLDS_SLOT_FLOATS + i * WL_PIECE) = stg[i];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)                   // fetch this wave's pieces of slot b+3
-                        stg[i] = ld_piece(wrs, lane_off, wp + ((b + 3) * 16 + wave * 4 + i) * PIECE_BYTES);
-                    __syncthreads();
-                }
-                const f32x4 wk = nk, wq = nq;
-                {   // operands of step s+1 (its slot was published at least one barrier ago)
-                    const int s1 = s + 1;
-                    const float* slot = wl_r + ((s1 >> 3) % WLDS_NSLOT) * WLDS_SLOT_FLOATS + (s1 & 7) * 2 * WL_PIECE;
-                    nk = *(const f32x4*)(slot);
-                    nq = *(const f32x4*)(slot + WL_PIECE);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ak = MFMA32(wk[e], q[4 * kg + e], ak);
-                    as = MFMA32(wq[e], q[4 * kg + e], as);
-                }
-#else
                 const f32x4 wk = rk[s % PF], wq = rq[s % PF];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -289,7 +256,6 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
                 // refill the ring slot just consumed with the piece PF steps ahead
                 rk[s % PF] = ld_piece(wrs, lane_off, wp + (2 * ABL_STEP(s + PF) + 0) * PIECE_BYTES);
                 rq[s % PF] = ld_piece(wrs, lane_off, wp + (2 * ABL_STEP(s + PF) + 1) * PIECE_BYTES);
-#endif
                 if (kg == 4) {                                    // seeds for the next tile
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -310,6 +276,9 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
 #pragma unroll
         for (int i = 0; i < 128; ++i) q[i] = qn[i];
         wp += (int)(WL_LAYER * sizeof(float));
+#ifdef DIINN_STAMPS
+        if (layer == 0) STAMP(2); else if (layer == 1) STAMP(3); else STAMP(4);
+#endif
     }
 
     // ---- head: out = L . q3 + bL   (diinn.py:138)
@@ -344,6 +313,7 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
         o[plane] = o1 + Wt[OFF_BL + 1];
         o[2 * plane] = o2 + Wt[OFF_BL + 2];
     }
+    STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------
@@ -361,6 +331,7 @@ struct PParams {
     const float* Wt;
     float* P;            // [B,H,W,1024]
     int B, H, W, r0, r1;
+    int msplit;          // the 16 M-tile pairs are divided over `msplit` workgroups (blockIdx.z = b*msplit + part)
 };
 
 constexpr int PT_ROWS = 4, PT_COLS = 32;                 // cells per workgroup: 4 x 32
@@ -373,13 +344,20 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
-    const int b = blockIdx.z;
+    const int b = blockIdx.z / p.msplit;
+    const int part = blockIdx.z - b * p.msplit;
+    const int mp_count = 16 / p.msplit, mp_begin = part * mp_count;
     const int x0 = blockIdx.x * PT_COLS;
     const int y0 = p.r0 + blockIdx.y * PT_ROWS;
 
     // stage feat[b, :, y0-1 .. y0+4, x0-1 .. x0+32] (zeros outside the map)
     const float* __restrict__ fb = p.feat + (size_t)b * C_IN * p.H * p.W;
-    for (int idx = threadIdx.x; idx < PT_LDS_FLOATS; idx += 256) {
+    static_assert(PT_LDS_FLOATS % 256 == 0, "staging loop has a fixed trip count");
+    // fixed trip count, unrolled in batches so that many loads are in flight (a rolled loop would pay
+    // one memory latency per element)
+#pragma unroll 17
+    for (int it = 0; it < PT_LDS_FLOATS / 256; ++it) {
+        const int idx = it * 256 + threadIdx.x;
         const int c = idx / PT_CH;
         const int rem = idx - c * PT_CH;
         const int ly = rem / PT_LC, lx = rem - ly * PT_LC;
@@ -401,17 +379,20 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
 
     constexpr int PF = P_PREFETCH;
     static_assert(WP_KG % PF == 0, "ring index must be static");
-    const float* __restrict__ wp = p.Wt + OFF_WP + lane * 4;    // advances one M-tile pair per iteration
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);   // reads past the end return 0
+    const int lane_off = lane * 16;
+    int wp = (int)(OFF_WP * sizeof(float)) + mp_begin * (WP_KG * 2 * PIECE_BYTES);   // advances one M-tile pair per iteration
     const float* __restrict__ Bk = p.Wt + OFF_BK + 4 * h;
     float* __restrict__ Pout = p.P + (((size_t)b * p.H + (y < p.H ? y : p.H - 1)) * p.W + (x < p.W ? x : p.W - 1)) * PCH + 4 * h;
     f32x4 r0v[PF], r1v[PF];
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
-        r0v[d] = *(const f32x4*)(wp + (size_t)(2 * d + 0) * WL_PIECE);
-        r1v[d] = *(const f32x4*)(wp + (size_t)(2 * d + 1) * WL_PIECE);
+        r0v[d] = ld_piece(wrs, lane_off, wp + (2 * d + 0) * PIECE_BYTES);
+        r1v[d] = ld_piece(wrs, lane_off, wp + (2 * d + 1) * PIECE_BYTES);
     }
 #pragma unroll 1
-    for (int mp = 0; mp < 16; ++mp) {
+    for (int mp = mp_begin; mp < mp_begin + mp_count; ++mp) {
         // the B operands do not depend on mp: hide the base from LICM, or all 288 LDS reads are
         // hoisted out of this loop and live (spilled) across it
         int off = tb_off;
@@ -439,8 +420,8 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
                 a0 = MFMA32(u0[e], bv, a0);
                 a1 = MFMA32(u1[e], bv, a1);
             }
-            r0v[kg % PF] = *(const f32x4*)(wp + (size_t)(2 * (kg + PF) + 0) * WL_PIECE);
-            r1v[kg % PF] = *(const f32x4*)(wp + (size_t)(2 * (kg + PF) + 1) * WL_PIECE);
+            r0v[kg % PF] = ld_piece(wrs, lane_off, wp + (2 * (kg + PF) + 0) * PIECE_BYTES);
+            r1v[kg % PF] = ld_piece(wrs, lane_off, wp + (2 * (kg + PF) + 1) * PIECE_BYTES);
         }
         if (store) {
 #pragma unroll
@@ -455,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
                 *(f32x4*)(Pout + 64 * mp + 32 + 8 * g) = v1;
             }
         }
-        wp += (size_t)WP_KG * 2 * WL_PIECE;
+        wp += WP_KG * 2 * PIECE_BYTES;
     }
 }
 
@@ -485,6 +466,10 @@ __global__ void axis_tables_kernel(Axis a, int n_out, int32_t* idx, float* rel) 
 // C ABI: launch functions
 // ---------------------------------------------------------------------------------
 static thread_local int g_last_hip_error = 0;
+#ifdef DIINN_STAMPS
+static unsigned long long* g_stamps = nullptr;
+extern "C" int diinn_debug_set_stamp_buffer(void* dev_ptr) { g_stamps = (unsigned long long*)dev_ptr; return 0; }
+#endif
 
 static int hip_status(hipError_t e) {
     if (e == hipSuccess) return DIINN_OK;
@@ -529,8 +514,14 @@ int diinn_precompute_P(void* stream, const float* feat_dev, const float* packed_
     int st = check_dims(B, H, W);
     if (st) return st;
     if (r0 < 0 || r1 > H || r0 >= r1) return DIINN_ERR_INVALID_ARG;
-    PParams p{feat_dev, packed_dev, P_dev, B, H, W, r0, r1};
-    const dim3 grid((W + PT_COLS - 1) / PT_COLS, (r1 - r0 + PT_ROWS - 1) / PT_ROWS, B);
+    // Small maps: split the 1024 output channels over up to 16 workgroups per cell block so the
+    // launch still fills the chip (2 workgroups/CU resident -> aim for >= 2 rounds of 512).
+    const long long blocks = (long long)((W + PT_COLS - 1) / PT_COLS) * ((r1 - r0 + PT_ROWS - 1) / PT_ROWS) * B;
+    int msplit = 1;
+    while (msplit < 16 && blocks * msplit < 1024) msplit *= 2;
+    if ((long long)B * msplit > 65535) return DIINN_ERR_TOO_LARGE;
+    PParams p{feat_dev, packed_dev, P_dev, B, H, W, r0, r1, msplit};
+    const dim3 grid((W + PT_COLS - 1) / PT_COLS, (r1 - r0 + PT_ROWS - 1) / PT_ROWS, B * msplit);
     hipLaunchKernelGGL(precompute_P_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
@@ -561,6 +552,9 @@ int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
     p.P = P_dev; p.Wt = packed_dev; p.out = out_dev;
     p.B = B; p.H = H; p.W = W; p.Hu = Hu; p.Wu = Wu; p.y0 = y0; p.y1 = y1;
     p.ratio = (float)(((double)H * (double)W) / ((double)Hu * (double)Wu));
+#ifdef DIINN_STAMPS
+    p.stamps = g_stamps;
+#endif
     const int small = diinn_uses_small_output_kernel(Hu, Wu);
     p.ah = make_axis(H, Hu, small);
     p.aw = make_axis(W, Wu, small);

@@ -158,3 +158,54 @@ def test_device_sine_accuracy(dev):
             report[(span, mode)] = err
             assert err <= bound, f"sin mode {mode} on [-{span},{span}]: max abs err {err:.3e} > {bound:.1e}"
     print("sine max abs error by (range, mode):", {k: f"{v:.2e}" for k, v in report.items()})
+
+
+def test_config5_shape_noninteger_720p_bands_vs_oracle(dev):
+    """BASELINE config 5 geometry (720x1280 LR -> 2376x4224 HR, x3.3) in fp32: full-size decode on
+    the GPU, HR row bands against the oracle (the tables for these axes are pinned bit-exactly by
+    the golden fixtures; the coordinates differ from exact arithmetic by 1.6e-4 here)."""
+    import diinn_amd.decoder as D
+    import diinn_oracle as orc
+    sd = synth.decoder_state_dict(123)
+    feat_np = synth.encoder_features(5, 1, 720, 1280)
+    feat = torch.from_numpy(feat_np).to(dev)
+    packed = D.pack_state_dict(sd).to(dev)
+    size = (2376, 4224)
+    out = D.decode_features(feat, packed, size)
+    torch.cuda.synchronize()
+    out_np = out.cpu().numpy()
+    assert np.isfinite(out_np).all()
+    for y0, y1 in [(0, 4), (1187, 1191), (2372, 2376)]:
+        ref = orc.decode_reference_form(sd, feat_np, size, 30000, row_range=(y0, y1)).numpy()
+        err = float(np.abs(out_np[:, :, y0:y1] - ref).max())
+        assert err <= _tol(ref), f"rows {y0}:{y1} err {err:.3e}"
+
+
+def test_x8_and_batch_bands_vs_oracle(dev):
+    """x8 (BASELINE config 4's scale) on a 96x80 map with B=2, compared in full with the oracle."""
+    import diinn_amd.decoder as D
+    import diinn_oracle as orc
+    sd = synth.decoder_state_dict(11)
+    feat_np = synth.encoder_features(11, 2, 24, 20)
+    size = (192, 160)
+    ref = orc.decode_reference_form(sd, feat_np, size, 30000).numpy()
+    got = _decode(sd, feat_np, size, dev)
+    assert float(np.abs(got - ref).max()) <= _tol(ref)
+
+
+def test_strided_input_and_stream(dev):
+    """Non-contiguous x (the boundary makes it contiguous) and a non-default stream."""
+    import diinn_amd.decoder as D
+    sd = synth.decoder_state_dict(123)
+    packed = D.pack_state_dict(sd).to(dev)
+    base = torch.from_numpy(synth.encoder_features(123, 1, 48, 48)).to(dev)
+    ref = D.decode_features(base, packed, (96, 96))
+    strided = torch.empty(1, 64, 48, 96, device=dev)[..., ::2]
+    strided.copy_(base)
+    assert not strided.is_contiguous()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        got = D.decode_features(strided, packed, (96, 96))
+    st.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(ref, got)
