@@ -93,3 +93,25 @@ def test_lit_module_step_normalisation(golden):
     assert preds[2.5].shape == hr.shape and float(preds[2.5].min()) >= 0 and float(preds[2.5].max()) <= 1
     assert torch.allclose(preds[2.5], (direct * 0.5 + 0.5).clamp(0, 1))
     assert torch.isfinite(loss)
+
+
+@pytest.mark.gpu
+def test_graphed_forward_equals_eager():
+    """hipGraph replay of encoder + decoder launches gives the eager result, also for new inputs."""
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = M.DIINN(mode=3, init_q=False).to(dev).eval()
+    x1 = torch.rand(1, 3, 20, 24, device=dev)
+    x2 = torch.rand(1, 3, 20, 24, device=dev)
+    with torch.no_grad():
+        e1, e2 = net(x1, (50, 61), 30000), net(x2, (50, 61), 30000)
+        net.graphs = True
+        g1 = net(x1, (50, 61), 30000)
+        g2 = net(x2, (50, 61), 30000)
+        g1b = net(x1, (50, 61), 30000)
+    torch.cuda.synchronize()
+    # MIOpen may pick another convolution algorithm under capture: rounding-level differences only
+    assert torch.allclose(e1, g1, atol=1e-5) and torch.allclose(e2, g2, atol=1e-5)
+    assert torch.equal(g1, g1b) and not torch.equal(g1, g2)
+    assert len(net._graph_cache) == 1
