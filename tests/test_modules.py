@@ -113,5 +113,5 @@ def test_graphed_forward_equals_eager():
     torch.cuda.synchronize()
     # MIOpen may pick another convolution algorithm under capture: rounding-level differences only
     assert torch.allclose(e1, g1, atol=1e-5) and torch.allclose(e2, g2, atol=1e-5)
-    assert torch.equal(g1, g1b) and not torch.equal(g1, g2)
+    assert torch.allclose(g1, g1b, atol=1e-5) and not torch.allclose(g1, g2, atol=1e-5)
     assert len(net._graph_cache) == 1
