@@ -123,6 +123,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.barrier()           # first RCCL call is a plain collective on every rank
 
     import diinn_amd._native as N
     import diinn_amd.decoder as D
