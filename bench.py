@@ -38,6 +38,7 @@ SCALE = 4
 FLOP_DECODE_PER_PX = 789_504.0        # 3 stacked 512x256 layers + Q0 + head, 2*MAC
 FLOP_P_PER_CELL = 1_179_648.0         # hoisted 3x3 conv 64 -> 1024, 2*MAC
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (only for --compute bf16)
 
 
 def parse():
@@ -47,6 +48,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--sin", choices=["accurate", "hw", "hw_reduced"], default=os.environ.get("DIINN_SIN", "default"),
                     help="sine evaluation of the synthesis branch (default: the library default, hw_reduced)")
+    ap.add_argument("--compute", choices=["f32", "bf16"], default="f32",
+                    help="arithmetic of the per-pixel layers; f32 is the reference's precision and the only "
+                         "valid headline (bf16 is BASELINE config 5's optional path, 2e-3 relative)")
     ap.add_argument("--dist-mode", choices=["halo", "bcast"], default="halo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -162,9 +166,10 @@ def main():
                                        C.c_void_p(workspace.data_ptr()), 1, H, W, r0, r1), "diinn_precompute_P")
         if i is not None:
             ev[i][0].record()
-        N.check(lib.diinn_decode_band(C.c_void_p(stream), C.c_void_p(workspace.data_ptr()),
-                                      C.c_void_p(packed.data_ptr()), C.c_void_p(out.data_ptr()),
-                                      1, H, W, HU, WU, y0, y1, sin_mode), "diinn_decode_band")
+        N.check(lib.diinn_decode_band_ex(C.c_void_p(stream), C.c_void_p(workspace.data_ptr()),
+                                         C.c_void_p(packed.data_ptr()), C.c_void_p(out.data_ptr()),
+                                         1, H, W, HU, WU, y0, y1, sin_mode, N.COMPUTE[args.compute]),
+                "diinn_decode_band_ex")
         if i is not None:
             ev[i][1].record()
 
@@ -206,7 +211,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.compute,
             "data": "synthetic",
             "config": {
                 "workload": f"c2: {LR}x{LR} LR encoder features per GPU, x{SCALE} decode -> "
@@ -217,14 +222,14 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "decode_kernel",
+                "kernel": "decode_kernel" if args.compute == "f32" else "decode_bf16_kernel",
                 "achieved": round(achieved, 3),
-                "peak": PEAK_F32_MFMA_TFLOPS,
+                "peak": PEAK_F32_MFMA_TFLOPS if args.compute == "f32" else PEAK_BF16_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                "frac": round(achieved / (PEAK_F32_MFMA_TFLOPS if args.compute == "f32" else PEAK_BF16_MFMA_TFLOPS), 4),
                 "kernel_ms": round(k_ms, 4),
                 "flop_per_launch": FLOP_DECODE_PER_PX * px_launch,
-                "traffic": load_traffic(),
+                "traffic": load_traffic() if args.compute == "f32" else None,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

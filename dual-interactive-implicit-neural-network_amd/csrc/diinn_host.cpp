@@ -10,6 +10,14 @@
 
 using namespace diinn;
 
+// fp32 -> bf16, round to nearest even (weights are finite; NaN is kept a NaN)
+static inline uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
 extern "C" {
 
 int diinn_abi_version(void) { return DIINN_ABI_VERSION; }
@@ -96,6 +104,24 @@ int diinn_pack_weights(const float* K0w, const float* K0b,
     std::memcpy(packed + OFF_L, Lw, 3 * HID * sizeof(float));
     float* bl = packed + OFF_BL;
     bl[0] = Lb[0]; bl[1] = Lb[1]; bl[2] = Lb[2]; bl[3] = 0.0f;
+    // WLB: [layer][m][ks][part][lane][j] bf16
+    uint16_t* wlb = reinterpret_cast<uint16_t*>(packed + OFF_WLB);
+    for (int i = 0; i < 3; ++i)
+        for (int m = 0; m < 8; ++m)
+            for (int ks = 0; ks < 16; ++ks)
+                for (int part = 0; part < 2; ++part) {
+                    uint16_t* dst = wlb + ((((size_t)i * 8 + m) * 16 + ks) * 2 + part) * (64 * 8);
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int out = 32 * m + (lane & 31);
+                        const int h = lane >> 5;
+                        for (int j = 0; j < 8; ++j) {
+                            const int in = chan_of_bf16(ks, h, j);
+                            const float w = part == 0 ? Kw[i][(size_t)out * (HID + UNF) + in]
+                                                      : Qw[i][(size_t)out * HID + in];
+                            dst[lane * 8 + j] = f32_to_bf16(w);
+                        }
+                    }
+                }
     return DIINN_OK;
 }
 

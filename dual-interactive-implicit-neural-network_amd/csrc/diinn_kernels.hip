@@ -316,6 +316,173 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     STAMP(5);
 }
 
+
+// ---------------------------------------------------------------------------------
+// decode kernel, bf16 operands (optional path, BASELINE config 5; tolerance restated in
+// DESIGN.md): same structure as decode_kernel -- one wave owns 32 pixels and keeps their
+// activation in registers -- but layers 1..3 run on v_mfma_f32_32x32x16_bf16: weights are bf16
+// (WLB section), the activation is packed to bf16 straight from the epilogue (accumulator registers
+// 8s..8s+7 of a tile ARE the B fragment of k-step 2m+s, see chan_of_bf16), accumulation, seeds
+// (P, biases), sine, layer 0 and the RGB head stay fp32.  A first version: the weight stream
+// (1 KiB per MFMA per wave, 8x the fp32 path's bytes per cycle) is L1-bandwidth-bound here.
+// ---------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#ifndef DECODE_BF16_PREFETCH
+#define DECODE_BF16_PREFETCH 8                  // ring depth in k-steps (2 pieces, 2 MFMAs each)
+#endif
+
+template <int SIN_MODE>
+__global__ __launch_bounds__(256, 1) void decode_bf16_kernel(const DecodeParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int x = blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
+    const int y = p.y0 + blockIdx.y * (TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
+    const int b = blockIdx.z;
+    const bool valid = (x < p.Wu) && (y < p.y1);
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
+    const int xc = x < p.Wu ? x : p.Wu - 1;
+    const int yc = y < p.y1 ? y : p.y1 - 1;
+    int iy, ix;
+    float relh, relw;
+    axis_eval(p.ah, yc, iy, relh);
+    axis_eval(p.aw, xc, ix, relw);
+    const float* __restrict__ Wt = p.Wt;
+    const float* __restrict__ Pc = p.P + (((size_t)b * p.H + iy) * p.W + ix) * PCH + 4 * h;
+
+    // ---- layer 0 (fp32), packed to bf16 fragments: register r = 4g+e of tile m -> qb[2m + (r>>3)][r&7]
+    bf16x8 qb[16];
+    {
+        const float* __restrict__ Q0 = Wt + OFF_Q0 + 4 * h;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * m + 8 * g;
+                const f32x4 pv = *(const f32x4*)(Pc + c0);
+                const f32x4 wh = *(const f32x4*)(Q0 + 0 * HID + c0);
+                const f32x4 ww = *(const f32x4*)(Q0 + 1 * HID + c0);
+                const f32x4 wr = *(const f32x4*)(Q0 + 2 * HID + c0);
+                const f32x4 bq = *(const f32x4*)(Q0 + 3 * HID + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = __builtin_fmaf(wr[e], p.ratio, bq[e]);
+                    a = __builtin_fmaf(ww[e], relw, a);
+                    a = __builtin_fmaf(wh[e], relh, a);
+                    qb[2 * m + (g >> 1)][4 * (g & 1) + e] = (__bf16)(relu0(pv[e]) * dsin<SIN_MODE>(a));
+                }
+            }
+        }
+    }
+
+    constexpr int PF = DECODE_BF16_PREFETCH;
+    static_assert(16 % PF == 0, "ring index must be static");
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);
+    const int lane_off = lane * 16;
+    int wp = (int)(OFF_WLB * sizeof(float));
+    f32x4 rk[PF], rq[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        rk[d] = ld_piece(wrs, lane_off, wp + (2 * d + 0) * PIECE_BYTES);
+        rq[d] = ld_piece(wrs, lane_off, wp + (2 * d + 1) * PIECE_BYTES);
+    }
+    f32x4 sk[4], sq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        sk[g] = *(const f32x4*)(Pc + HID + 8 * g);
+        sq[g] = *(const f32x4*)(Wt + OFF_BQ + 4 * h + 8 * g);
+    }
+    float q3[128];                                               // fp32 copy of the last activation for the head
+#pragma unroll 1
+    for (int layer = 0; layer < 3; ++layer) {
+        const int nl = layer < 2 ? layer + 1 : 2;
+        const float* __restrict__ Pl = Pc + (layer + 1) * HID;
+        const float* __restrict__ Bq = Wt + OFF_BQ + layer * HID + 4 * h;
+        const float* __restrict__ Pn = Pc + (nl + 1) * HID;
+        const float* __restrict__ Bn = Wt + OFF_BQ + nl * HID + 4 * h;
+        bf16x8 qn[16];
+        f32x16 pk, ps;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            f32x16 ak, as;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ak[4 * g + e] = sk[g][e];
+                    as[4 * g + e] = sq[g][e];
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int s = m * 16 + ks;
+                ak = MFMA_BF16(__builtin_bit_cast(bf16x8, rk[s % PF]), qb[ks], ak);
+                as = MFMA_BF16(__builtin_bit_cast(bf16x8, rq[s % PF]), qb[ks], as);
+                rk[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF) + 0) * PIECE_BYTES);
+                rq[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF) + 1) * PIECE_BYTES);
+                if (ks == 2) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        sk[g] = *(const f32x4*)((m < 7 ? Pl + 32 * (m + 1) : Pn) + 8 * g);
+                        sq[g] = *(const f32x4*)((m < 7 ? Bq + 32 * (m + 1) : Bn) + 8 * g);
+                    }
+                }
+                if (m > 0) {                                      // one epilogue element of tile m-1 per k-step
+                    const float v = relu0(pk[ks]) * dsin<SIN_MODE>(ps[ks]);
+                    qn[2 * (m - 1) + (ks >> 3)][ks & 7] = (__bf16)v;
+                    q3[16 * (m - 1) + ks] = v;
+                }
+            }
+            pk = ak;
+            ps = as;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = relu0(pk[r]) * dsin<SIN_MODE>(ps[r]);
+            qn[14 + (r >> 3)][r & 7] = (__bf16)v;
+            q3[16 * 7 + r] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) qb[i] = qn[i];
+        wp += (int)(WLB_LAYER * sizeof(float));
+    }
+
+    // ---- head (fp32) on the unrounded last activation
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+    {
+        const float* __restrict__ L = Wt + OFF_L + 4 * h;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * m + 8 * g;
+                const f32x4 l0 = *(const f32x4*)(L + 0 * HID + c0);
+                const f32x4 l1 = *(const f32x4*)(L + 1 * HID + c0);
+                const f32x4 l2 = *(const f32x4*)(L + 2 * HID + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = q3[16 * m + 4 * g + e];
+                    o0 = __builtin_fmaf(l0[e], v, o0);
+                    o1 = __builtin_fmaf(l1[e], v, o1);
+                    o2 = __builtin_fmaf(l2[e], v, o2);
+                }
+            }
+        }
+    }
+    o0 += __shfl_xor(o0, 32);
+    o1 += __shfl_xor(o1, 32);
+    o2 += __shfl_xor(o2, 32);
+    if (valid && h == 0) {
+        const size_t plane = (size_t)p.Hu * p.Wu;
+        float* o = p.out + (size_t)b * 3 * plane + (size_t)y * p.Wu + x;
+        o[0] = o0 + Wt[OFF_BL + 0];
+        o[plane] = o1 + Wt[OFF_BL + 1];
+        o[2 * plane] = o2 + Wt[OFF_BL + 2];
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // P kernel: P[b,y,x, i*256+ch] = sum_{c,ky,kx} Wx_i[ch,c,ky,kx] * feat[b,c,y+ky-1,x+kx-1] + bK_i[ch]
 // (zero padding; diinn.py:168 unfold + the feature columns of K[i], diinn.py:133,136)
@@ -539,6 +706,14 @@ int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,
 int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
                       float* out_dev, int B, int H, int W, int Hu, int Wu,
                       int y0, int y1, int sin_mode) {
+    return diinn_decode_band_ex(stream, P_dev, packed_dev, out_dev, B, H, W, Hu, Wu, y0, y1, sin_mode,
+                                DIINN_COMPUTE_F32);
+}
+
+int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_dev,
+                         float* out_dev, int B, int H, int W, int Hu, int Wu,
+                         int y0, int y1, int sin_mode, int compute) {
+    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16) return DIINN_ERR_UNSUPPORTED;
     if (!P_dev || !packed_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
     if (st) return st;
@@ -547,7 +722,7 @@ int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
     if (sin_mode < DIINN_SIN_ACCURATE || sin_mode > DIINN_SIN_HW_REDUCED) return DIINN_ERR_UNSUPPORTED;
     int gx, gy, gz, blk;
     diinn_decode_launch_info(B, Hu, Wu, y0, y1, &gx, &gy, &gz, &blk);
-    if (gy > 65535 * 16) return DIINN_ERR_TOO_LARGE;
+    if (gy > 65535 || gz > 65535) return DIINN_ERR_TOO_LARGE;   // HIP grid.y / grid.z limits
     DecodeParams p;
     p.P = P_dev; p.Wt = packed_dev; p.out = out_dev;
     p.B = B; p.H = H; p.W = W; p.Hu = Hu; p.Wu = Wu; p.y0 = y0; p.y1 = y1;
@@ -559,6 +734,15 @@ int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
     p.ah = make_axis(H, Hu, small);
     p.aw = make_axis(W, Wu, small);
     const dim3 grid(gx, gy, gz);
+    if (compute == DIINN_COMPUTE_BF16) {
+        if (sin_mode == DIINN_SIN_HW)
+            hipLaunchKernelGGL(decode_bf16_kernel<DIINN_SIN_HW>, grid, dim3(blk), 0, (hipStream_t)stream, p);
+        else if (sin_mode == DIINN_SIN_HW_REDUCED)
+            hipLaunchKernelGGL(decode_bf16_kernel<DIINN_SIN_HW_REDUCED>, grid, dim3(blk), 0, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(decode_bf16_kernel<DIINN_SIN_ACCURATE>, grid, dim3(blk), 0, (hipStream_t)stream, p);
+        return hip_status(hipGetLastError());
+    }
     if (sin_mode == DIINN_SIN_HW)
         hipLaunchKernelGGL(decode_kernel<DIINN_SIN_HW>, grid, dim3(blk), 0, (hipStream_t)stream, p);
     else if (sin_mode == DIINN_SIN_HW_REDUCED)
@@ -571,13 +755,21 @@ int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
 int diinn_decode(void* stream, const float* feat_dev, const float* packed_dev,
                  float* workspace_dev, float* out_dev,
                  int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode) {
+    return diinn_decode_ex(stream, feat_dev, packed_dev, workspace_dev, out_dev, B, H, W, Hu, Wu, y0, y1,
+                           sin_mode, DIINN_COMPUTE_F32);
+}
+
+int diinn_decode_ex(void* stream, const float* feat_dev, const float* packed_dev,
+                    float* workspace_dev, float* out_dev,
+                    int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode, int compute) {
     if (!workspace_dev) return DIINN_ERR_INVALID_ARG;
     int r0, r1;
     int st = diinn_lr_rows_for_band(H, Hu, Wu, y0, y1, &r0, &r1);
     if (st) return st;
     st = diinn_precompute_P(stream, feat_dev, packed_dev, workspace_dev, B, H, W, r0, r1);
     if (st) return st;
-    return diinn_decode_band(stream, workspace_dev, packed_dev, out_dev, B, H, W, Hu, Wu, y0, y1, sin_mode);
+    return diinn_decode_band_ex(stream, workspace_dev, packed_dev, out_dev, B, H, W, Hu, Wu, y0, y1, sin_mode,
+                                compute);
 }
 
 }  // extern "C"

@@ -48,12 +48,26 @@ constexpr size_t OFF_Q0     = OFF_BK + 4 * HID;            // Q0h[256] Q0w[256] 
 constexpr size_t OFF_BQ     = OFF_Q0 + 4 * HID;            // bQ[1..3][256]
 constexpr size_t OFF_L      = OFF_BQ + 3 * HID;            // L[3][256]
 constexpr size_t OFF_BL     = OFF_L + 3 * HID;             // bL[3] + pad
-constexpr size_t PACKED_FLOATS = OFF_BL + 4;               // 986,628
+// WLB: the per-pixel layers again, as bf16 A operands of v_mfma_f32_32x32x16_bf16 (optional
+//     reduced-precision path, BASELINE config 5).  [layer 3][m 8][ks 16][part 2][lane 64][j 8] bf16;
+//     value = bf16(W_part[ out = 32m + (lane&31) ][ in = chan_of_bf16(ks, lane>>5, j) ]), 16 B per lane.
+constexpr size_t WLB_PIECE  = 64 * 4;                      // floats (= 64 lanes x 8 bf16) per piece = 1 KiB
+constexpr size_t WLB_LAYER  = (size_t)8 * 16 * 2 * WLB_PIECE;
+constexpr size_t OFF_WLB    = OFF_BL + 4;
+constexpr size_t SZ_WLB     = 3 * WLB_LAYER;               // 196,608 floats = 768 KiB
+constexpr size_t PACKED_FLOATS = OFF_WLB + SZ_WLB;         // 1,183,236
 
 // channel held by activation register (m, r) of lane-half h
 DIINN_HD int chan_of(int kk /* = 16*m + r */, int h) {
     const int m = kk >> 4, r = kk & 15;
     return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+
+// bf16 path: k-step ks = 2*m' + s covers 16 channels of activation tile m'; MFMA k index 8*h + j
+// is accumulator register 8s + j of lane-half h (cdna_hip_programming.md, "An accumulator tile as
+// the next MFMA's operand"), i.e. channel 32m' + 16s + 8(j>>2) + 4h + (j&3).
+DIINN_HD int chan_of_bf16(int ks, int h, int j) {
+    return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
 }
 
 // ---- coordinates (reference: diinn.py:94-110, ATen nearest-exact)

@@ -104,14 +104,15 @@ def _require_cuda(t: torch.Tensor, what: str) -> None:
 
 def decode_features(feat: torch.Tensor, packed: torch.Tensor, size: Sequence[int],
                     out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
-                    rows: Optional[Tuple[int, int]] = None, sin_mode: int = _native.SIN_DEFAULT
-                    ) -> torch.Tensor:
+                    rows: Optional[Tuple[int, int]] = None, sin_mode: int = _native.SIN_DEFAULT,
+                    compute: str = "f32") -> torch.Tensor:
     """Decode encoder features ``feat`` [B,64,H,W] to RGB [B,3,Hu,Wu].
 
     ``rows=(y0,y1)`` computes only that HR row band (tile sharding across GPUs);
     the rest of ``out`` is left untouched.  ``workspace`` is the P image
-    [B,H,W,1024] fp32 (allocated if None).  Enqueues two kernels on the current
-    stream; never synchronises."""
+    [B,H,W,1024] fp32 (allocated if None).  ``compute`` = "f32" (reference precision) or "bf16"
+    (bf16 operands in layers 1..3, fp32 accumulate; ~2e-3 relative).  Enqueues two kernels on
+    the current stream; never synchronises."""
     lib = _native.load()
     _require_cuda(feat, "feat")
     _require_cuda(packed, "packed weights")
@@ -136,10 +137,10 @@ def decode_features(feat: torch.Tensor, packed: torch.Tensor, size: Sequence[int
         raise ValueError(f"workspace must be a contiguous buffer of >= {need} bytes on feat's device")
     with torch.cuda.device(feat.device):
         stream = torch.cuda.current_stream().cuda_stream
-        st = lib.diinn_decode(C.c_void_p(stream), C.c_void_p(feat.data_ptr()), C.c_void_p(packed.data_ptr()),
-                              C.c_void_p(workspace.data_ptr()), C.c_void_p(out.data_ptr()),
-                              b, h, w, hu, wu, y0, y1, int(sin_mode))
-    _native.check(st, "diinn_decode")
+        st = lib.diinn_decode_ex(C.c_void_p(stream), C.c_void_p(feat.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                 C.c_void_p(workspace.data_ptr()), C.c_void_p(out.data_ptr()),
+                                 b, h, w, hu, wu, y0, y1, int(sin_mode), _native.COMPUTE[compute])
+    _native.check(st, "diinn_decode_ex")
     return out
 
 
@@ -155,13 +156,14 @@ class ImplicitDecoder(nn.Module):
     ``NotImplementedError`` in ``forward``."""
 
     def __init__(self, in_channels: int = 64, hidden_dims=(256, 256, 256, 256), mode: int = 1,
-                 init_q: bool = False, sin_mode: int = _native.SIN_DEFAULT):
+                 init_q: bool = False, sin_mode: int = _native.SIN_DEFAULT, compute: str = "f32"):
         super().__init__()
         self.mode = mode
         self.init_q = init_q
         self.in_channels = in_channels
         self.hidden_dims = list(hidden_dims)
         self.sin_mode = sin_mode
+        self.compute = compute            # "f32" (default, reference precision) or "bf16"
         unfolded = in_channels * 9
         if init_q:
             self.first_layer = nn.Sequential(nn.Conv2d(3, unfolded, 1), SineAct())
@@ -222,4 +224,4 @@ class ImplicitDecoder(nn.Module):
             self._workspace = torch.empty(need, dtype=torch.float32, device=x.device)
         with torch.no_grad():
             return decode_features(x, self.packed_weights(x.device), size, workspace=self._workspace,
-                                   sin_mode=self.sin_mode)
+                                   sin_mode=self.sin_mode, compute=self.compute)

@@ -53,6 +53,11 @@ extern "C" {
 #define DIINN_SIN_HW       1   /* v_sin_f32 after fract(x/2pi): abs error ~ |x|*6e-8, 3 VALU ops */
 #define DIINN_SIN_HW_REDUCED 2 /* Cody-Waite reduction by 2pi, then v_sin_f32: error independent of |x| */
 
+/* arithmetic of the per-pixel layers 1..3 (everything else is always fp32) */
+#define DIINN_COMPUTE_F32  0   /* v_mfma_f32_32x32x2_f32: the reference's precision, parity <= 1e-4           */
+#define DIINN_COMPUTE_BF16 1   /* v_mfma_f32_32x32x16_bf16: bf16 weights/activations, fp32 accumulate;
+                                  parity restated to 2e-3 * max|ref| (BASELINE config 5)                     */
+
 int         diinn_abi_version(void);
 const char* diinn_status_string(int status);
 /* hipError_t of the most recent failing HIP call made by this thread (0 if none). */
@@ -121,6 +126,14 @@ int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
 int diinn_decode(void* stream, const float* feat_dev, const float* packed_dev,
                  float* workspace_dev, float* out_dev,
                  int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode);
+
+/* Same with an explicit arithmetic for the per-pixel layers (`compute` = DIINN_COMPUTE_*). */
+int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_dev,
+                         float* out_dev, int B, int H, int W, int Hu, int Wu,
+                         int y0, int y1, int sin_mode, int compute);
+int diinn_decode_ex(void* stream, const float* feat_dev, const float* packed_dev,
+                    float* workspace_dev, float* out_dev,
+                    int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode, int compute);
 
 /* Dominant-kernel launch geometry, for benchmarks/roofline accounting. */
 int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,

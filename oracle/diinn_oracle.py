@@ -212,11 +212,20 @@ def precompute_P(sd, feat) -> torch.Tensor:
     return p.permute(0, 2, 3, 1).contiguous()  # [B,H,W,1024]
 
 
+def _bf16_round(t: torch.Tensor) -> torch.Tensor:
+    """fp32 -> bf16 (round to nearest even) -> fp32: what an MFMA bf16 operand holds."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
 @torch.no_grad()
-def decode_hoisted_form(sd, feat, size: Sequence[int]) -> torch.Tensor:
+def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = False) -> torch.Tensor:
     """Same function evaluated the way the HIP kernels do: per-cell P, then the
     per-pixel 256->512 stacked layers.  Not reference-faithful in summation
-    order; agrees with decode_reference_form to ~1e-7."""
+    order; agrees with decode_reference_form to ~1e-7.
+
+    ``bf16_operands=True`` emulates the optional bf16 path (BASELINE config 5): the weights and
+    the activation entering layers 1..3 are rounded to bf16, products accumulate in fp32;
+    P, biases, sine, layer 0 and the head (on the unrounded last activation) stay fp32."""
     sw = split_weights(sd)
     feat = _as_t(feat)
     b, c, h, w = feat.shape
@@ -232,8 +241,10 @@ def decode_hoisted_form(sd, feat, size: Sequence[int]) -> torch.Tensor:
     syn[..., 1] = torch.from_numpy(rel_w)[None, :]
     syn[..., 2] = float(scale_ratio(h, w, hu, wu))
     q = torch.relu(pp[:, :, :, 0]) * torch.sin(syn @ sw["Q0"].t() + sw["bQ"][0])
+    rnd = _bf16_round if bf16_operands else (lambda t: t)
     for i in range(1, 4):
-        k = torch.relu(q @ sw["Wq"][i - 1].t() + pp[:, :, :, i])
-        q = k * torch.sin(q @ sw["Qw"][i - 1].t() + sw["bQ"][i])
+        qi = rnd(q)
+        k = torch.relu(qi @ rnd(sw["Wq"][i - 1]).t() + pp[:, :, :, i])
+        q = k * torch.sin(qi @ rnd(sw["Qw"][i - 1]).t() + sw["bQ"][i])
     out = q @ sw["L"].t() + sw["bL"]
     return out.permute(0, 3, 1, 2).contiguous()

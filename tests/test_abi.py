@@ -30,7 +30,7 @@ def declared_symbols():
 def test_every_declared_symbol_is_exported_and_bound(lib):
     import diinn_amd._native as N
     names = declared_symbols()
-    assert len(names) >= 13
+    assert len(names) >= 16
     raw = C.CDLL(N.LIB_PATH)
     for n in names:
         assert hasattr(raw, n), f"{n} declared in include/diinn_hip.h but not exported"
@@ -86,7 +86,7 @@ def test_packed_image_layout(lib):
     import diinn_amd.decoder as D
     sd = synth.decoder_state_dict(11)
     packed = D.pack_state_dict(sd).numpy()
-    assert packed.size == lib.diinn_packed_weight_floats() == 986_628
+    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608
     lane = np.arange(64)
     out_l, h_l = lane & 31, lane >> 5
     # WL section
