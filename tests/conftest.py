@@ -17,6 +17,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a ROCm GPU (MI355X); run with -m gpu")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_library_is_built():
+    """The tests exercise the in-tree libdiinn_hip.so; (re)build it when sources are newer.
+    hipcc cross-compiles gfx950 without a GPU.  No fallback: a failed build fails the session."""
+    import diinn_amd.build as b
+    b.build(verbose=False)
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     """Outputs/tables produced by the real reference decoder (tests/golden/make_golden.py)."""
