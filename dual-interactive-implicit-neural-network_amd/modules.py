@@ -47,7 +47,26 @@ class RDB(nn.Module):
         self.LFF = nn.Conv2d(growRate0 + nConvLayers * growRate, growRate0, 1)
 
     def forward(self, x):
+        if not torch.is_grad_enabled():
+            return self._forward_dense_buffer(x)
         return self.LFF(self.convs(x)) + x
+
+    def _forward_dense_buffer(self, x):
+        """Inference form of the dense block: one [B, G0 + C*G, H, W] buffer, every conv reads the
+        channels written so far and appends its G outputs in place -- the reference's
+        ``torch.cat((x, out), 1)`` (rdn.py:15-17) re-copies the whole growing stack at every conv
+        (2,816 channel-planes per block instead of 576).  Same arithmetic, same results."""
+        b, g0, h, w = x.shape
+        convs = list(self.convs)
+        g = convs[0].conv[0].out_channels
+        buf = x.new_empty((b, g0 + len(convs) * g, h, w))
+        buf[:, :g0] = x
+        c_in = g0
+        for layer in convs:
+            conv = layer.conv[0]
+            buf[:, c_in:c_in + g] = F.relu(F.conv2d(buf[:, :c_in], conv.weight, conv.bias, padding=conv.padding))
+            c_in += g
+        return self.LFF(buf) + x
 
 
 class RDN(nn.Module):
