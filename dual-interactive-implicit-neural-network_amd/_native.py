@@ -18,7 +18,7 @@ DIINN_OK = 0
 SIN_ACCURATE = 0
 SIN_HW = 1
 SIN_HW_REDUCED = 2
-# default: 2-term Cody-Waite reduction + v_sin_f32 (max abs error 4e-7 for |x| <= 1e4, measured in
+# default: 2-term reduction in revolutions + v_sin_f32 (max abs error 2.5e-7 for |x| <= 1e4, measured in
 # tests/test_gpu_parity.py::test_device_sine_accuracy); SIN_ACCURATE (1e-7) costs ~4 % more time
 SIN_DEFAULT = SIN_HW_REDUCED
 ABI_VERSION = 1
