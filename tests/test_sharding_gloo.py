@@ -93,3 +93,48 @@ def test_two_rank_feature_handoff_and_stitch(mode):
         assert p.exitcode == 0
     assert all(r[0] for r in res)
     assert max(r[1] for r in res) <= 1e-6
+
+
+def _gpu_worker(rank, world, port, q):
+    """Two ranks sharing cuda:0 (the test box has one GPU): gloo carries the broadcast, the HIP
+    kernels decode each rank's band.  (RCCL refuses two ranks on one device; the halo P2P form is
+    covered on CPU above.)"""
+    import diinn_amd.decoder as D
+    import diinn_amd.sharded as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        b, h, w, hu, wu = 1, 40, 56, 132, 185
+        shape = (b, 64, h, w)
+        packed = D.pack_state_dict(synth.decoder_state_dict(21)).to(dev)
+        feat = torch.from_numpy(synth.encoder_features(21, b, h, w)).to(dev) if rank == 0 else None
+        out, (y0, y1) = S.decode_sharded(feat, shape, packed, (hu, wu), src=0, mode="bcast")
+        torch.cuda.synchronize()
+        band = out[:, :, y0:y1].cpu().numpy()
+        outs = [None] * world
+        dist.all_gather_object(outs, (y0, y1, band))
+        if rank == 0:
+            full = D.decode_features(feat, packed, (hu, wu)).cpu().numpy()
+            stitched = np.concatenate([o[2] for o in sorted(outs, key=lambda t: t[0])], axis=2)
+            q.put(bool(np.array_equal(stitched, full)))
+        else:
+            q.put(True)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_decode_bands_on_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(res)
