@@ -125,3 +125,19 @@ def test_packed_image_layout(lib):
     # every channel appears exactly once per lane-half in the activation register order
     seen = sorted(_chan_of(kk, h) for kk in range(128) for h in range(2))
     assert seen == list(range(256))
+
+
+def test_host_axis_tables_match_oracle_on_random_pairs(lib):
+    """The C-ABI coordinate code (csrc/diinn_layout.h axis_eval) against the numpy oracle on random
+    size pairs, both ATen index-kernel variants: bit-exact."""
+    import diinn_amd.decoder as D
+    import diinn_oracle as orc
+    rng = np.random.default_rng(2024)
+    for _ in range(400):
+        n_in = int(rng.integers(1, 1500))
+        n_out = int(rng.integers(1, 6000))
+        for small in (False, True):
+            idx, rel = D.axis_tables(n_in, n_out, small)
+            oi, orl = orc.axis_tables(n_in, n_out, small)
+            assert np.array_equal(idx, oi), (n_in, n_out, small)
+            assert np.array_equal(rel.view(np.uint32), orl.view(np.uint32)), (n_in, n_out, small)

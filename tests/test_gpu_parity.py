@@ -234,3 +234,33 @@ def test_bf16_path_restated_tolerance(golden, dev):
         err2 = float(np.abs(got - emu).max())
         assert err2 <= rel * scale + 1e-6, f"{name}: bf16 kernel vs bf16 emulation {err2:.3e}"
         print(f"bf16 {name}: max|ref| {scale:.3f}  vs fp32 reference {err:.2e} ({err/scale:.1e} rel)  vs emulation {err2:.2e}")
+
+
+def test_random_shapes_vs_oracle(dev):
+    """Fuzz: random LR/HR shapes, batch sizes and scales (up- and down-scaling, tile edges that do
+    not divide the 16x8 workgroup block or the 4x32 cell block) against the oracle."""
+    import diinn_oracle as orc
+    rng = np.random.default_rng(7)
+    sd = synth.decoder_state_dict(31)
+    for case in range(12):
+        b = int(rng.integers(1, 3))
+        h, w = int(rng.integers(1, 45)), int(rng.integers(1, 70))
+        hu, wu = int(rng.integers(1, 150)), int(rng.integers(1, 200))
+        feat = synth.encoder_features(100 + case, b, h, w)
+        ref = orc.decode_reference_form(sd, feat, (hu, wu), 30000).numpy()
+        got = _decode(sd, feat, (hu, wu), dev)
+        err = float(np.abs(got - ref).max())
+        assert err <= _tol(ref), f"case {case}: B{b} {h}x{w} -> {hu}x{wu}: err {err:.3e}"
+
+
+def test_invalid_sizes_raise(dev):
+    import diinn_amd.decoder as D
+    import diinn_amd._native as N
+    packed = D.pack_state_dict(synth.decoder_state_dict(123)).to(dev)
+    x = torch.zeros(1, 64, 4, 4, device=dev)
+    with pytest.raises(ValueError):
+        D.decode_features(x, packed, (8, 8, 8))              # reference: unpack error for len(size) != 2
+    with pytest.raises(N.DiinnNativeError):
+        D.decode_features(x, packed, (0, 8))
+    with pytest.raises(ValueError):
+        D.decode_features(torch.zeros(1, 32, 4, 4, device=dev), packed, (8, 8))
