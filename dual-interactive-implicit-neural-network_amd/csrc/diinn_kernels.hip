@@ -534,7 +534,12 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
         const int ly = rem / PT_LC, lx = rem - ly * PT_LC;
         const int yy = y0 + ly - 1, xx = x0 + lx - 1;
         const bool ok = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
-        tile[idx] = ok ? fb[((size_t)c * p.H + yy) * p.W + xx] : 0.0f;
+        // unconditional load from a clamped address, then select: a load under `ok ? .. : 0` compiles
+        // to a branch and a vmcnt(0) per element (51 serial memory round trips per workgroup)
+        const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+        const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
+        const float v = fb[((size_t)c * p.H + yc) * p.W + xc];
+        tile[idx] = ok ? v : 0.0f;
     }
     __syncthreads();
 
