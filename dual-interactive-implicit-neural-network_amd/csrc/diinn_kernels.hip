@@ -4,14 +4,19 @@
 // Reference path replaced: ImplicitDecoder.forward, mode 3
 //   /root/reference/src/models/components/diinn.py:163-173 (+ :94-110, :132-139, :149-160)
 //
-// Two kernels (DESIGN.md has the derivation and the roofline of each):
+// Kernels (DESIGN.md has the derivation, the roofline and the measurements of each):
 //   precompute_P_kernel : per LR cell, P_i = Wx_i . unfold3x3(feat) + bK_i, i=0..3
-//                         (implicit-im2col GEMM 576 -> 1024 on v_mfma_f32_32x32x2_f32)
+//                         (implicit-im2col GEMM 576 -> 1024 on v_mfma_f32_32x32x2_f32,
+//                         feature halo tile in LDS)
 //   decode_kernel       : per HR pixel, the dual-branch MLP.  One wave owns 32 pixels
 //                         and keeps their 256-channel activation in registers for the
 //                         whole network: the accumulator layout of one layer IS the
 //                         B-operand layout of the next (diinn_layout.h), so activations
 //                         never touch LDS or HBM.  Weights stream from the packed image.
+//   decode_bf16_kernel  : the same with bf16 operands in layers 1..3 (optional path).
+//   axis_tables_kernel, sin_kernel : the device coordinate / sine code, exposed for tests.
+// Compile-time hooks that never ship enabled: ABL_* (timing ablations, wrong results),
+// DIINN_STAMPS (s_memtime stamps for tools/stamp_report.py).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (explicit fmaf where wanted)
 #include <hip/hip_runtime.h>
