@@ -149,6 +149,20 @@ def make_syn_inp(b: int, h: int, w: int, hu: int, wu: int) -> Tuple[torch.Tensor
 
 
 @torch.no_grad()
+def decode_reference_form_f64(sd, feat, size: Sequence[int]) -> torch.Tensor:
+    """The same mathematics in float64 (coordinates and indices stay the reference's fp32 tables):
+    a ground truth against which the fp32 reference and the fp32 HIP path can both be measured."""
+    sd64 = {k: _as_t(v).double() for k, v in sd.items()}
+    feat = _as_t(feat).double()
+    b, c, h, w = feat.shape
+    hu, wu = int(size[0]), int(size[1])
+    syn, idx_h, idx_w = make_syn_inp(b, h, w, hu, wu)
+    u = unfold3x3(feat)
+    x = u[:, :, torch.from_numpy(idx_h.astype(np.int64))][:, :, :, torch.from_numpy(idx_w.astype(np.int64))]
+    return _step_mode3(sd64, x, syn.double())
+
+
+@torch.no_grad()
 def decode_reference_form(sd, feat, size: Sequence[int], bsize: Optional[int] = None,
                           row_range: Optional[Tuple[int, int]] = None) -> torch.Tensor:
     """Reference-faithful CPU decode: unfold -> nearest-exact replicate ->
