@@ -6,12 +6,12 @@ import diinn_amd._native as N, diinn_amd.decoder as D, diinn_amd.synth as synth
 dev = torch.device("cuda:0")
 lib = N.load()
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-H = 1024
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 packed = D.pack_state_dict(synth.decoder_state_dict(123)).to(dev)
 feat = torch.randn(1, 64, H, W, device=dev)
 ws = torch.empty(H * W * 1024, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-for rows in (4, 8, 16, 32, 64, 128, 256, 512, 1024):
+for rows in [r for r in (4, 8, 16, 32, 64, 128, 256, 512, 1024) if r <= H]:
     def run():
         N.check(lib.diinn_precompute_P(C.c_void_p(st), C.c_void_p(feat.data_ptr()), C.c_void_p(packed.data_ptr()),
                                        C.c_void_p(ws.data_ptr()), 1, H, W, 0, rows), "P")
