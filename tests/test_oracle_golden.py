@@ -82,3 +82,31 @@ def test_synth_is_deterministic_and_shaped():
     b = synth.encoder_features(123, 1, 8, 8)
     assert np.array_equal(a, b) and abs(float(a.mean())) < 0.1 and 0.8 < float(a.std()) < 1.2
     assert float(np.abs(sd["K.0.0.weight"]).max()) <= 1 / 24.0
+
+
+def test_plain_c_oracle_tables_bit_exact(golden):
+    """Third, independent restatement (plain C, oracle/diinn_oracle_c.c) of the coordinate code."""
+    import diinn_oracle_c as oc
+    for k in golden.files:
+        if not k.startswith("idx/"):
+            continue
+        _, path, pair = k.split("/")
+        n_in, n_out = map(int, pair.split("_"))
+        idx, rel = oc.axis_tables(n_in, n_out, path == "small")
+        assert np.array_equal(idx, golden[k]), k
+        assert np.array_equal(rel.view(np.uint32), golden[f"rel/{path}/{pair}"].view(np.uint32)), k
+
+
+def test_plain_c_oracle_matches_reference_outputs(golden):
+    """The per-pixel C evaluation of diinn.py:163-173 as written (no hoisting, index-order sums)
+    against the real reference's outputs; small fixtures only (it is a scalar loop)."""
+    import diinn_oracle_c as oc
+    for name, b, h, w, hu, wu, gain in golden_cases(golden):
+        if b * hu * wu > 12000:
+            continue
+        sd = synth.decoder_state_dict(123, gain)
+        feat = synth.encoder_features(123, b, h, w)
+        ref = golden[f"out/{name}"]
+        got = oc.decode(sd, feat, (hu, wu))
+        err = float(np.abs(got - ref).max())
+        assert err <= 5e-6 * max(1.0, float(np.abs(ref).max())), (name, err)   # index-order fp32 sums vs mkldnn blocking
