@@ -264,3 +264,14 @@ def test_invalid_sizes_raise(dev):
         D.decode_features(x, packed, (0, 8))
     with pytest.raises(ValueError):
         D.decode_features(torch.zeros(1, 32, 4, 4, device=dev), packed, (8, 8))
+
+
+def test_against_plain_c_oracle(dev):
+    """HIP path vs the independent plain-C restatement (oracle/diinn_oracle_c.c), a shape with no fixture."""
+    import diinn_oracle_c as oc
+    sd = synth.decoder_state_dict(77)
+    feat = synth.encoder_features(77, 1, 9, 13)
+    size = (31, 40)
+    ref = oc.decode(sd, feat, size)
+    got = _decode(sd, feat, size, dev)
+    assert float(np.abs(got - ref).max()) <= _tol(ref)
