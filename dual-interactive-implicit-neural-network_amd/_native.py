@@ -24,6 +24,7 @@ SIN_DEFAULT = SIN_HW_REDUCED
 ABI_VERSION = 1
 COMPUTE_F32 = 0
 COMPUTE_BF16 = 1
+COMPUTE_F32_QONLY = 2
 COMPUTE = {"f32": COMPUTE_F32, "fp32": COMPUTE_F32, "bf16": COMPUTE_BF16}
 
 _f = C.POINTER(C.c_float)

@@ -151,7 +151,10 @@ __device__ __forceinline__ f32x4 ld_piece(__amdgpu_buffer_rsrc_t rsrc, int lane_
 constexpr int PIECE_BYTES = (int)(WL_PIECE * sizeof(float));
 constexpr int WG_TILES_X = 2, WG_TILES_Y = 2;   // 4 waves -> 16x8 HR pixels per workgroup
 
-template <int SIN_MODE>
+// KPART = false (decoder modes 1 and 2, diinn.py:116-131): the modulation chain k_i depends on the LR
+// cell only, so the caller leaves k_i[cell] (already rectified) in the workspace slot of P_i and the
+// per-pixel layers run the synthesis GEMM alone: half the MFMAs, half the weight stream.
+template <int SIN_MODE, bool KPART = true>
 __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform (scalar offsets)
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     f32x4 rk[PF], rq[PF];
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
-        rk[d] = ld_piece(wrs, lane_off, wp + (2 * d + 0) * PIECE_BYTES);
+        if constexpr (KPART) rk[d] = ld_piece(wrs, lane_off, wp + (2 * d + 0) * PIECE_BYTES);
         rq[d] = ld_piece(wrs, lane_off, wp + (2 * d + 1) * PIECE_BYTES);
     }
     f32x4 sk[4], sq[4];                                          // seeds of the next tile
@@ -256,14 +259,20 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
 #pragma unroll
             for (int kg = 0; kg < WL_KG; ++kg) {
                 const int s = m * WL_KG + kg;
-                const f32x4 wk = rk[s % PF], wq = rq[s % PF];
+                const f32x4 wq = rq[s % PF];
+                if constexpr (KPART) {
+                    const f32x4 wk = rk[s % PF];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ak = MFMA32(wk[e], q[4 * kg + e], ak);
-                    as = MFMA32(wq[e], q[4 * kg + e], as);
+                    for (int e = 0; e < 4; ++e) {
+                        ak = MFMA32(wk[e], q[4 * kg + e], ak);
+                        as = MFMA32(wq[e], q[4 * kg + e], as);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) as = MFMA32(wq[e], q[4 * kg + e], as);
                 }
                 // refill the ring slot just consumed with the piece PF steps ahead
-                rk[s % PF] = ld_piece(wrs, lane_off, wp + (2 * ABL_STEP(s + PF) + 0) * PIECE_BYTES);
+                if constexpr (KPART) rk[s % PF] = ld_piece(wrs, lane_off, wp + (2 * ABL_STEP(s + PF) + 0) * PIECE_BYTES);
                 rq[s % PF] = ld_piece(wrs, lane_off, wp + (2 * ABL_STEP(s + PF) + 1) * PIECE_BYTES);
                 if (kg == 4) {                                    // seeds for the next tile
 #pragma unroll
@@ -727,7 +736,8 @@ int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
 int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_dev,
                          float* out_dev, int B, int H, int W, int Hu, int Wu,
                          int y0, int y1, int sin_mode, int compute) {
-    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16) return DIINN_ERR_UNSUPPORTED;
+    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY)
+        return DIINN_ERR_UNSUPPORTED;
     if (!P_dev || !packed_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
     if (st) return st;
@@ -757,6 +767,15 @@ int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_d
             hipLaunchKernelGGL(decode_bf16_kernel<DIINN_SIN_ACCURATE>, grid, dim3(blk), 0, (hipStream_t)stream, p);
         return hip_status(hipGetLastError());
     }
+    if (compute == DIINN_COMPUTE_F32_QONLY) {
+        if (sin_mode == DIINN_SIN_HW)
+            hipLaunchKernelGGL((decode_kernel<DIINN_SIN_HW, false>), grid, dim3(blk), 0, (hipStream_t)stream, p);
+        else if (sin_mode == DIINN_SIN_HW_REDUCED)
+            hipLaunchKernelGGL((decode_kernel<DIINN_SIN_HW_REDUCED, false>), grid, dim3(blk), 0, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL((decode_kernel<DIINN_SIN_ACCURATE, false>), grid, dim3(blk), 0, (hipStream_t)stream, p);
+        return hip_status(hipGetLastError());
+    }
     if (sin_mode == DIINN_SIN_HW)
         hipLaunchKernelGGL(decode_kernel<DIINN_SIN_HW>, grid, dim3(blk), 0, (hipStream_t)stream, p);
     else if (sin_mode == DIINN_SIN_HW_REDUCED)
@@ -777,6 +796,7 @@ int diinn_decode_ex(void* stream, const float* feat_dev, const float* packed_dev
                     float* workspace_dev, float* out_dev,
                     int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode, int compute) {
     if (!workspace_dev) return DIINN_ERR_INVALID_ARG;
+    if (compute == DIINN_COMPUTE_F32_QONLY) return DIINN_ERR_UNSUPPORTED;   // the caller runs the cell chain between the kernels
     int r0, r1;
     int st = diinn_lr_rows_for_band(H, Hu, Wu, y0, y1, &r0, &r1);
     if (st) return st;

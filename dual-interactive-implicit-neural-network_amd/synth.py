@@ -76,12 +76,13 @@ def normalish(seed: int, name: str, shape) -> np.ndarray:
     return acc.astype(np.float32).reshape(shape)
 
 
-def decoder_param_shapes() -> "OrderedDict[str, tuple]":
-    """Reference ``ImplicitDecoder(mode=3, init_q=False).state_dict()`` layout
-    (diinn.py:53-92)."""
+def decoder_param_shapes(mode: int = 3) -> "OrderedDict[str, tuple]":
+    """Reference ``ImplicitDecoder(mode=mode, init_q=False).state_dict()`` layout
+    (diinn.py:53-92).  Mode 1 chains k -> K[i] (256 inputs); modes 2-4 feed
+    [k or q ; unfolded features] (832 inputs)."""
     shapes: "OrderedDict[str, tuple]" = OrderedDict()
     for i in range(N_LAYERS):
-        kin = UNFOLD if i == 0 else HIDDEN + UNFOLD
+        kin = UNFOLD if i == 0 else (HIDDEN if mode == 1 else HIDDEN + UNFOLD)
         qin = 3 if i == 0 else HIDDEN
         shapes[f"K.{i}.0.weight"] = (HIDDEN, kin, 1, 1)
         shapes[f"K.{i}.0.bias"] = (HIDDEN,)
@@ -92,15 +93,16 @@ def decoder_param_shapes() -> "OrderedDict[str, tuple]":
     return shapes
 
 
-def decoder_state_dict(seed: int = 123, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+def decoder_state_dict(seed: int = 123, gain: float = 1.0, mode: int = 3) -> "OrderedDict[str, np.ndarray]":
     """Synthetic decoder weights in the reference's state_dict naming.
 
     ``gain`` scales every tensor (gain=3 is the SURVEY §8(d2) stress set:
     larger sine arguments and output magnitude)."""
     sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
-    for name, shape in decoder_param_shapes().items():
+    shapes = decoder_param_shapes(mode)
+    for name, shape in shapes.items():
         layer = name.rsplit(".", 1)[0] + ".weight"
-        wshape = decoder_param_shapes()[layer]
+        wshape = shapes[layer]
         fan_in = wshape[1] * wshape[2] * wshape[3]
         bound = 1.0 / math.sqrt(fan_in)
         sd[name] = (uniform(seed, name, shape, bound) * np.float32(gain)).astype(np.float32)

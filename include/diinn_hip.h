@@ -58,6 +58,11 @@ extern "C" {
 #define DIINN_COMPUTE_BF16 1   /* v_mfma_f32_32x32x16_bf16: bf16 weights/activations, fp32 accumulate;
                                   parity restated to 2e-3 * max|ref| (BASELINE config 5)                     */
 
+#define DIINN_COMPUTE_F32_QONLY 2 /* decoder modes 1 and 2 (diinn.py:116-131): fp32, synthesis GEMM only; the
+                                  workspace slots 1..3 hold the per-cell modulation k_i (>= 0) the caller
+                                  computed from P (a chain of three 256x256 layers per LR cell); only valid
+                                  for diinn_decode_band_ex                                                     */
+
 int         diinn_abi_version(void);
 const char* diinn_status_string(int status);
 /* hipError_t of the most recent failing HIP call made by this thread (0 if none). */

@@ -126,12 +126,19 @@ def _conv1x1(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return F.conv2d(x, w.view(w.shape[0], -1, 1, 1), b)
 
 
-def _step_mode3(sd: Dict[str, torch.Tensor], x: torch.Tensor, syn: torch.Tensor) -> torch.Tensor:
-    """diinn.py:132-139 with K[i]/Q[i] = Conv1x1 + ReLU / sin (diinn.py:73-78)."""
+def _step_mode3(sd: Dict[str, torch.Tensor], x: torch.Tensor, syn: torch.Tensor, mode: int = 3) -> torch.Tensor:
+    """diinn.py:116-139 with K[i]/Q[i] = Conv1x1 + ReLU / sin (diinn.py:53-78).
+    mode 3 (:132-139): K[i] sees [q; x].  mode 2 (:124-131): K[i] sees [k; x].  mode 1 (:116-123): K[i] sees k."""
     k = torch.relu(_conv1x1(x, sd["K.0.0.weight"], sd["K.0.0.bias"]))
     q = k * torch.sin(_conv1x1(syn, sd["Q.0.0.weight"], sd["Q.0.0.bias"]))
     for i in range(1, 4):
-        k = torch.relu(_conv1x1(torch.cat([q, x], dim=1), sd[f"K.{i}.0.weight"], sd[f"K.{i}.0.bias"]))
+        if mode == 3:
+            kin = torch.cat([q, x], dim=1)
+        elif mode == 2:
+            kin = torch.cat([k, x], dim=1)
+        else:
+            kin = k
+        k = torch.relu(_conv1x1(kin, sd[f"K.{i}.0.weight"], sd[f"K.{i}.0.bias"]))
         q = k * torch.sin(_conv1x1(q, sd[f"Q.{i}.0.weight"], sd[f"Q.{i}.0.bias"]))
     return _conv1x1(q, sd["last_layer.weight"], sd["last_layer.bias"])
 
@@ -164,7 +171,7 @@ def decode_reference_form_f64(sd, feat, size: Sequence[int]) -> torch.Tensor:
 
 @torch.no_grad()
 def decode_reference_form(sd, feat, size: Sequence[int], bsize: Optional[int] = None,
-                          row_range: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+                          row_range: Optional[Tuple[int, int]] = None, mode: int = 3) -> torch.Tensor:
     """Reference-faithful CPU decode: unfold -> nearest-exact replicate ->
     9 conv1x1 + 3 cat + 4 sin, optional column strips of ``bsize//Hu`` columns
     (diinn.py:149-160).  ``row_range=(y0,y1)`` restricts the output to an HR
@@ -182,14 +189,14 @@ def decode_reference_form(sd, feat, size: Sequence[int], bsize: Optional[int] = 
     x = u[:, :, ih][:, :, :, iw]  # nearest-exact replication through the tables
     syn = syn[:, :, y0:y1]
     if bsize is None:
-        return _step_mode3(sd, x, syn)
+        return _step_mode3(sd, x, syn, mode)
     hh = y1 - y0
     cols = max(int(bsize) // hh, 1)  # reference hangs when bsize < Hu (diinn.py:155); clamp instead
     preds = []
     ql = 0
     while ql < wu:
         qr = min(ql + cols, wu)
-        preds.append(_step_mode3(sd, x[..., ql:qr], syn[..., ql:qr]))
+        preds.append(_step_mode3(sd, x[..., ql:qr], syn[..., ql:qr], mode))
         ql = qr
     return torch.cat(preds, dim=-1)
 

@@ -91,6 +91,15 @@ def main():
             out[f"out/{name}"] = y.numpy().astype(np.float32)
             out[f"meta/{name}"] = np.array([b, h, w, hu, wu, gain, -1 if bsize is None else bsize], dtype=np.float64)
             print(name, tuple(y.shape), "max|y|=%.4f" % float(y.abs().max()))
+        # decoder modes 1 and 2 (ablation variants of the reference, diinn.py:116-131)
+        for mode in (1, 2):
+            dec = ImplicitDecoder(mode=mode, init_q=False)
+            sdm = synth.decoder_state_dict(seed=123, mode=mode)
+            dec.load_state_dict({k: torch.from_numpy(v) for k, v in sdm.items()}, strict=True)
+            feat = torch.from_numpy(synth.encoder_features(123, 1, 24, 20))
+            y = dec.eval()(feat, [79, 66], 30000)
+            out[f"mode{mode}/out_24x20_79x66"] = y.numpy().astype(np.float32)
+            print("mode", mode, tuple(y.shape), "max|y|=%.4f" % float(y.abs().max()))
         for n_in, n_out in TABLE_PAIRS:
             idx, rel = reference_axis_tables(n_in, n_out, 129)      # generic kernel (sum > 128)
             out[f"idx/generic/{n_in}_{n_out}"] = idx

@@ -275,3 +275,25 @@ def test_against_plain_c_oracle(dev):
     ref = oc.decode(sd, feat, size)
     got = _decode(sd, feat, size, dev)
     assert float(np.abs(got - ref).max()) <= _tol(ref)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_modes_1_and_2(golden, dev, mode):
+    """Decoder modes 1 and 2 (diinn.py:116-131): per-cell modulation chain + synthesis-only decode
+    kernel, against the reference's outputs and, on another shape, the oracle."""
+    import diinn_amd.decoder as D
+    import diinn_oracle as orc
+    sd = synth.decoder_state_dict(123, mode=mode)
+    dec = D.ImplicitDecoder(mode=mode, init_q=False)
+    dec.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    dec = dec.to(dev).eval()
+    feat = synth.encoder_features(123, 1, 24, 20)
+    with torch.no_grad():
+        got = dec(torch.from_numpy(feat).to(dev), (79, 66), 30000).cpu().numpy()
+    ref = golden[f"mode{mode}/out_24x20_79x66"]
+    assert float(np.abs(got - ref).max()) <= _tol(ref)
+    feat2 = synth.encoder_features(5, 2, 17, 33)
+    with torch.no_grad():
+        got2 = dec(torch.from_numpy(feat2).to(dev), (40, 100), 30000).cpu().numpy()
+    ref2 = orc.decode_reference_form(sd, feat2, (40, 100), 30000, mode=mode).numpy()
+    assert float(np.abs(got2 - ref2).max()) <= _tol(ref2)

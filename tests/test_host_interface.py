@@ -36,7 +36,7 @@ def test_cpu_tensor_fails_loudly_no_fallback():
 
 def test_unsupported_variants_raise():
     import diinn_amd.decoder as D
-    for kw in (dict(mode=1), dict(mode=2), dict(mode=4), dict(mode=3, init_q=True)):
+    for kw in (dict(mode=4), dict(mode=3, init_q=True), dict(mode=1, init_q=True)):
         with pytest.raises(NotImplementedError):
             D.ImplicitDecoder(**kw)(torch.zeros(1, 64, 4, 4), (8, 8))
 

@@ -110,3 +110,13 @@ def test_plain_c_oracle_matches_reference_outputs(golden):
         got = oc.decode(sd, feat, (hu, wu))
         err = float(np.abs(got - ref).max())
         assert err <= 5e-6 * max(1.0, float(np.abs(ref).max())), (name, err)   # index-order fp32 sums vs mkldnn blocking
+
+
+def test_oracle_modes_1_and_2_match_reference(golden):
+    """Ablation modes of the reference decoder (diinn.py:116-131) restated in the oracle."""
+    feat = synth.encoder_features(123, 1, 24, 20)
+    for mode in (1, 2):
+        sd = synth.decoder_state_dict(123, mode=mode)
+        ref = golden[f"mode{mode}/out_24x20_79x66"]
+        got = orc.decode_reference_form(sd, feat, (79, 66), 30000, mode=mode).numpy()
+        assert float(np.abs(got - ref).max()) <= 1e-6
