@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .decoder import ImplicitDecoder
+from .metrics import calc_psnr, psnr, resize_fn, ssim  # noqa: F401  (re-exported like the reference's sr_module)
 
 
 # ---------------------------------------------------------------------------
@@ -200,13 +201,18 @@ class SRLitModule(nn.Module):
 
     @torch.no_grad()
     def test_step(self, batch: Any, batch_idx: int = 0, dataloader_idx: Optional[int] = None):
-        """Decode with the checkpoint's eval_bsize and report PSNR per scale (torchmetrics' definition,
-        data_range=1; SSIM / LR-PSNR of sr_module.py:167-175 need torchmetrics/torchvision)."""
+        """sr_module.py:159-180: decode with the checkpoint's eval_bsize, then PSNR, SSIM and the PSNR of
+        the re-downsampled prediction against the re-downsampled target, per scale (data_range=1)."""
         _, pred_hrs = self.step(batch, self.hparams.eval_bsize)
         res = {}
         for scale in batch:
-            mse = torch.mean((pred_hrs[scale] - batch[scale][1]) ** 2)
-            res[scale] = {"psnr_res": 10.0 * torch.log10(1.0 / mse)}
+            hr = batch[scale][1]
+            lr_size = (round(hr.shape[-2] / scale), round(hr.shape[-1] / scale))
+            res[scale] = {
+                "psnr_res": psnr(pred_hrs[scale], hr, data_range=1),
+                "ssim_res": ssim(pred_hrs[scale], hr, data_range=1),
+                "lr_psnr_res": psnr(resize_fn(pred_hrs[scale], lr_size), resize_fn(hr, lr_size), data_range=1),
+            }
         return res
 
     @classmethod

@@ -7,7 +7,8 @@ The reference drives `Trainer.test` over SRDataModule(B100, Set5, Set14, Urban10
 this counterpart walks `--data_root/<set>/HR/*.png` itself, makes the LR input by antialiased
 bicubic down-sampling (the reference's resize_fn, srdata.py:163-166), and calls
 `SRLitModule.test_step` -- normalise, forward(lr, hr.shape[-2:], eval_bsize=30000), de-normalise
-and clamp exactly as sr_module.py:113-125,159-160 -- reporting PSNR per set and scale.
+and clamp exactly as sr_module.py:113-125,159-160 -- reporting PSNR, SSIM and LR-PSNR per set and
+scale (sr_module.py:167-175; metrics re-implemented in diinn_amd/metrics.py).
 """
 import glob
 import os
@@ -40,7 +41,7 @@ def test(args):
     for name in TESTSETS:
         files = sorted(glob.glob(os.path.join(args.data_root, name, "HR", "*.png")))
         for scale in TEST_SCALES:
-            psnrs = []
+            psnrs, ssims, lr_psnrs = [], [], []
             for f in files:
                 hr = torch.from_numpy(np.asarray(Image.open(f).convert("RGB"), np.float32) / 255.0)
                 hr = hr.permute(2, 0, 1).unsqueeze(0).to(dev)
@@ -48,8 +49,12 @@ def test(args):
                 lr = resize_fn(hr, lr_size).clamp(0, 1)
                 res = model.test_step({scale: (lr, hr, os.path.basename(f))}, 0, 0)
                 psnrs.append(float(res[scale]["psnr_res"]))
+                ssims.append(float(res[scale]["ssim_res"]))
+                lr_psnrs.append(float(res[scale]["lr_psnr_res"]))
             if psnrs:
                 results[f"{name}/psnr_x{scale}"] = sum(psnrs) / len(psnrs)
+                results[f"{name}/ssim_x{scale}"] = sum(ssims) / len(ssims)
+                results[f"{name}/lr_psnr_x{scale}"] = sum(lr_psnrs) / len(lr_psnrs)
     print(results)
     return results
 

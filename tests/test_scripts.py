@@ -56,3 +56,4 @@ def test_demo2_and_benchmarks_run_end_to_end(tmp_path, golden):
                         "--data_root", str(tmp_path / "data")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Set5/psnr_x4" in r.stdout and "Set5/psnr_x3.14" in r.stdout and "Set5/psnr_x8" in r.stdout
+    assert "Set5/ssim_x4" in r.stdout and "Set5/lr_psnr_x4" in r.stdout
