@@ -2,7 +2,6 @@
 reference decoder (tests/golden/make_golden.py imports /root/reference in the build container).
 This is what pins the oracle; the GPU tests then compare the HIP path with it."""
 import numpy as np
-import pytest
 import torch
 
 import diinn_amd.synth as synth

@@ -1,4 +1,4 @@
-import os, sys
+import sys
 sys.path.insert(0, "/root/repo")
 import torch
 import diinn_amd.modules as M

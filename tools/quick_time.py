@@ -1,5 +1,5 @@
 """Scratch timing of the decode path on one GPU (not the bench contract; see bench.py)."""
-import sys, time, os
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import diinn_amd.synth as synth, diinn_amd.decoder as D, diinn_amd._native as N
