@@ -335,6 +335,88 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
 }
 
 
+
+// ---------------------------------------------------------------------------------
+// cell_chain_kernel (decoder modes 1 and 2, diinn.py:116-131): the modulation chain depends on the
+// LR cell only: k_0 = relu(P_0), k_i = relu(K_i^k k_{i-1} + P_i), i = 1..3.  Same register-resident
+// scheme as decode_kernel with LR cells in place of HR pixels and the modulation half of the
+// stacked weights alone (part 0 of the WL image holds K.i[:, :256] in A-operand order already).
+// k_i overwrites the P_i slot of the workspace; decode_kernel<SIN, KPART=false> then reads it as
+// the multiplier of the synthesis branch.
+// ---------------------------------------------------------------------------------
+struct ChainParams {
+    float* P;            // [B,H,W,1024], slots 1..3 updated in place for rows [r0,r1)
+    const float* Wt;
+    int B, H, W, r0, r1;
+};
+
+__global__ __launch_bounds__(256, 1) void cell_chain_kernel(const ChainParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int x = blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
+    const int y = p.r0 + blockIdx.y * (TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
+    const int b = blockIdx.z;
+    const bool valid = (x < p.W) && (y < p.r1);
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
+    const int xc = x < p.W ? x : p.W - 1;
+    const int yc = y < p.r1 ? y : p.r1 - 1;
+    float* __restrict__ Pc = p.P + (((size_t)b * p.H + yc) * p.W + xc) * PCH + 4 * h;
+
+    float k[128];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const f32x4 pv = *(const f32x4*)(Pc + 8 * i);             // channels 32m + 8g + 4h .., i = 4m + g
+#pragma unroll
+        for (int e = 0; e < 4; ++e) k[4 * i + e] = relu0(pv[e]);
+    }
+
+    constexpr int PF = DECODE_PREFETCH;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);
+    const int lane_off = lane * 16;
+    int wp = (int)(OFF_WL * sizeof(float));
+    f32x4 rk[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) rk[d] = ld_piece(wrs, lane_off, wp + (2 * d) * PIECE_BYTES);
+#pragma unroll 1
+    for (int layer = 0; layer < 3; ++layer) {
+        float* __restrict__ Pl = Pc + (layer + 1) * HID;
+        float kn[128];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            f32x16 ak;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 pv = *(const f32x4*)(Pl + 32 * m + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ak[4 * g + e] = pv[e];
+            }
+#pragma unroll
+            for (int kg = 0; kg < WL_KG; ++kg) {
+                const int s = m * WL_KG + kg;
+                const f32x4 wk = rk[s % PF];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ak = MFMA32(wk[e], k[4 * kg + e], ak);
+                rk[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF)) * PIECE_BYTES);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = relu0(ak[4 * g + e]);
+                    kn[16 * m + 4 * g + e] = v[e];
+                }
+                if (valid) *(f32x4*)(Pl + 32 * m + 8 * g) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 128; ++i) k[i] = kn[i];
+        wp += (int)(WL_LAYER * sizeof(float));
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // decode kernel, bf16 operands (optional path, BASELINE config 5; tolerance restated in
 // DESIGN.md): same structure as decode_kernel -- one wave owns 32 pixels and keeps their
@@ -716,6 +798,19 @@ int diinn_precompute_P(void* stream, const float* feat_dev, const float* packed_
     return hip_status(hipGetLastError());
 }
 
+int diinn_cell_chain(void* stream, float* P_dev, const float* packed_dev, int B, int H, int W, int r0, int r1) {
+    if (!P_dev || !packed_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (r0 < 0 || r1 > H || r0 >= r1) return DIINN_ERR_INVALID_ARG;
+    ChainParams p{P_dev, packed_dev, B, H, W, r0, r1};
+    const dim3 grid((W + TILE_W * WG_TILES_X - 1) / (TILE_W * WG_TILES_X),
+                    (r1 - r0 + TILE_H * WG_TILES_Y - 1) / (TILE_H * WG_TILES_Y), B);
+    if (grid.y > 65535) return DIINN_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(cell_chain_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
 int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,
                              int* grid_x, int* grid_y, int* grid_z, int* block) {
     if (B <= 0 || Hu <= 0 || Wu <= 0 || y0 < 0 || y1 > Hu || y0 >= y1) return DIINN_ERR_INVALID_ARG;
@@ -796,12 +891,16 @@ int diinn_decode_ex(void* stream, const float* feat_dev, const float* packed_dev
                     float* workspace_dev, float* out_dev,
                     int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode, int compute) {
     if (!workspace_dev) return DIINN_ERR_INVALID_ARG;
-    if (compute == DIINN_COMPUTE_F32_QONLY) return DIINN_ERR_UNSUPPORTED;   // the caller runs the cell chain between the kernels
+
     int r0, r1;
     int st = diinn_lr_rows_for_band(H, Hu, Wu, y0, y1, &r0, &r1);
     if (st) return st;
     st = diinn_precompute_P(stream, feat_dev, packed_dev, workspace_dev, B, H, W, r0, r1);
     if (st) return st;
+    if (compute == DIINN_COMPUTE_F32_QONLY) {                   // modes 1 and 2: per-cell modulation chain
+        st = diinn_cell_chain(stream, workspace_dev, packed_dev, B, H, W, r0, r1);
+        if (st) return st;
+    }
     return diinn_decode_band_ex(stream, workspace_dev, packed_dev, out_dev, B, H, W, Hu, Wu, y0, y1, sin_mode,
                                 compute);
 }

@@ -81,31 +81,6 @@ def pack_state_dict(sd, prefix: str = "", mode: int = 3) -> torch.Tensor:
     return torch.from_numpy(packed)
 
 
-def chain_weights(sd, prefix: str = "", device=None) -> torch.Tensor:
-    """[3,256,256] weights of the per-cell modulation chain of modes 1 and 2: the first 256 input
-    columns of K.1..K.3 (they multiply k_{i-1}; diinn.py:120,128)."""
-    ws = []
-    for i in (1, 2, 3):
-        t = sd[prefix + f"K.{i}.0.weight"]
-        t = t.detach() if isinstance(t, torch.Tensor) else torch.from_numpy(np.asarray(t, np.float32))
-        ws.append(t.reshape(HIDDEN, -1)[:, :HIDDEN].to(torch.float32))
-    w = torch.stack(ws).contiguous()
-    return w.to(device) if device is not None else w
-
-
-def _cell_chain_(workspace: torch.Tensor, b: int, h: int, w: int, r0: int, r1: int, chain: torch.Tensor) -> None:
-    """Modes 1 and 2: k_0 = relu(P_0); k_i = relu(K_i^k k_{i-1} + P_i) for every LR cell of rows
-    [r0,r1), written back over P_i (i = 1..3) so that the decode kernel reads k_i[cell] where mode 3
-    reads P_i[cell].  Three [cells,256] x [256,256] products per cell block: plain library GEMMs
-    (rocBLAS through torch.matmul) on 1/s^2 of the pixel count; the per-pixel work stays in the
-    HIP kernel."""
-    p = workspace[: b * h * w * P_CHANNELS].view(b, h, w, 4, HIDDEN)[:, r0:r1]
-    k = torch.relu(p[..., 0, :])
-    for i in range(1, 4):
-        k = torch.relu(torch.matmul(k, chain[i - 1].t()) + p[..., i, :])
-        p[..., i, :] = k
-
-
 def axis_tables(n_in: int, n_out: int, small_output: bool = False) -> Tuple[np.ndarray, np.ndarray]:
     """Host tables (idx int32, rel fp32) from the C ABI ``diinn_make_axis_tables``."""
     lib = _native.load()
@@ -139,16 +114,16 @@ def _require_cuda(t: torch.Tensor, what: str) -> None:
 def decode_features(feat: torch.Tensor, packed: torch.Tensor, size: Sequence[int],
                     out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
                     rows: Optional[Tuple[int, int]] = None, sin_mode: int = _native.SIN_DEFAULT,
-                    compute: str = "f32", mode: int = 3, chain: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    compute: str = "f32", mode: int = 3) -> torch.Tensor:
     """Decode encoder features ``feat`` [B,64,H,W] to RGB [B,3,Hu,Wu].
 
     ``rows=(y0,y1)`` computes only that HR row band (tile sharding across GPUs);
     the rest of ``out`` is left untouched.  ``workspace`` is the P image
     [B,H,W,1024] fp32 (allocated if None).  ``compute`` = "f32" (reference precision) or "bf16"
     (bf16 operands in layers 1..3, fp32 accumulate; ~2e-3 relative).  ``mode`` 3 (default) is the
-    reference's final model; modes 1 and 2 need ``chain`` = ``chain_weights(sd)`` on the device
-    and run fp32 only.  Enqueues two kernels (plus three small GEMMs for modes 1/2) on the current
-    stream; never synchronises."""
+    reference's final model; modes 1 and 2 (packed with ``pack_state_dict(..., mode=...)``) run fp32
+    only.  Enqueues two kernels (three for modes 1/2: + the per-cell modulation chain) on the
+    current stream; never synchronises."""
     lib = _native.load()
     _require_cuda(feat, "feat")
     _require_cuda(packed, "packed weights")
@@ -173,26 +148,15 @@ def decode_features(feat: torch.Tensor, packed: torch.Tensor, size: Sequence[int
         raise ValueError(f"workspace must be a contiguous buffer of >= {need} bytes on feat's device")
     if mode not in (1, 2, 3):
         raise NotImplementedError(f"mode {mode}: the HIP path covers modes 1-3")
+    if mode != 3 and compute != "f32":
+        raise ValueError("modes 1 and 2 run in fp32 only")
+    comp = _native.COMPUTE[compute] if mode == 3 else _native.COMPUTE_F32_QONLY
     with torch.cuda.device(feat.device):
         stream = torch.cuda.current_stream().cuda_stream
-        if mode == 3:
-            st = lib.diinn_decode_ex(C.c_void_p(stream), C.c_void_p(feat.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                     C.c_void_p(workspace.data_ptr()), C.c_void_p(out.data_ptr()),
-                                     b, h, w, hu, wu, y0, y1, int(sin_mode), _native.COMPUTE[compute])
-            _native.check(st, "diinn_decode_ex")
-            return out
-        # modes 1 and 2: P -> per-cell modulation chain -> synthesis-only decode
-        if chain is None or compute != "f32":
-            raise ValueError("modes 1 and 2 need chain=chain_weights(sd) on the device and compute='f32'")
-        r0, r1 = lr_rows_for_band(h, hu, wu, y0, y1)
-        _native.check(lib.diinn_precompute_P(C.c_void_p(stream), C.c_void_p(feat.data_ptr()),
-                                             C.c_void_p(packed.data_ptr()), C.c_void_p(workspace.data_ptr()),
-                                             b, h, w, r0, r1), "diinn_precompute_P")
-        _cell_chain_(workspace, b, h, w, r0, r1, chain)
-        st = lib.diinn_decode_band_ex(C.c_void_p(stream), C.c_void_p(workspace.data_ptr()),
-                                      C.c_void_p(packed.data_ptr()), C.c_void_p(out.data_ptr()),
-                                      b, h, w, hu, wu, y0, y1, int(sin_mode), _native.COMPUTE_F32_QONLY)
-    _native.check(st, "diinn_decode_band_ex")
+        st = lib.diinn_decode_ex(C.c_void_p(stream), C.c_void_p(feat.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                 C.c_void_p(workspace.data_ptr()), C.c_void_p(out.data_ptr()),
+                                 b, h, w, hu, wu, y0, y1, int(sin_mode), comp)
+    _native.check(st, "diinn_decode_ex")
     return out
 
 
@@ -235,7 +199,6 @@ class ImplicitDecoder(nn.Module):
             self.last_layer = nn.Conv2d(self.hidden_dims[-1], 3, 1)
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
-        self._chain: Optional[torch.Tensor] = None
         self._workspace: Optional[torch.Tensor] = None
 
     # -- packed-weight cache ---------------------------------------------------
@@ -247,7 +210,6 @@ class ImplicitDecoder(nn.Module):
         if self._packed is None or self._packed_key != key:
             sd = self.state_dict()
             self._packed = pack_state_dict(sd, mode=self.mode).to(device)
-            self._chain = chain_weights(sd, device=device) if self.mode in (1, 2) else None
             self._packed_key = key
         return self._packed
 
@@ -281,4 +243,4 @@ class ImplicitDecoder(nn.Module):
         with torch.no_grad():
             packed = self.packed_weights(x.device)
             return decode_features(x, packed, size, workspace=self._workspace, sin_mode=self.sin_mode,
-                                   compute=self.compute, mode=self.mode, chain=self._chain)
+                                   compute=self.compute, mode=self.mode)

@@ -59,9 +59,8 @@ extern "C" {
                                   parity restated to 2e-3 * max|ref| (BASELINE config 5)                     */
 
 #define DIINN_COMPUTE_F32_QONLY 2 /* decoder modes 1 and 2 (diinn.py:116-131): fp32, synthesis GEMM only; the
-                                  workspace slots 1..3 hold the per-cell modulation k_i (>= 0) the caller
-                                  computed from P (a chain of three 256x256 layers per LR cell); only valid
-                                  for diinn_decode_band_ex                                                     */
+                                  workspace slots 1..3 hold the per-cell modulation k_i (>= 0) produced by
+                                  diinn_cell_chain from P (diinn_decode_ex runs P, the chain and the decode) */
 
 int         diinn_abi_version(void);
 const char* diinn_status_string(int status);
@@ -139,6 +138,10 @@ int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_d
 int diinn_decode_ex(void* stream, const float* feat_dev, const float* packed_dev,
                     float* workspace_dev, float* out_dev,
                     int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode, int compute);
+
+/* Modes 1 and 2 only: the modulation chain per LR cell, k_0 = relu(P_0), k_i = relu(K_i^k k_{i-1} + P_i)
+ * (diinn.py:118-121,126-129), for LR rows [r0,r1); k_i overwrites the P_i slot (i = 1..3) of P_dev. */
+int diinn_cell_chain(void* stream, float* P_dev, const float* packed_dev, int B, int H, int W, int r0, int r1);
 
 /* Dominant-kernel launch geometry, for benchmarks/roofline accounting. */
 int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,
