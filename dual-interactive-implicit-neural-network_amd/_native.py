@@ -15,6 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIINN_HIP_LIB") or os.path.join(PKG_DIR, "libdiinn_hip.so")
 
 DIINN_OK = 0
+ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_TOO_LARGE = 1, 2, 3, 4
 SIN_ACCURATE = 0
 SIN_HW = 1
 SIN_HW_REDUCED = 2
@@ -38,6 +39,7 @@ SIGNATURES = {
     "diinn_status_string": (C.c_char_p, [C.c_int]),
     "diinn_last_hip_error": (C.c_int, []),
     "diinn_packed_weight_floats": (C.c_size_t, []),
+    "diinn_packed_section": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "diinn_pack_weights": (C.c_int, [_f, _f, _f3, _f3, _f, _f, _f3, _f3, _f, _f, _f]),
     "diinn_make_axis_tables": (C.c_int, [C.c_int, C.c_int, C.c_int, _i32, _f]),
     "diinn_uses_small_output_kernel": (C.c_int, [C.c_int, C.c_int]),
@@ -57,6 +59,9 @@ SIGNATURES = {
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_cell_chain": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_decode_launch_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip]),
+    "diinn_saved_activation_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "diinn_decode_train_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
 }
 
 _lib = None

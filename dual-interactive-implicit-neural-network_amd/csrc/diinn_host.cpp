@@ -35,6 +35,15 @@ const char* diinn_status_string(int status) {
 
 size_t diinn_packed_weight_floats(void) { return PACKED_FLOATS; }
 
+int diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats) {
+    static const size_t off[8] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB};
+    static const size_t sz[8]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB};
+    if (section < 0 || section > 7 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
+    *offset_floats = off[section];
+    *size_floats = sz[section];
+    return DIINN_OK;
+}
+
 // Reference layouts:
 //   K.i weight [256, 832]: input channel 0..255 = q, 256..831 = unfolded feature c*9+ky*3+kx
 //   (torch.cat([q, x]) at diinn.py:136; unfold order at diinn.py:168)

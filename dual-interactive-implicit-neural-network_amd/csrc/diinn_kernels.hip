@@ -88,6 +88,8 @@ struct DecodeParams {
     int B, H, W, Hu, Wu, y0, y1;
     float ratio;           // fp32(H*W / (Hu*Wu))   (diinn.py:166)
     Axis ah, aw;
+    float* acts;           // training forward only (SAVE): [4 layers][2: k, s][256][npix] saved activations
+    unsigned act_row_bytes;  // npix * 4 (npix = B*Hu*Wu)
 #ifdef DIINN_STAMPS
     unsigned long long* stamps;   // diagnostic build only: 8 x u64 per wave (never in the shipped library)
 #endif
@@ -154,14 +156,27 @@ constexpr int WG_TILES_X = 2, WG_TILES_Y = 2;   // 4 waves -> 16x8 HR pixels per
 // KPART = false (decoder modes 1 and 2, diinn.py:116-131): the modulation chain k_i depends on the LR
 // cell only, so the caller leaves k_i[cell] (already rectified) in the workspace slot of P_i and the
 // per-pixel layers run the synthesis GEMM alone: half the MFMAs, half the weight stream.
-template <int SIN_MODE, bool KPART = true>
+//
+// SAVE = true (training forward, reference step() under autograd: diinn.py:132-139 called with
+// bsize=None from sr_module.py:127-129): the same network, and every layer's rectified modulation
+// k_i and sine argument s_i are written to p.acts as plain [channel][pixel] planes (standard
+// channel order, pixel = (b*Hu + y)*Wu + x) for the backward pass.  One wave then owns a 32x1 pixel
+// run so each store instruction writes two full 128-byte lines.
+constexpr int SAVE_TILE_W = 32;
+__device__ __forceinline__ void st_act(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, (int)soff, 0);
+}
+
+template <int SIN_MODE, bool KPART = true, bool SAVE = false>
 __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform (scalar offsets)
     const int h = lane >> 5, j = lane & 31;
 
-    const int x = blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
-    const int y = p.y0 + blockIdx.y * (TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
+    const int x = SAVE ? blockIdx.x * (SAVE_TILE_W * WG_TILES_X) + (wave & 1) * SAVE_TILE_W + j
+                       : blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
+    const int y = SAVE ? p.y0 + blockIdx.y * WG_TILES_Y + (wave >> 1)
+                       : p.y0 + blockIdx.y * (TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
     const int b = blockIdx.z;
     const bool valid = (x < p.Wu) && (y < p.y1);
     // whole wave outside the band/image: nothing to do (wave-uniform, no barriers in this kernel)
@@ -186,10 +201,22 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     const float* __restrict__ Wt = p.Wt;
     const float* __restrict__ Pc = p.P + (((size_t)b * p.H + iy) * p.W + ix) * PCH + 4 * h;
 
+    // saved-activation planes (SAVE): one buffer descriptor per (layer, k|s) plane group of 256 rows;
+    // a lane's offset is its pixel inside the row of channel 4h, rows advance by a scalar offset.
+    // Lanes outside the image carry an offset past the descriptor's range: the store is dropped.
+    const unsigned act_rows = 256u * p.act_row_bytes;           // bytes of one plane group (< 4 GiB, checked by the ABI)
+    const unsigned act_voff = !SAVE ? 0u
+        : valid ? (unsigned)(((size_t)b * p.Hu + y) * p.Wu + x) * 4u + 4u * h * p.act_row_bytes : 0xFFFFFFF0u;
+    auto act_rsrc = [&](int layer, int which) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.acts + (size_t)(2 * layer + which) * act_rows),
+                                                 0, (int)act_rows, 0x00020000);
+    };
+
     // ---- layer 0: q0 = relu(P_0[cell]) * sin(Q0 . (rel_h, rel_w, ratio) + bQ0)   (diinn.py:133-134)
     float q[128];
     {
         const float* __restrict__ Q0 = Wt + OFF_Q0 + 4 * h;
+        const __amdgpu_buffer_rsrc_t ak0 = act_rsrc(0, 0), as0 = act_rsrc(0, 1);
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
 #pragma unroll
@@ -205,7 +232,12 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
                     float a = __builtin_fmaf(wr[e], p.ratio, bq[e]);
                     a = __builtin_fmaf(ww[e], relw, a);
                     a = __builtin_fmaf(wh[e], relh, a);
-                    q[16 * m + 4 * g + e] = relu0(pv[e]) * dsin<SIN_MODE>(a);
+                    const float kv = relu0(pv[e]);
+                    q[16 * m + 4 * g + e] = kv * dsin<SIN_MODE>(a);
+                    if constexpr (SAVE) {
+                        st_act(ak0, act_voff, (unsigned)(c0 + e) * p.act_row_bytes, kv);
+                        st_act(as0, act_voff, (unsigned)(c0 + e) * p.act_row_bytes, a);
+                    }
                 }
             }
         }
@@ -245,6 +277,8 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
         const float* __restrict__ Bn = Wt + OFF_BQ + nl * HID + 4 * h;
         float qn[128];
         f32x16 pk, ps;                                           // finished accumulators of the previous tile
+        const __amdgpu_buffer_rsrc_t akl = act_rsrc(layer + 1, 0), asl = act_rsrc(layer + 1, 1);
+        (void)akl; (void)asl;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             f32x16 ak, as;
@@ -283,14 +317,28 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
                 }
                 if (m > 0 && (kg & 1) == 0) {                     // one epilogue element of tile m-1 every 16 MFMAs
                     const int r = kg >> 1;
-                    qn[16 * (m - 1) + r] = relu0(pk[r]) * ABL_SIN(ps[r]);
+                    const float kv = relu0(pk[r]);
+                    qn[16 * (m - 1) + r] = kv * ABL_SIN(ps[r]);
+                    if constexpr (SAVE) {                        // register r of tile m-1 = channel 32(m-1) + (r&3) + 8(r>>2) + 4h
+                        const unsigned so = (unsigned)(32 * (m - 1) + (r & 3) + 8 * (r >> 2)) * p.act_row_bytes;
+                        st_act(akl, act_voff, so, kv);
+                        st_act(asl, act_voff, so, ps[r]);
+                    }
                 }
             }
             pk = ak;
             ps = as;
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) qn[16 * 7 + r] = relu0(pk[r]) * dsin<SIN_MODE>(ps[r]);
+        for (int r = 0; r < 16; ++r) {
+            const float kv = relu0(pk[r]);
+            qn[16 * 7 + r] = kv * dsin<SIN_MODE>(ps[r]);
+            if constexpr (SAVE) {
+                const unsigned so = (unsigned)(32 * 7 + (r & 3) + 8 * (r >> 2)) * p.act_row_bytes;
+                st_act(akl, act_voff, so, kv);
+                st_act(asl, act_voff, so, ps[r]);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 128; ++i) q[i] = qn[i];
         wp += (int)(WL_LAYER * sizeof(float));
@@ -846,6 +894,7 @@ int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_d
     p.P = P_dev; p.Wt = packed_dev; p.out = out_dev;
     p.B = B; p.H = H; p.W = W; p.Hu = Hu; p.Wu = Wu; p.y0 = y0; p.y1 = y1;
     p.ratio = (float)(((double)H * (double)W) / ((double)Hu * (double)Wu));
+    p.acts = nullptr; p.act_row_bytes = 0;
 #ifdef DIINN_STAMPS
     p.stamps = g_stamps;
 #endif
@@ -877,6 +926,45 @@ int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_d
         hipLaunchKernelGGL(decode_kernel<DIINN_SIN_HW_REDUCED>, grid, dim3(blk), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(decode_kernel<DIINN_SIN_ACCURATE>, grid, dim3(blk), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+long long diinn_saved_activation_floats(int B, int Hu, int Wu) {
+    if (B <= 0 || Hu <= 0 || Wu <= 0) return -1;
+    const long long npix = (long long)B * Hu * Wu;
+    if (npix > DIINN_TRAIN_MAX_PIXELS) return -1;
+    return 4LL * 2 * HID * npix;
+}
+
+int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed_dev, float* out_dev,
+                           float* acts_dev, int B, int H, int W, int Hu, int Wu, int sin_mode) {
+    if (!P_dev || !packed_dev || !out_dev || !acts_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (Hu <= 0 || Wu <= 0) return DIINN_ERR_INVALID_ARG;
+    if (sin_mode < DIINN_SIN_ACCURATE || sin_mode > DIINN_SIN_HW_REDUCED) return DIINN_ERR_UNSUPPORTED;
+    const long long npix = (long long)B * Hu * Wu;
+    // one plane group (256 channel rows) must stay below the 4 GiB range of a buffer descriptor
+    if (npix > DIINN_TRAIN_MAX_PIXELS) return DIINN_ERR_TOO_LARGE;
+    const dim3 grid((Wu + SAVE_TILE_W * WG_TILES_X - 1) / (SAVE_TILE_W * WG_TILES_X), (Hu + WG_TILES_Y - 1) / WG_TILES_Y, B);
+    if (grid.y > 65535 || grid.z > 65535) return DIINN_ERR_TOO_LARGE;
+    DecodeParams p;
+    p.P = P_dev; p.Wt = packed_dev; p.out = out_dev;
+    p.B = B; p.H = H; p.W = W; p.Hu = Hu; p.Wu = Wu; p.y0 = 0; p.y1 = Hu;
+    p.ratio = (float)(((double)H * (double)W) / ((double)Hu * (double)Wu));
+    p.acts = acts_dev; p.act_row_bytes = (unsigned)(npix * 4);
+#ifdef DIINN_STAMPS
+    p.stamps = nullptr;
+#endif
+    const int small = diinn_uses_small_output_kernel(Hu, Wu);
+    p.ah = make_axis(H, Hu, small);
+    p.aw = make_axis(W, Wu, small);
+    if (sin_mode == DIINN_SIN_HW)
+        hipLaunchKernelGGL((decode_kernel<DIINN_SIN_HW, true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (sin_mode == DIINN_SIN_HW_REDUCED)
+        hipLaunchKernelGGL((decode_kernel<DIINN_SIN_HW_REDUCED, true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((decode_kernel<DIINN_SIN_ACCURATE, true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
 

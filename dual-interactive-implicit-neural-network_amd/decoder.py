@@ -8,9 +8,11 @@ Mirrors /root/reference/src/models/components/diinn.py:
     checkpoints ``load_state_dict`` unchanged;
   * ``forward(x, size, bsize=None)`` has the argument meaning of diinn.py:163-173.
 
-The compute is the HIP path and only the HIP path: CPU tensors, missing
-library, autograd or decoder variants the kernels do not cover raise instead of
-silently falling back.  PyTorch is used for device memory and the stream only.
+The compute is the HIP path and only the HIP path: CPU tensors, a missing
+library or decoder variants the kernels do not cover raise instead of silently
+falling back.  PyTorch is used for device memory and the stream; under autograd
+(training, mode 3) the forward is the HIP kernel with saved activations and the
+backward is library GEMMs over those (training.py).
 """
 from __future__ import annotations
 
@@ -233,9 +235,12 @@ class ImplicitDecoder(nn.Module):
         if bsize is None and torch.is_grad_enabled() and (
                 x.requires_grad or any(p.requires_grad for p in self.parameters())):
             # reference: bsize=None runs step() under autograd (training, sr_module.py:128)
-            raise RuntimeError(
-                "diinn_amd: autograd through the HIP decode path is not implemented; call under "
-                "torch.no_grad()/inference_mode (or pass bsize, which the reference also runs without grad)")
+            if self.mode != 3 or self.compute != "f32":
+                raise NotImplementedError(
+                    "diinn_amd: autograd through the HIP decode path covers mode 3 in fp32 (the reference's final "
+                    "model); call modes 1/2 or the bf16 path under torch.no_grad()")
+            from .training import decode_with_grad
+            return decode_with_grad(self, x, size)
         b, c, h, w = x.shape
         need = b * h * w * P_CHANNELS
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != x.device:

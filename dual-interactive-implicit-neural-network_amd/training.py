@@ -1,0 +1,255 @@
+"""Training path of the mode-3 decoder: autograd through the HIP kernels.
+
+The reference trains by calling ``ImplicitDecoder.forward(x, size, bsize=None)`` with autograd on
+(diinn.py:170-171 -> step(), :132-139; caller SRLitModule.training_step, sr_module.py:127-129), which
+records ~30 ATen ops per call on the materialised [B,576,Hu,Wu] tensor.  Here:
+
+  forward   precompute_P_kernel, then decode_kernel<SAVE> (C ABI ``diinn_decode_train_fwd``): the fused
+            inference kernel that additionally writes every layer's rectified modulation k_i and sine
+            argument s_i as [channel][pixel] planes -- all the backward pass needs.
+  backward  ``backward_from_saved``: with the saved planes the whole backward is a chain of PLAIN GEMMs
+            over the pixel axis (rocBLAS through torch.matmul: data gradients [256x512].[512xN],
+            weight gradients [512xN].[Nx256]), elementwise gates, a per-cell segment sum (two one-hot
+            GEMMs, deterministic) and the 3x3 conv's input/weight gradients (MIOpen through
+            torch.nn.grad).  It is written in device-agnostic tensor algebra so the gradient formulas
+            are unit-tested on CPU against autograd of the oracle; the forward has no CPU form.
+
+Weights change every optimiser step, so the packed image is rebuilt on the device each forward by one
+gather through a permutation index derived once from the host packer (``pack_gather_index``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _native
+
+HIDDEN = 256
+IN_CHANNELS = 64
+UNFOLD = IN_CHANNELS * 9
+
+# the reference's registration order (ImplicitDecoder.__init__, diinn.py:73-80,92)
+PARAM_NAMES: List[str] = (
+    [f"K.{i}.0.{t}" for i in range(4) for t in ("weight", "bias")]
+    + [f"Q.{i}.0.{t}" for i in range(4) for t in ("weight", "bias")]
+    + ["last_layer.weight", "last_layer.bias"]
+)
+PARAM_SHAPES: Dict[str, Tuple[int, ...]] = {
+    "K.0.0.weight": (HIDDEN, UNFOLD, 1, 1), "K.0.0.bias": (HIDDEN,),
+    **{f"K.{i}.0.weight": (HIDDEN, HIDDEN + UNFOLD, 1, 1) for i in (1, 2, 3)},
+    **{f"K.{i}.0.bias": (HIDDEN,) for i in (1, 2, 3)},
+    "Q.0.0.weight": (HIDDEN, 3, 1, 1), "Q.0.0.bias": (HIDDEN,),
+    **{f"Q.{i}.0.weight": (HIDDEN, HIDDEN, 1, 1) for i in (1, 2, 3)},
+    **{f"Q.{i}.0.bias": (HIDDEN,) for i in (1, 2, 3)},
+    "last_layer.weight": (3, HIDDEN, 1, 1), "last_layer.bias": (3,),
+}
+
+_gather_index_cpu: Optional[torch.Tensor] = None
+_gather_index_dev: Dict[str, torch.Tensor] = {}
+
+
+def pack_gather_index() -> torch.Tensor:
+    """int64 [packed floats]: packed[i] = flat[index[i]] where ``flat`` is the 18 reference tensors
+    flattened in PARAM_NAMES order followed by one 0.0 (padding and the bf16 section point at it).
+    Derived by packing a state dict whose values are their own flat position (exact in fp32)."""
+    global _gather_index_cpu
+    if _gather_index_cpu is not None:
+        return _gather_index_cpu
+    from .decoder import pack_state_dict
+    lib = _native.load()
+    sd = {}
+    pos = 1
+    for name in PARAM_NAMES:
+        n = int(np.prod(PARAM_SHAPES[name]))
+        sd[name] = np.arange(pos, pos + n, dtype=np.float32).reshape(PARAM_SHAPES[name])
+        pos += n
+    total = pos - 1
+    assert total < (1 << 24)
+    packed = pack_state_dict(sd, mode=3).numpy()
+    idx = np.rint(packed).astype(np.int64) - 1
+    off, size = C.c_size_t(), C.c_size_t()
+    _native.check(lib.diinn_packed_section(7, C.byref(off), C.byref(size)), "diinn_packed_section")
+    idx[off.value:off.value + size.value] = -1          # bf16 copy: rounded values, not a permutation
+    if idx.max() >= total or idx.min() < -1:
+        raise RuntimeError("packed image is not a permutation of the reference tensors")
+    used = np.zeros(total, bool)
+    used[idx[idx >= 0]] = True
+    if not used.all():
+        raise RuntimeError("packed image does not reference every parameter element")
+    idx[idx < 0] = total                                # the appended zero
+    _gather_index_cpu = torch.from_numpy(idx)
+    return _gather_index_cpu
+
+
+def pack_on_device(params: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Reference-ordered parameter tensors (PARAM_NAMES) on a GPU -> packed image on that GPU."""
+    dev = params[0].device
+    key = str(dev)
+    idx = _gather_index_dev.get(key)
+    if idx is None:
+        idx = pack_gather_index().to(dev)
+        _gather_index_dev[key] = idx
+    flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in params] + [torch.zeros(1, device=dev)])
+    return flat.index_select(0, idx)
+
+
+# ---------------------------------------------------------------------------
+# coordinates as tensors (host tables from the C ABI, bit-exact with the kernels)
+# ---------------------------------------------------------------------------
+def coordinate_tensors(h: int, w: int, hu: int, wu: int, device) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, float]:
+    from .decoder import axis_tables
+    lib = _native.load()
+    small = bool(lib.diinn_uses_small_output_kernel(hu, wu))
+    idx_h, rel_h = axis_tables(h, hu, small)
+    idx_w, rel_w = axis_tables(w, wu, small)
+    ratio = float(np.float32((h * w) / (hu * wu)))
+    return (torch.from_numpy(idx_h.astype(np.int64)).to(device), torch.from_numpy(rel_h).to(device),
+            torch.from_numpy(idx_w.astype(np.int64)).to(device), torch.from_numpy(rel_w).to(device), ratio)
+
+
+# ---------------------------------------------------------------------------
+# backward from the saved planes (device-agnostic tensor algebra)
+# ---------------------------------------------------------------------------
+def _cell_sum(g: torch.Tensor, b: int, hu: int, wu: int, h: int, w: int,
+              idx_h: torch.Tensor, idx_w: torch.Tensor) -> torch.Tensor:
+    """g [C, B*Hu*Wu] -> [B, C, H, W]: sum over the HR pixels of every LR cell (adjoint of the nearest-exact
+    replication, diinn.py:168), as two one-hot GEMMs so the summation order is fixed."""
+    c = g.shape[0]
+    mw = torch.zeros((wu, w), dtype=g.dtype, device=g.device)
+    mw[torch.arange(wu, device=g.device), idx_w] = 1
+    mh = torch.zeros((h, hu), dtype=g.dtype, device=g.device)
+    mh[idx_h, torch.arange(hu, device=g.device)] = 1
+    t = g.reshape(c * b * hu, wu) @ mw                       # [C*B*Hu, W]
+    t = torch.matmul(mh, t.view(c * b, hu, w))               # [C*B, H, W]
+    return t.view(c, b, h, w).permute(1, 0, 2, 3)
+
+
+def backward_from_saved(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tensor,
+                        params: Sequence[torch.Tensor], size: Sequence[int],
+                        need_feat_grad: bool = True) -> Tuple[Optional[torch.Tensor], List[torch.Tensor]]:
+    """Gradients of the mode-3 decoder given d(loss)/d(out).
+
+    gout [B,3,Hu,Wu]; feat [B,64,H,W]; acts [4,2,256,N] (k_i, s_i planes from the training forward);
+    params in PARAM_NAMES order.  Returns (d feat or None, [d param ...] in PARAM_NAMES order).
+
+    With q_i = k_i * sin(s_i), k_0 = relu(P_0[cell]), k_i = relu(Wq_i q_{i-1} + P_i[cell]),
+    s_0 = Q0 syn + bQ0, s_i = Qw_i q_{i-1} + bQ_i, out = L q_3 + bL:
+        g_a,i = g_q,i * sin(s_i) * [k_i > 0]          g_s,i = g_q,i * k_i * cos(s_i)
+        g_q,i-1 = Wq_i^T g_a,i + Qw_i^T g_s,i         dWq_i = g_a,i q_{i-1}^T   dQw_i = g_s,i q_{i-1}^T
+        dP_i[cell] = sum over the cell's pixels of g_a,i;  P = conv3x3(feat; Wx) + bK."""
+    p = dict(zip(PARAM_NAMES, params))
+    b, _, h, w = feat.shape
+    hu, wu = int(size[0]), int(size[1])
+    n = b * hu * wu
+    dev = gout.device
+    idx_h, rel_h, idx_w, rel_w, ratio = coordinate_tensors(h, w, hu, wu, dev)
+    grads: Dict[str, torch.Tensor] = {}
+
+    g_out = gout.to(torch.float32).permute(1, 0, 2, 3).reshape(3, n)
+    lw = p["last_layer.weight"].reshape(3, HIDDEN)
+    q3 = acts[3, 0] * torch.sin(acts[3, 1])
+    grads["last_layer.weight"] = (g_out @ q3.t()).reshape(3, HIDDEN, 1, 1)
+    grads["last_layer.bias"] = g_out.sum(1)
+    del q3
+    g_q = lw.t() @ g_out                                          # [256, N]
+
+    d_p: List[Optional[torch.Tensor]] = [None] * 4                # each [B,256,H,W]
+    d_wq: List[Optional[torch.Tensor]] = [None] * 4
+    for i in (3, 2, 1):
+        k, s = acts[i, 0], acts[i, 1]
+        g_a = g_q * torch.sin(s) * (k > 0)
+        g_s = g_q * k * torch.cos(s)
+        q_prev = acts[i - 1, 0] * torch.sin(acts[i - 1, 1])
+        wfull = p[f"K.{i}.0.weight"].reshape(HIDDEN, HIDDEN + UNFOLD)
+        qw = p[f"Q.{i}.0.weight"].reshape(HIDDEN, HIDDEN)
+        d_wq[i] = g_a @ q_prev.t()
+        grads[f"Q.{i}.0.weight"] = (g_s @ q_prev.t()).reshape(HIDDEN, HIDDEN, 1, 1)
+        grads[f"Q.{i}.0.bias"] = g_s.sum(1)
+        d_p[i] = _cell_sum(g_a, b, hu, wu, h, w, idx_h, idx_w)
+        g_q = wfull[:, :HIDDEN].t() @ g_a + qw.t() @ g_s
+        del g_a, g_s, q_prev
+    k, s = acts[0, 0], acts[0, 1]
+    g_a = g_q * torch.sin(s) * (k > 0)
+    g_s = g_q * k * torch.cos(s)
+    d_p[0] = _cell_sum(g_a, b, hu, wu, h, w, idx_h, idx_w)
+    # syn = (rel_h, rel_w, ratio) per pixel (diinn.py:165-167): dQ0 = g_s syn^T without materialising syn
+    g_s4 = g_s.view(HIDDEN, b, hu, wu)
+    d_q0 = torch.stack([(g_s4.sum((1, 3)) * rel_h).sum(1), (g_s4.sum((1, 2)) * rel_w).sum(1),
+                        g_s4.sum((1, 2, 3)) * ratio], dim=1)
+    grads["Q.0.0.weight"] = d_q0.reshape(HIDDEN, 3, 1, 1)
+    grads["Q.0.0.bias"] = g_s.sum(1)
+    del g_a, g_s, g_q
+
+    # P = conv3x3(feat; Wx[1024,64,3,3]) + bK: weight / input gradients of that one convolution
+    dp = torch.cat(d_p, dim=1).contiguous()                       # [B,1024,H,W]
+    wx = torch.cat([p["K.0.0.weight"].reshape(HIDDEN, UNFOLD)]
+                   + [p[f"K.{i}.0.weight"].reshape(HIDDEN, HIDDEN + UNFOLD)[:, HIDDEN:] for i in (1, 2, 3)], 0)
+    wx = wx.reshape(4 * HIDDEN, IN_CHANNELS, 3, 3).contiguous()
+    d_wx = torch.nn.grad.conv2d_weight(feat, wx.shape, dp, padding=1).reshape(4, HIDDEN, UNFOLD)
+    d_bk = dp.sum((0, 2, 3)).view(4, HIDDEN)
+    d_feat = torch.nn.grad.conv2d_input(feat.shape, wx, dp, padding=1) if need_feat_grad else None
+    grads["K.0.0.weight"] = d_wx[0].reshape(HIDDEN, UNFOLD, 1, 1)
+    grads["K.0.0.bias"] = d_bk[0]
+    for i in (1, 2, 3):
+        grads[f"K.{i}.0.weight"] = torch.cat([d_wq[i], d_wx[i]], dim=1).reshape(HIDDEN, HIDDEN + UNFOLD, 1, 1)
+        grads[f"K.{i}.0.bias"] = d_bk[i]
+    return d_feat, [grads[name] for name in PARAM_NAMES]
+
+
+# ---------------------------------------------------------------------------
+# autograd function
+# ---------------------------------------------------------------------------
+class DecodeMode3Function(torch.autograd.Function):
+    """out = decoder(feat) on the HIP kernels, differentiable in feat and the 18 parameter tensors."""
+
+    @staticmethod
+    def forward(ctx, feat: torch.Tensor, hu: int, wu: int, sin_mode: int, *params: torch.Tensor) -> torch.Tensor:
+        lib = _native.load()
+        if not feat.is_cuda:
+            raise RuntimeError("diinn_amd: the training forward runs on a ROCm GPU only (no CPU implementation)")
+        if len(params) != len(PARAM_NAMES):
+            raise ValueError(f"expected {len(PARAM_NAMES)} parameter tensors in PARAM_NAMES order")
+        feat_c = feat.detach().contiguous().to(torch.float32)
+        b, c, h, w = feat_c.shape
+        if c != IN_CHANNELS:
+            raise ValueError(f"feat must be [B,{IN_CHANNELS},H,W]")
+        n_act = lib.diinn_saved_activation_floats(b, hu, wu)
+        if n_act < 0:
+            raise RuntimeError(f"diinn_amd: B*Hu*Wu = {b * hu * wu} HR pixels in one training forward exceeds the "
+                               f"saved-activation limit (4,194,303); split the batch")
+        dev = feat_c.device
+        packed = pack_on_device(params)
+        workspace = torch.empty(b * h * w * 4 * HIDDEN, dtype=torch.float32, device=dev)
+        acts = torch.empty((4, 2, HIDDEN, b * hu * wu), dtype=torch.float32, device=dev)
+        out = torch.empty((b, 3, hu, wu), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _native.check(lib.diinn_precompute_P(stream, C.c_void_p(feat_c.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                                 C.c_void_p(workspace.data_ptr()), b, h, w, 0, h), "diinn_precompute_P")
+            _native.check(lib.diinn_decode_train_fwd(stream, C.c_void_p(workspace.data_ptr()),
+                                                     C.c_void_p(packed.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                     C.c_void_p(acts.data_ptr()), b, h, w, hu, wu, int(sin_mode)),
+                          "diinn_decode_train_fwd")
+        ctx.save_for_backward(feat_c, acts, *[p_.detach() for p_ in params])
+        ctx.size = (hu, wu)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout: torch.Tensor):
+        feat, acts, *params = ctx.saved_tensors
+        d_feat, d_params = backward_from_saved(gout.contiguous(), feat, acts, params, ctx.size,
+                                               need_feat_grad=ctx.needs_input_grad[0])
+        need = ctx.needs_input_grad[4:]
+        return (d_feat, None, None, None, *[g if nd else None for g, nd in zip(d_params, need)])
+
+
+def decode_with_grad(decoder, feat: torch.Tensor, size: Sequence[int]) -> torch.Tensor:
+    """``ImplicitDecoder.forward(x, size, None)`` under autograd (mode 3)."""
+    named = dict(decoder.named_parameters())
+    params = [named[name] for name in PARAM_NAMES]
+    hu, wu = size
+    return DecodeMode3Function.apply(feat, int(hu), int(wu), int(decoder.sin_mode), *params)

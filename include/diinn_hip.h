@@ -81,6 +81,11 @@ int         diinn_last_hip_error(void);
  * Output: `packed` HOST buffer of diinn_packed_weight_floats() floats, to be
  * copied verbatim to the device by the caller.  Pure host function. */
 size_t diinn_packed_weight_floats(void);
+/* Sections of the packed image (offset and size in floats): 0 WL stacked per-pixel layers, 1 WP the
+ * hoisted 3x3 conv, 2 bK, 3 Q0 (+bQ0), 4 bQ1..3, 5 L, 6 bL, 7 WLB (bf16 copy of WL).  Sections 0-6 are a
+ * pure permutation (plus zero padding) of the reference tensors, so a training loop can re-pack on the
+ * device with one gather; section 7 holds rounded values and is only read by DIINN_COMPUTE_BF16. */
+int    diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats);
 int    diinn_pack_weights(const float* K0w, const float* K0b,
                           const float* const Kw[3], const float* const Kb[3],
                           const float* Q0w, const float* Q0b,
@@ -142,6 +147,20 @@ int diinn_decode_ex(void* stream, const float* feat_dev, const float* packed_dev
 /* Modes 1 and 2 only: the modulation chain per LR cell, k_0 = relu(P_0), k_i = relu(K_i^k k_{i-1} + P_i)
  * (diinn.py:118-121,126-129), for LR rows [r0,r1); k_i overwrites the P_i slot (i = 1..3) of P_dev. */
 int diinn_cell_chain(void* stream, float* P_dev, const float* packed_dev, int B, int H, int W, int r0, int r1);
+
+/* ---- training forward ----------------------------
+ * Replaces: ImplicitDecoder.step(), mode 3, run under autograd -- what forward() does when
+ * bsize is None (diinn.py:170-171, called from SRLitModule.training_step, sr_module.py:127-129).
+ * Same network as diinn_decode_band (whole image, fp32), and in addition every layer's rectified
+ * modulation k_i = relu(.) and sine argument s_i (i = 0..3; q_i = k_i * sin(s_i)) are written to
+ * `acts_dev` for the backward pass: fp32 [4 layers][2: k, s][256 channels][npix], channels in the
+ * reference's order, npix = B*Hu*Wu with pixel index (b*Hu + y)*Wu + x.
+ * diinn_saved_activation_floats() gives the element count (or -1 when B*Hu*Wu exceeds
+ * DIINN_TRAIN_MAX_PIXELS: one 256-row plane group must stay below 4 GiB). */
+#define DIINN_TRAIN_MAX_PIXELS 4194303LL
+long long diinn_saved_activation_floats(int B, int Hu, int Wu);
+int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed_dev, float* out_dev,
+                           float* acts_dev, int B, int H, int W, int Hu, int Wu, int sin_mode);
 
 /* Dominant-kernel launch geometry, for benchmarks/roofline accounting. */
 int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,

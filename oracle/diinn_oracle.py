@@ -269,3 +269,54 @@ def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = Fal
         q = k * torch.sin(qi @ rnd(sw["Qw"][i - 1]).t() + sw["bQ"][i])
     out = q @ sw["L"].t() + sw["bL"]
     return out.permute(0, 3, 1, 2).contiguous()
+
+
+# --------------------------------------------------------------------------
+# training path (reference: step() under autograd, diinn.py:132-139 via forward(bsize=None) :170-171;
+# caller SRLitModule.training_step, sr_module.py:127-129)
+# --------------------------------------------------------------------------
+def reference_gradients(sd, feat, size: Sequence[int], grad_out, dtype=torch.float32):
+    """d sum(out * grad_out) / d(feat, every parameter) by autograd through the reference-form graph
+    (unfold -> nearest-exact replicate -> the 9 conv1x1 of step()).  Pinned by
+    tests/golden/diinn_golden_grad.npz (the real reference's .grad values).  ``dtype=torch.float64``
+    gives a ground truth for error budgets.  Returns (out, d_feat, {name: grad})."""
+    params = {k: _as_t(v).to(dtype).requires_grad_(True) for k, v in sd.items()}
+    f = _as_t(feat).to(dtype).requires_grad_(True)
+    b, c, h, w = f.shape
+    hu, wu = int(size[0]), int(size[1])
+    syn, idx_h, idx_w = make_syn_inp(b, h, w, hu, wu)
+    u = unfold3x3(f)
+    x = u[:, :, torch.from_numpy(idx_h.astype(np.int64))][:, :, :, torch.from_numpy(idx_w.astype(np.int64))]
+    out = _step_mode3(params, x, syn.to(dtype))
+    (out * _as_t(grad_out).to(dtype)).sum().backward()
+    return out.detach(), f.grad, {k: v.grad for k, v in params.items()}
+
+
+@torch.no_grad()
+def saved_planes(sd, feat, size: Sequence[int]):
+    """What the training forward kernel leaves for the backward pass, restated on the CPU:
+    acts[i, 0] = k_i (rectified modulation), acts[i, 1] = s_i (sine argument), i = 0..3, as
+    [256, B*Hu*Wu] planes with pixel index (b*Hu + y)*Wu + x; plus the decoder output."""
+    sd = {k: _as_t(v) for k, v in sd.items()}
+    f = _as_t(feat)
+    b, c, h, w = f.shape
+    hu, wu = int(size[0]), int(size[1])
+    syn, idx_h, idx_w = make_syn_inp(b, h, w, hu, wu)
+    u = unfold3x3(f)
+    x = u[:, :, torch.from_numpy(idx_h.astype(np.int64))][:, :, :, torch.from_numpy(idx_w.astype(np.int64))]
+    n = b * hu * wu
+    acts = torch.empty((4, 2, HIDDEN, n))
+
+    def plane(t):
+        return t.permute(1, 0, 2, 3).reshape(HIDDEN, n)
+
+    k = torch.relu(_conv1x1(x, sd["K.0.0.weight"], sd["K.0.0.bias"]))
+    s = _conv1x1(syn, sd["Q.0.0.weight"], sd["Q.0.0.bias"])
+    acts[0, 0], acts[0, 1] = plane(k), plane(s)
+    q = k * torch.sin(s)
+    for i in range(1, 4):
+        k = torch.relu(_conv1x1(torch.cat([q, x], dim=1), sd[f"K.{i}.0.weight"], sd[f"K.{i}.0.bias"]))
+        s = _conv1x1(q, sd[f"Q.{i}.0.weight"], sd[f"Q.{i}.0.bias"])
+        acts[i, 0], acts[i, 1] = plane(k), plane(s)
+        q = k * torch.sin(s)
+    return _conv1x1(q, sd["last_layer.weight"], sd["last_layer.bias"]), acts

@@ -1,0 +1,188 @@
+"""Training path: gradients of the mode-3 decoder.
+
+CPU part: the oracle's autograd against the REAL reference's .grad fixtures
+(tests/golden/diinn_golden_grad.npz), and the product's backward formulas
+(``training.backward_from_saved``) fed with oracle-computed saved planes against the same fixtures.
+GPU part: the full autograd function (HIP forward with saved activations + library-GEMM backward)
+against fixtures and the float64 oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import diinn_amd.synth as synth
+import diinn_oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROW_STRIDE = 8
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(HERE, "golden", "diinn_golden_grad.npz"))
+
+
+def grad_cases(gold):
+    for key in gold.files:
+        if key.startswith("meta/"):
+            name = key[5:]
+            b, h, w, hu, wu, gain = gold[key]
+            yield name, int(b), int(h), int(w), int(hu), int(wu), float(gain)
+
+
+def _inputs(name, b, h, w, hu, wu, gain):
+    sd = synth.decoder_state_dict(123, gain)
+    feat = synth.encoder_features(123, b, h, w)
+    r = synth.uniform(123, f"gradw:{name}", (b, 3, hu, wu), 1.0)
+    return sd, feat, r
+
+
+def _check_against_fixture(gold, name, d_feat, grads, rtol):
+    """max|g - ref| <= rtol * max|ref| per tensor (K weights: every 8th output row is pinned)."""
+    ref = gold[f"grad/{name}/feat"]
+    err = float(np.abs(d_feat - ref).max())
+    assert err <= rtol * float(np.abs(ref).max()), f"{name} d_feat err {err:.3e}"
+    for pname, g in grads.items():
+        ref = gold[f"grad/{name}/{pname}"]
+        if pname.startswith("K.") and pname.endswith("weight"):
+            g = g[::ROW_STRIDE]
+        assert g.shape == ref.shape, (pname, g.shape, ref.shape)
+        err = float(np.abs(g - ref).max())
+        assert err <= rtol * max(float(np.abs(ref).max()), 1e-6), f"{name} {pname} err {err:.3e}"
+
+
+def test_oracle_autograd_matches_reference_fixture(gold):
+    for name, b, h, w, hu, wu, gain in grad_cases(gold):
+        sd, feat, r = _inputs(name, b, h, w, hu, wu, gain)
+        out, d_feat, grads = orc.reference_gradients(sd, feat, (hu, wu), r)
+        assert float(np.abs(out.numpy() - gold[f"out/{name}"]).max()) <= 1e-6 * max(1.0, float(np.abs(gold[f"out/{name}"]).max()))
+        _check_against_fixture(gold, name, d_feat.numpy(), {k: v.numpy() for k, v in grads.items()}, 2e-5)
+
+
+def test_pack_gather_index_is_the_host_packer():
+    """The device re-pack (one gather) reproduces diinn_pack_weights outside the bf16 section."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.decoder as D
+    import diinn_amd.training as T
+    lib = N.load()
+    sd = synth.decoder_state_dict(7)
+    idx = T.pack_gather_index()
+    flat = torch.cat([torch.from_numpy(sd[n]).reshape(-1) for n in T.PARAM_NAMES] + [torch.zeros(1)])
+    got = flat[idx].numpy()
+    ref = D.pack_state_dict(sd).numpy()
+    off, size = C.c_size_t(), C.c_size_t()
+    assert lib.diinn_packed_section(7, C.byref(off), C.byref(size)) == 0
+    assert off.value + size.value == ref.size
+    assert np.array_equal(got[:off.value], ref[:off.value])
+    assert not got[off.value:].any()
+    total = 0
+    for s in range(8):
+        o, z = C.c_size_t(), C.c_size_t()
+        assert lib.diinn_packed_section(s, C.byref(o), C.byref(z)) == 0
+        assert o.value == total or s == 7          # sections are contiguous (bL padded to 4 before WLB)
+        total = o.value + z.value
+    assert lib.diinn_packed_section(8, C.byref(off), C.byref(size)) != 0
+
+
+def test_backward_formulas_on_cpu(gold):
+    """training.backward_from_saved (the product's backward algebra) with oracle-computed saved planes."""
+    import diinn_amd.training as T
+    for name, b, h, w, hu, wu, gain in grad_cases(gold):
+        sd, feat, r = _inputs(name, b, h, w, hu, wu, gain)
+        _, acts = orc.saved_planes(sd, feat, (hu, wu))
+        params = [torch.from_numpy(sd[n]) for n in T.PARAM_NAMES]
+        d_feat, d_params = T.backward_from_saved(torch.from_numpy(r), torch.from_numpy(feat), acts, params, (hu, wu))
+        grads = {n: g.numpy() for n, g in zip(T.PARAM_NAMES, d_params)}
+        for n in T.PARAM_NAMES:
+            assert grads[n].shape == tuple(T.PARAM_SHAPES[n])
+        _check_against_fixture(gold, name, d_feat.numpy(), grads, 5e-5)
+
+
+@pytest.mark.gpu
+def test_hip_training_forward_saves_the_oracle_planes(gold):
+    """decode_kernel<SAVE>: output equals the inference kernel's, saved planes equal the oracle's."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.decoder as D
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    for (b, h, w, hu, wu, gain) in [(2, 12, 10, 31, 27, 1.0), (1, 9, 14, 36, 56, 3.0), (1, 20, 33, 47, 130, 1.0)]:
+        sd = synth.decoder_state_dict(123, gain)
+        feat = synth.encoder_features(123, b, h, w)
+        ref_out, ref_acts = orc.saved_planes(sd, feat, (hu, wu))
+        packed = D.pack_state_dict(sd).to(dev)
+        f = torch.from_numpy(feat).to(dev)
+        ws = torch.empty(b * h * w * 1024, device=dev)
+        n = b * hu * wu
+        assert lib.diinn_saved_activation_floats(b, hu, wu) == 8 * 256 * n
+        acts = torch.full((4, 2, 256, n), float("nan"), device=dev)
+        out = torch.empty((b, 3, hu, wu), device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        N.check(lib.diinn_precompute_P(stream, C.c_void_p(f.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                       C.c_void_p(ws.data_ptr()), b, h, w, 0, h), "P")
+        N.check(lib.diinn_decode_train_fwd(stream, C.c_void_p(ws.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                           C.c_void_p(out.data_ptr()), C.c_void_p(acts.data_ptr()),
+                                           b, h, w, hu, wu, N.SIN_DEFAULT), "train_fwd")
+        torch.cuda.synchronize()
+        infer = D.decode_features(f, packed, (hu, wu))
+        assert torch.equal(out, infer)                     # same arithmetic, different pixel-to-lane mapping
+        tol = 1e-4 * max(1.0, float(ref_out.abs().max()))
+        assert float((out.cpu() - ref_out).abs().max()) <= tol
+        a = acts.cpu()
+        assert torch.isfinite(a).all()                     # every plane element written
+        scale = max(1.0, float(ref_acts.abs().max()))
+        assert float((a - ref_acts).abs().max()) <= 2e-5 * scale
+    assert lib.diinn_saved_activation_floats(1, 4096, 4096) == -1
+    assert lib.diinn_decode_train_fwd(None, C.c_void_p(ws.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                      C.c_void_p(out.data_ptr()), C.c_void_p(acts.data_ptr()),
+                                      1, 8, 8, 4096, 4096, N.SIN_DEFAULT) == N.ERR_TOO_LARGE
+
+
+@pytest.mark.gpu
+def test_autograd_through_hip_decoder(gold):
+    """ImplicitDecoder.forward(x, size) with autograd on (training call, sr_module.py:128): gradients of
+    every parameter and of the features against the real reference's fixtures and the fp64 oracle."""
+    import diinn_amd.decoder as D
+    dev = torch.device("cuda:0")
+    for name, b, h, w, hu, wu, gain in grad_cases(gold):
+        sd, feat, r = _inputs(name, b, h, w, hu, wu, gain)
+        dec = D.ImplicitDecoder(mode=3, init_q=False)
+        dec.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        dec = dec.to(dev).train()
+        x = torch.from_numpy(feat).to(dev).requires_grad_(True)
+        y = dec(x, [hu, wu])
+        (y * torch.from_numpy(r).to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.cpu().numpy() for n, p in dec.named_parameters()}
+        _check_against_fixture(gold, name, x.grad.cpu().numpy(), grads, 1e-4)
+        # full tensors (not only the pinned rows) against the float64 oracle
+        _, d_feat64, g64 = orc.reference_gradients(sd, feat, (hu, wu), r, dtype=torch.float64)
+        for n, g in grads.items():
+            ref = g64[n].numpy()
+            assert float(np.abs(g - ref).max()) <= 1e-4 * max(float(np.abs(ref).max()), 1e-6), n
+        assert float(np.abs(x.grad.cpu().numpy() - d_feat64.numpy()).max()) <= 1e-4 * float(d_feat64.abs().max())
+
+
+@pytest.mark.gpu
+def test_training_step_decreases_loss():
+    """A few Adam steps of SRLitModule.step (sr_module.py:113-125,127-129) on one synthetic batch: the
+    L1 loss goes down, i.e. encoder and decoder gradients flow through the HIP forward."""
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = M.SRLitModule(arch="diinn", mode=3, init_q=False).to(dev).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    lr = torch.rand(2, 3, 16, 16, device=dev)
+    batch = {2: (lr, torch.rand(2, 3, 32, 32, device=dev), ["a", "b"]),
+             3: (lr, torch.rand(2, 3, 48, 48, device=dev), ["a", "b"])}
+    losses = []
+    for _ in range(6):
+        opt.zero_grad(set_to_none=True)
+        loss, _ = net.step(batch)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0], losses
