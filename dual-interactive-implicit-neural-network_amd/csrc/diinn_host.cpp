@@ -36,9 +36,9 @@ const char* diinn_status_string(int status) {
 size_t diinn_packed_weight_floats(void) { return PACKED_FLOATS; }
 
 int diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats) {
-    static const size_t off[8] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB};
-    static const size_t sz[8]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB};
-    if (section < 0 || section > 7 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
+    static const size_t off[9] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT};
+    static const size_t sz[9]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT};
+    if (section < 0 || section > 8 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
     *offset_floats = off[section];
     *size_floats = sz[section];
     return DIINN_OK;
@@ -72,6 +72,26 @@ int diinn_pack_weights(const float* K0w, const float* K0b,
                         const int h = lane >> 5;
                         for (int e = 0; e < 4; ++e) {
                             const int in = chan_of(4 * kg + e, h);
+                            dst[lane * 4 + e] = part == 0 ? wk[(size_t)out * (HID + UNF) + in]
+                                                          : wq[(size_t)out * HID + in];
+                        }
+                    }
+                }
+    }
+    // WLT: WL with the two channel indices swapped (backward pass)
+    for (int i = 0; i < 3; ++i) {
+        const float* wk = Kw[i];
+        const float* wq = Qw[i];
+        for (int m = 0; m < 8; ++m)
+            for (int kg = 0; kg < WL_KG; ++kg)
+                for (int part = 0; part < 2; ++part) {
+                    float* dst = packed + OFF_WLT + (size_t)i * WL_LAYER +
+                                 (((size_t)m * WL_KG + kg) * 2 + part) * WL_PIECE;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int in = 32 * m + (lane & 31);
+                        const int h = lane >> 5;
+                        for (int e = 0; e < 4; ++e) {
+                            const int out = chan_of(4 * kg + e, h);
                             dst[lane * 4 + e] = part == 0 ? wk[(size_t)out * (HID + UNF) + in]
                                                           : wq[(size_t)out * HID + in];
                         }

@@ -466,6 +466,168 @@ __global__ __launch_bounds__(256, 1) void cell_chain_kernel(const ChainParams p)
 }
 
 // ---------------------------------------------------------------------------------
+// backward pass of the per-pixel layers (training; reference: autograd through step(), diinn.py:132-139)
+//
+// With q_i = k_i * sin(s_i) and the planes k_i, s_i saved by decode_kernel<SAVE>:
+//     g_a,i = g_q,i * sin(s_i) * [k_i > 0]      (gradient at the modulation pre-activation)
+//     g_s,i = g_q,i * k_i * cos(s_i)            (gradient at the sine argument)
+//     g_q,i-1 = Wq_i^T g_a,i + Qw_i^T g_s,i     (stacked [256 x 512] GEMM per pixel)
+// bwd_head_kernel  : g_q,3 = L^T g_out, gates of layer 3 (elementwise, HBM-bound).
+// bwd_layer_kernel : one launch per layer i = 3, 2, 1.  A wave owns 32 pixels, loads their 512 gate
+//                    gradients G_i = (g_a,i ; g_s,i) into registers as the MFMA B operand (the plane
+//                    rows are read in accumulator order, so no shuffle is needed), streams the
+//                    transposed weights (WLT section) exactly like the forward kernel streams WL, and
+//                    its epilogue applies the gates of layer i-1 and writes G_{i-1} and q_{i-1}.
+// The weight gradients are then plain GEMMs over the pixel axis of the planes written here
+// (dW_i = G_i q_{i-1}^T), left to the BLAS library by the host side.
+// ---------------------------------------------------------------------------------
+struct BwdParams {
+    const float* Wt;         // packed image
+    const float* acts;       // [4][2][256][npix]  k_i, s_i
+    const float* gout;       // [3][npix]
+    float* G;                // [4][2][256][npix]  g_a,i, g_s,i
+    float* Q;                // [4][257][npix]     q_i (row 256 is the caller's ones row, never written)
+    long long npix;
+    unsigned row_bytes;      // npix * 4
+    int layer;               // bwd_layer_kernel: consumes G_layer, produces G_{layer-1}, Q_{layer-1}
+};
+
+__device__ __forceinline__ void dsincos(float x, float& sn, float& cs) {
+    constexpr float C_HI = 0.15915494309189533577f;
+    constexpr float C_LO = 6.4206383650924e-09f;
+    const float k = __builtin_rintf(x * C_HI);
+    float r = __builtin_fmaf(x, C_HI, -k);
+    r = __builtin_fmaf(x, C_LO, r);
+    sn = __builtin_amdgcn_sinf(r);
+    cs = __builtin_amdgcn_cosf(r);
+}
+
+__device__ __forceinline__ float ld_act(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
+}
+
+__global__ __launch_bounds__(256) void bwd_head_kernel(const BwdParams p) {
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= p.npix) return;
+    const size_t n = (size_t)p.npix;
+    const float g0 = p.gout[pix], g1 = p.gout[n + pix], g2 = p.gout[2 * n + pix];
+    const float* __restrict__ L = p.Wt + OFF_L;
+    const int c0 = blockIdx.y * 16;
+#pragma unroll 4
+    for (int c = c0; c < c0 + 16; ++c) {
+        float g = L[c] * g0;
+        g = __builtin_fmaf(L[HID + c], g1, g);
+        g = __builtin_fmaf(L[2 * HID + c], g2, g);
+        const float kv = p.acts[((size_t)(6 * HID + c)) * n + pix];
+        const float sv = p.acts[((size_t)(7 * HID + c)) * n + pix];
+        float sn, cs;
+        dsincos(sv, sn, cs);
+        p.G[((size_t)(6 * HID + c)) * n + pix] = kv > 0.0f ? g * sn : 0.0f;
+        p.G[((size_t)(7 * HID + c)) * n + pix] = g * kv * cs;
+        p.Q[((size_t)(3 * (HID + 1) + c)) * n + pix] = kv * sn;
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const long long pix = ((long long)blockIdx.x * 4 + wave) * 32 + j;
+    const bool valid = pix < p.npix;
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
+
+    const int li = p.layer;                                     // 1..3
+    const unsigned rowb = p.row_bytes;
+    const size_t group = (size_t)HID * rowb;                    // bytes of one 256-row plane group (< 4 GiB)
+    const unsigned voff = valid ? (unsigned)pix * 4u + 4u * h * rowb : 0xFFFFFFF0u;   // out of range: loads 0, stores dropped
+    auto rsrc_of = [&](const void* base) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)group, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t inA = rsrc_of((const char*)p.G + (size_t)(2 * li + 0) * group);
+    const __amdgpu_buffer_rsrc_t inS = rsrc_of((const char*)p.G + (size_t)(2 * li + 1) * group);
+    const __amdgpu_buffer_rsrc_t actK = rsrc_of((const char*)p.acts + (size_t)(2 * (li - 1) + 0) * group);
+    const __amdgpu_buffer_rsrc_t actS = rsrc_of((const char*)p.acts + (size_t)(2 * (li - 1) + 1) * group);
+    const __amdgpu_buffer_rsrc_t outA = rsrc_of((const char*)p.G + (size_t)(2 * (li - 1) + 0) * group);
+    const __amdgpu_buffer_rsrc_t outS = rsrc_of((const char*)p.G + (size_t)(2 * (li - 1) + 1) * group);
+    const __amdgpu_buffer_rsrc_t outQ = rsrc_of((const char*)p.Q + (size_t)(li - 1) * (HID + 1) * rowb);
+
+    // B operand: register kk = 16m + r of lane-half h holds channel chan_of(kk, h) of this lane's pixel
+    float ga[128], gs[128];
+#pragma unroll
+    for (int kk = 0; kk < 128; ++kk) {
+        const unsigned so = (unsigned)(32 * (kk >> 4) + (kk & 3) + 8 * ((kk & 15) >> 2)) * rowb;
+        ga[kk] = ld_act(inA, voff, so);
+        gs[kk] = ld_act(inS, voff, so);
+    }
+
+    constexpr int PF = DECODE_PREFETCH;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);   // reads past the end return 0
+    const int lane_off = lane * 16;
+    const int wp = (int)((OFF_WLT + (size_t)(li - 1) * WL_LAYER) * sizeof(float));
+    f32x4 rk[PF], rq[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        rk[d] = ld_piece(wrs, lane_off, wp + (2 * d + 0) * PIECE_BYTES);
+        rq[d] = ld_piece(wrs, lane_off, wp + (2 * d + 1) * PIECE_BYTES);
+    }
+
+    // gates of layer li-1 for one finished element: g = d loss / d q_{li-1}[channel, pixel]
+    auto gate_store = [&](int mt, int r, float g, float kv, float sv) {
+        const unsigned so = (unsigned)(32 * mt + (r & 3) + 8 * (r >> 2)) * rowb;
+        float sn, cs;
+        dsincos(sv, sn, cs);
+        st_act(outA, voff, so, kv > 0.0f ? g * sn : 0.0f);
+        st_act(outS, voff, so, g * kv * cs);
+        st_act(outQ, voff, so, kv * sn);
+    };
+
+    f32x16 pg;                                                   // finished g_q tile (sum of the two accumulators)
+    float kt[16], st[16];                                        // saved k, s of the tile being finished
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 ak, as;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ak[r] = 0.0f; as[r] = 0.0f; }
+#pragma unroll
+        for (int kg = 0; kg < WL_KG; ++kg) {
+            const int s = m * WL_KG + kg;
+            const f32x4 wk = rk[s % PF];
+            const f32x4 wq = rq[s % PF];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ak = MFMA32(wk[e], ga[4 * kg + e], ak);
+                as = MFMA32(wq[e], gs[4 * kg + e], as);
+            }
+            rk[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF) + 0) * PIECE_BYTES);
+            rq[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF) + 1) * PIECE_BYTES);
+            if (m > 0 && kg == 0) {                               // saved planes of tile m-1, used from kg = 8 on
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned so = (unsigned)(32 * (m - 1) + (r & 3) + 8 * (r >> 2)) * rowb;
+                    kt[r] = ld_act(actK, voff, so);
+                    st[r] = ld_act(actS, voff, so);
+                }
+            }
+            if (m > 0 && kg >= 8 && kg < 24) {                    // one epilogue element of tile m-1 every 8 MFMAs
+                const int r = kg - 8;
+                gate_store(m - 1, r, pg[r], kt[r], st[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pg[r] = ak[r] + as[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned so = (unsigned)(32 * 7 + (r & 3) + 8 * (r >> 2)) * rowb;
+        kt[r] = ld_act(actK, voff, so);
+        st[r] = ld_act(actS, voff, so);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gate_store(7, r, pg[r], kt[r], st[r]);
+}
+
+// ---------------------------------------------------------------------------------
 // decode kernel, bf16 operands (optional path, BASELINE config 5; tolerance restated in
 // DESIGN.md): same structure as decode_kernel -- one wave owns 32 pixels and keeps their
 // activation in registers -- but layers 1..3 run on v_mfma_f32_32x32x16_bf16: weights are bf16
@@ -966,6 +1128,28 @@ int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed
     else
         hipLaunchKernelGGL((decode_kernel<DIINN_SIN_ACCURATE, true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
+}
+
+int diinn_backward_data(void* stream, const float* gout_planes_dev, const float* acts_dev,
+                        const float* packed_dev, float* G_dev, float* Q_dev, long long npix) {
+    if (!gout_planes_dev || !acts_dev || !packed_dev || !G_dev || !Q_dev) return DIINN_ERR_INVALID_ARG;
+    if (npix <= 0) return DIINN_ERR_INVALID_ARG;
+    if (npix > DIINN_TRAIN_MAX_PIXELS) return DIINN_ERR_TOO_LARGE;
+    BwdParams p;
+    p.Wt = packed_dev; p.acts = acts_dev; p.gout = gout_planes_dev; p.G = G_dev; p.Q = Q_dev;
+    p.npix = npix; p.row_bytes = (unsigned)(npix * 4); p.layer = 0;
+    hipLaunchKernelGGL(bwd_head_kernel, dim3((unsigned)((npix + 255) / 256), HID / 16), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_status(e);
+    const unsigned blocks = (unsigned)((npix + 127) / 128);
+    for (int layer = 3; layer >= 1; --layer) {
+        p.layer = layer;
+        hipLaunchKernelGGL(bwd_layer_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_status(e);
+    }
+    return DIINN_OK;
 }
 
 int diinn_decode(void* stream, const float* feat_dev, const float* packed_dev,

@@ -55,7 +55,12 @@ constexpr size_t WLB_PIECE  = 64 * 4;                      // floats (= 64 lanes
 constexpr size_t WLB_LAYER  = (size_t)8 * 16 * 2 * WLB_PIECE;
 constexpr size_t OFF_WLB    = OFF_BL + 4;
 constexpr size_t SZ_WLB     = 3 * WLB_LAYER;               // 196,608 floats = 768 KiB
-constexpr size_t PACKED_FLOATS = OFF_WLB + SZ_WLB;         // 1,183,236
+// WLT: the per-pixel layers transposed, for the backward pass (training): g_q[i-1] = Wq_i^T g_a + Qw_i^T g_s.
+//     Same shape as WL, [layer 3][m 8][kg 32][part 2][lane 64][e 4], with the roles of the two channel
+//     indices swapped: value = W_part[ out = chan_of(4kg+e, lane>>5) ][ in = 32m + (lane&31) ].
+constexpr size_t OFF_WLT    = OFF_WLB + SZ_WLB;
+constexpr size_t SZ_WLT     = SZ_WL;
+constexpr size_t PACKED_FLOATS = OFF_WLT + SZ_WLT;         // 1,576,452
 
 // channel held by activation register (m, r) of lane-half h
 DIINN_HD int chan_of(int kk /* = 16*m + r */, int h) {

@@ -7,12 +7,16 @@ records ~30 ATen ops per call on the materialised [B,576,Hu,Wu] tensor.  Here:
   forward   precompute_P_kernel, then decode_kernel<SAVE> (C ABI ``diinn_decode_train_fwd``): the fused
             inference kernel that additionally writes every layer's rectified modulation k_i and sine
             argument s_i as [channel][pixel] planes -- all the backward pass needs.
-  backward  ``backward_from_saved``: with the saved planes the whole backward is a chain of PLAIN GEMMs
-            over the pixel axis (rocBLAS through torch.matmul: data gradients [256x512].[512xN],
-            weight gradients [512xN].[Nx256]), elementwise gates, a per-cell segment sum (two one-hot
-            GEMMs, deterministic) and the 3x3 conv's input/weight gradients (MIOpen through
-            torch.nn.grad).  It is written in device-agnostic tensor algebra so the gradient formulas
-            are unit-tested on CPU against autograd of the oracle; the forward has no CPU form.
+  backward  ``backward_fused``: the per-pixel chain (gates and the transposed stacked GEMMs
+            g_q[i-1] = Wq_i^T g_a + Qw_i^T g_s) runs on bwd_head_kernel + 3 x bwd_layer_kernel (C ABI
+            ``diinn_backward_data``), which leave the gate-gradient planes G_i and the activations q_i
+            as [channel][pixel] planes; every parameter gradient is then ONE plain library GEMM over
+            the pixel axis per layer (rocBLAS through torch.matmul), plus a per-cell segment sum (two
+            one-hot GEMMs, deterministic) and the 3x3 conv's input/weight gradients (MIOpen through
+            torch.nn.grad).
+            ``backward_from_saved`` states the same gradients in device-agnostic tensor algebra; it
+            is the unit-tested formula sheet (CPU, against the reference's own .grad fixtures) and
+            the on-GPU cross-check of the fused path.  The forward has no CPU form.
 
 Weights change every optimiser step, so the packed image is rebuilt on the device each forward by one
 gather through a permutation index derived once from the host packer (``pack_gather_index``).
@@ -184,19 +188,76 @@ def backward_from_saved(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tens
     grads["Q.0.0.bias"] = g_s.sum(1)
     del g_a, g_s, g_q
 
-    # P = conv3x3(feat; Wx[1024,64,3,3]) + bK: weight / input gradients of that one convolution
     dp = torch.cat(d_p, dim=1).contiguous()                       # [B,1024,H,W]
+    d_bk = dp.sum((0, 2, 3)).view(4, HIDDEN)
+    d_feat = _conv_and_assemble(p, feat, dp, d_wq, d_bk, grads, need_feat_grad)
+    return d_feat, [grads[name] for name in PARAM_NAMES]
+
+
+def _conv_and_assemble(p: Dict[str, torch.Tensor], feat: torch.Tensor, dp: torch.Tensor, d_wq, d_bk,
+                       grads: Dict[str, torch.Tensor], need_feat_grad: bool) -> Optional[torch.Tensor]:
+    """P = conv3x3(feat; Wx[1024,64,3,3]) + bK: weight / input gradients of that one convolution (MIOpen),
+    then the K.i gradients in the reference's [256, 256+576] layout."""
     wx = torch.cat([p["K.0.0.weight"].reshape(HIDDEN, UNFOLD)]
                    + [p[f"K.{i}.0.weight"].reshape(HIDDEN, HIDDEN + UNFOLD)[:, HIDDEN:] for i in (1, 2, 3)], 0)
     wx = wx.reshape(4 * HIDDEN, IN_CHANNELS, 3, 3).contiguous()
     d_wx = torch.nn.grad.conv2d_weight(feat, wx.shape, dp, padding=1).reshape(4, HIDDEN, UNFOLD)
-    d_bk = dp.sum((0, 2, 3)).view(4, HIDDEN)
     d_feat = torch.nn.grad.conv2d_input(feat.shape, wx, dp, padding=1) if need_feat_grad else None
     grads["K.0.0.weight"] = d_wx[0].reshape(HIDDEN, UNFOLD, 1, 1)
     grads["K.0.0.bias"] = d_bk[0]
     for i in (1, 2, 3):
         grads[f"K.{i}.0.weight"] = torch.cat([d_wq[i], d_wx[i]], dim=1).reshape(HIDDEN, HIDDEN + UNFOLD, 1, 1)
         grads[f"K.{i}.0.bias"] = d_bk[i]
+    return d_feat
+
+
+def backward_fused(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tensor, params: Sequence[torch.Tensor],
+                   packed: torch.Tensor, size: Sequence[int],
+                   need_feat_grad: bool = True) -> Tuple[Optional[torch.Tensor], List[torch.Tensor]]:
+    """The same gradients as ``backward_from_saved`` with the per-pixel chain on the HIP kernels
+    (C ABI ``diinn_backward_data``: bwd_head_kernel + 3 x bwd_layer_kernel write the gate-gradient planes
+    G_i and the activations q_i), followed by one library GEMM per layer over the pixel axis:
+    [dWq_i ; dQw_i | bias sums] = G_i [512 x N] . (q_{i-1} ; 1)^T [N x 257]."""
+    lib = _native.load()
+    p = dict(zip(PARAM_NAMES, params))
+    b, _, h, w = feat.shape
+    hu, wu = int(size[0]), int(size[1])
+    n = b * hu * wu
+    dev = gout.device
+    idx_h, rel_h, idx_w, rel_w, ratio = coordinate_tensors(h, w, hu, wu, dev)
+    gp = gout.to(torch.float32).permute(1, 0, 2, 3).reshape(3, n).contiguous()
+    g = torch.empty((4, 2, HIDDEN, n), dtype=torch.float32, device=dev)
+    q = torch.empty((4, HIDDEN + 1, n), dtype=torch.float32, device=dev)
+    q[:, HIDDEN] = 1.0
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _native.check(lib.diinn_backward_data(stream, C.c_void_p(gp.data_ptr()), C.c_void_p(acts.data_ptr()),
+                                              C.c_void_p(packed.data_ptr()), C.c_void_p(g.data_ptr()),
+                                              C.c_void_p(q.data_ptr()), n), "diinn_backward_data")
+    grads: Dict[str, torch.Tensor] = {}
+    dl = gp @ q[3].t()                                            # [3, 257]
+    grads["last_layer.weight"] = dl[:, :HIDDEN].reshape(3, HIDDEN, 1, 1)
+    grads["last_layer.bias"] = dl[:, HIDDEN]
+    d_wq: List[Optional[torch.Tensor]] = [None] * 4
+    d_bk: List[Optional[torch.Tensor]] = [None] * 4
+    for i in (3, 2, 1):
+        dw = g[i].view(2 * HIDDEN, n) @ q[i - 1].t()             # [512, 257]
+        d_wq[i] = dw[:HIDDEN, :HIDDEN]
+        d_bk[i] = dw[:HIDDEN, HIDDEN]
+        grads[f"Q.{i}.0.weight"] = dw[HIDDEN:, :HIDDEN].reshape(HIDDEN, HIDDEN, 1, 1)
+        grads[f"Q.{i}.0.bias"] = dw[HIDDEN:, HIDDEN]
+    # layer 0: (g_a,0 ; g_s,0) . (rel_h, rel_w, ratio, 1)^T  (syn of diinn.py:165-167 plus the bias column)
+    syn = torch.empty((4, b, hu, wu), dtype=torch.float32, device=dev)
+    syn[0] = rel_h[None, :, None]
+    syn[1] = rel_w[None, None, :]
+    syn[2] = ratio
+    syn[3] = 1.0
+    d0 = g[0].view(2 * HIDDEN, n) @ syn.view(4, n).t()            # [512, 4]
+    d_bk[0] = d0[:HIDDEN, 3]
+    grads["Q.0.0.weight"] = d0[HIDDEN:, :3].reshape(HIDDEN, 3, 1, 1)
+    grads["Q.0.0.bias"] = d0[HIDDEN:, 3]
+    dp = _cell_sum(g[:, 0].reshape(4 * HIDDEN, n), b, hu, wu, h, w, idx_h, idx_w).contiguous()   # [B,1024,H,W]
+    d_feat = _conv_and_assemble(p, feat, dp, d_wq, d_bk, grads, need_feat_grad)
     return d_feat, [grads[name] for name in PARAM_NAMES]
 
 
@@ -234,15 +295,15 @@ class DecodeMode3Function(torch.autograd.Function):
                                                      C.c_void_p(packed.data_ptr()), C.c_void_p(out.data_ptr()),
                                                      C.c_void_p(acts.data_ptr()), b, h, w, hu, wu, int(sin_mode)),
                           "diinn_decode_train_fwd")
-        ctx.save_for_backward(feat_c, acts, *[p_.detach() for p_ in params])
+        ctx.save_for_backward(feat_c, acts, packed, *[p_.detach() for p_ in params])
         ctx.size = (hu, wu)
         return out
 
     @staticmethod
     def backward(ctx, gout: torch.Tensor):
-        feat, acts, *params = ctx.saved_tensors
-        d_feat, d_params = backward_from_saved(gout.contiguous(), feat, acts, params, ctx.size,
-                                               need_feat_grad=ctx.needs_input_grad[0])
+        feat, acts, packed, *params = ctx.saved_tensors
+        d_feat, d_params = backward_fused(gout.contiguous(), feat, acts, params, packed, ctx.size,
+                                          need_feat_grad=ctx.needs_input_grad[0])
         need = ctx.needs_input_grad[4:]
         return (d_feat, None, None, None, *[g if nd else None for g, nd in zip(d_params, need)])
 

@@ -82,9 +82,10 @@ int         diinn_last_hip_error(void);
  * copied verbatim to the device by the caller.  Pure host function. */
 size_t diinn_packed_weight_floats(void);
 /* Sections of the packed image (offset and size in floats): 0 WL stacked per-pixel layers, 1 WP the
- * hoisted 3x3 conv, 2 bK, 3 Q0 (+bQ0), 4 bQ1..3, 5 L, 6 bL, 7 WLB (bf16 copy of WL).  Sections 0-6 are a
- * pure permutation (plus zero padding) of the reference tensors, so a training loop can re-pack on the
- * device with one gather; section 7 holds rounded values and is only read by DIINN_COMPUTE_BF16. */
+ * hoisted 3x3 conv, 2 bK, 3 Q0 (+bQ0), 4 bQ1..3, 5 L, 6 bL, 7 WLB (bf16 copy of WL), 8 WLT (WL transposed,
+ * read by the backward pass).  Every section but 7 is a pure permutation (plus zero padding) of the
+ * reference tensors, so a training loop can re-pack on the device with one gather; section 7 holds
+ * rounded values and is only read by DIINN_COMPUTE_BF16. */
 int    diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats);
 int    diinn_pack_weights(const float* K0w, const float* K0b,
                           const float* const Kw[3], const float* const Kb[3],
@@ -161,6 +162,21 @@ int diinn_cell_chain(void* stream, float* P_dev, const float* packed_dev, int B,
 long long diinn_saved_activation_floats(int B, int Hu, int Wu);
 int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed_dev, float* out_dev,
                            float* acts_dev, int B, int H, int W, int Hu, int Wu, int sin_mode);
+
+/* ---- backward pass of the per-pixel layers (training) ------------------------------
+ * Replaces: autograd's backward through step() (diinn.py:132-139), the part that runs per HR pixel.
+ * Inputs: gout_planes_dev [3][npix] = d loss / d out as channel planes; acts_dev from
+ * diinn_decode_train_fwd; the packed image (section 8, the transposed layers, is read).
+ * Outputs, fp32 channel planes over the same pixel index:
+ *   G_dev [4][2][256][npix]: g_a,i = d loss / d (modulation pre-activation of layer i) and
+ *                            g_s,i = d loss / d (sine argument of layer i), i = 0..3;
+ *   Q_dev [4][257][npix]   : rows 0..255 of layer i = q_i = k_i * sin(s_i); row 256 is never written
+ *                            (callers keep it at 1.0 so G_i . Q_{i-1}^T also carries the bias sums).
+ * From these every parameter gradient is a plain GEMM over the pixel axis (left to the BLAS library):
+ *   d[Wq_i ; Qw_i] = G_i Q_{i-1}^T,  dL = gout Q_3^T,  dQ0 = g_s,0 syn^T,  dP_i[cell] = sum g_a,i.
+ * Enqueues 4 kernels on `stream`; no allocation, no synchronisation. */
+int diinn_backward_data(void* stream, const float* gout_planes_dev, const float* acts_dev,
+                        const float* packed_dev, float* G_dev, float* Q_dev, long long npix);
 
 /* Dominant-kernel launch geometry, for benchmarks/roofline accounting. */
 int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,

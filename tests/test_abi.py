@@ -86,7 +86,7 @@ def test_packed_image_layout(lib):
     import diinn_amd.decoder as D
     sd = synth.decoder_state_dict(11)
     packed = D.pack_state_dict(sd).numpy()
-    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608
+    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608 + 393_216
     lane = np.arange(64)
     out_l, h_l = lane & 31, lane >> 5
     # WL section
@@ -122,6 +122,13 @@ def test_packed_image_layout(lib):
     assert np.array_equal(packed[off: off + 768].reshape(3, 256), sd["last_layer.weight"][:, :, 0, 0])
     off += 768
     assert np.array_equal(packed[off: off + 3], sd["last_layer.bias"])
+    # WLT section (backward pass): WL with the two channel indices swapped
+    WLT = packed[986_628 + 196_608:].reshape(3, 8, 32, 2, 64, 4)
+    for _ in range(200):
+        i, m, kg, part, l, e = (int(rng.integers(n)) for n in (3, 8, 32, 2, 64, 4))
+        cin, o = 32 * m + (l & 31), _chan_of(4 * kg + e, l >> 5)
+        w = sd[f"K.{i + 1}.0.weight"][o, cin, 0, 0] if part == 0 else sd[f"Q.{i + 1}.0.weight"][o, cin, 0, 0]
+        assert WLT[i, m, kg, part, l, e] == w
     # every channel appears exactly once per lane-half in the activation register order
     seen = sorted(_chan_of(kk, h) for kk in range(128) for h in range(2))
     assert seen == list(range(256))

@@ -74,16 +74,17 @@ def test_pack_gather_index_is_the_host_packer():
     ref = D.pack_state_dict(sd).numpy()
     off, size = C.c_size_t(), C.c_size_t()
     assert lib.diinn_packed_section(7, C.byref(off), C.byref(size)) == 0
-    assert off.value + size.value == ref.size
-    assert np.array_equal(got[:off.value], ref[:off.value])
-    assert not got[off.value:].any()
+    lo, hi = off.value, off.value + size.value
+    assert np.array_equal(got[:lo], ref[:lo]) and np.array_equal(got[hi:], ref[hi:])
+    assert not got[lo:hi].any()                    # bf16 section: rounded values, left zero by the gather
     total = 0
-    for s in range(8):
+    for s in range(9):
         o, z = C.c_size_t(), C.c_size_t()
         assert lib.diinn_packed_section(s, C.byref(o), C.byref(z)) == 0
-        assert o.value == total or s == 7          # sections are contiguous (bL padded to 4 before WLB)
+        assert o.value == total                    # sections are contiguous
         total = o.value + z.value
-    assert lib.diinn_packed_section(8, C.byref(off), C.byref(size)) != 0
+    assert total == ref.size == lib.diinn_packed_weight_floats()
+    assert lib.diinn_packed_section(9, C.byref(off), C.byref(size)) != 0
 
 
 def test_backward_formulas_on_cpu(gold):
@@ -183,6 +184,72 @@ def test_training_step_decreases_loss():
         loss, _ = net.step(batch)
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert all(np.isfinite(losses))
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.gpu
+def test_fused_backward_equals_formula_backward_on_gpu():
+    """bwd_head_kernel + bwd_layer_kernel (C ABI diinn_backward_data) against the same gradients stated as
+    plain tensor algebra (backward_from_saved) on the same saved planes, at a size with ragged tiles
+    (N not a multiple of 128) and rectified-to-zero channels; also the planes themselves."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.decoder as D
+    import diinn_amd.training as T
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    for (b, h, w, hu, wu, gain) in [(3, 17, 13, 50, 41, 1.0), (1, 8, 8, 24, 24, 3.0)]:
+        sd = synth.decoder_state_dict(5, gain)
+        feat = torch.from_numpy(synth.encoder_features(5, b, h, w)).to(dev)
+        params = [torch.from_numpy(sd[n]).to(dev) for n in T.PARAM_NAMES]
+        gout = torch.from_numpy(synth.uniform(5, "g", (b, 3, hu, wu), 1.0)).to(dev)
+        n = b * hu * wu
+        packed = T.pack_on_device(params)
+        assert torch.equal(packed[: 986_628].cpu(), D.pack_state_dict(sd)[: 986_628])
+        ws = torch.empty(b * h * w * 1024, device=dev)
+        acts = torch.empty((4, 2, 256, n), device=dev)
+        out = torch.empty((b, 3, hu, wu), device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        N.check(lib.diinn_precompute_P(stream, C.c_void_p(feat.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                       C.c_void_p(ws.data_ptr()), b, h, w, 0, h), "P")
+        N.check(lib.diinn_decode_train_fwd(stream, C.c_void_p(ws.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                           C.c_void_p(out.data_ptr()), C.c_void_p(acts.data_ptr()),
+                                           b, h, w, hu, wu, N.SIN_DEFAULT), "fwd")
+        # planes
+        gp = gout.permute(1, 0, 2, 3).reshape(3, n).contiguous()
+        g = torch.full((4, 2, 256, n), float("nan"), device=dev)
+        q = torch.full((4, 257, n), float("nan"), device=dev)
+        q[:, 256] = 1.0
+        N.check(lib.diinn_backward_data(stream, C.c_void_p(gp.data_ptr()), C.c_void_p(acts.data_ptr()),
+                                        C.c_void_p(packed.data_ptr()), C.c_void_p(g.data_ptr()),
+                                        C.c_void_p(q.data_ptr()), n), "bwd")
+        torch.cuda.synchronize()
+        assert torch.isfinite(g).all() and torch.isfinite(q).all()
+        assert torch.equal(q[:, 256], torch.ones_like(q[:, 256]))
+        a64 = acts.double()
+        q_ref = a64[:, 0] * torch.sin(a64[:, 1])
+        assert float((q[:, :256].double() - q_ref).abs().max()) <= 2e-6 * max(1.0, float(q_ref.abs().max()))
+        g_q = params[T.PARAM_NAMES.index("last_layer.weight")].view(3, 256).double().t() @ gp.double()
+        for i in (3, 2, 1, 0):
+            ga = g_q * torch.sin(a64[i, 1]) * (a64[i, 0] > 0)
+            gs = g_q * a64[i, 0] * torch.cos(a64[i, 1])
+            scale = max(float(ga.abs().max()), float(gs.abs().max()), 1e-12)
+            assert float((g[i, 0].double() - ga).abs().max()) <= 2e-5 * scale, i
+            assert float((g[i, 1].double() - gs).abs().max()) <= 2e-5 * scale, i
+            if i:
+                wq = params[T.PARAM_NAMES.index(f"K.{i}.0.weight")].view(256, 832)[:, :256].double()
+                qw = params[T.PARAM_NAMES.index(f"Q.{i}.0.weight")].view(256, 256).double()
+                g_q = wq.t() @ ga + qw.t() @ gs
+        # gradients
+        df_a, dp_a = T.backward_fused(gout, feat, acts, params, packed, (hu, wu))
+        df_b, dp_b = T.backward_from_saved(gout, feat, acts, params, (hu, wu))
+        torch.cuda.synchronize()
+        assert float((df_a - df_b).abs().max()) <= 5e-5 * float(df_b.abs().max())
+        for name, x, y in zip(T.PARAM_NAMES, dp_a, dp_b):
+            assert x.shape == y.shape
+            assert float((x - y).abs().max()) <= 5e-5 * max(float(y.abs().max()), 1e-6), name
+    assert lib.diinn_backward_data(None, C.c_void_p(gp.data_ptr()), C.c_void_p(acts.data_ptr()),
+                                   C.c_void_p(packed.data_ptr()), C.c_void_p(g.data_ptr()),
+                                   C.c_void_p(q.data_ptr()), 1 << 23) == N.ERR_TOO_LARGE
