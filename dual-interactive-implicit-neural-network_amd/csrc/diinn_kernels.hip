@@ -628,6 +628,166 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
 }
 
 // ---------------------------------------------------------------------------------
+// cell_sum_kernel (training backward): dP_i[b, ch, cy, cx] = sum of g_a,i over the HR pixels whose
+// nearest LR cell is (cy, cx) -- the adjoint of the nearest-exact replication (diinn.py:168).  The
+// index tables are monotone, so a cell's pixels are the rectangle [seg_h[cy], seg_h[cy+1]) x
+// [seg_w[cx], seg_w[cx+1]).  One thread per output element, cx fastest: neighbouring lanes read
+// neighbouring column segments of the same HR rows, so a wave's loads cover contiguous row spans.
+// Fixed summation order (no atomics).  Output is NCHW [B][1024][H][W], channel = 256 i + ch: the
+// layout the 3x3 convolution's weight/input gradients are taken in.  HBM-bound (reads the g_a planes once).
+// ---------------------------------------------------------------------------------
+struct CellSumParams {
+    const float* G;          // [4][2][256][npix]; the a-planes (second index 0) are summed
+    float* dP;               // [B][1024][H][W]
+    const int* seg_h;        // [H+1] first HR row of every LR row (seg_h[H] = Hu)
+    const int* seg_w;        // [W+1]
+    int B, H, W, Hu, Wu;
+};
+
+__global__ __launch_bounds__(256) void cell_sum_kernel(const CellSumParams p) {
+    const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int hb = (p.H + 3) / 4;
+    const int b = blockIdx.y / hb;
+    const int cy = (blockIdx.y - b * hb) * 4 + (threadIdx.x >> 6);
+    if (cx >= p.W || cy >= p.H) return;
+    const int plane = blockIdx.z;                                    // 256 i + ch
+    const size_t npix = (size_t)p.B * p.Hu * p.Wu;
+    const float* __restrict__ src = p.G + ((size_t)(2 * (plane >> 8)) * HID + (plane & 255)) * npix
+                                    + (size_t)b * p.Hu * p.Wu;
+    const int y0 = p.seg_h[cy], y1 = p.seg_h[cy + 1];
+    const int x0 = p.seg_w[cx], x1 = p.seg_w[cx + 1];
+    float acc = 0.0f;
+    for (int y = y0; y < y1; ++y) {
+        const float* __restrict__ row = src + (size_t)y * p.Wu;
+        float r = 0.0f;
+        for (int x = x0; x < x1; ++x) r += row[x];
+        acc += r;
+    }
+    p.dP[(((size_t)b * PCH + plane) * p.H + cy) * p.W + cx] = acc;
+}
+
+// ---------------------------------------------------------------------------------
+// plane_gemm_kernel (training backward, weight gradients): C[M x Nc] = A[M x npix] . B[Nc x npix]^T with
+// both operands stored as pixel-contiguous planes (the G_i and q_i planes), i.e. a GEMM whose reduction
+// axis is the pixel axis.  Split-K: workgroup (block, ks) reduces pixels [ks*kchunk, (ks+1)*kchunk)
+// for a 128 x 256 output block and writes its partial product to part[ks]; the caller adds the ksplit
+// partials (fixed order, no atomics).  4 waves = 2 (M) x 2 (N), wave tile 64 x 128 = 2 x 4 MFMA tiles
+// (128 accumulator registers).  Operand fragments go global -> registers directly: lane (row = l&31,
+// half = l>>5) reads 16 bytes of its row, four loads per 32-pixel step cover the row's whole 128-byte
+// line while it is hot; the MFMA k-pair (pixel e, pixel 4+e) is the same for A and B, and the sum
+// over pixels does not care about the order.  Optional extra column Nc: row sums of A (bias gradients).
+// ---------------------------------------------------------------------------------
+struct PlaneGemmParams {
+    const float* A;          // [M][npix]
+    const float* Bm;         // [Nc][npix]
+    float* part;             // [ksplit][M][ldc]
+    long long npix;
+    int M, Nc, ldc, kchunk, with_rowsum;
+};
+
+__global__ __launch_bounds__(256, 1) void plane_gemm_kernel(const PlaneGemmParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int nblk = p.Nc / 256;
+    const int m0 = (blockIdx.x / nblk) * 128 + (wave & 1) * 64;
+    const int n0 = (blockIdx.x % nblk) * 256 + (wave >> 1) * 128;
+    const int ks = blockIdx.y;
+    const long long kbeg = (long long)ks * p.kchunk;
+    long long kend = kbeg + p.kchunk;
+    if (kend > p.npix) kend = p.npix;
+
+    const size_t rowb = (size_t)p.npix * 4;
+    // descriptors start at the wave's first row and end with the operand: reads past it return 0
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.A + (size_t)m0 * rowb), 0, (int)(unsigned)((size_t)(p.M - m0) * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.Bm + (size_t)n0 * rowb), 0, (int)(unsigned)((size_t)(p.Nc - n0) * rowb), 0x00020000);
+    const unsigned voff = (unsigned)j * (unsigned)rowb + 16u * h;
+    const unsigned tile_rows = 32u * (unsigned)rowb;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float rs[2] = {0.0f, 0.0f};
+
+    f32x4 fa[2][2][4], fb[2][4][4];                              // [buffer][tile][t]: 4 pixels each
+    auto load = [&](int buf, long long k) {
+        const unsigned kb = (unsigned)(k * 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                fa[buf][a][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    ra, (int)voff, (int)(a * tile_rows + kb + 32u * t), 0));
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                fb[buf][b][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rb, (int)voff, (int)(b * tile_rows + kb + 32u * t), 0));
+        }
+    };
+    auto compute = [&](int buf, long long k) {
+        if (k + 32 > kend) {                                     // ragged last step: drop pixels >= kend (wave-uniform branch)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = k + 8 * t + 4 * h + e < kend;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) fa[buf][a][t][e] = in ? fa[buf][a][t][e] : 0.0f;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) fb[buf][b][t][e] = in ? fb[buf][b][t][e] : 0.0f;
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = MFMA32(fa[buf][a][t][e], fb[buf][b][t][e], acc[a][b]);
+                    rs[a] += fa[buf][a][t][e];
+                }
+            }
+    };
+
+    if (kbeg < kend) {
+        load(0, kbeg);
+        for (long long k = kbeg; k < kend; k += 64) {
+            if (k + 32 < kend) load(1, k + 32);
+            compute(0, k);
+            if (k + 32 < kend) {
+                if (k + 64 < kend) load(0, k + 64);
+                compute(1, k + 32);
+            }
+        }
+    }
+
+    float* __restrict__ dst = p.part + (size_t)ks * p.M * p.ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                dst[(size_t)row * p.ldc + n0 + 32 * b + j] = acc[a][b][r];
+            }
+    if (p.with_rowsum && n0 == 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float v = rs[a] + __shfl_xor(rs[a], 32);
+            if (h == 0) dst[(size_t)(m0 + 32 * a + j) * p.ldc + p.Nc] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // decode kernel, bf16 operands (optional path, BASELINE config 5; tolerance restated in
 // DESIGN.md): same structure as decode_kernel -- one wave owns 32 pixels and keeps their
 // activation in registers -- but layers 1..3 run on v_mfma_f32_32x32x16_bf16: weights are bf16
@@ -1150,6 +1310,36 @@ int diinn_backward_data(void* stream, const float* gout_planes_dev, const float*
         if (e != hipSuccess) return hip_status(e);
     }
     return DIINN_OK;
+}
+
+int diinn_plane_gemm_nt(void* stream, const float* A_dev, const float* B_dev, float* part_dev,
+                        int M, int Nc, long long npix, int ksplit, int with_rowsum) {
+    if (!A_dev || !B_dev || !part_dev || M <= 0 || Nc <= 0 || npix <= 0 || ksplit <= 0) return DIINN_ERR_INVALID_ARG;
+    if (M % 128 || Nc % 256) return DIINN_ERR_UNSUPPORTED;
+    if (npix > DIINN_TRAIN_MAX_PIXELS || (long long)M * npix * 4 > 0xFFFFFFFFLL || (long long)Nc * npix * 4 > 0xFFFFFFFFLL ||
+        ksplit > 65535)
+        return DIINN_ERR_TOO_LARGE;                           // one operand must fit a buffer descriptor (4 GiB)
+    PlaneGemmParams p;
+    p.A = A_dev; p.Bm = B_dev; p.part = part_dev; p.npix = npix; p.M = M; p.Nc = Nc;
+    p.ldc = Nc + (with_rowsum ? 1 : 0);
+    p.with_rowsum = with_rowsum ? 1 : 0;
+    const long long per = (npix + ksplit - 1) / ksplit;
+    p.kchunk = (int)((per + 31) / 32 * 32);
+    hipLaunchKernelGGL(plane_gemm_kernel, dim3((M / 128) * (Nc / 256), ksplit), dim3(256), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+int diinn_backward_cell_sum(void* stream, const float* G_dev, const int32_t* seg_h_dev, const int32_t* seg_w_dev,
+                            float* dP_dev, int B, int H, int W, int Hu, int Wu) {
+    if (!G_dev || !seg_h_dev || !seg_w_dev || !dP_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (Hu <= 0 || Wu <= 0) return DIINN_ERR_INVALID_ARG;
+    if ((long long)B * Hu * Wu > DIINN_TRAIN_MAX_PIXELS || (long long)((H + 3) / 4) * B > 65535)
+        return DIINN_ERR_TOO_LARGE;
+    CellSumParams p{G_dev, dP_dev, seg_h_dev, seg_w_dev, B, H, W, Hu, Wu};
+    hipLaunchKernelGGL(cell_sum_kernel, dim3((W + 63) / 64, ((H + 3) / 4) * B, PCH), dim3(256), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
 }
 
 int diinn_decode(void* stream, const float* feat_dev, const float* packed_dev,

@@ -52,6 +52,8 @@ PARAM_SHAPES: Dict[str, Tuple[int, ...]] = {
     "last_layer.weight": (3, HIDDEN, 1, 1), "last_layer.bias": (3,),
 }
 
+WGRAD_KSPLIT = 64          # pixel-axis splits of the weight-gradient GEMM: 4 output blocks x 64 = one workgroup per CU
+
 _gather_index_cpu: Optional[torch.Tensor] = None
 _gather_index_dev: Dict[str, torch.Tensor] = {}
 
@@ -216,8 +218,9 @@ def backward_fused(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tensor, p
                    need_feat_grad: bool = True) -> Tuple[Optional[torch.Tensor], List[torch.Tensor]]:
     """The same gradients as ``backward_from_saved`` with the per-pixel chain on the HIP kernels
     (C ABI ``diinn_backward_data``: bwd_head_kernel + 3 x bwd_layer_kernel write the gate-gradient planes
-    G_i and the activations q_i), followed by one library GEMM per layer over the pixel axis:
-    [dWq_i ; dQw_i | bias sums] = G_i [512 x N] . (q_{i-1} ; 1)^T [N x 257]."""
+    G_i and the activations q_i), followed by one GEMM per layer over the pixel axis
+    (plane_gemm_kernel, C ABI ``diinn_plane_gemm_nt``): [dWq_i ; dQw_i | bias sums] = G_i [512 x N] . q_{i-1}^T
+    [N x 256] plus the row sums of G_i; the two skinny products (head, layer 0) stay with the BLAS library."""
     lib = _native.load()
     p = dict(zip(PARAM_NAMES, params))
     b, _, h, w = feat.shape
@@ -240,8 +243,16 @@ def backward_fused(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tensor, p
     grads["last_layer.bias"] = dl[:, HIDDEN]
     d_wq: List[Optional[torch.Tensor]] = [None] * 4
     d_bk: List[Optional[torch.Tensor]] = [None] * 4
+    ksplit = max(1, min(WGRAD_KSPLIT, (n + 31) // 32))
+    part = torch.empty((3, ksplit, 2 * HIDDEN, HIDDEN + 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        for i in (3, 2, 1):                                       # plane_gemm_kernel: G_i . q_{i-1}^T, split over pixels
+            _native.check(lib.diinn_plane_gemm_nt(stream, C.c_void_p(g[i].data_ptr()), C.c_void_p(q[i - 1].data_ptr()),
+                                                  C.c_void_p(part[i - 1].data_ptr()), 2 * HIDDEN, HIDDEN, n, ksplit, 1),
+                          "diinn_plane_gemm_nt")
+    dws = part.sum(1)                                             # [3, 512, 257]: [dWq_i ; dQw_i | bias sums]
     for i in (3, 2, 1):
-        dw = g[i].view(2 * HIDDEN, n) @ q[i - 1].t()             # [512, 257]
+        dw = dws[i - 1]
         d_wq[i] = dw[:HIDDEN, :HIDDEN]
         d_bk[i] = dw[:HIDDEN, HIDDEN]
         grads[f"Q.{i}.0.weight"] = dw[HIDDEN:, :HIDDEN].reshape(HIDDEN, HIDDEN, 1, 1)
@@ -256,7 +267,14 @@ def backward_fused(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tensor, p
     d_bk[0] = d0[:HIDDEN, 3]
     grads["Q.0.0.weight"] = d0[HIDDEN:, :3].reshape(HIDDEN, 3, 1, 1)
     grads["Q.0.0.bias"] = d0[HIDDEN:, 3]
-    dp = _cell_sum(g[:, 0].reshape(4 * HIDDEN, n), b, hu, wu, h, w, idx_h, idx_w).contiguous()   # [B,1024,H,W]
+    # dP: per-cell sums of the g_a planes (cell_sum_kernel; rectangles from the monotone index tables)
+    seg_h = torch.searchsorted(idx_h, torch.arange(h + 1, device=dev)).to(torch.int32)
+    seg_w = torch.searchsorted(idx_w, torch.arange(w + 1, device=dev)).to(torch.int32)
+    dp = torch.empty((b, 4 * HIDDEN, h, w), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _native.check(lib.diinn_backward_cell_sum(stream, C.c_void_p(g.data_ptr()), C.c_void_p(seg_h.data_ptr()),
+                                                  C.c_void_p(seg_w.data_ptr()), C.c_void_p(dp.data_ptr()),
+                                                  b, h, w, hu, wu), "diinn_backward_cell_sum")
     d_feat = _conv_and_assemble(p, feat, dp, d_wq, d_bk, grads, need_feat_grad)
     return d_feat, [grads[name] for name in PARAM_NAMES]
 

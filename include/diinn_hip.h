@@ -178,6 +178,23 @@ int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed
 int diinn_backward_data(void* stream, const float* gout_planes_dev, const float* acts_dev,
                         const float* packed_dev, float* G_dev, float* Q_dev, long long npix);
 
+/* Weight-gradient GEMM over the pixel axis: C[M x Nc] = A[M x npix] . B[Nc x npix]^T, A and B fp32 planes
+ * (row stride npix) such as G_i and q_{i-1} above; M % 128 == 0, Nc % 256 == 0; each operand < 4 GiB.
+ * Split-K without atomics: part_dev is [ksplit][M][ldc] and slice ks holds the product over pixels
+ * [ks*chunk, (ks+1)*chunk); the caller adds the slices.  ldc = Nc, or Nc + 1 with `with_rowsum`, whose
+ * extra column receives the row sums of A (the bias gradients).  Replaces the weight-gradient GEMMs
+ * autograd runs for the nine 1x1 convolutions of step() (diinn.py:132-139). */
+int diinn_plane_gemm_nt(void* stream, const float* A_dev, const float* B_dev, float* part_dev,
+                        int M, int Nc, long long npix, int ksplit, int with_rowsum);
+
+/* dP[b][256 i + ch][cy][cx] = sum of g_a,i (G_dev, from diinn_backward_data) over the HR pixels whose
+ * nearest LR cell is (cy, cx): the adjoint of the nearest-exact replication of diinn.py:168, i.e. the
+ * gradient at the hoisted 3x3 convolution's output, NCHW [B][1024][H][W].  seg_h_dev [H+1] / seg_w_dev
+ * [W+1] (int32, device) give the first HR row / column of every LR row / column (last entry Hu / Wu);
+ * the index tables are monotone, so a cell's pixels form a rectangle.  Deterministic (no atomics). */
+int diinn_backward_cell_sum(void* stream, const float* G_dev, const int32_t* seg_h_dev, const int32_t* seg_w_dev,
+                            float* dP_dev, int B, int H, int W, int Hu, int Wu);
+
 /* Dominant-kernel launch geometry, for benchmarks/roofline accounting. */
 int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,
                              int* grid_x, int* grid_y, int* grid_z, int* block);

@@ -253,3 +253,33 @@ def test_fused_backward_equals_formula_backward_on_gpu():
     assert lib.diinn_backward_data(None, C.c_void_p(gp.data_ptr()), C.c_void_p(acts.data_ptr()),
                                    C.c_void_p(packed.data_ptr()), C.c_void_p(g.data_ptr()),
                                    C.c_void_p(q.data_ptr()), 1 << 23) == N.ERR_TOO_LARGE
+
+
+@pytest.mark.gpu
+def test_plane_gemm_kernel():
+    """C = A . B^T over the pixel axis with split-K partials and the row-sum column, against float64,
+    for ragged pixel counts (tails inside a 32-pixel step, empty trailing splits)."""
+    import ctypes as C
+    import diinn_amd._native as N
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    gen = torch.Generator(device=dev).manual_seed(1)
+    for (m, nc, npix, ksplit) in [(128, 256, 1000, 3), (512, 256, 4099, 64), (256, 512, 77, 8), (128, 256, 31, 1)]:
+        a = torch.randn((m, npix), device=dev, generator=gen)
+        b = torch.randn((nc, npix), device=dev, generator=gen)
+        part = torch.full((ksplit, m, nc + 1), float("nan"), device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        N.check(lib.diinn_plane_gemm_nt(stream, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()),
+                                        C.c_void_p(part.data_ptr()), m, nc, npix, ksplit, 1), "plane_gemm")
+        torch.cuda.synchronize()
+        got = part.double().sum(0)
+        ref = torch.cat([a.double() @ b.double().t(), a.double().sum(1, keepdim=True)], dim=1)
+        assert torch.isfinite(got).all()
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * max(1.0, (npix / 1000) ** 0.5), (m, nc, npix)
+        part2 = torch.full((ksplit, m, nc), float("nan"), device=dev)
+        N.check(lib.diinn_plane_gemm_nt(stream, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()),
+                                        C.c_void_p(part2.data_ptr()), m, nc, npix, ksplit, 0), "plane_gemm")
+        torch.cuda.synchronize()
+        assert torch.equal(part2, part[:, :, :nc])
+    assert lib.diinn_plane_gemm_nt(None, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()),
+                                   C.c_void_p(part.data_ptr()), 100, 256, 31, 1, 0) == N.ERR_UNSUPPORTED

@@ -6,7 +6,7 @@
            9 conv1x1 + 3 cat + 4 sin under autograd), restated inline (the reference itself does not
            travel to the GPU box)
 
-usage: train_time.py [B] [LR] [SCALE]     (default 16 48 4: the reference's training patch geometry,
+usage: train_time.py [B] [LR] [SCALE] [--only-ours]     (default 16 48 4: the reference's training patch geometry,
        configs/default.yaml: batch 16, 48x48 LR patches, scales 2-4)
 """
 import os
@@ -46,9 +46,11 @@ def timeit(fn, n=5, warm=2):
 
 
 def main():
-    b = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-    lr = int(sys.argv[2]) if len(sys.argv) > 2 else 48
-    sc = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    only_ours = "--only-ours" in sys.argv          # for profiling: skip the eager comparison
+    argv = [a for a in sys.argv if not a.startswith("--")]
+    b = int(argv[1]) if len(argv) > 1 else 16
+    lr = int(argv[2]) if len(argv) > 2 else 48
+    sc = int(argv[3]) if len(argv) > 3 else 4
     dev = torch.device("cuda:0")
     hu = wu = lr * sc
     dec = D.ImplicitDecoder(mode=3, init_q=False)
@@ -85,6 +87,8 @@ def main():
     print(f"  training forward (saves planes)    {timeit(ours_train_fwd):8.2f} ms")
     t_ours = timeit(ours_step)
     print(f"  training step fwd+bwd (ours)       {t_ours:8.2f} ms   {n / t_ours / 1e3:.1f} Mpix/s")
+    if only_ours:
+        return
     y = eager_forward(dec, feat, (hu, wu), idx_h, idx_w, syn)
     with torch.no_grad():
         err = float((y - dec(feat, [hu, wu], 30000)).abs().max())
