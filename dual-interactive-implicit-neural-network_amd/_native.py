@@ -61,11 +61,13 @@ SIGNATURES = {
     "diinn_decode_launch_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip]),
     "diinn_backward_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_longlong]),
+    "diinn_plane_gemm_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int]),
+    "diinn_plane_rowdot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_longlong, C.c_int]),
     "diinn_backward_cell_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "diinn_plane_gemm_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                      C.c_longlong, C.c_int, C.c_int]),
-    "diinn_saved_activation_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "diinn_training_plane_floats": (C.c_longlong, [C.c_longlong, C.c_int]),
     "diinn_decode_train_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
 }

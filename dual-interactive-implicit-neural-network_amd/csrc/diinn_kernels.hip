@@ -88,8 +88,8 @@ struct DecodeParams {
     int B, H, W, Hu, Wu, y0, y1;
     float ratio;           // fp32(H*W / (Hu*Wu))   (diinn.py:166)
     Axis ah, aw;
-    float* acts;           // training forward only (SAVE): [4 layers][2: k, s][256][npix] saved activations
-    unsigned act_row_bytes;  // npix * 4 (npix = B*Hu*Wu)
+    float* acts;           // training forward only (SAVE): saved activations, tiled planes [4 layers][ntiles][512][32]
+    long long npix;        // SAVE: B*Hu*Wu
 #ifdef DIINN_STAMPS
     unsigned long long* stamps;   // diagnostic build only: 8 x u64 per wave (never in the shipped library)
 #endif
@@ -159,12 +159,25 @@ constexpr int WG_TILES_X = 2, WG_TILES_Y = 2;   // 4 waves -> 16x8 HR pixels per
 //
 // SAVE = true (training forward, reference step() under autograd: diinn.py:132-139 called with
 // bsize=None from sr_module.py:127-129): the same network, and every layer's rectified modulation
-// k_i and sine argument s_i are written to p.acts as plain [channel][pixel] planes (standard
-// channel order, pixel = (b*Hu + y)*Wu + x) for the backward pass.  One wave then owns a 32x1 pixel
-// run so each store instruction writes two full 128-byte lines.
-constexpr int SAVE_TILE_W = 32;
+// k_i and sine argument s_i are written to p.acts for the backward pass.  One wave then owns 32
+// consecutive pixels of the flattened (b, y, x) index -- one PLANE TILE.
+//
+// Training planes are stored tiled: a group of C channel rows over npix pixels is
+// [ceil(npix/32) tiles][C rows][32 pixels], element (c, pix) at ((pix >> 5) * C + c) * 32 + (pix & 31).
+// Everything a wave touches for its 32 pixels is one contiguous block (64 KiB for C = 512), every
+// row segment is a full 128-byte line, and the weight-gradient GEMM over the pixel axis reads
+// contiguous [rows][32] panels (with plain [C][npix] planes each of its loads touched 32 rows
+// megabytes apart: 1.6x slower, measured).
+constexpr int PLANE_TILE = 32;
+constexpr int ACT_ROWS = 2 * HID;                               // rows 0..255: k_i (or g_a,i); 256..511: s_i (or g_s,i)
+constexpr unsigned PLANE_ROW_BYTES = PLANE_TILE * sizeof(float);   // 128
 __device__ __forceinline__ void st_act(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, (int)soff, 0);
+}
+// descriptor of one tile (rows x 32 floats) of a tiled plane group
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* group, long long tile, int rows) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(group + (size_t)tile * rows * PLANE_TILE), 0,
+                                             rows * (int)PLANE_ROW_BYTES, 0x00020000);
 }
 
 template <int SIN_MODE, bool KPART = true, bool SAVE = false>
@@ -173,11 +186,21 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform (scalar offsets)
     const int h = lane >> 5, j = lane & 31;
 
-    const int x = SAVE ? blockIdx.x * (SAVE_TILE_W * WG_TILES_X) + (wave & 1) * SAVE_TILE_W + j
-                       : blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
-    const int y = SAVE ? p.y0 + blockIdx.y * WG_TILES_Y + (wave >> 1)
-                       : p.y0 + blockIdx.y * (TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
-    const int b = blockIdx.z;
+    int x, y, b;
+    const long long ptile = (long long)blockIdx.x * 4 + wave;   // SAVE: plane tile of this wave
+    if constexpr (SAVE) {                                        // 32 consecutive flattened pixels
+        const long long pix = ptile * PLANE_TILE + j;
+        const long long pc = pix < p.npix ? pix : p.npix - 1;    // lanes past the end compute on the last pixel
+        const int hw = p.Hu * p.Wu;
+        b = (int)(pc / hw);
+        const int rem = (int)(pc - (long long)b * hw);
+        y = rem / p.Wu;
+        x = pix < p.npix ? rem - y * p.Wu : p.Wu;                // ... and are marked invalid below
+    } else {
+        x = blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
+        y = p.y0 + blockIdx.y * (TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
+        b = blockIdx.z;
+    }
     const bool valid = (x < p.Wu) && (y < p.y1);
     // whole wave outside the band/image: nothing to do (wave-uniform, no barriers in this kernel)
     if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
@@ -201,22 +224,21 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     const float* __restrict__ Wt = p.Wt;
     const float* __restrict__ Pc = p.P + (((size_t)b * p.H + iy) * p.W + ix) * PCH + 4 * h;
 
-    // saved-activation planes (SAVE): one buffer descriptor per (layer, k|s) plane group of 256 rows;
-    // a lane's offset is its pixel inside the row of channel 4h, rows advance by a scalar offset.
-    // Lanes outside the image carry an offset past the descriptor's range: the store is dropped.
-    const unsigned act_rows = 256u * p.act_row_bytes;           // bytes of one plane group (< 4 GiB, checked by the ABI)
-    const unsigned act_voff = !SAVE ? 0u
-        : valid ? (unsigned)(((size_t)b * p.Hu + y) * p.Wu + x) * 4u + 4u * h * p.act_row_bytes : 0xFFFFFFF0u;
-    auto act_rsrc = [&](int layer, int which) {
-        return __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.acts + (size_t)(2 * layer + which) * act_rows),
-                                                 0, (int)act_rows, 0x00020000);
+    // saved-activation planes (SAVE): one buffer descriptor per layer covering this wave's plane tile
+    // (512 rows x 32 pixels); a lane's offset is its pixel inside the row of channel 4h, the channel
+    // row is a compile-time scalar offset.  Lanes past the end carry an offset outside the
+    // descriptor's range: the store is dropped.
+    const long long act_tiles = (p.npix + PLANE_TILE - 1) / PLANE_TILE;
+    const unsigned act_voff = (SAVE && valid) ? 4u * j + 4u * h * PLANE_ROW_BYTES : 0xFFFFFFF0u;
+    auto act_rsrc = [&](int layer) {
+        return tile_rsrc(p.acts + (size_t)layer * act_tiles * ACT_ROWS * PLANE_TILE, ptile, ACT_ROWS);
     };
 
     // ---- layer 0: q0 = relu(P_0[cell]) * sin(Q0 . (rel_h, rel_w, ratio) + bQ0)   (diinn.py:133-134)
     float q[128];
     {
         const float* __restrict__ Q0 = Wt + OFF_Q0 + 4 * h;
-        const __amdgpu_buffer_rsrc_t ak0 = act_rsrc(0, 0), as0 = act_rsrc(0, 1);
+        const __amdgpu_buffer_rsrc_t ar0 = act_rsrc(0);
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
 #pragma unroll
@@ -235,8 +257,8 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
                     const float kv = relu0(pv[e]);
                     q[16 * m + 4 * g + e] = kv * dsin<SIN_MODE>(a);
                     if constexpr (SAVE) {
-                        st_act(ak0, act_voff, (unsigned)(c0 + e) * p.act_row_bytes, kv);
-                        st_act(as0, act_voff, (unsigned)(c0 + e) * p.act_row_bytes, a);
+                        st_act(ar0, act_voff, (unsigned)(c0 + e) * PLANE_ROW_BYTES, kv);
+                        st_act(ar0, act_voff, (unsigned)(HID + c0 + e) * PLANE_ROW_BYTES, a);
                     }
                 }
             }
@@ -277,8 +299,8 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
         const float* __restrict__ Bn = Wt + OFF_BQ + nl * HID + 4 * h;
         float qn[128];
         f32x16 pk, ps;                                           // finished accumulators of the previous tile
-        const __amdgpu_buffer_rsrc_t akl = act_rsrc(layer + 1, 0), asl = act_rsrc(layer + 1, 1);
-        (void)akl; (void)asl;
+        const __amdgpu_buffer_rsrc_t arl = act_rsrc(layer + 1);
+        (void)arl;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             f32x16 ak, as;
@@ -320,9 +342,9 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
                     const float kv = relu0(pk[r]);
                     qn[16 * (m - 1) + r] = kv * ABL_SIN(ps[r]);
                     if constexpr (SAVE) {                        // register r of tile m-1 = channel 32(m-1) + (r&3) + 8(r>>2) + 4h
-                        const unsigned so = (unsigned)(32 * (m - 1) + (r & 3) + 8 * (r >> 2)) * p.act_row_bytes;
-                        st_act(akl, act_voff, so, kv);
-                        st_act(asl, act_voff, so, ps[r]);
+                        const unsigned so = (unsigned)(32 * (m - 1) + (r & 3) + 8 * (r >> 2)) * PLANE_ROW_BYTES;
+                        st_act(arl, act_voff, so, kv);
+                        st_act(arl, act_voff, so + HID * PLANE_ROW_BYTES, ps[r]);
                     }
                 }
             }
@@ -334,9 +356,9 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
             const float kv = relu0(pk[r]);
             qn[16 * 7 + r] = kv * dsin<SIN_MODE>(ps[r]);
             if constexpr (SAVE) {
-                const unsigned so = (unsigned)(32 * 7 + (r & 3) + 8 * (r >> 2)) * p.act_row_bytes;
-                st_act(akl, act_voff, so, kv);
-                st_act(asl, act_voff, so, ps[r]);
+                const unsigned so = (unsigned)(32 * 7 + (r & 3) + 8 * (r >> 2)) * PLANE_ROW_BYTES;
+                st_act(arl, act_voff, so, kv);
+                st_act(arl, act_voff, so + HID * PLANE_ROW_BYTES, ps[r]);
             }
         }
 #pragma unroll
@@ -473,22 +495,22 @@ __global__ __launch_bounds__(256, 1) void cell_chain_kernel(const ChainParams p)
 //     g_s,i = g_q,i * k_i * cos(s_i)            (gradient at the sine argument)
 //     g_q,i-1 = Wq_i^T g_a,i + Qw_i^T g_s,i     (stacked [256 x 512] GEMM per pixel)
 // bwd_head_kernel  : g_q,3 = L^T g_out, gates of layer 3 (elementwise, HBM-bound).
-// bwd_layer_kernel : one launch per layer i = 3, 2, 1.  A wave owns 32 pixels, loads their 512 gate
-//                    gradients G_i = (g_a,i ; g_s,i) into registers as the MFMA B operand (the plane
-//                    rows are read in accumulator order, so no shuffle is needed), streams the
+// bwd_layer_kernel : one launch per layer i = 3, 2, 1.  A wave owns one plane tile (32 pixels), loads
+//                    their 512 gate gradients G_i = (g_a,i ; g_s,i) into registers as the MFMA B operand
+//                    (the rows are read in accumulator order, so no shuffle is needed), streams the
 //                    transposed weights (WLT section) exactly like the forward kernel streams WL, and
 //                    its epilogue applies the gates of layer i-1 and writes G_{i-1} and q_{i-1}.
-// The weight gradients are then plain GEMMs over the pixel axis of the planes written here
-// (dW_i = G_i q_{i-1}^T), left to the BLAS library by the host side.
+// plane_gemm_kernel / plane_rowdot_kernel : the parameter gradients, GEMMs over the pixel axis of the
+//                    planes written here (dW_i = G_i q_{i-1}^T ...).
+// All planes are tiled (see PLANE_TILE above): acts, G [4][ntiles][512][32]; Q [4][ntiles][256][32].
 // ---------------------------------------------------------------------------------
 struct BwdParams {
     const float* Wt;         // packed image
-    const float* acts;       // [4][2][256][npix]  k_i, s_i
-    const float* gout;       // [3][npix]
-    float* G;                // [4][2][256][npix]  g_a,i, g_s,i
-    float* Q;                // [4][257][npix]     q_i (row 256 is the caller's ones row, never written)
-    long long npix;
-    unsigned row_bytes;      // npix * 4
+    const float* acts;       // k_i (rows 0..255), s_i (rows 256..511)
+    const float* gout;       // [3][npix] plain planes: d loss / d out
+    float* G;                // g_a,i (rows 0..255), g_s,i (rows 256..511)
+    float* Q;                // q_i
+    long long npix, ntiles;
     int layer;               // bwd_layer_kernel: consumes G_layer, produces G_{layer-1}, Q_{layer-1}
 };
 
@@ -509,22 +531,25 @@ __device__ __forceinline__ float ld_act(__amdgpu_buffer_rsrc_t rsrc, unsigned vo
 __global__ __launch_bounds__(256) void bwd_head_kernel(const BwdParams p) {
     const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
     if (pix >= p.npix) return;
-    const size_t n = (size_t)p.npix;
-    const float g0 = p.gout[pix], g1 = p.gout[n + pix], g2 = p.gout[2 * n + pix];
+    const size_t np = (size_t)p.npix;
+    const float g0 = p.gout[pix], g1 = p.gout[np + pix], g2 = p.gout[2 * np + pix];
     const float* __restrict__ L = p.Wt + OFF_L;
+    const size_t tile = (size_t)(pix >> 5), lane = (size_t)(pix & 31);
+    const size_t a0 = ((size_t)3 * p.ntiles + tile) * ACT_ROWS * PLANE_TILE + lane;   // layer 3 tile, row 0
+    const size_t q0 = ((size_t)3 * p.ntiles + tile) * HID * PLANE_TILE + lane;
     const int c0 = blockIdx.y * 16;
 #pragma unroll 4
     for (int c = c0; c < c0 + 16; ++c) {
         float g = L[c] * g0;
         g = __builtin_fmaf(L[HID + c], g1, g);
         g = __builtin_fmaf(L[2 * HID + c], g2, g);
-        const float kv = p.acts[((size_t)(6 * HID + c)) * n + pix];
-        const float sv = p.acts[((size_t)(7 * HID + c)) * n + pix];
+        const float kv = p.acts[a0 + (size_t)c * PLANE_TILE];
+        const float sv = p.acts[a0 + (size_t)(HID + c) * PLANE_TILE];
         float sn, cs;
         dsincos(sv, sn, cs);
-        p.G[((size_t)(6 * HID + c)) * n + pix] = kv > 0.0f ? g * sn : 0.0f;
-        p.G[((size_t)(7 * HID + c)) * n + pix] = g * kv * cs;
-        p.Q[((size_t)(3 * (HID + 1) + c)) * n + pix] = kv * sn;
+        p.G[a0 + (size_t)c * PLANE_TILE] = kv > 0.0f ? g * sn : 0.0f;
+        p.G[a0 + (size_t)(HID + c) * PLANE_TILE] = g * kv * cs;
+        p.Q[q0 + (size_t)c * PLANE_TILE] = kv * sn;
     }
 }
 
@@ -532,32 +557,27 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
-    const long long pix = ((long long)blockIdx.x * 4 + wave) * 32 + j;
-    const bool valid = pix < p.npix;
-    if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
+    const long long tile = (long long)blockIdx.x * 4 + wave;
+    if (tile >= p.ntiles) return;                                // wave-uniform
+    const bool valid = tile * PLANE_TILE + j < p.npix;
 
     const int li = p.layer;                                     // 1..3
-    const unsigned rowb = p.row_bytes;
-    const size_t group = (size_t)HID * rowb;                    // bytes of one 256-row plane group (< 4 GiB)
-    const unsigned voff = valid ? (unsigned)pix * 4u + 4u * h * rowb : 0xFFFFFFF0u;   // out of range: loads 0, stores dropped
-    auto rsrc_of = [&](const void* base) {
-        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)group, 0x00020000);
-    };
-    const __amdgpu_buffer_rsrc_t inA = rsrc_of((const char*)p.G + (size_t)(2 * li + 0) * group);
-    const __amdgpu_buffer_rsrc_t inS = rsrc_of((const char*)p.G + (size_t)(2 * li + 1) * group);
-    const __amdgpu_buffer_rsrc_t actK = rsrc_of((const char*)p.acts + (size_t)(2 * (li - 1) + 0) * group);
-    const __amdgpu_buffer_rsrc_t actS = rsrc_of((const char*)p.acts + (size_t)(2 * (li - 1) + 1) * group);
-    const __amdgpu_buffer_rsrc_t outA = rsrc_of((const char*)p.G + (size_t)(2 * (li - 1) + 0) * group);
-    const __amdgpu_buffer_rsrc_t outS = rsrc_of((const char*)p.G + (size_t)(2 * (li - 1) + 1) * group);
-    const __amdgpu_buffer_rsrc_t outQ = rsrc_of((const char*)p.Q + (size_t)(li - 1) * (HID + 1) * rowb);
+    const size_t agroup = (size_t)p.ntiles * ACT_ROWS * PLANE_TILE;     // floats per layer of acts / G
+    const size_t qgroup = (size_t)p.ntiles * HID * PLANE_TILE;
+    // lanes past the end: offset outside the descriptor, loads return 0 and stores are dropped
+    const unsigned voff = valid ? 4u * j + 4u * h * PLANE_ROW_BYTES : 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t inG = tile_rsrc(p.G + (size_t)li * agroup, tile, ACT_ROWS);
+    const __amdgpu_buffer_rsrc_t act = tile_rsrc(p.acts + (size_t)(li - 1) * agroup, tile, ACT_ROWS);
+    const __amdgpu_buffer_rsrc_t outG = tile_rsrc(p.G + (size_t)(li - 1) * agroup, tile, ACT_ROWS);
+    const __amdgpu_buffer_rsrc_t outQ = tile_rsrc(p.Q + (size_t)(li - 1) * qgroup, tile, HID);
 
     // B operand: register kk = 16m + r of lane-half h holds channel chan_of(kk, h) of this lane's pixel
     float ga[128], gs[128];
 #pragma unroll
     for (int kk = 0; kk < 128; ++kk) {
-        const unsigned so = (unsigned)(32 * (kk >> 4) + (kk & 3) + 8 * ((kk & 15) >> 2)) * rowb;
-        ga[kk] = ld_act(inA, voff, so);
-        gs[kk] = ld_act(inS, voff, so);
+        const unsigned so = (unsigned)(32 * (kk >> 4) + (kk & 3) + 8 * ((kk & 15) >> 2)) * PLANE_ROW_BYTES;
+        ga[kk] = ld_act(inG, voff, so);
+        gs[kk] = ld_act(inG, voff, so + HID * PLANE_ROW_BYTES);
     }
 
     constexpr int PF = DECODE_PREFETCH;
@@ -574,11 +594,11 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
 
     // gates of layer li-1 for one finished element: g = d loss / d q_{li-1}[channel, pixel]
     auto gate_store = [&](int mt, int r, float g, float kv, float sv) {
-        const unsigned so = (unsigned)(32 * mt + (r & 3) + 8 * (r >> 2)) * rowb;
+        const unsigned so = (unsigned)(32 * mt + (r & 3) + 8 * (r >> 2)) * PLANE_ROW_BYTES;
         float sn, cs;
         dsincos(sv, sn, cs);
-        st_act(outA, voff, so, kv > 0.0f ? g * sn : 0.0f);
-        st_act(outS, voff, so, g * kv * cs);
+        st_act(outG, voff, so, kv > 0.0f ? g * sn : 0.0f);
+        st_act(outG, voff, so + HID * PLANE_ROW_BYTES, g * kv * cs);
         st_act(outQ, voff, so, kv * sn);
     };
 
@@ -604,9 +624,9 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
             if (m > 0 && kg == 0) {                               // saved planes of tile m-1, used from kg = 8 on
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const unsigned so = (unsigned)(32 * (m - 1) + (r & 3) + 8 * (r >> 2)) * rowb;
-                    kt[r] = ld_act(actK, voff, so);
-                    st[r] = ld_act(actS, voff, so);
+                    const unsigned so = (unsigned)(32 * (m - 1) + (r & 3) + 8 * (r >> 2)) * PLANE_ROW_BYTES;
+                    kt[r] = ld_act(act, voff, so);
+                    st[r] = ld_act(act, voff, so + HID * PLANE_ROW_BYTES);
                 }
             }
             if (m > 0 && kg >= 8 && kg < 24) {                    // one epilogue element of tile m-1 every 8 MFMAs
@@ -619,9 +639,9 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const unsigned so = (unsigned)(32 * 7 + (r & 3) + 8 * (r >> 2)) * rowb;
-        kt[r] = ld_act(actK, voff, so);
-        st[r] = ld_act(actS, voff, so);
+        const unsigned so = (unsigned)(32 * 7 + (r & 3) + 8 * (r >> 2)) * PLANE_ROW_BYTES;
+        kt[r] = ld_act(act, voff, so);
+        st[r] = ld_act(act, voff, so + HID * PLANE_ROW_BYTES);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) gate_store(7, r, pg[r], kt[r], st[r]);
@@ -632,16 +652,17 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
 // nearest LR cell is (cy, cx) -- the adjoint of the nearest-exact replication (diinn.py:168).  The
 // index tables are monotone, so a cell's pixels are the rectangle [seg_h[cy], seg_h[cy+1]) x
 // [seg_w[cx], seg_w[cx+1]).  One thread per output element, cx fastest: neighbouring lanes read
-// neighbouring column segments of the same HR rows, so a wave's loads cover contiguous row spans.
-// Fixed summation order (no atomics).  Output is NCHW [B][1024][H][W], channel = 256 i + ch: the
-// layout the 3x3 convolution's weight/input gradients are taken in.  HBM-bound (reads the g_a planes once).
+// neighbouring column segments of the same HR rows.  Fixed summation order (no atomics).  Output is
+// NCHW [B][1024][H][W], channel = 256 i + ch: the layout the 3x3 convolution's weight/input
+// gradients are taken in.  HBM-bound (reads the g_a rows of G once).
 // ---------------------------------------------------------------------------------
 struct CellSumParams {
-    const float* G;          // [4][2][256][npix]; the a-planes (second index 0) are summed
+    const float* G;          // tiled [4][ntiles][512][32]; rows 0..255 (g_a) are summed
     float* dP;               // [B][1024][H][W]
     const int* seg_h;        // [H+1] first HR row of every LR row (seg_h[H] = Hu)
     const int* seg_w;        // [W+1]
     int B, H, W, Hu, Wu;
+    long long ntiles;
 };
 
 __global__ __launch_bounds__(256) void cell_sum_kernel(const CellSumParams p) {
@@ -651,38 +672,41 @@ __global__ __launch_bounds__(256) void cell_sum_kernel(const CellSumParams p) {
     const int cy = (blockIdx.y - b * hb) * 4 + (threadIdx.x >> 6);
     if (cx >= p.W || cy >= p.H) return;
     const int plane = blockIdx.z;                                    // 256 i + ch
-    const size_t npix = (size_t)p.B * p.Hu * p.Wu;
-    const float* __restrict__ src = p.G + ((size_t)(2 * (plane >> 8)) * HID + (plane & 255)) * npix
-                                    + (size_t)b * p.Hu * p.Wu;
+    const float* __restrict__ src = p.G + ((size_t)(plane >> 8) * p.ntiles * ACT_ROWS + (plane & 255)) * PLANE_TILE;
     const int y0 = p.seg_h[cy], y1 = p.seg_h[cy + 1];
     const int x0 = p.seg_w[cx], x1 = p.seg_w[cx + 1];
     float acc = 0.0f;
     for (int y = y0; y < y1; ++y) {
-        const float* __restrict__ row = src + (size_t)y * p.Wu;
+        const long long rowpix = ((long long)b * p.Hu + y) * p.Wu;
         float r = 0.0f;
-        for (int x = x0; x < x1; ++x) r += row[x];
+        for (int x = x0; x < x1; ++x) {
+            const long long pix = rowpix + x;
+            r += src[(size_t)(pix >> 5) * (ACT_ROWS * PLANE_TILE) + (size_t)(pix & 31)];
+        }
         acc += r;
     }
     p.dP[(((size_t)b * PCH + plane) * p.H + cy) * p.W + cx] = acc;
 }
 
 // ---------------------------------------------------------------------------------
-// plane_gemm_kernel (training backward, weight gradients): C[M x Nc] = A[M x npix] . B[Nc x npix]^T with
-// both operands stored as pixel-contiguous planes (the G_i and q_i planes), i.e. a GEMM whose reduction
-// axis is the pixel axis.  Split-K: workgroup (block, ks) reduces pixels [ks*kchunk, (ks+1)*kchunk)
-// for a 128 x 256 output block and writes its partial product to part[ks]; the caller adds the ksplit
+// plane_gemm_kernel (training backward, weight gradients): C[M x Nc] = A[M x npix] . B[Nc x npix]^T, A and B
+// being rows [a_row0, a_row0+M) / [b_row0, b_row0+Nc) of tiled plane groups, i.e. a GEMM whose reduction
+// axis is the pixel axis.  Split-K: workgroup (block, ks) reduces the plane tiles of chunk ks for a
+// 128 x 256 output block and writes its partial product to part[ks]; the caller adds the ksplit
 // partials (fixed order, no atomics).  4 waves = 2 (M) x 2 (N), wave tile 64 x 128 = 2 x 4 MFMA tiles
-// (128 accumulator registers).  Operand fragments go global -> registers directly: lane (row = l&31,
-// half = l>>5) reads 16 bytes of its row, four loads per 32-pixel step cover the row's whole 128-byte
-// line while it is hot; the MFMA k-pair (pixel e, pixel 4+e) is the same for A and B, and the sum
-// over pixels does not care about the order.  Optional extra column Nc: row sums of A (bias gradients).
+// (128 accumulator registers).  Operand fragments go global -> registers directly: with tiled planes a
+// 32-row x 32-pixel MFMA panel is one contiguous 4 KiB block; lane (row = l&31, half = l>>5) reads
+// 16 bytes of its row per load, four loads cover the row's whole 128-byte line.  The MFMA k-pair
+// (pixel e, pixel 4+e) is the same for A and B, and the sum over pixels does not care about the order.
+// Optional extra column Nc: row sums of A (bias gradients).
 // ---------------------------------------------------------------------------------
 struct PlaneGemmParams {
-    const float* A;          // [M][npix]
-    const float* Bm;         // [Nc][npix]
+    const float* A;          // tiled group, a_rows rows per tile; rows [a_row0, a_row0 + M) are used
+    const float* Bm;         // tiled group, b_rows rows per tile; rows [b_row0, b_row0 + Nc)
     float* part;             // [ksplit][M][ldc]
     long long npix;
-    int M, Nc, ldc, kchunk, with_rowsum;
+    int a_rows, a_row0, b_rows, b_row0;
+    int M, Nc, ldc, tiles_per_split, with_rowsum;
 };
 
 __global__ __launch_bounds__(256, 1) void plane_gemm_kernel(const PlaneGemmParams p) {
@@ -693,18 +717,20 @@ __global__ __launch_bounds__(256, 1) void plane_gemm_kernel(const PlaneGemmParam
     const int m0 = (blockIdx.x / nblk) * 128 + (wave & 1) * 64;
     const int n0 = (blockIdx.x % nblk) * 256 + (wave >> 1) * 128;
     const int ks = blockIdx.y;
-    const long long kbeg = (long long)ks * p.kchunk;
-    long long kend = kbeg + p.kchunk;
-    if (kend > p.npix) kend = p.npix;
+    const long long ntiles = (p.npix + PLANE_TILE - 1) / PLANE_TILE;
+    const long long t0 = (long long)ks * p.tiles_per_split;
+    long long t1 = t0 + p.tiles_per_split;
+    if (t1 > ntiles) t1 = ntiles;
+    const int nt = t1 > t0 ? (int)(t1 - t0) : 0;                 // tiles this workgroup reduces
 
-    const size_t rowb = (size_t)p.npix * 4;
-    // descriptors start at the wave's first row and end with the operand: reads past it return 0
+    // descriptors start at this split's first tile (offsets inside a split stay far below 4 GiB)
+    const unsigned a_pitch = (unsigned)p.a_rows * PLANE_ROW_BYTES, b_pitch = (unsigned)p.b_rows * PLANE_ROW_BYTES;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.A + (size_t)m0 * rowb), 0, (int)(unsigned)((size_t)(p.M - m0) * rowb), 0x00020000);
+        (void*)(p.A + ((size_t)t0 * p.a_rows + p.a_row0 + m0) * PLANE_TILE), 0, (int)(nt * a_pitch), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.Bm + (size_t)n0 * rowb), 0, (int)(unsigned)((size_t)(p.Nc - n0) * rowb), 0x00020000);
-    const unsigned voff = (unsigned)j * (unsigned)rowb + 16u * h;
-    const unsigned tile_rows = 32u * (unsigned)rowb;
+        (void*)(p.Bm + ((size_t)t0 * p.b_rows + p.b_row0 + n0) * PLANE_TILE), 0, (int)(nt * b_pitch), 0x00020000);
+    const unsigned voff = (unsigned)j * PLANE_ROW_BYTES + 16u * h;
+    constexpr unsigned MFMA_ROWS = 32u * PLANE_ROW_BYTES;        // one 32-row MFMA panel: 4 KiB
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -715,55 +741,55 @@ __global__ __launch_bounds__(256, 1) void plane_gemm_kernel(const PlaneGemmParam
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     float rs[2] = {0.0f, 0.0f};
 
-    f32x4 fa[2][2][4], fb[2][4][4];                              // [buffer][tile][t]: 4 pixels each
-    auto load = [&](int buf, long long k) {
-        const unsigned kb = (unsigned)(k * 4);
+    f32x4 fa[2][2][4], fb[2][4][4];                              // [buffer][panel][t]: 4 pixels each
+    auto load = [&](int buf, int t) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
-                fa[buf][a][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    ra, (int)voff, (int)(a * tile_rows + kb + 32u * t), 0));
+                fa[buf][a][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    ra, (int)voff, (int)(t * a_pitch + a * MFMA_ROWS + 32u * q), 0));
 #pragma unroll
             for (int b = 0; b < 4; ++b)
-                fb[buf][b][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    rb, (int)voff, (int)(b * tile_rows + kb + 32u * t), 0));
+                fb[buf][b][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rb, (int)voff, (int)(t * b_pitch + b * MFMA_ROWS + 32u * q), 0));
         }
     };
-    auto compute = [&](int buf, long long k) {
-        if (k + 32 > kend) {                                     // ragged last step: drop pixels >= kend (wave-uniform branch)
+    auto compute = [&](int buf, int t) {
+        const long long pix0 = (t0 + t) * PLANE_TILE;
+        if (pix0 + PLANE_TILE > p.npix) {                        // ragged last tile: its padding was never written
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const bool in = k + 8 * t + 4 * h + e < kend;
+                    const bool in = pix0 + 8 * q + 4 * h + e < p.npix;
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) fa[buf][a][t][e] = in ? fa[buf][a][t][e] : 0.0f;
+                    for (int a = 0; a < 2; ++a) fa[buf][a][q][e] = in ? fa[buf][a][q][e] : 0.0f;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) fb[buf][b][t][e] = in ? fb[buf][b][t][e] : 0.0f;
+                    for (int b = 0; b < 4; ++b) fb[buf][b][q][e] = in ? fb[buf][b][q][e] : 0.0f;
                 }
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[a][b] = MFMA32(fa[buf][a][t][e], fb[buf][b][t][e], acc[a][b]);
-                    rs[a] += fa[buf][a][t][e];
+                    for (int b = 0; b < 4; ++b) acc[a][b] = MFMA32(fa[buf][a][q][e], fb[buf][b][q][e], acc[a][b]);
+                    rs[a] += fa[buf][a][q][e];
                 }
             }
     };
 
-    if (kbeg < kend) {
-        load(0, kbeg);
-        for (long long k = kbeg; k < kend; k += 64) {
-            if (k + 32 < kend) load(1, k + 32);
-            compute(0, k);
-            if (k + 32 < kend) {
-                if (k + 64 < kend) load(0, k + 64);
-                compute(1, k + 32);
+    if (nt > 0) {
+        load(0, 0);
+        for (int t = 0; t < nt; t += 2) {
+            if (t + 1 < nt) load(1, t + 1);
+            compute(0, t);
+            if (t + 1 < nt) {
+                if (t + 2 < nt) load(0, t + 2);
+                compute(1, t + 1);
             }
         }
     }
@@ -784,6 +810,54 @@ __global__ __launch_bounds__(256, 1) void plane_gemm_kernel(const PlaneGemmParam
             const float v = rs[a] + __shfl_xor(rs[a], 32);
             if (h == 0) dst[(size_t)(m0 + 32 * a + j) * p.ldc + p.Nc] = v;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// plane_rowdot_kernel (training backward, the two skinny products): C[M x 4] = A[M x npix] . S[4 x npix]^T
+// with A rows of a tiled group (M = 256 or 512) and S a tiled 4-row group.  Used for
+//   layer 0: (g_a,0 ; g_s,0) . (rel_h, rel_w, ratio, 1)^T  -> dbK_0, dQ0, dbQ0          (diinn.py:133-134,165-167)
+//   head   : q_3 . (g_out0, g_out1, g_out2, 0)^T            -> d last_layer.weight      (diinn.py:138)
+// HBM-bound (reads A once); split over the tiles like plane_gemm_kernel, partials added by the caller.
+// ---------------------------------------------------------------------------------
+struct RowDotParams {
+    const float* A;          // tiled, a_rows per tile, rows [0, M)
+    const float* S;          // tiled [ntiles][4][32]
+    float* part;             // [splits][M][4]
+    long long npix;
+    int a_rows, M, tiles_per_split;
+};
+
+__global__ __launch_bounds__(256) void plane_rowdot_kernel(const RowDotParams p) {
+    const long long ntiles = (p.npix + PLANE_TILE - 1) / PLANE_TILE;
+    const long long t0 = (long long)blockIdx.x * p.tiles_per_split;
+    long long t1 = t0 + p.tiles_per_split;
+    if (t1 > ntiles) t1 = ntiles;
+    for (int row = threadIdx.x; row < p.M; row += 256) {
+        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+        for (long long t = t0; t < t1; ++t) {
+            const f32x4* __restrict__ a = (const f32x4*)(p.A + ((size_t)t * p.a_rows + row) * PLANE_TILE);
+            const f32x4* __restrict__ s = (const f32x4*)(p.S + (size_t)t * 4 * PLANE_TILE);
+            const int left = (int)(p.npix - t * PLANE_TILE < PLANE_TILE ? p.npix - t * PLANE_TILE : PLANE_TILE);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                f32x4 av = a[q];
+                if (left < PLANE_TILE) {                          // ragged last tile: padding was never written
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[e] = 4 * q + e < left ? av[e] : 0.0f;
+                }
+                const f32x4 s0 = s[q], s1 = s[8 + q], s2 = s[16 + q], s3 = s[24 + q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    c0 = __builtin_fmaf(av[e], s0[e], c0);
+                    c1 = __builtin_fmaf(av[e], s1[e], c1);
+                    c2 = __builtin_fmaf(av[e], s2[e], c2);
+                    c3 = __builtin_fmaf(av[e], s3[e], c3);
+                }
+            }
+        }
+        float* __restrict__ dst = p.part + ((size_t)blockIdx.x * p.M + row) * 4;
+        dst[0] = c0; dst[1] = c1; dst[2] = c2; dst[3] = c3;
     }
 }
 
@@ -1216,7 +1290,7 @@ int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_d
     p.P = P_dev; p.Wt = packed_dev; p.out = out_dev;
     p.B = B; p.H = H; p.W = W; p.Hu = Hu; p.Wu = Wu; p.y0 = y0; p.y1 = y1;
     p.ratio = (float)(((double)H * (double)W) / ((double)Hu * (double)Wu));
-    p.acts = nullptr; p.act_row_bytes = 0;
+    p.acts = nullptr; p.npix = 0;
 #ifdef DIINN_STAMPS
     p.stamps = g_stamps;
 #endif
@@ -1251,11 +1325,15 @@ int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_d
     return hip_status(hipGetLastError());
 }
 
-long long diinn_saved_activation_floats(int B, int Hu, int Wu) {
-    if (B <= 0 || Hu <= 0 || Wu <= 0) return -1;
-    const long long npix = (long long)B * Hu * Wu;
-    if (npix > DIINN_TRAIN_MAX_PIXELS) return -1;
-    return 4LL * 2 * HID * npix;
+long long diinn_training_plane_floats(long long npix, int rows) {
+    if (npix <= 0 || rows <= 0 || npix > DIINN_TRAIN_MAX_PIXELS) return -1;
+    return (npix + PLANE_TILE - 1) / PLANE_TILE * rows * PLANE_TILE;
+}
+
+static int check_npix(long long npix) {
+    if (npix <= 0) return DIINN_ERR_INVALID_ARG;
+    if (npix > DIINN_TRAIN_MAX_PIXELS) return DIINN_ERR_TOO_LARGE;
+    return DIINN_OK;
 }
 
 int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed_dev, float* out_dev,
@@ -1265,16 +1343,16 @@ int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed
     if (st) return st;
     if (Hu <= 0 || Wu <= 0) return DIINN_ERR_INVALID_ARG;
     if (sin_mode < DIINN_SIN_ACCURATE || sin_mode > DIINN_SIN_HW_REDUCED) return DIINN_ERR_UNSUPPORTED;
+    if ((double)Hu * Wu >= 2.0e9) return DIINN_ERR_TOO_LARGE;
     const long long npix = (long long)B * Hu * Wu;
-    // one plane group (256 channel rows) must stay below the 4 GiB range of a buffer descriptor
-    if (npix > DIINN_TRAIN_MAX_PIXELS) return DIINN_ERR_TOO_LARGE;
-    const dim3 grid((Wu + SAVE_TILE_W * WG_TILES_X - 1) / (SAVE_TILE_W * WG_TILES_X), (Hu + WG_TILES_Y - 1) / WG_TILES_Y, B);
-    if (grid.y > 65535 || grid.z > 65535) return DIINN_ERR_TOO_LARGE;
+    st = check_npix(npix);
+    if (st) return st;
+    const dim3 grid((unsigned)((npix + 4 * PLANE_TILE - 1) / (4 * PLANE_TILE)));
     DecodeParams p;
     p.P = P_dev; p.Wt = packed_dev; p.out = out_dev;
     p.B = B; p.H = H; p.W = W; p.Hu = Hu; p.Wu = Wu; p.y0 = 0; p.y1 = Hu;
     p.ratio = (float)(((double)H * (double)W) / ((double)Hu * (double)Wu));
-    p.acts = acts_dev; p.act_row_bytes = (unsigned)(npix * 4);
+    p.acts = acts_dev; p.npix = npix;
 #ifdef DIINN_STAMPS
     p.stamps = nullptr;
 #endif
@@ -1293,16 +1371,16 @@ int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed
 int diinn_backward_data(void* stream, const float* gout_planes_dev, const float* acts_dev,
                         const float* packed_dev, float* G_dev, float* Q_dev, long long npix) {
     if (!gout_planes_dev || !acts_dev || !packed_dev || !G_dev || !Q_dev) return DIINN_ERR_INVALID_ARG;
-    if (npix <= 0) return DIINN_ERR_INVALID_ARG;
-    if (npix > DIINN_TRAIN_MAX_PIXELS) return DIINN_ERR_TOO_LARGE;
+    const int stp = check_npix(npix);
+    if (stp) return stp;
     BwdParams p;
     p.Wt = packed_dev; p.acts = acts_dev; p.gout = gout_planes_dev; p.G = G_dev; p.Q = Q_dev;
-    p.npix = npix; p.row_bytes = (unsigned)(npix * 4); p.layer = 0;
+    p.npix = npix; p.ntiles = (npix + PLANE_TILE - 1) / PLANE_TILE; p.layer = 0;
     hipLaunchKernelGGL(bwd_head_kernel, dim3((unsigned)((npix + 255) / 256), HID / 16), dim3(256), 0,
                        (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_status(e);
-    const unsigned blocks = (unsigned)((npix + 127) / 128);
+    const unsigned blocks = (unsigned)((p.ntiles + 3) / 4);
     for (int layer = 3; layer >= 1; --layer) {
         p.layer = layer;
         hipLaunchKernelGGL(bwd_layer_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
@@ -1312,20 +1390,40 @@ int diinn_backward_data(void* stream, const float* gout_planes_dev, const float*
     return DIINN_OK;
 }
 
-int diinn_plane_gemm_nt(void* stream, const float* A_dev, const float* B_dev, float* part_dev,
-                        int M, int Nc, long long npix, int ksplit, int with_rowsum) {
-    if (!A_dev || !B_dev || !part_dev || M <= 0 || Nc <= 0 || npix <= 0 || ksplit <= 0) return DIINN_ERR_INVALID_ARG;
+int diinn_plane_gemm_nt(void* stream, const float* A_dev, int a_rows, int a_row0, const float* B_dev, int b_rows,
+                        int b_row0, float* part_dev, int M, int Nc, long long npix, int ksplit, int with_rowsum) {
+    if (!A_dev || !B_dev || !part_dev || M <= 0 || Nc <= 0 || ksplit <= 0 || a_row0 < 0 || b_row0 < 0 ||
+        a_row0 + M > a_rows || b_row0 + Nc > b_rows)
+        return DIINN_ERR_INVALID_ARG;
+    const int stp = check_npix(npix);
+    if (stp) return stp;
     if (M % 128 || Nc % 256) return DIINN_ERR_UNSUPPORTED;
-    if (npix > DIINN_TRAIN_MAX_PIXELS || (long long)M * npix * 4 > 0xFFFFFFFFLL || (long long)Nc * npix * 4 > 0xFFFFFFFFLL ||
-        ksplit > 65535)
-        return DIINN_ERR_TOO_LARGE;                           // one operand must fit a buffer descriptor (4 GiB)
+    if (ksplit > 65535) return DIINN_ERR_TOO_LARGE;
     PlaneGemmParams p;
-    p.A = A_dev; p.Bm = B_dev; p.part = part_dev; p.npix = npix; p.M = M; p.Nc = Nc;
+    p.A = A_dev; p.Bm = B_dev; p.part = part_dev; p.npix = npix;
+    p.a_rows = a_rows; p.a_row0 = a_row0; p.b_rows = b_rows; p.b_row0 = b_row0;
+    p.M = M; p.Nc = Nc;
     p.ldc = Nc + (with_rowsum ? 1 : 0);
     p.with_rowsum = with_rowsum ? 1 : 0;
-    const long long per = (npix + ksplit - 1) / ksplit;
-    p.kchunk = (int)((per + 31) / 32 * 32);
+    const long long ntiles = (npix + PLANE_TILE - 1) / PLANE_TILE;
+    const long long per = (ntiles + ksplit - 1) / ksplit;
+    // offsets inside one split are 32-bit: tiles_per_split * rows * 128 bytes must stay below 2 GiB
+    if (per * (long long)(a_rows > b_rows ? a_rows : b_rows) * PLANE_ROW_BYTES >= 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;
+    p.tiles_per_split = (int)per;
     hipLaunchKernelGGL(plane_gemm_kernel, dim3((M / 128) * (Nc / 256), ksplit), dim3(256), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+int diinn_plane_rowdot(void* stream, const float* A_dev, int a_rows, const float* S_dev, float* part_dev,
+                       int M, long long npix, int splits) {
+    if (!A_dev || !S_dev || !part_dev || M <= 0 || M > a_rows || splits <= 0) return DIINN_ERR_INVALID_ARG;
+    const int stp = check_npix(npix);
+    if (stp) return stp;
+    RowDotParams p;
+    p.A = A_dev; p.S = S_dev; p.part = part_dev; p.npix = npix; p.a_rows = a_rows; p.M = M;
+    const long long ntiles = (npix + PLANE_TILE - 1) / PLANE_TILE;
+    p.tiles_per_split = (int)((ntiles + splits - 1) / splits);
+    hipLaunchKernelGGL(plane_rowdot_kernel, dim3(splits), dim3(256), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
 
@@ -1335,9 +1433,11 @@ int diinn_backward_cell_sum(void* stream, const float* G_dev, const int32_t* seg
     int st = check_dims(B, H, W);
     if (st) return st;
     if (Hu <= 0 || Wu <= 0) return DIINN_ERR_INVALID_ARG;
-    if ((long long)B * Hu * Wu > DIINN_TRAIN_MAX_PIXELS || (long long)((H + 3) / 4) * B > 65535)
-        return DIINN_ERR_TOO_LARGE;
-    CellSumParams p{G_dev, dP_dev, seg_h_dev, seg_w_dev, B, H, W, Hu, Wu};
+    const long long npix = (long long)B * Hu * Wu;
+    st = check_npix(npix);
+    if (st) return st;
+    if ((long long)((H + 3) / 4) * B > 65535) return DIINN_ERR_TOO_LARGE;
+    CellSumParams p{G_dev, dP_dev, seg_h_dev, seg_w_dev, B, H, W, Hu, Wu, (npix + PLANE_TILE - 1) / PLANE_TILE};
     hipLaunchKernelGGL(cell_sum_kernel, dim3((W + 63) / 64, ((H + 3) / 4) * B, PCH), dim3(256), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }

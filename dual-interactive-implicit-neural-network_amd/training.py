@@ -9,11 +9,11 @@ records ~30 ATen ops per call on the materialised [B,576,Hu,Wu] tensor.  Here:
             argument s_i as [channel][pixel] planes -- all the backward pass needs.
   backward  ``backward_fused``: the per-pixel chain (gates and the transposed stacked GEMMs
             g_q[i-1] = Wq_i^T g_a + Qw_i^T g_s) runs on bwd_head_kernel + 3 x bwd_layer_kernel (C ABI
-            ``diinn_backward_data``), which leave the gate-gradient planes G_i and the activations q_i
-            as [channel][pixel] planes; every parameter gradient is then ONE plain library GEMM over
-            the pixel axis per layer (rocBLAS through torch.matmul), plus a per-cell segment sum (two
-            one-hot GEMMs, deterministic) and the 3x3 conv's input/weight gradients (MIOpen through
-            torch.nn.grad).
+            ``diinn_backward_data``), which leave the gate gradients G_i and the activations q_i as
+            tiled planes; every parameter gradient is then one GEMM over the pixel axis per layer
+            (plane_gemm_kernel, split-K, no atomics), two skinny products (plane_rowdot_kernel), a
+            per-cell segment sum (cell_sum_kernel) and the 3x3 conv's input/weight gradients (MIOpen
+            through torch.nn.grad).
             ``backward_from_saved`` states the same gradients in device-agnostic tensor algebra; it
             is the unit-tested formula sheet (CPU, against the reference's own .grad fixtures) and
             the on-GPU cross-check of the fused path.  The forward has no CPU form.
@@ -53,6 +53,7 @@ PARAM_SHAPES: Dict[str, Tuple[int, ...]] = {
 }
 
 WGRAD_KSPLIT = 64          # pixel-axis splits of the weight-gradient GEMM: 4 output blocks x 64 = one workgroup per CU
+ROWDOT_SPLITS = 1024       # workgroups of the skinny products (HBM-bound)
 
 _gather_index_cpu: Optional[torch.Tensor] = None
 _gather_index_dev: Dict[str, torch.Tensor] = {}
@@ -139,7 +140,8 @@ def backward_from_saved(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tens
                         need_feat_grad: bool = True) -> Tuple[Optional[torch.Tensor], List[torch.Tensor]]:
     """Gradients of the mode-3 decoder given d(loss)/d(out).
 
-    gout [B,3,Hu,Wu]; feat [B,64,H,W]; acts [4,2,256,N] (k_i, s_i planes from the training forward);
+    gout [B,3,Hu,Wu]; feat [B,64,H,W]; acts [4,2,256,N] plain planes k_i, s_i (``untile_planes`` of the
+    training forward's buffer, viewed [4,2,256,N]);
     params in PARAM_NAMES order.  Returns (d feat or None, [d param ...] in PARAM_NAMES order).
 
     With q_i = k_i * sin(s_i), k_0 = relu(P_0[cell]), k_i = relu(Wq_i q_{i-1} + P_i[cell]),
@@ -213,68 +215,97 @@ def _conv_and_assemble(p: Dict[str, torch.Tensor], feat: torch.Tensor, dp: torch
     return d_feat
 
 
+PLANE_TILE = 32
+
+
+def tile_planes(x: torch.Tensor) -> torch.Tensor:
+    """Plain planes [C, n] -> tiled group [ceil(n/32), C, 32] (zero padding), the layout of include/diinn_hip.h."""
+    c, n = x.shape
+    t = (n + PLANE_TILE - 1) // PLANE_TILE
+    out = x.new_zeros((c, t * PLANE_TILE))
+    out[:, :n] = x
+    return out.view(c, t, PLANE_TILE).permute(1, 0, 2).contiguous()
+
+
+def untile_planes(x: torch.Tensor, n: int) -> torch.Tensor:
+    """Tiled groups [..., T, C, 32] -> plain planes [..., C, n] (a copy; tests and the formula path)."""
+    *lead, t, c, w = x.shape
+    d = len(lead)
+    return x.permute(*range(d), d + 1, d, d + 2).reshape(*lead, c, t * w)[..., :n]
+
+
 def backward_fused(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tensor, params: Sequence[torch.Tensor],
                    packed: torch.Tensor, size: Sequence[int],
                    need_feat_grad: bool = True) -> Tuple[Optional[torch.Tensor], List[torch.Tensor]]:
-    """The same gradients as ``backward_from_saved`` with the per-pixel chain on the HIP kernels
-    (C ABI ``diinn_backward_data``: bwd_head_kernel + 3 x bwd_layer_kernel write the gate-gradient planes
-    G_i and the activations q_i), followed by one GEMM per layer over the pixel axis
-    (plane_gemm_kernel, C ABI ``diinn_plane_gemm_nt``): [dWq_i ; dQw_i | bias sums] = G_i [512 x N] . q_{i-1}^T
-    [N x 256] plus the row sums of G_i; the two skinny products (head, layer 0) stay with the BLAS library."""
+    """The same gradients as ``backward_from_saved``, on the HIP kernels throughout:
+      diinn_backward_data   bwd_head_kernel + 3 x bwd_layer_kernel: the per-pixel chain; leaves the gate
+                            gradients G_i = (g_a,i ; g_s,i) and the activations q_i as tiled planes
+      diinn_plane_gemm_nt   [dWq_i ; dQw_i | bias sums] = G_i [512 x N] . q_{i-1}^T [N x 256], split over pixels
+      diinn_plane_rowdot    the two skinny products (layer 0 against (rel_h, rel_w, ratio, 1); head against g_out)
+      diinn_backward_cell_sum   dP = per-cell sums of g_a
+    and the 3x3 convolution's input/weight gradients from MIOpen (torch.nn.grad).
+    ``acts`` is the tiled buffer [4, T, 512, 32] of the training forward."""
     lib = _native.load()
     p = dict(zip(PARAM_NAMES, params))
     b, _, h, w = feat.shape
     hu, wu = int(size[0]), int(size[1])
     n = b * hu * wu
+    t = (n + PLANE_TILE - 1) // PLANE_TILE
     dev = gout.device
+    if tuple(acts.shape) != (4, t, 2 * HIDDEN, PLANE_TILE) or not acts.is_contiguous():
+        raise ValueError("acts must be the contiguous tiled [4, T, 512, 32] buffer of the training forward")
     idx_h, rel_h, idx_w, rel_w, ratio = coordinate_tensors(h, w, hu, wu, dev)
     gp = gout.to(torch.float32).permute(1, 0, 2, 3).reshape(3, n).contiguous()
-    g = torch.empty((4, 2, HIDDEN, n), dtype=torch.float32, device=dev)
-    q = torch.empty((4, HIDDEN + 1, n), dtype=torch.float32, device=dev)
-    q[:, HIDDEN] = 1.0
+    g = torch.empty((4, t, 2 * HIDDEN, PLANE_TILE), dtype=torch.float32, device=dev)
+    q = torch.empty((4, t, HIDDEN, PLANE_TILE), dtype=torch.float32, device=dev)
+    # the two 4-row right-hand sides of the skinny products, tiled (padding zero)
+    syn = torch.empty((4, b, hu, wu), dtype=torch.float32, device=dev)
+    syn[0] = rel_h[None, :, None]
+    syn[1] = rel_w[None, None, :]
+    syn[2] = ratio
+    syn[3] = 1.0
+    syn_t = tile_planes(syn.view(4, n))
+    gout_t = tile_planes(torch.cat([gp, gp.new_zeros((1, n))], 0))
+    ksplit = max(1, min(WGRAD_KSPLIT, t))
+    rsplit = max(1, min(ROWDOT_SPLITS, t))
+    part = torch.empty((3, ksplit, 2 * HIDDEN, HIDDEN + 1), dtype=torch.float32, device=dev)
+    part0 = torch.empty((rsplit, 2 * HIDDEN, 4), dtype=torch.float32, device=dev)
+    partl = torch.empty((rsplit, HIDDEN, 4), dtype=torch.float32, device=dev)
+    seg_h = torch.searchsorted(idx_h, torch.arange(h + 1, device=dev)).to(torch.int32)
+    seg_w = torch.searchsorted(idx_w, torch.arange(w + 1, device=dev)).to(torch.int32)
+    dp = torch.empty((b, 4 * HIDDEN, h, w), dtype=torch.float32, device=dev)
+    ptr = lambda x: C.c_void_p(x.data_ptr())                      # noqa: E731
     with torch.cuda.device(dev):
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _native.check(lib.diinn_backward_data(stream, C.c_void_p(gp.data_ptr()), C.c_void_p(acts.data_ptr()),
-                                              C.c_void_p(packed.data_ptr()), C.c_void_p(g.data_ptr()),
-                                              C.c_void_p(q.data_ptr()), n), "diinn_backward_data")
+        _native.check(lib.diinn_backward_data(stream, ptr(gp), ptr(acts), ptr(packed), ptr(g), ptr(q), n),
+                      "diinn_backward_data")
+        for i in (3, 2, 1):
+            _native.check(lib.diinn_plane_gemm_nt(stream, ptr(g[i]), 2 * HIDDEN, 0, ptr(q[i - 1]), HIDDEN, 0,
+                                                  ptr(part[i - 1]), 2 * HIDDEN, HIDDEN, n, ksplit, 1),
+                          "diinn_plane_gemm_nt")
+        _native.check(lib.diinn_plane_rowdot(stream, ptr(g[0]), 2 * HIDDEN, ptr(syn_t), ptr(part0), 2 * HIDDEN, n, rsplit),
+                      "diinn_plane_rowdot")
+        _native.check(lib.diinn_plane_rowdot(stream, ptr(q[3]), HIDDEN, ptr(gout_t), ptr(partl), HIDDEN, n, rsplit),
+                      "diinn_plane_rowdot")
+        _native.check(lib.diinn_backward_cell_sum(stream, ptr(g), ptr(seg_h), ptr(seg_w), ptr(dp), b, h, w, hu, wu),
+                      "diinn_backward_cell_sum")
     grads: Dict[str, torch.Tensor] = {}
-    dl = gp @ q[3].t()                                            # [3, 257]
-    grads["last_layer.weight"] = dl[:, :HIDDEN].reshape(3, HIDDEN, 1, 1)
-    grads["last_layer.bias"] = dl[:, HIDDEN]
+    dl = partl.sum(0)                                             # [256, 4]: q_3 . (g_out ; 0)^T
+    grads["last_layer.weight"] = dl[:, :3].t().reshape(3, HIDDEN, 1, 1)
+    grads["last_layer.bias"] = gp.sum(1)
+    dws = part.sum(1)                                             # [3, 512, 257]: [dWq_i ; dQw_i | bias sums]
     d_wq: List[Optional[torch.Tensor]] = [None] * 4
     d_bk: List[Optional[torch.Tensor]] = [None] * 4
-    ksplit = max(1, min(WGRAD_KSPLIT, (n + 31) // 32))
-    part = torch.empty((3, ksplit, 2 * HIDDEN, HIDDEN + 1), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        for i in (3, 2, 1):                                       # plane_gemm_kernel: G_i . q_{i-1}^T, split over pixels
-            _native.check(lib.diinn_plane_gemm_nt(stream, C.c_void_p(g[i].data_ptr()), C.c_void_p(q[i - 1].data_ptr()),
-                                                  C.c_void_p(part[i - 1].data_ptr()), 2 * HIDDEN, HIDDEN, n, ksplit, 1),
-                          "diinn_plane_gemm_nt")
-    dws = part.sum(1)                                             # [3, 512, 257]: [dWq_i ; dQw_i | bias sums]
     for i in (3, 2, 1):
         dw = dws[i - 1]
         d_wq[i] = dw[:HIDDEN, :HIDDEN]
         d_bk[i] = dw[:HIDDEN, HIDDEN]
         grads[f"Q.{i}.0.weight"] = dw[HIDDEN:, :HIDDEN].reshape(HIDDEN, HIDDEN, 1, 1)
         grads[f"Q.{i}.0.bias"] = dw[HIDDEN:, HIDDEN]
-    # layer 0: (g_a,0 ; g_s,0) . (rel_h, rel_w, ratio, 1)^T  (syn of diinn.py:165-167 plus the bias column)
-    syn = torch.empty((4, b, hu, wu), dtype=torch.float32, device=dev)
-    syn[0] = rel_h[None, :, None]
-    syn[1] = rel_w[None, None, :]
-    syn[2] = ratio
-    syn[3] = 1.0
-    d0 = g[0].view(2 * HIDDEN, n) @ syn.view(4, n).t()            # [512, 4]
+    d0 = part0.sum(0)                                             # [512, 4]: (g_a,0 ; g_s,0) . (rel_h, rel_w, ratio, 1)^T
     d_bk[0] = d0[:HIDDEN, 3]
     grads["Q.0.0.weight"] = d0[HIDDEN:, :3].reshape(HIDDEN, 3, 1, 1)
     grads["Q.0.0.bias"] = d0[HIDDEN:, 3]
-    # dP: per-cell sums of the g_a planes (cell_sum_kernel; rectangles from the monotone index tables)
-    seg_h = torch.searchsorted(idx_h, torch.arange(h + 1, device=dev)).to(torch.int32)
-    seg_w = torch.searchsorted(idx_w, torch.arange(w + 1, device=dev)).to(torch.int32)
-    dp = torch.empty((b, 4 * HIDDEN, h, w), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        _native.check(lib.diinn_backward_cell_sum(stream, C.c_void_p(g.data_ptr()), C.c_void_p(seg_h.data_ptr()),
-                                                  C.c_void_p(seg_w.data_ptr()), C.c_void_p(dp.data_ptr()),
-                                                  b, h, w, hu, wu), "diinn_backward_cell_sum")
     d_feat = _conv_and_assemble(p, feat, dp, d_wq, d_bk, grads, need_feat_grad)
     return d_feat, [grads[name] for name in PARAM_NAMES]
 
@@ -296,14 +327,13 @@ class DecodeMode3Function(torch.autograd.Function):
         b, c, h, w = feat_c.shape
         if c != IN_CHANNELS:
             raise ValueError(f"feat must be [B,{IN_CHANNELS},H,W]")
-        n_act = lib.diinn_saved_activation_floats(b, hu, wu)
-        if n_act < 0:
-            raise RuntimeError(f"diinn_amd: B*Hu*Wu = {b * hu * wu} HR pixels in one training forward exceeds the "
-                               f"saved-activation limit (4,194,303); split the batch")
+        n = b * hu * wu
+        if lib.diinn_training_plane_floats(n, 2 * HIDDEN) < 0:
+            raise RuntimeError(f"diinn_amd: B*Hu*Wu = {n} HR pixels in one training forward exceeds the limit; split the batch")
         dev = feat_c.device
         packed = pack_on_device(params)
         workspace = torch.empty(b * h * w * 4 * HIDDEN, dtype=torch.float32, device=dev)
-        acts = torch.empty((4, 2, HIDDEN, b * hu * wu), dtype=torch.float32, device=dev)
+        acts = torch.empty((4, (n + PLANE_TILE - 1) // PLANE_TILE, 2 * HIDDEN, PLANE_TILE), dtype=torch.float32, device=dev)
         out = torch.empty((b, 3, hu, wu), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -149,43 +149,52 @@ int diinn_decode_ex(void* stream, const float* feat_dev, const float* packed_dev
  * (diinn.py:118-121,126-129), for LR rows [r0,r1); k_i overwrites the P_i slot (i = 1..3) of P_dev. */
 int diinn_cell_chain(void* stream, float* P_dev, const float* packed_dev, int B, int H, int W, int r0, int r1);
 
-/* ---- training forward ----------------------------
- * Replaces: ImplicitDecoder.step(), mode 3, run under autograd -- what forward() does when
- * bsize is None (diinn.py:170-171, called from SRLitModule.training_step, sr_module.py:127-129).
- * Same network as diinn_decode_band (whole image, fp32), and in addition every layer's rectified
- * modulation k_i = relu(.) and sine argument s_i (i = 0..3; q_i = k_i * sin(s_i)) are written to
- * `acts_dev` for the backward pass: fp32 [4 layers][2: k, s][256 channels][npix], channels in the
- * reference's order, npix = B*Hu*Wu with pixel index (b*Hu + y)*Wu + x.
- * diinn_saved_activation_floats() gives the element count (or -1 when B*Hu*Wu exceeds
- * DIINN_TRAIN_MAX_PIXELS: one 256-row plane group must stay below 4 GiB). */
-#define DIINN_TRAIN_MAX_PIXELS 4194303LL
-long long diinn_saved_activation_floats(int B, int Hu, int Wu);
+/* ---- training ------------------------------------
+ * TILED PLANES.  Every per-pixel training buffer is a group of C channel rows over npix = B*Hu*Wu
+ * pixels (pixel index (b*Hu + y)*Wu + x), stored as [ceil(npix/32) tiles][C rows][32 pixels] fp32:
+ * element (c, pix) at ((pix >> 5) * C + c) * 32 + (pix & 31).  The padding of the last tile is never
+ * read as data and never written.  diinn_training_plane_floats(npix, C) = ceil(npix/32) * C * 32
+ * (or -1 for npix > DIINN_TRAIN_MAX_PIXELS). */
+#define DIINN_TRAIN_MAX_PIXELS 1073741824LL
+long long diinn_training_plane_floats(long long npix, int rows);
+
+/* Training forward.  Replaces: ImplicitDecoder.step(), mode 3, run under autograd -- what forward()
+ * does when bsize is None (diinn.py:170-171, called from SRLitModule.training_step,
+ * sr_module.py:127-129).  Same network as diinn_decode_band (whole image, fp32); in addition
+ * `acts_dev` = 4 tiled groups of 512 rows, one per layer i = 0..3, receives the rectified modulation
+ * k_i = relu(.) in rows 0..255 and the sine argument s_i in rows 256..511 (q_i = k_i * sin(s_i)),
+ * channels in the reference's order. */
 int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed_dev, float* out_dev,
                            float* acts_dev, int B, int H, int W, int Hu, int Wu, int sin_mode);
 
-/* ---- backward pass of the per-pixel layers (training) ------------------------------
- * Replaces: autograd's backward through step() (diinn.py:132-139), the part that runs per HR pixel.
- * Inputs: gout_planes_dev [3][npix] = d loss / d out as channel planes; acts_dev from
+/* Backward pass of the per-pixel layers.  Replaces: autograd's backward through step()
+ * (diinn.py:132-139), the part that runs per HR pixel.
+ * Inputs: gout_planes_dev = d loss / d out as PLAIN planes [3][npix]; acts_dev from
  * diinn_decode_train_fwd; the packed image (section 8, the transposed layers, is read).
- * Outputs, fp32 channel planes over the same pixel index:
- *   G_dev [4][2][256][npix]: g_a,i = d loss / d (modulation pre-activation of layer i) and
- *                            g_s,i = d loss / d (sine argument of layer i), i = 0..3;
- *   Q_dev [4][257][npix]   : rows 0..255 of layer i = q_i = k_i * sin(s_i); row 256 is never written
- *                            (callers keep it at 1.0 so G_i . Q_{i-1}^T also carries the bias sums).
- * From these every parameter gradient is a plain GEMM over the pixel axis (left to the BLAS library):
- *   d[Wq_i ; Qw_i] = G_i Q_{i-1}^T,  dL = gout Q_3^T,  dQ0 = g_s,0 syn^T,  dP_i[cell] = sum g_a,i.
+ * Outputs (tiled): G_dev, 4 groups of 512 rows: rows 0..255 of group i = g_a,i = d loss / d (modulation
+ * pre-activation of layer i), rows 256..511 = g_s,i = d loss / d (sine argument of layer i);
+ * Q_dev, 4 groups of 256 rows: q_i = k_i * sin(s_i).
+ * From these every parameter gradient is a GEMM over the pixel axis (the two functions below):
+ *   d[Wq_i ; Qw_i] = G_i q_{i-1}^T,  dL = g_out q_3^T,  (dbK_0 ; dQ0, dbQ0) = G_0 (syn, 1)^T,
+ *   dP_i[cell] = sum of g_a,i (diinn_backward_cell_sum).
  * Enqueues 4 kernels on `stream`; no allocation, no synchronisation. */
 int diinn_backward_data(void* stream, const float* gout_planes_dev, const float* acts_dev,
                         const float* packed_dev, float* G_dev, float* Q_dev, long long npix);
 
-/* Weight-gradient GEMM over the pixel axis: C[M x Nc] = A[M x npix] . B[Nc x npix]^T, A and B fp32 planes
- * (row stride npix) such as G_i and q_{i-1} above; M % 128 == 0, Nc % 256 == 0; each operand < 4 GiB.
- * Split-K without atomics: part_dev is [ksplit][M][ldc] and slice ks holds the product over pixels
- * [ks*chunk, (ks+1)*chunk); the caller adds the slices.  ldc = Nc, or Nc + 1 with `with_rowsum`, whose
- * extra column receives the row sums of A (the bias gradients).  Replaces the weight-gradient GEMMs
- * autograd runs for the nine 1x1 convolutions of step() (diinn.py:132-139). */
-int diinn_plane_gemm_nt(void* stream, const float* A_dev, const float* B_dev, float* part_dev,
-                        int M, int Nc, long long npix, int ksplit, int with_rowsum);
+/* Weight-gradient GEMM over the pixel axis: C[M x Nc] = A . B^T where A = rows [a_row0, a_row0+M) of a tiled
+ * group with a_rows rows per tile and B = rows [b_row0, b_row0+Nc) of a tiled group with b_rows rows;
+ * M % 128 == 0, Nc % 256 == 0.  Split-K without atomics: part_dev is [ksplit][M][ldc] and slice ks
+ * holds the product over its share of the plane tiles; the caller adds the slices.  ldc = Nc, or
+ * Nc + 1 with `with_rowsum`, whose extra column receives the row sums of A (the bias gradients).
+ * Replaces the weight-gradient GEMMs autograd runs for the 1x1 convolutions of step() (diinn.py:132-139). */
+int diinn_plane_gemm_nt(void* stream, const float* A_dev, int a_rows, int a_row0, const float* B_dev, int b_rows,
+                        int b_row0, float* part_dev, int M, int Nc, long long npix, int ksplit, int with_rowsum);
+
+/* Skinny product over the pixel axis: C[M x 4] = A . S^T, A = rows [0, M) of a tiled group with a_rows rows,
+ * S a tiled 4-row group (its last-tile padding must be zero).  part_dev [splits][M][4], added by the
+ * caller.  Used for layer 0 (S = rel_h, rel_w, ratio, 1: diinn.py:165-167) and the head (S = g_out rows). */
+int diinn_plane_rowdot(void* stream, const float* A_dev, int a_rows, const float* S_dev, float* part_dev,
+                       int M, long long npix, int splits);
 
 /* dP[b][256 i + ch][cy][cx] = sum of g_a,i (G_dev, from diinn_backward_data) over the HR pixels whose
  * nearest LR cell is (cy, cx): the adjoint of the nearest-exact replication of diinn.py:168, i.e. the

@@ -101,12 +101,32 @@ def test_backward_formulas_on_cpu(gold):
         _check_against_fixture(gold, name, d_feat.numpy(), grads, 5e-5)
 
 
+def _train_forward(lib, N, sd_packed, feat, b, h, w, hu, wu, dev, fill=float("nan")):
+    """precompute_P + decode_kernel<SAVE> through the C ABI; returns (out, tiled acts [4,T,512,32])."""
+    import ctypes as C
+    n = b * hu * wu
+    t = (n + 31) // 32
+    assert lib.diinn_training_plane_floats(n, 512) == t * 512 * 32
+    ws = torch.empty(b * h * w * 1024, device=dev)
+    acts = torch.full((4, t, 512, 32), fill, device=dev)
+    out = torch.empty((b, 3, hu, wu), device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N.check(lib.diinn_precompute_P(stream, C.c_void_p(feat.data_ptr()), C.c_void_p(sd_packed.data_ptr()),
+                                   C.c_void_p(ws.data_ptr()), b, h, w, 0, h), "P")
+    N.check(lib.diinn_decode_train_fwd(stream, C.c_void_p(ws.data_ptr()), C.c_void_p(sd_packed.data_ptr()),
+                                       C.c_void_p(out.data_ptr()), C.c_void_p(acts.data_ptr()),
+                                       b, h, w, hu, wu, N.SIN_DEFAULT), "train_fwd")
+    torch.cuda.synchronize()
+    return out, acts
+
+
 @pytest.mark.gpu
 def test_hip_training_forward_saves_the_oracle_planes(gold):
     """decode_kernel<SAVE>: output equals the inference kernel's, saved planes equal the oracle's."""
     import ctypes as C
     import diinn_amd._native as N
     import diinn_amd.decoder as D
+    import diinn_amd.training as T
     dev = torch.device("cuda:0")
     lib = N.load()
     for (b, h, w, hu, wu, gain) in [(2, 12, 10, 31, 27, 1.0), (1, 9, 14, 36, 56, 3.0), (1, 20, 33, 47, 130, 1.0)]:
@@ -115,30 +135,19 @@ def test_hip_training_forward_saves_the_oracle_planes(gold):
         ref_out, ref_acts = orc.saved_planes(sd, feat, (hu, wu))
         packed = D.pack_state_dict(sd).to(dev)
         f = torch.from_numpy(feat).to(dev)
-        ws = torch.empty(b * h * w * 1024, device=dev)
         n = b * hu * wu
-        assert lib.diinn_saved_activation_floats(b, hu, wu) == 8 * 256 * n
-        acts = torch.full((4, 2, 256, n), float("nan"), device=dev)
-        out = torch.empty((b, 3, hu, wu), device=dev)
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        N.check(lib.diinn_precompute_P(stream, C.c_void_p(f.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                       C.c_void_p(ws.data_ptr()), b, h, w, 0, h), "P")
-        N.check(lib.diinn_decode_train_fwd(stream, C.c_void_p(ws.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                           C.c_void_p(out.data_ptr()), C.c_void_p(acts.data_ptr()),
-                                           b, h, w, hu, wu, N.SIN_DEFAULT), "train_fwd")
-        torch.cuda.synchronize()
+        out, acts = _train_forward(lib, N, packed, f, b, h, w, hu, wu, dev)
         infer = D.decode_features(f, packed, (hu, wu))
         assert torch.equal(out, infer)                     # same arithmetic, different pixel-to-lane mapping
         tol = 1e-4 * max(1.0, float(ref_out.abs().max()))
         assert float((out.cpu() - ref_out).abs().max()) <= tol
-        a = acts.cpu()
+        flat = acts.permute(0, 2, 1, 3).reshape(4, 512, -1)
+        assert torch.isnan(flat[..., n:]).all()            # padding of the last tile is never written
+        a = T.untile_planes(acts, n).view(4, 2, 256, n).cpu()
         assert torch.isfinite(a).all()                     # every plane element written
         scale = max(1.0, float(ref_acts.abs().max()))
         assert float((a - ref_acts).abs().max()) <= 2e-5 * scale
-    assert lib.diinn_saved_activation_floats(1, 4096, 4096) == -1
-    assert lib.diinn_decode_train_fwd(None, C.c_void_p(ws.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                      C.c_void_p(out.data_ptr()), C.c_void_p(acts.data_ptr()),
-                                      1, 8, 8, 4096, 4096, N.SIN_DEFAULT) == N.ERR_TOO_LARGE
+    assert lib.diinn_training_plane_floats(1 << 31, 512) == -1
 
 
 @pytest.mark.gpu
@@ -191,46 +200,43 @@ def test_training_step_decreases_loss():
 
 @pytest.mark.gpu
 def test_fused_backward_equals_formula_backward_on_gpu():
-    """bwd_head_kernel + bwd_layer_kernel (C ABI diinn_backward_data) against the same gradients stated as
-    plain tensor algebra (backward_from_saved) on the same saved planes, at a size with ragged tiles
-    (N not a multiple of 128) and rectified-to-zero channels; also the planes themselves."""
+    """bwd_head_kernel + bwd_layer_kernel (diinn_backward_data), plane_gemm / rowdot / cell_sum kernels
+    against the same gradients stated as plain tensor algebra (backward_from_saved) on the same saved
+    planes, at sizes with a ragged last tile and rectified-to-zero channels; also the planes themselves."""
     import ctypes as C
     import diinn_amd._native as N
     import diinn_amd.decoder as D
     import diinn_amd.training as T
     dev = torch.device("cuda:0")
     lib = N.load()
-    for (b, h, w, hu, wu, gain) in [(3, 17, 13, 50, 41, 1.0), (1, 8, 8, 24, 24, 3.0)]:
+    for (b, h, w, hu, wu, gain) in [(3, 17, 13, 50, 41, 1.0), (1, 8, 8, 24, 24, 3.0), (2, 5, 40, 3, 9, 1.0)]:
         sd = synth.decoder_state_dict(5, gain)
         feat = torch.from_numpy(synth.encoder_features(5, b, h, w)).to(dev)
         params = [torch.from_numpy(sd[n]).to(dev) for n in T.PARAM_NAMES]
         gout = torch.from_numpy(synth.uniform(5, "g", (b, 3, hu, wu), 1.0)).to(dev)
         n = b * hu * wu
+        t = (n + 31) // 32
         packed = T.pack_on_device(params)
         assert torch.equal(packed[: 986_628].cpu(), D.pack_state_dict(sd)[: 986_628])
-        ws = torch.empty(b * h * w * 1024, device=dev)
-        acts = torch.empty((4, 2, 256, n), device=dev)
-        out = torch.empty((b, 3, hu, wu), device=dev)
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        N.check(lib.diinn_precompute_P(stream, C.c_void_p(feat.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                       C.c_void_p(ws.data_ptr()), b, h, w, 0, h), "P")
-        N.check(lib.diinn_decode_train_fwd(stream, C.c_void_p(ws.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                           C.c_void_p(out.data_ptr()), C.c_void_p(acts.data_ptr()),
-                                           b, h, w, hu, wu, N.SIN_DEFAULT), "fwd")
+        out, acts_t = _train_forward(lib, N, packed, feat, b, h, w, hu, wu, dev, fill=0.0)
+        acts = T.untile_planes(acts_t, n).view(4, 2, 256, n)
         # planes
         gp = gout.permute(1, 0, 2, 3).reshape(3, n).contiguous()
-        g = torch.full((4, 2, 256, n), float("nan"), device=dev)
-        q = torch.full((4, 257, n), float("nan"), device=dev)
-        q[:, 256] = 1.0
-        N.check(lib.diinn_backward_data(stream, C.c_void_p(gp.data_ptr()), C.c_void_p(acts.data_ptr()),
-                                        C.c_void_p(packed.data_ptr()), C.c_void_p(g.data_ptr()),
-                                        C.c_void_p(q.data_ptr()), n), "bwd")
+        g_t = torch.full((4, t, 512, 32), float("nan"), device=dev)
+        q_t = torch.full((4, t, 256, 32), float("nan"), device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        N.check(lib.diinn_backward_data(stream, C.c_void_p(gp.data_ptr()), C.c_void_p(acts_t.data_ptr()),
+                                        C.c_void_p(packed.data_ptr()), C.c_void_p(g_t.data_ptr()),
+                                        C.c_void_p(q_t.data_ptr()), n), "bwd")
         torch.cuda.synchronize()
+        g = T.untile_planes(g_t, n).view(4, 2, 256, n)
+        q = T.untile_planes(q_t, n)
         assert torch.isfinite(g).all() and torch.isfinite(q).all()
-        assert torch.equal(q[:, 256], torch.ones_like(q[:, 256]))
+        if n % 32:
+            assert torch.isnan(g_t.permute(0, 2, 1, 3).reshape(4, 512, -1)[..., n:]).all()   # padding untouched
         a64 = acts.double()
         q_ref = a64[:, 0] * torch.sin(a64[:, 1])
-        assert float((q[:, :256].double() - q_ref).abs().max()) <= 2e-6 * max(1.0, float(q_ref.abs().max()))
+        assert float((q.double() - q_ref).abs().max()) <= 2e-6 * max(1.0, float(q_ref.abs().max()))
         g_q = params[T.PARAM_NAMES.index("last_layer.weight")].view(3, 256).double().t() @ gp.double()
         for i in (3, 2, 1, 0):
             ga = g_q * torch.sin(a64[i, 1]) * (a64[i, 0] > 0)
@@ -243,43 +249,60 @@ def test_fused_backward_equals_formula_backward_on_gpu():
                 qw = params[T.PARAM_NAMES.index(f"Q.{i}.0.weight")].view(256, 256).double()
                 g_q = wq.t() @ ga + qw.t() @ gs
         # gradients
-        df_a, dp_a = T.backward_fused(gout, feat, acts, params, packed, (hu, wu))
+        df_a, dp_a = T.backward_fused(gout, feat, acts_t, params, packed, (hu, wu))
         df_b, dp_b = T.backward_from_saved(gout, feat, acts, params, (hu, wu))
         torch.cuda.synchronize()
         assert float((df_a - df_b).abs().max()) <= 5e-5 * float(df_b.abs().max())
         for name, x, y in zip(T.PARAM_NAMES, dp_a, dp_b):
             assert x.shape == y.shape
             assert float((x - y).abs().max()) <= 5e-5 * max(float(y.abs().max()), 1e-6), name
-    assert lib.diinn_backward_data(None, C.c_void_p(gp.data_ptr()), C.c_void_p(acts.data_ptr()),
-                                   C.c_void_p(packed.data_ptr()), C.c_void_p(g.data_ptr()),
-                                   C.c_void_p(q.data_ptr()), 1 << 23) == N.ERR_TOO_LARGE
+    assert lib.diinn_backward_data(None, C.c_void_p(gp.data_ptr()), C.c_void_p(acts_t.data_ptr()),
+                                   C.c_void_p(packed.data_ptr()), C.c_void_p(g_t.data_ptr()),
+                                   C.c_void_p(q_t.data_ptr()), 0) == N.ERR_INVALID_ARG
 
 
 @pytest.mark.gpu
 def test_plane_gemm_kernel():
-    """C = A . B^T over the pixel axis with split-K partials and the row-sum column, against float64,
-    for ragged pixel counts (tails inside a 32-pixel step, empty trailing splits)."""
+    """C = A . B^T over the pixel axis of tiled planes with split-K partials and the row-sum column, and the
+    skinny rowdot product, against float64, for ragged pixel counts, row windows and empty trailing splits."""
     import ctypes as C
     import diinn_amd._native as N
+    import diinn_amd.training as T
     dev = torch.device("cuda:0")
     lib = N.load()
     gen = torch.Generator(device=dev).manual_seed(1)
-    for (m, nc, npix, ksplit) in [(128, 256, 1000, 3), (512, 256, 4099, 64), (256, 512, 77, 8), (128, 256, 31, 1)]:
-        a = torch.randn((m, npix), device=dev, generator=gen)
-        b = torch.randn((nc, npix), device=dev, generator=gen)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda x: C.c_void_p(x.data_ptr())                      # noqa: E731
+    for (a_rows, a0, m, b_rows, b0, nc, npix, ksplit) in [(128, 0, 128, 256, 0, 256, 1000, 3), (512, 0, 512, 256, 0, 256, 4099, 64),
+                                                          (512, 256, 256, 768, 256, 512, 77, 8), (128, 0, 128, 256, 0, 256, 31, 1)]:
+        a_full = torch.randn((a_rows, npix), device=dev, generator=gen)
+        b_full = torch.randn((b_rows, npix), device=dev, generator=gen)
+        a_t, b_t = T.tile_planes(a_full), T.tile_planes(b_full)
+        if npix % 32:                                             # garbage in the padding must not matter
+            a_t.view(-1, a_rows, 32)[-1, :, npix % 32:] = float("nan")
+            b_t.view(-1, b_rows, 32)[-1, :, npix % 32:] = float("inf")
         part = torch.full((ksplit, m, nc + 1), float("nan"), device=dev)
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        N.check(lib.diinn_plane_gemm_nt(stream, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()),
-                                        C.c_void_p(part.data_ptr()), m, nc, npix, ksplit, 1), "plane_gemm")
+        N.check(lib.diinn_plane_gemm_nt(stream, ptr(a_t), a_rows, a0, ptr(b_t), b_rows, b0, ptr(part), m, nc, npix, ksplit, 1),
+                "plane_gemm")
         torch.cuda.synchronize()
         got = part.double().sum(0)
-        ref = torch.cat([a.double() @ b.double().t(), a.double().sum(1, keepdim=True)], dim=1)
+        a, b = a_full[a0:a0 + m].double(), b_full[b0:b0 + nc].double()
+        ref = torch.cat([a @ b.t(), a.sum(1, keepdim=True)], dim=1)
         assert torch.isfinite(got).all()
         assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * max(1.0, (npix / 1000) ** 0.5), (m, nc, npix)
         part2 = torch.full((ksplit, m, nc), float("nan"), device=dev)
-        N.check(lib.diinn_plane_gemm_nt(stream, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()),
-                                        C.c_void_p(part2.data_ptr()), m, nc, npix, ksplit, 0), "plane_gemm")
+        N.check(lib.diinn_plane_gemm_nt(stream, ptr(a_t), a_rows, a0, ptr(b_t), b_rows, b0, ptr(part2), m, nc, npix, ksplit, 0),
+                "plane_gemm")
         torch.cuda.synchronize()
         assert torch.equal(part2, part[:, :, :nc])
-    assert lib.diinn_plane_gemm_nt(None, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()),
-                                   C.c_void_p(part.data_ptr()), 100, 256, 31, 1, 0) == N.ERR_UNSUPPORTED
+        # skinny product against a 4-row group
+        s_full = torch.randn((4, npix), device=dev, generator=gen)
+        s_t = T.tile_planes(s_full)
+        splits = 5
+        pr = torch.full((splits, a_rows, 4), float("nan"), device=dev)
+        N.check(lib.diinn_plane_rowdot(stream, ptr(a_t), a_rows, ptr(s_t), ptr(pr), a_rows, npix, splits), "rowdot")
+        torch.cuda.synchronize()
+        ref = a_full.double() @ s_full.double().t()
+        assert float((pr.double().sum(0) - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * max(1.0, (npix / 1000) ** 0.5)
+    assert lib.diinn_plane_gemm_nt(None, ptr(a_t), 128, 0, ptr(b_t), 256, 0, ptr(part), 256, 256, 31, 1, 0) == N.ERR_INVALID_ARG
+    assert lib.diinn_plane_gemm_nt(None, ptr(a_t), 128, 0, ptr(b_t), 256, 0, ptr(part), 64, 256, 31, 1, 0) == N.ERR_UNSUPPORTED
