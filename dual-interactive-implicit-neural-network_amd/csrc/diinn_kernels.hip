@@ -571,14 +571,23 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
     const __amdgpu_buffer_rsrc_t outG = tile_rsrc(p.G + (size_t)(li - 1) * agroup, tile, ACT_ROWS);
     const __amdgpu_buffer_rsrc_t outQ = tile_rsrc(p.Q + (size_t)(li - 1) * qgroup, tile, HID);
 
-    // B operand: register kk = 16m + r of lane-half h holds channel chan_of(kk, h) of this lane's pixel
+    // B operand: register kk = 16m + r of lane-half h holds channel chan_of(kk, h) of this lane's pixel.
+    // Only the first BLD k-groups are fetched up front; the rest stream in BLD groups ahead of the
+    // MFMAs of the first output tile (which walks all 32 k-groups), so the 64 KiB a wave reads
+    // hide behind its own arithmetic instead of in front of it.
+    constexpr int BLD = 8;
     float ga[128], gs[128];
+    auto load_group = [&](int kg) {
 #pragma unroll
-    for (int kk = 0; kk < 128; ++kk) {
-        const unsigned so = (unsigned)(32 * (kk >> 4) + (kk & 3) + 8 * ((kk & 15) >> 2)) * PLANE_ROW_BYTES;
-        ga[kk] = ld_act(inG, voff, so);
-        gs[kk] = ld_act(inG, voff, so + HID * PLANE_ROW_BYTES);
-    }
+        for (int e = 0; e < 4; ++e) {
+            const int kk = 4 * kg + e;
+            const unsigned so = (unsigned)(32 * (kk >> 4) + (kk & 3) + 8 * ((kk & 15) >> 2)) * PLANE_ROW_BYTES;
+            ga[kk] = ld_act(inG, voff, so);
+            gs[kk] = ld_act(inG, voff, so + HID * PLANE_ROW_BYTES);
+        }
+    };
+#pragma unroll
+    for (int kg = 0; kg < BLD; ++kg) load_group(kg);
 
     constexpr int PF = DECODE_PREFETCH;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -621,6 +630,7 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
             }
             rk[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF) + 0) * PIECE_BYTES);
             rq[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF) + 1) * PIECE_BYTES);
+            if (m == 0 && kg + BLD < WL_KG) load_group(kg + BLD); // rest of the B operand, BLD groups ahead
             if (m > 0 && kg == 0) {                               // saved planes of tile m-1, used from kg = 8 on
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {

@@ -92,8 +92,23 @@ def pack_gather_index() -> torch.Tensor:
     return _gather_index_cpu
 
 
+_packed_cache: Tuple[Optional[tuple], Optional[torch.Tensor]] = (None, None)
+
+
 def pack_on_device(params: Sequence[torch.Tensor]) -> torch.Tensor:
-    """Reference-ordered parameter tensors (PARAM_NAMES) on a GPU -> packed image on that GPU."""
+    """Reference-ordered parameter tensors (PARAM_NAMES) on a GPU -> packed image on that GPU.
+    The last image is kept while no parameter has been modified (a training step decodes once per
+    scale with the same weights, sr_module.py:116-121)."""
+    global _packed_cache
+    key = tuple((p.data_ptr(), p._version) for p in params)
+    if _packed_cache[0] == key:
+        return _packed_cache[1]
+    packed = _pack_on_device(params)
+    _packed_cache = (key, packed)
+    return packed
+
+
+def _pack_on_device(params: Sequence[torch.Tensor]) -> torch.Tensor:
     dev = params[0].device
     key = str(dev)
     idx = _gather_index_dev.get(key)
@@ -234,6 +249,34 @@ def untile_planes(x: torch.Tensor, n: int) -> torch.Tensor:
     return x.permute(*range(d), d + 1, d, d + 2).reshape(*lead, c, t * w)[..., :n]
 
 
+_geometry_cache: "Dict[tuple, dict]" = {}
+GEOMETRY_CACHE_ENTRIES = 8
+
+
+def _geometry(b: int, h: int, w: int, hu: int, wu: int, dev) -> dict:
+    """Per-shape constants of the backward pass, built once per (B, LR size, HR size, device): the cell
+    rectangles of cell_sum_kernel and the tiled right-hand side (rel_h, rel_w, ratio, 1) of the layer-0
+    product.  Training revisits a handful of shapes (one per scale), so a small LRU suffices."""
+    key = (b, h, w, hu, wu, str(dev))
+    geo = _geometry_cache.pop(key, None)
+    if geo is None:
+        idx_h, rel_h, idx_w, rel_w, ratio = coordinate_tensors(h, w, hu, wu, dev)
+        syn = torch.empty((4, b, hu, wu), dtype=torch.float32, device=dev)
+        syn[0] = rel_h[None, :, None]
+        syn[1] = rel_w[None, None, :]
+        syn[2] = ratio
+        syn[3] = 1.0
+        geo = {
+            "seg_h": torch.searchsorted(idx_h, torch.arange(h + 1, device=dev)).to(torch.int32),
+            "seg_w": torch.searchsorted(idx_w, torch.arange(w + 1, device=dev)).to(torch.int32),
+            "syn_t": tile_planes(syn.view(4, b * hu * wu)),
+        }
+        while len(_geometry_cache) >= GEOMETRY_CACHE_ENTRIES:
+            _geometry_cache.pop(next(iter(_geometry_cache)))
+    _geometry_cache[key] = geo
+    return geo
+
+
 def backward_fused(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tensor, params: Sequence[torch.Tensor],
                    packed: torch.Tensor, size: Sequence[int],
                    need_feat_grad: bool = True) -> Tuple[Optional[torch.Tensor], List[torch.Tensor]]:
@@ -254,25 +297,17 @@ def backward_fused(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tensor, p
     dev = gout.device
     if tuple(acts.shape) != (4, t, 2 * HIDDEN, PLANE_TILE) or not acts.is_contiguous():
         raise ValueError("acts must be the contiguous tiled [4, T, 512, 32] buffer of the training forward")
-    idx_h, rel_h, idx_w, rel_w, ratio = coordinate_tensors(h, w, hu, wu, dev)
+    geo = _geometry(b, h, w, hu, wu, dev)
+    seg_h, seg_w, syn_t = geo["seg_h"], geo["seg_w"], geo["syn_t"]
     gp = gout.to(torch.float32).permute(1, 0, 2, 3).reshape(3, n).contiguous()
     g = torch.empty((4, t, 2 * HIDDEN, PLANE_TILE), dtype=torch.float32, device=dev)
     q = torch.empty((4, t, HIDDEN, PLANE_TILE), dtype=torch.float32, device=dev)
-    # the two 4-row right-hand sides of the skinny products, tiled (padding zero)
-    syn = torch.empty((4, b, hu, wu), dtype=torch.float32, device=dev)
-    syn[0] = rel_h[None, :, None]
-    syn[1] = rel_w[None, None, :]
-    syn[2] = ratio
-    syn[3] = 1.0
-    syn_t = tile_planes(syn.view(4, n))
-    gout_t = tile_planes(torch.cat([gp, gp.new_zeros((1, n))], 0))
+    gout_t = tile_planes(torch.cat([gp, gp.new_zeros((1, n))], 0))     # 4-row right-hand side of the head product
     ksplit = max(1, min(WGRAD_KSPLIT, t))
     rsplit = max(1, min(ROWDOT_SPLITS, t))
     part = torch.empty((3, ksplit, 2 * HIDDEN, HIDDEN + 1), dtype=torch.float32, device=dev)
     part0 = torch.empty((rsplit, 2 * HIDDEN, 4), dtype=torch.float32, device=dev)
     partl = torch.empty((rsplit, HIDDEN, 4), dtype=torch.float32, device=dev)
-    seg_h = torch.searchsorted(idx_h, torch.arange(h + 1, device=dev)).to(torch.int32)
-    seg_w = torch.searchsorted(idx_w, torch.arange(w + 1, device=dev)).to(torch.int32)
     dp = torch.empty((b, 4 * HIDDEN, h, w), dtype=torch.float32, device=dev)
     ptr = lambda x: C.c_void_p(x.data_ptr())                      # noqa: E731
     with torch.cuda.device(dev):

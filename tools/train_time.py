@@ -45,8 +45,55 @@ def timeit(fn, n=5, warm=2):
     return (time.perf_counter() - t0) / n * 1e3
 
 
+def e2e():
+    """One optimiser step of the whole network the way the reference trains it (configs/default.yaml:
+    batch 16, 48x48 LR patches; SRLitModule.step loops over the scales of the batch, sr_module.py:113-125),
+    RDN encoder on PyTorch-ROCm/MIOpen in both cases; decoder on the HIP path vs the eager op sequence."""
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = M.SRLitModule(arch="diinn", mode=3, init_q=False).to(dev).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    lr = torch.rand(16, 3, 48, 48, device=dev)
+    batch = {s: (lr, torch.rand(16, 3, 48 * s, 48 * s, device=dev), None) for s in (2, 3, 4)}
+    dec = net.net.decoder
+    tabs = {}
+    for s in batch:
+        idx_h, rel_h, idx_w, rel_w, ratio = T.coordinate_tensors(48, 48, 48 * s, 48 * s, dev)
+        syn = torch.empty(16, 3, 48 * s, 48 * s, device=dev)
+        syn[:, 0] = rel_h[None, :, None]
+        syn[:, 1] = rel_w[None, None, :]
+        syn[:, 2] = ratio
+        tabs[s] = (idx_h, idx_w, syn)
+
+    def step_ours():
+        opt.zero_grad(set_to_none=True)
+        loss, _ = net.step(batch)
+        loss.backward()
+        opt.step()
+
+    def step_eager():
+        opt.zero_grad(set_to_none=True)
+        loss = 0
+        for s, (x, hr, _) in batch.items():
+            feat = net.net.encoder((x - net.sub) / net.div)
+            pred = eager_forward(dec, feat, hr.shape[-2:], tabs[s][0], tabs[s][1], tabs[s][2])
+            loss = loss + net.criterion(pred, (hr - net.sub) / net.div)
+        (loss / len(batch)).backward()
+        opt.step()
+
+    t_ours = timeit(step_ours, n=5, warm=3)
+    print(f"full training step, batch 16 x 48x48 LR, scales 2+3+4 (encoder + decoder + Adam)")
+    print(f"  decoder on the HIP path   {t_ours:8.1f} ms")
+    t_eager = timeit(step_eager, n=3, warm=2)
+    print(f"  decoder as eager ops      {t_eager:8.1f} ms   ({t_eager / t_ours:.2f}x)")
+    print(f"  peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+
+
 def main():
     only_ours = "--only-ours" in sys.argv          # for profiling: skip the eager comparison
+    if "--e2e" in sys.argv:
+        return e2e()
     argv = [a for a in sys.argv if not a.startswith("--")]
     b = int(argv[1]) if len(argv) > 1 else 16
     lr = int(argv[2]) if len(argv) > 2 else 48
