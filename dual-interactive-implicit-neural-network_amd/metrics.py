@@ -77,5 +77,10 @@ def resize_fn(img: torch.Tensor, size) -> torch.Tensor:
     ``Resize(size, BICUBIC, antialias=True)`` lowers to for tensors)."""
     squeeze = img.dim() == 3
     x = img.unsqueeze(0) if squeeze else img
+    integer = not torch.is_floating_point(x)
+    if integer:                                  # uint8 images (the data loaders): resize in fp32, clamp, round, cast back
+        x = x.to(torch.float32)
     y = F.interpolate(x, size=tuple(int(s) for s in size), mode="bicubic", align_corners=False, antialias=True)
+    if integer:
+        y = y.clamp_(0, 255).round_().to(img.dtype)
     return y.squeeze(0) if squeeze else y

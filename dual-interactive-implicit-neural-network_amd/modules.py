@@ -8,9 +8,9 @@ surface around the decoder, so its workflows run on the MI355X path unchanged.
   make_net           reference sr_module.py:42-50
   SRLitModule        reference sr_module.py:62-194, the parts the inference callers use:
                      ctor hparams, ``net``, ``sub``/``div`` buffers, forward, step,
+                     training_step / validation_step / test_step, configure_optimizers,
                      load_from_checkpoint.  pytorch_lightning is not required (it is absent from
-                     the target image); training hooks, losses' optimisers and metrics are out of
-                     scope for this tier.
+                     the target image); scripts/train.py is the plain loop around these hooks.
 """
 from __future__ import annotations
 
@@ -198,6 +198,32 @@ class SRLitModule(nn.Module):
             loss += self.criterion(pred_hr, hr)
             pred_hrs[scale] = (pred_hr * self.div + self.sub).clamp_(0, 1)
         return loss / len(batch), pred_hrs
+
+    def training_step(self, batch: Any, batch_idx: int = 0):
+        """sr_module.py:127-137: the decoder runs under autograd with bsize=None (training.py: HIP forward
+        with saved planes + HIP backward)."""
+        loss, _ = self.step(batch)
+        return {"loss": loss}
+
+    @torch.no_grad()
+    def validation_step(self, batch: Any, batch_idx: int = 0):
+        """sr_module.py:143-154: loss and the DIV2K-style PSNR (border shaved by the scale) per scale."""
+        loss, pred_hrs = self.step(batch, self.hparams.eval_bsize)
+        res = {"val/loss": loss}
+        for scale in batch:
+            res[f"val/psnr_x{scale}"] = calc_psnr(pred_hrs[scale], batch[scale][1], dataset="div2k", scale=scale, rgb_range=1)
+        return res
+
+    def configure_optimizers(self):
+        """sr_module.py:185-194: Adam(lr) + StepLR(lr_step, lr_gamma), one scheduler step per epoch."""
+        optimizer = torch.optim.Adam(self.parameters(), lr=self.hparams.lr)
+        scheduler = torch.optim.lr_scheduler.StepLR(optimizer=optimizer, step_size=self.hparams.lr_step,
+                                                    gamma=self.hparams.lr_gamma)
+        return [optimizer], [scheduler]
+
+    def checkpoint(self) -> Dict[str, Any]:
+        """The two entries of a Lightning checkpoint that ``load_from_checkpoint`` (here and in the reference) reads."""
+        return {"state_dict": self.state_dict(), "hyper_parameters": dict(vars(self.hparams))}
 
     @torch.no_grad()
     def test_step(self, batch: Any, batch_idx: int = 0, dataloader_idx: Optional[int] = None):
