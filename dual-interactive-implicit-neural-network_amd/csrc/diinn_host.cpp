@@ -35,6 +35,14 @@ const char* diinn_status_string(int status) {
 
 size_t diinn_packed_weight_floats(void) { return PACKED_FLOATS; }
 
+int diinn_liif_make_axis_tables(int n_in, int n_out, int v, int32_t* idx, float* rel, float* rel_cell) {
+    if (n_in <= 0 || n_out <= 0 || (v != -1 && v != 1) || !idx || !rel) return DIINN_ERR_INVALID_ARG;
+    const LiifAxis a = make_liif_axis(n_in, n_out);
+    for (int j = 0; j < n_out; ++j) liif_axis_eval(a, j, v > 0 ? 1 : 0, idx[j], rel[j]);
+    if (rel_cell) *rel_cell = a.rel_cell;
+    return DIINN_OK;
+}
+
 int diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats) {
     static const size_t off[9] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT};
     static const size_t sz[9]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT};

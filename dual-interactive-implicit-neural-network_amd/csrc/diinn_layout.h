@@ -119,4 +119,40 @@ DIINN_HD void axis_eval(const Axis& a, int j, int& idx, float& rel) {
     rel = (g_out - g_in) * a.n_in_f;
 }
 
+// ---- LIIF comparison decoder (reference liif.py:59-127): nearest cell of the coordinate shifted by
+// v/n_in + 1e-6 (v = -1, +1), through grid_sample(mode='nearest', align_corners=False) as ATen's
+// vectorised CPU kernel evaluates it: idx = nearbyint((c + 1) * (n_in / 2) - 0.5), half to even.
+struct LiifAxis {
+    Axis  base;             // centres of both grids (make_coord == the DIINN centres)
+    float shift[2];         // fp32(v / n_in + 1e-6) for v = -1, +1   (liif.py:91-92)
+    float lo, hi;           // fp32(-1 + 1e-6), fp32(1 - 1e-6)         (liif.py:93)
+    float half_n;           // fp32(n_in) / 2
+    float rel_cell;         // fp32(2 / n_out) * fp32(n_in)            (liif.py:55-56,108-110)
+};
+
+inline LiifAxis make_liif_axis(int n_in, int n_out) {
+    LiifAxis a;
+    a.base = make_axis(n_in, n_out, 0);
+    a.shift[0] = (float)(-1.0 * (2.0 / (double)n_in / 2.0) + 1e-6);
+    a.shift[1] = (float)(1.0 * (2.0 / (double)n_in / 2.0) + 1e-6);
+    a.lo = (float)(-1.0 + 1e-6);
+    a.hi = (float)(1.0 - 1e-6);
+    a.half_n = (float)n_in / 2.0f;
+    a.rel_cell = (float)(2.0 / (double)n_out) * (float)n_in;
+    return a;
+}
+
+// vi = 0 (v = -1) or 1 (v = +1)
+DIINN_HD void liif_axis_eval(const LiifAxis& a, int j, int vi, int& idx, float& rel) {
+    const float c = a.base.c1_out * (float)j + a.base.c0_out;
+    float cs = c + a.shift[vi];
+    cs = cs < a.lo ? a.lo : (cs > a.hi ? a.hi : cs);
+    const float x = (cs + 1.0f) * a.half_n - 0.5f;
+    int id = (int)__builtin_rintf(x);
+    id = id < 0 ? 0 : (id > a.base.n_in - 1 ? a.base.n_in - 1 : id);       // in range by construction; guards the gather
+    const float q = a.base.c1_in * (float)id + a.base.c0_in;
+    idx = id;
+    rel = (c - q) * a.base.n_in_f;
+}
+
 }  // namespace diinn

@@ -163,6 +163,69 @@ def decode_features(feat: torch.Tensor, packed: torch.Tensor, size: Sequence[int
 
 
 # ---------------------------------------------------------------------------
+# LIIF comparison decoder (reference liif.py)
+# ---------------------------------------------------------------------------
+def pack_liif_state_dict(sd, prefix: str = "imnet.") -> torch.Tensor:
+    """``imnet`` of the reference LIIF (MLP 580 -> 256 x4 -> 3, liif.py:24, mlp.py) -> the DIINN packed image,
+    with the slot mapping documented at ``diinn_liif_decode`` in include/diinn_hip.h: the 576 feature
+    columns of layer 0 become the hoisted 3x3 conv, its 4 coordinate columns the Q0 table, layers 2/4/6
+    the synthesis slots of the stacked per-pixel layers, layer 8 the RGB head."""
+    def get(name, shape):
+        t = sd[prefix + name]
+        a = t.detach().to("cpu", torch.float32).numpy() if isinstance(t, torch.Tensor) else np.asarray(t, np.float32)
+        return np.ascontiguousarray(a.reshape(shape), dtype=np.float32)
+
+    w0 = get("layers.0.weight", (HIDDEN, 580))
+    mapped = {
+        "K.0.0.weight": w0[:, :576], "K.0.0.bias": get("layers.0.bias", (HIDDEN,)),
+        "Q.0.0.weight": w0[:, 576:579], "Q.0.0.bias": w0[:, 579],
+        "last_layer.weight": get("layers.8.weight", (3, HIDDEN)), "last_layer.bias": get("layers.8.bias", (3,)),
+    }
+    for i, layer in ((1, 2), (2, 4), (3, 6)):
+        mapped[f"K.{i}.0.weight"] = np.zeros((HIDDEN, HIDDEN + 576), np.float32)
+        mapped[f"K.{i}.0.bias"] = np.zeros((HIDDEN,), np.float32)
+        mapped[f"Q.{i}.0.weight"] = get(f"layers.{layer}.weight", (HIDDEN, HIDDEN))
+        mapped[f"Q.{i}.0.bias"] = get(f"layers.{layer}.bias", (HIDDEN,))
+    return pack_state_dict(mapped, mode=3)
+
+
+def liif_axis_tables(n_in: int, n_out: int, v: int) -> Tuple[np.ndarray, np.ndarray, float]:
+    """Host tables (idx int32, rel fp32) and rel_cell of one axis for ensemble shift v (C ABI)."""
+    lib = _native.load()
+    idx = np.empty(n_out, np.int32)
+    rel = np.empty(n_out, np.float32)
+    cell = C.c_float()
+    _native.check(lib.diinn_liif_make_axis_tables(n_in, n_out, v, idx.ctypes.data_as(_native._i32), _native.fptr(rel),
+                                                  C.byref(cell)), "diinn_liif_make_axis_tables")
+    return idx, rel, cell.value
+
+
+def liif_decode_features(feat: torch.Tensor, packed: torch.Tensor, size: Sequence[int],
+                         out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LIIF query of every HR pixel: encoder features [B,64,H,W] -> RGB [B,3,Hu,Wu] (liif.py:59-127,148-155)."""
+    lib = _native.load()
+    _require_cuda(feat, "feat")
+    _require_cuda(packed, "packed weights")
+    if feat.dtype != torch.float32 or feat.dim() != 4 or feat.shape[1] != IN_CHANNELS:
+        raise ValueError(f"feat must be fp32 [B,{IN_CHANNELS},H,W], got {feat.dtype} {tuple(feat.shape)}")
+    hu, wu = size
+    hu, wu = int(hu), int(wu)
+    feat = feat.contiguous()
+    b, _, h, w = feat.shape
+    if out is None:
+        out = torch.empty((b, 3, hu, wu), dtype=torch.float32, device=feat.device)
+    need = lib.diinn_workspace_bytes(b, h, w)
+    if workspace is None or workspace.numel() * 4 < need or workspace.device != feat.device:
+        workspace = torch.empty(need // 4, dtype=torch.float32, device=feat.device)
+    with torch.cuda.device(feat.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        st = lib.diinn_liif_decode(C.c_void_p(stream), C.c_void_p(feat.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                   C.c_void_p(workspace.data_ptr()), C.c_void_p(out.data_ptr()), b, h, w, hu, wu)
+    _native.check(st, "diinn_liif_decode")
+    return out
+
+
+# ---------------------------------------------------------------------------
 # nn.Module mirror of the reference class
 # ---------------------------------------------------------------------------
 class ImplicitDecoder(nn.Module):

@@ -151,6 +151,58 @@ class DIINN(nn.Module):
         return static_y.clone()
 
 
+class MLP(nn.Module):
+    """Linear/ReLU stack with the reference's parameter names ``layers.{0,2,4,...}`` (mlp.py:3-20)."""
+
+    def __init__(self, in_dim, out_dim, hidden_list):
+        super().__init__()
+        layers, last = [], in_dim
+        for width in hidden_list:
+            layers += [nn.Linear(last, width), nn.ReLU()]
+            last = width
+        layers.append(nn.Linear(last, out_dim))
+        self.layers = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.layers(x.reshape(-1, x.shape[-1])).view(*x.shape[:-1], -1)
+
+
+class LIIF(nn.Module):
+    """The LIIF comparison model (reference liif.py:9-155; Chen et al. 2021) behind the same
+    ``forward(inp, size, bsize=None)`` boundary: RDN encoder (PyTorch-ROCm) + the implicit MLP decoder on
+    the HIP path (``liif_kernel``).  Constructor defaults only (local ensemble, feature unfolding, cell
+    decoding -- what ``make_net('liif')`` builds, sr_module.py:45-46); inference only.  ``bsize`` is the
+    reference's query-chunk size, a memory knob: accepted and ignored."""
+
+    def __init__(self, local_ensemble=True, feat_unfold=True, cell_decode=True):
+        super().__init__()
+        if not (local_ensemble and feat_unfold and cell_decode):
+            raise NotImplementedError("the HIP path implements LIIF with local_ensemble, feat_unfold and cell_decode on")
+        self.local_ensemble, self.feat_unfold, self.cell_decode = local_ensemble, feat_unfold, cell_decode
+        self.encoder = make_rdn()
+        self.imnet = MLP(self.encoder.out_dim * 9 + 4, 3, [256, 256, 256, 256])
+        self._packed = None
+        self._packed_key = None
+
+    def gen_feat(self, inp):
+        return self.encoder(inp)
+
+    def _packed_weights(self, device):
+        from .decoder import pack_liif_state_dict
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.imnet.parameters())
+        if self._packed is None or self._packed_key != key:
+            self._packed = pack_liif_state_dict(self.imnet.state_dict(), prefix="").to(device)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, inp, size, bsize=None):
+        from .decoder import liif_decode_features
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("diinn_amd: LIIF runs on the HIP path for inference only; call under torch.no_grad()")
+        feat = self.gen_feat(inp)
+        return liif_decode_features(feat, self._packed_weights(feat.device), size)
+
+
 class BICUBIC_NET(nn.Module):
     """Antialiased bicubic resize baseline (reference sr_module.py:53-60 via torchvision.Resize,
     which lowers to this interpolate call)."""
@@ -164,9 +216,11 @@ def make_net(arch, mode, init_q):
         return DIINN(mode=mode, init_q=init_q)
     if arch == "bicubic":
         return BICUBIC_NET()
-    if arch in ("liif", "metasr"):
-        raise NotImplementedError(f"arch={arch!r}: comparison baselines of the reference are outside this build "
-                                  f"(SURVEY.md §2 rows 7-8)")
+    if arch == "liif":
+        return LIIF()
+    if arch == "metasr":
+        raise NotImplementedError("arch='metasr': this comparison baseline of the reference is not built "
+                                  "(SURVEY.md §8 row f4 covers LIIF so far)")
     return None   # the reference's make_net falls through to None for unknown names
 
 

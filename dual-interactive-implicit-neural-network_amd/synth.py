@@ -114,14 +114,14 @@ def encoder_features(seed: int, b: int, h: int, w: int, tag: str = "feat") -> np
     return normalish(seed, f"{tag}:{b}x{h}x{w}", (b, IN_CHANNELS, h, w))
 
 
-def state_dict_for(shapes, seed: int = 123, prefix: str = "") -> "OrderedDict[str, np.ndarray]":
+def state_dict_for(shapes, seed: int = 123, prefix: str = "", gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
     """Synthetic tensors for any conv-style module given ``{name: shape}`` (names ending in
-    ``.weight``/``.bias``): U(+-1/sqrt(fan_in)) with fan_in taken from the sibling weight."""
+    ``.weight``/``.bias``): U(+-gain/sqrt(fan_in)) with fan_in taken from the sibling weight."""
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     for name, shape in shapes.items():
         shape = tuple(int(x) for x in shape)
         wname = name.rsplit(".", 1)[0] + ".weight"
         wshape = tuple(int(x) for x in shapes.get(wname, shape))
         fan_in = int(np.prod(wshape[1:])) if len(wshape) > 1 else 1
-        out[name] = uniform(seed, prefix + name, shape, 1.0 / math.sqrt(max(fan_in, 1)))
+        out[name] = uniform(seed, prefix + name, shape, gain / math.sqrt(max(fan_in, 1)))
     return out

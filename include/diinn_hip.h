@@ -204,6 +204,20 @@ int diinn_plane_rowdot(void* stream, const float* A_dev, int a_rows, const float
 int diinn_backward_cell_sum(void* stream, const float* G_dev, const int32_t* seg_h_dev, const int32_t* seg_w_dev,
                             float* dP_dev, int B, int H, int W, int Hu, int Wu);
 
+/* ---- LIIF comparison decoder ------------------------
+ * Replaces: LIIF.query_rgb + batched_predict + reshape_pred (liif.py:59-127,129-146), constructor
+ * defaults (local_ensemble, feat_unfold, cell_decode): for every HR pixel the 580->256->256->256->256->3
+ * ReLU MLP on the unfolded features of the 4 shifted nearest cells, blended by opposite areas.
+ * The weights travel in the DIINN packed image (diinn_pack_weights) with this mapping:
+ *   K0w/K0b <- imnet.layers.0 weight[:, :576] / bias;  Q0w [256,3] <- weight[:, 576:579]; Q0b <- weight[:, 579];
+ *   Qw[i]/Qb[i] <- imnet.layers.{2,4,6} weight / bias;  Lw/Lb <- imnet.layers.8;  Kw[i], Kb[i] <- zeros.
+ * workspace_dev: diinn_workspace_bytes(B,H,W) bytes.  Enqueues 2 kernels; no allocation, no sync.
+ * diinn_liif_make_axis_tables: host restatement of the per-axis nearest index / relative coordinate for
+ * ensemble shift v = -1 or +1 (grid_sample nearest, align_corners=False, as ATen's CPU kernel rounds). */
+int diinn_liif_decode(void* stream, const float* feat_dev, const float* packed_dev, float* workspace_dev,
+                      float* out_dev, int B, int H, int W, int Hu, int Wu);
+int diinn_liif_make_axis_tables(int n_in, int n_out, int v, int32_t* idx, float* rel, float* rel_cell);
+
 /* Dominant-kernel launch geometry, for benchmarks/roofline accounting. */
 int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,
                              int* grid_x, int* grid_y, int* grid_z, int* block);
