@@ -59,6 +59,12 @@ SIGNATURES = {
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_cell_chain": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_decode_launch_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip]),
+    "diinn_metasr_packed_floats": (C.c_size_t, []),
+    "diinn_metasr_pack_weights": (C.c_int, [_f, _f, _f, _f, _f]),
+    "diinn_metasr_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "diinn_metasr_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "diinn_metasr_make_axis_tables": (C.c_int, [C.c_int, C.c_int, _i32, _f, _f]),
     "diinn_liif_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_liif_make_axis_tables": (C.c_int, [C.c_int, C.c_int, C.c_int, _i32, _f, _f]),

@@ -43,6 +43,45 @@ int diinn_liif_make_axis_tables(int n_in, int n_out, int v, int32_t* idx, float*
     return DIINN_OK;
 }
 
+size_t diinn_metasr_packed_floats(void) { return MS_PACKED_FLOATS; }
+
+int diinn_metasr_pack_weights(const float* W1, const float* b1, const float* W2, const float* b2, float* packed) {
+    if (!W1 || !b1 || !W2 || !b2 || !packed) return DIINN_ERR_INVALID_ARG;
+    for (int o = 0; o < 3; ++o)
+        for (int mm = 0; mm < MS_MM; ++mm)
+            for (int kg = 0; kg < WL_KG; ++kg) {
+                float* dst = packed + MS_OFF_W2 + (((size_t)o * MS_MM + mm) * WL_KG + kg) * WL_PIECE;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int n = 3 * (32 * mm + (lane & 31)) + o;          // row of imnet.layers.2.weight
+                    const int h = lane >> 5;
+                    for (int e = 0; e < 4; ++e) dst[lane * 4 + e] = W2[(size_t)n * HID + chan_of(4 * kg + e, h)];
+                }
+            }
+    float* q0 = packed + MS_OFF_Q0;
+    for (int ch = 0; ch < HID; ++ch) {
+        q0[0 * HID + ch] = W1[ch * 3 + 0];   // rel_h
+        q0[1 * HID + ch] = W1[ch * 3 + 1];   // rel_w
+        q0[2 * HID + ch] = W1[ch * 3 + 2];   // r_rev
+        q0[3 * HID + ch] = b1[ch];
+    }
+    for (int o = 0; o < 3; ++o)
+        for (int k = 0; k < MS_K; ++k) packed[MS_OFF_B2 + (size_t)o * MS_K + k] = b2[3 * k + o];
+    return DIINN_OK;
+}
+
+int diinn_metasr_make_axis_tables(int n_in, int n_out, int32_t* idx, float* rel, float* r_rev) {
+    if (n_in <= 0 || n_out <= 0 || !idx || !rel) return DIINN_ERR_INVALID_ARG;
+    const MetaAxis a = make_meta_axis(n_in, n_out);
+    for (int j = 0; j < n_out; ++j) meta_axis_eval(a, j, idx[j], rel[j]);
+    if (r_rev) *r_rev = a.r_rev;
+    return DIINN_OK;
+}
+
+size_t diinn_metasr_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * H * W * MS_K * sizeof(float);
+}
+
 int diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats) {
     static const size_t off[9] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT};
     static const size_t sz[9]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT};

@@ -659,6 +659,146 @@ __global__ __launch_bounds__(256, 1) void liif_kernel(const LiifParams p) {
 }
 
 // ---------------------------------------------------------------------------------
+// MetaSR comparison decoder (reference metasr.py:70-104): per HR pixel the
+// meta-network 3 -> 256 -> 1728 predicts a [576 x 3] filter from (rel_h, rel_w, r_rev) and applies it to
+// the unfolded 3x3 features of the pixel's cell.
+//   unfold_cells_kernel : U[cell][k = c*9 + ky*3 + kx] = feat[c][cy+ky-1][cx+kx-1] (zero outside): the rows
+//                         the final contraction gathers, contiguous per cell (2,304 B).
+//   metasr_kernel       : one wave per 32 pixels; hidden = relu(W1 . inp + b1) in registers (128), then the
+//                         1728 x 256 second layer as 54 MFMA tiles whose rows are regrouped by RGB
+//                         component (diinn_layout.h): the epilogue of a tile is 16 FMAs against the
+//                         tile's 32 feature values, so the 1728 predicted weights never leave registers.
+// ---------------------------------------------------------------------------------
+struct UnfoldParams {
+    const float* feat;     // [B,64,H,W]
+    float* U;              // [B,H,W,576]
+    int B, H, W;
+};
+
+__global__ __launch_bounds__(192) void unfold_cells_kernel(const UnfoldParams p) {
+    const int cx = blockIdx.x, cy = blockIdx.y, b = blockIdx.z;
+    float* __restrict__ dst = p.U + (((size_t)b * p.H + cy) * p.W + cx) * MS_K;
+    for (int k = threadIdx.x; k < MS_K; k += 192) {
+        const int c = k / 9, t = k - 9 * c;
+        const int yy = cy + t / 3 - 1, xx = cx + t % 3 - 1;
+        float v = 0.0f;
+        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) v = p.feat[(((size_t)b * C_IN + c) * p.H + yy) * p.W + xx];
+        dst[k] = v;
+    }
+}
+
+struct MetaParams {
+    const float* U;        // [B,H,W,576]
+    const float* Wt;       // MetaSR packed image
+    float* out;            // [B,3,Hu,Wu]
+    int B, H, W, Hu, Wu;
+    MetaAxis ah, aw;
+};
+
+__global__ __launch_bounds__(256, 1) void metasr_kernel(const MetaParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int x = blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
+    const int y = blockIdx.y * (TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
+    const int b = blockIdx.z;
+    const bool valid = (x < p.Wu) && (y < p.Hu);
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
+    const int xc = x < p.Wu ? x : p.Wu - 1;
+    const int yc = y < p.Hu ? y : p.Hu - 1;
+    int iy, ix;
+    float relh, relw;
+    meta_axis_eval(p.ah, yc, iy, relh);
+    meta_axis_eval(p.aw, xc, ix, relw);
+    const float* __restrict__ Wt = p.Wt;
+    const float* __restrict__ Uc = p.U + (((size_t)b * p.H + iy) * p.W + ix) * MS_K + 4 * h;
+
+    // ---- hidden = relu(W1 . (rel_h, rel_w, r_rev) + b1)   (imnet.layers.0, metasr.py:98-101)
+    float q[128];
+    {
+        const float* __restrict__ Q0 = Wt + MS_OFF_Q0 + 4 * h;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * m + 8 * g;
+                const f32x4 wh = *(const f32x4*)(Q0 + 0 * HID + c0);
+                const f32x4 ww = *(const f32x4*)(Q0 + 1 * HID + c0);
+                const f32x4 wr = *(const f32x4*)(Q0 + 2 * HID + c0);
+                const f32x4 bq = *(const f32x4*)(Q0 + 3 * HID + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = __builtin_fmaf(wr[e], p.ah.r_rev, bq[e]);
+                    a = __builtin_fmaf(ww[e], relw, a);
+                    a = __builtin_fmaf(wh[e], relh, a);
+                    q[16 * m + 4 * g + e] = relu0(a);
+                }
+            }
+        }
+    }
+
+    // ---- second layer (1728 x 256) and the contraction with the cell's 576 unfolded features
+    constexpr int PF = DECODE_PREFETCH;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Wt, 0, (int)(MS_PACKED_FLOATS * sizeof(float)), 0x00020000);   // reads past the end return 0
+    const int lane_off = lane * 16;
+    int wp = (int)(MS_OFF_W2 * sizeof(float));
+    f32x4 rq[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) rq[d] = ld_piece(wrs, lane_off, wp + d * PIECE_BYTES);
+    f32x4 sq[4], uv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) sq[g] = *(const f32x4*)(Wt + MS_OFF_B2 + 4 * h + 8 * g);
+    const size_t plane = (size_t)p.Hu * p.Wu;
+    float* __restrict__ o = p.out + (size_t)b * 3 * plane + (size_t)y * p.Wu + x;
+
+#pragma unroll 1
+    for (int comp = 0; comp < 3; ++comp) {
+        const int nc = comp < 2 ? comp + 1 : 2;                       // seeds of the next component's first tile (clamped)
+        const float* __restrict__ B2 = Wt + MS_OFF_B2 + comp * MS_K + 4 * h;
+        const float* __restrict__ Bn = Wt + MS_OFF_B2 + nc * MS_K + 4 * h;
+        float acc = 0.0f;
+        f32x16 ps;
+        f32x4 pu[4];
+#pragma unroll
+        for (int mm = 0; mm < MS_MM; ++mm) {
+            f32x16 as;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) as[4 * g + e] = sq[g][e];
+#pragma unroll
+            for (int kg = 0; kg < WL_KG; ++kg) {
+                const int s = mm * WL_KG + kg;
+                const f32x4 wq = rq[s % PF];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) as = MFMA32(wq[e], q[4 * kg + e], as);
+                rq[s % PF] = ld_piece(wrs, lane_off, wp + (s + PF) * PIECE_BYTES);
+                if (kg == 4) {                                        // next tile's bias seeds, this tile's feature values
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        sq[g] = *(const f32x4*)((mm < MS_MM - 1 ? B2 + 32 * (mm + 1) : Bn) + 8 * g);
+                        uv[g] = *(const f32x4*)(Uc + 32 * mm + 8 * g);
+                    }
+                }
+                if (mm > 0 && (kg & 1) == 0) {                        // one epilogue element of tile mm-1 every 8 MFMAs
+                    const int r = kg >> 1;
+                    acc = __builtin_fmaf(ps[r], pu[r >> 2][r & 3], acc);
+                }
+            }
+            ps = as;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pu[g] = uv[g];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc = __builtin_fmaf(ps[r], pu[r >> 2][r & 3], acc);
+        acc += __shfl_xor(acc, 32);
+        if (valid && h == 0) o[comp * plane] = acc;
+        wp += (int)(MS_MM * WL_KG * PIECE_BYTES);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // backward pass of the per-pixel layers (training; reference: autograd through step(), diinn.py:132-139)
 //
 // With q_i = k_i * sin(s_i) and the planes k_i, s_i saved by decode_kernel<SAVE>:
@@ -1629,6 +1769,29 @@ int diinn_backward_cell_sum(void* stream, const float* G_dev, const int32_t* seg
     if ((long long)((H + 3) / 4) * B > 65535) return DIINN_ERR_TOO_LARGE;
     CellSumParams p{G_dev, dP_dev, seg_h_dev, seg_w_dev, B, H, W, Hu, Wu, (npix + PLANE_TILE - 1) / PLANE_TILE};
     hipLaunchKernelGGL(cell_sum_kernel, dim3((W + 63) / 64, ((H + 3) / 4) * B, PCH), dim3(256), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+int diinn_metasr_decode(void* stream, const float* feat_dev, const float* packed_dev, float* workspace_dev,
+                        float* out_dev, int B, int H, int W, int Hu, int Wu) {
+    if (!feat_dev || !packed_dev || !workspace_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (Hu <= 0 || Wu <= 0) return DIINN_ERR_INVALID_ARG;
+    if ((double)Hu * Wu >= 2.0e9) return DIINN_ERR_TOO_LARGE;
+    UnfoldParams u{feat_dev, workspace_dev, B, H, W};
+    hipLaunchKernelGGL(unfold_cells_kernel, dim3(W, H, B), dim3(192), 0, (hipStream_t)stream, u);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_status(e);
+    int gx, gy, gz, blk;
+    diinn_decode_launch_info(B, Hu, Wu, 0, Hu, &gx, &gy, &gz, &blk);
+    if (gy > 65535 || gz > 65535) return DIINN_ERR_TOO_LARGE;
+    MetaParams p;
+    p.U = workspace_dev; p.Wt = packed_dev; p.out = out_dev;
+    p.B = B; p.H = H; p.W = W; p.Hu = Hu; p.Wu = Wu;
+    p.ah = make_meta_axis(H, Hu);
+    p.aw = make_meta_axis(W, Wu);
+    hipLaunchKernelGGL(metasr_kernel, dim3(gx, gy, gz), dim3(blk), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
 

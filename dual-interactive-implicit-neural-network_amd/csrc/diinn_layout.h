@@ -155,4 +155,54 @@ DIINN_HD void liif_axis_eval(const LiifAxis& a, int j, int vi, int& idx, float& 
     rel = (c - q) * a.base.n_in_f;
 }
 
+// ---- MetaSR comparison decoder (reference metasr.py:70-104)
+// Packed image of its own: W2 [o 3][mm 18][kg 32][lane 64][e 4] = imnet.layers.2.weight[n = 3k + o][chan_of(4kg+e, lane>>5)],
+// k = 32mm + (lane&31): output channels regrouped by RGB component so that an M-tile feeds one
+// component and its rows are 32 consecutive unfolded-feature indices k; then the first layer as a
+// [4][256] table (columns rel_h, rel_w, r_rev, bias) and the second bias as [3][576].
+constexpr int    MS_K       = UNF;                             // 576 predicted weights per RGB component
+constexpr int    MS_MM      = MS_K / 32;                       // 18 M-tiles per component
+constexpr size_t MS_OFF_W2  = 0;
+constexpr size_t MS_SZ_W2   = (size_t)3 * MS_MM * WL_KG * WL_PIECE;   // 442,368 floats
+constexpr size_t MS_OFF_Q0  = MS_OFF_W2 + MS_SZ_W2;
+constexpr size_t MS_OFF_B2  = MS_OFF_Q0 + 4 * HID;
+constexpr size_t MS_PACKED_FLOATS = MS_OFF_B2 + 3 * MS_K;      // 445,120
+
+struct MetaAxis {
+    Axis  base;
+    float half_cell;        // fp32(2 / n_out) / 2                     (metasr.py:64-66,80-82)
+    float eps, lo, hi;      // fp32(1e-6), fp32(-1 + 1e-6), fp32(1 - 1e-6)   (metasr.py:83)
+    float half_n;           // fp32(n_in) / 2  (grid_sample unnormalise)
+    float corner;           // fp32((2 / n_in) / 2): feat_coord is shifted to the cell corner (metasr.py:75-76)
+    float rel_scale;        // fp32(n_in / 2)                          (metasr.py:94-95)
+    float r_rev;            // fp32(2 / n_out) * fp32(n_in / 2)        (metasr.py:97; rows axis)
+};
+
+inline MetaAxis make_meta_axis(int n_in, int n_out) {
+    MetaAxis a;
+    a.base = make_axis(n_in, n_out, 0);
+    a.half_cell = (float)(2.0 / (double)n_out) / 2.0f;
+    a.eps = (float)1e-6;
+    a.lo = (float)(-1.0 + 1e-6);
+    a.hi = (float)(1.0 - 1e-6);
+    a.half_n = (float)n_in / 2.0f;
+    a.corner = (float)((2.0 / (double)n_in) / 2.0);
+    a.rel_scale = (float)((double)n_in / 2.0);
+    a.r_rev = (float)(2.0 / (double)n_out) * a.rel_scale;
+    return a;
+}
+
+DIINN_HD void meta_axis_eval(const MetaAxis& a, int j, int& idx, float& rel) {
+    const float c = a.base.c1_out * (float)j + a.base.c0_out;
+    const float c_ = c - a.half_cell;
+    float cq = c_ + a.eps;
+    cq = cq < a.lo ? a.lo : (cq > a.hi ? a.hi : cq);
+    const float x = (cq + 1.0f) * a.half_n - 0.5f;
+    int id = (int)__builtin_rintf(x);
+    id = id < 0 ? 0 : (id > a.base.n_in - 1 ? a.base.n_in - 1 : id);
+    const float q = (a.base.c1_in * (float)id + a.base.c0_in) - a.corner;
+    idx = id;
+    rel = (c_ - q) * a.rel_scale;
+}
+
 }  // namespace diinn

@@ -226,6 +226,62 @@ def liif_decode_features(feat: torch.Tensor, packed: torch.Tensor, size: Sequenc
 
 
 # ---------------------------------------------------------------------------
+# MetaSR comparison decoder (reference metasr.py)
+# ---------------------------------------------------------------------------
+def pack_metasr_state_dict(sd, prefix: str = "imnet.") -> torch.Tensor:
+    """``imnet`` of the reference MetaSR (Linear(3,256), ReLU, Linear(256,1728); metasr.py:27-35) -> its packed
+    image (C ABI ``diinn_metasr_pack_weights``)."""
+    lib = _native.load()
+
+    def get(name, shape):
+        t = sd[prefix + name]
+        a = t.detach().to("cpu", torch.float32).numpy() if isinstance(t, torch.Tensor) else np.asarray(t, np.float32)
+        return np.ascontiguousarray(a.reshape(shape), dtype=np.float32)
+
+    w1, b1 = get("layers.0.weight", (HIDDEN, 3)), get("layers.0.bias", (HIDDEN,))
+    w2, b2 = get("layers.2.weight", (1728, HIDDEN)), get("layers.2.bias", (1728,))
+    packed = np.empty(lib.diinn_metasr_packed_floats(), dtype=np.float32)
+    _native.check(lib.diinn_metasr_pack_weights(_native.fptr(w1), _native.fptr(b1), _native.fptr(w2), _native.fptr(b2),
+                                                _native.fptr(packed)), "diinn_metasr_pack_weights")
+    return torch.from_numpy(packed)
+
+
+def metasr_axis_tables(n_in: int, n_out: int) -> Tuple[np.ndarray, np.ndarray, float]:
+    lib = _native.load()
+    idx = np.empty(n_out, np.int32)
+    rel = np.empty(n_out, np.float32)
+    r_rev = C.c_float()
+    _native.check(lib.diinn_metasr_make_axis_tables(n_in, n_out, idx.ctypes.data_as(_native._i32), _native.fptr(rel),
+                                                    C.byref(r_rev)), "diinn_metasr_make_axis_tables")
+    return idx, rel, r_rev.value
+
+
+def metasr_decode_features(feat: torch.Tensor, packed: torch.Tensor, size: Sequence[int],
+                           out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """MetaSR query of every HR pixel: encoder features [B,64,H,W] -> RGB [B,3,Hu,Wu] (metasr.py:70-104,125-135)."""
+    lib = _native.load()
+    _require_cuda(feat, "feat")
+    _require_cuda(packed, "packed weights")
+    if feat.dtype != torch.float32 or feat.dim() != 4 or feat.shape[1] != IN_CHANNELS:
+        raise ValueError(f"feat must be fp32 [B,{IN_CHANNELS},H,W], got {feat.dtype} {tuple(feat.shape)}")
+    hu, wu = size
+    hu, wu = int(hu), int(wu)
+    feat = feat.contiguous()
+    b, _, h, w = feat.shape
+    if out is None:
+        out = torch.empty((b, 3, hu, wu), dtype=torch.float32, device=feat.device)
+    need = lib.diinn_metasr_workspace_bytes(b, h, w)
+    if workspace is None or workspace.numel() * 4 < need or workspace.device != feat.device:
+        workspace = torch.empty(need // 4, dtype=torch.float32, device=feat.device)
+    with torch.cuda.device(feat.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        st = lib.diinn_metasr_decode(C.c_void_p(stream), C.c_void_p(feat.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                     C.c_void_p(workspace.data_ptr()), C.c_void_p(out.data_ptr()), b, h, w, hu, wu)
+    _native.check(st, "diinn_metasr_decode")
+    return out
+
+
+# ---------------------------------------------------------------------------
 # nn.Module mirror of the reference class
 # ---------------------------------------------------------------------------
 class ImplicitDecoder(nn.Module):

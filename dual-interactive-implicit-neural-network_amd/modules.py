@@ -203,6 +203,38 @@ class LIIF(nn.Module):
         return liif_decode_features(feat, self._packed_weights(feat.device), size)
 
 
+class MetaSR(nn.Module):
+    """The MetaSR comparison model (reference metasr.py:22-135; Hu et al. 2019 as re-implemented by LIIF)
+    behind ``forward(inp, size, bsize=None)``: RDN encoder (PyTorch-ROCm) + the meta-upscale decoder on the
+    HIP path (``metasr_kernel``).  Inference only; ``bsize`` accepted and ignored."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = make_rdn()
+        self.imnet = MLP(3, self.encoder.out_dim * 9 * 3, [256])
+        self._packed = None
+        self._packed_key = None
+
+    def gen_feat(self, inp):
+        self.feat = self.encoder(inp)
+        return self.feat
+
+    def _packed_weights(self, device):
+        from .decoder import pack_metasr_state_dict
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.imnet.parameters())
+        if self._packed is None or self._packed_key != key:
+            self._packed = pack_metasr_state_dict(self.imnet.state_dict(), prefix="").to(device)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, inp, size, bsize=None):
+        from .decoder import metasr_decode_features
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("diinn_amd: MetaSR runs on the HIP path for inference only; call under torch.no_grad()")
+        feat = self.gen_feat(inp)
+        return metasr_decode_features(feat, self._packed_weights(feat.device), size)
+
+
 class BICUBIC_NET(nn.Module):
     """Antialiased bicubic resize baseline (reference sr_module.py:53-60 via torchvision.Resize,
     which lowers to this interpolate call)."""
@@ -219,8 +251,7 @@ def make_net(arch, mode, init_q):
     if arch == "liif":
         return LIIF()
     if arch == "metasr":
-        raise NotImplementedError("arch='metasr': this comparison baseline of the reference is not built "
-                                  "(SURVEY.md §8 row f4 covers LIIF so far)")
+        return MetaSR()
     return None   # the reference's make_net falls through to None for unknown names
 
 

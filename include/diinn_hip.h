@@ -218,6 +218,21 @@ int diinn_liif_decode(void* stream, const float* feat_dev, const float* packed_d
                       float* out_dev, int B, int H, int W, int Hu, int Wu);
 int diinn_liif_make_axis_tables(int n_in, int n_out, int v, int32_t* idx, float* rel, float* rel_cell);
 
+/* ---- MetaSR comparison decoder ----------------------
+ * Replaces: MetaSR.query_rgb + batched_predict + reshape_pred (metasr.py:70-104,106-123): per HR pixel the
+ * meta-network imnet = Linear(3,256)+ReLU+Linear(256,1728) predicts a [576 x 3] filter from
+ * (rel_h, rel_w, r_rev), applied to the unfolded 3x3 features of the pixel's nearest (corner-anchored) cell.
+ * Own packed image: diinn_metasr_pack_weights(W1 [256,3], b1 [256], W2 [1728,256], b2 [1728]) ->
+ * diinn_metasr_packed_floats() floats (host).  workspace_dev: diinn_metasr_workspace_bytes(B,H,W) bytes
+ * (the per-cell unfolded features).  Enqueues 2 kernels; no allocation, no synchronisation.
+ * diinn_metasr_make_axis_tables: host restatement of the per-axis index / relative coordinate. */
+size_t diinn_metasr_packed_floats(void);
+int    diinn_metasr_pack_weights(const float* W1, const float* b1, const float* W2, const float* b2, float* packed);
+size_t diinn_metasr_workspace_bytes(int B, int H, int W);
+int    diinn_metasr_decode(void* stream, const float* feat_dev, const float* packed_dev, float* workspace_dev,
+                           float* out_dev, int B, int H, int W, int Hu, int Wu);
+int    diinn_metasr_make_axis_tables(int n_in, int n_out, int32_t* idx, float* rel, float* r_rev);
+
 /* Dominant-kernel launch geometry, for benchmarks/roofline accounting. */
 int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,
                              int* grid_x, int* grid_y, int* grid_z, int* block);

@@ -70,8 +70,6 @@ def test_liif_module_has_reference_parameter_names(gold):
     net = M.make_net("liif", 3, False)
     ref = json.loads(str(gold["liif/shapes_json"]))
     assert {k: list(v.shape) for k, v in net.state_dict().items()} == ref
-    with pytest.raises(NotImplementedError):
-        M.make_net("metasr", 3, False)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""MetaSR decoder timing on one GPU: HIP path (unfold_cells + metasr_kernel) vs the reference's op sequence
+(unfold, grid_sample nearest, 3->256->1728 MLP, bmm; metasr.py:70-104) in PyTorch-ROCm eager mode with query
+chunks of 30000.  usage: metasr_time.py [LR] [SCALE]"""
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import diinn_amd.decoder as D  # noqa: E402
+import diinn_amd.modules as M  # noqa: E402
+import diinn_amd.synth as synth  # noqa: E402
+
+
+def make_coord(shape, dev):
+    seqs = [(-1 + 1 / n) + (2 / n) * torch.arange(n, device=dev).float() for n in shape]
+    return torch.stack(torch.meshgrid(*seqs, indexing="ij"), dim=-1)
+
+
+def eager_query(imnet, feat, coord, cell):
+    u = F.unfold(feat, 3, padding=1).view(feat.shape[0], feat.shape[1] * 9, feat.shape[2], feat.shape[3])
+    h, w = feat.shape[-2:]
+    fc = make_coord((h, w), feat.device)
+    fc[:, :, 0] -= (2 / h) / 2
+    fc[:, :, 1] -= (2 / w) / 2
+    fc = fc.permute(2, 0, 1).unsqueeze(0)
+    c_ = coord.clone()
+    c_[:, :, 0] -= cell[:, :, 0] / 2
+    c_[:, :, 1] -= cell[:, :, 1] / 2
+    cq = (c_ + 1e-6).clamp(-1 + 1e-6, 1 - 1e-6)
+    g = cq.flip(-1).unsqueeze(1)
+    qf = F.grid_sample(u, g, mode="nearest", align_corners=False)[:, :, 0, :].permute(0, 2, 1)
+    qc = F.grid_sample(fc, g, mode="nearest", align_corners=False)[:, :, 0, :].permute(0, 2, 1)
+    rel = c_ - qc
+    rel[:, :, 0] *= h / 2
+    rel[:, :, 1] *= w / 2
+    inp = torch.cat([rel, (cell[:, :, 0] * (h / 2)).unsqueeze(-1)], dim=-1)
+    bs, q = coord.shape[:2]
+    pred = imnet(inp.view(bs * q, -1)).view(bs * q, u.shape[1], 3)
+    return torch.bmm(qf.contiguous().view(bs * q, 1, -1), pred).view(bs, q, 3)
+
+
+def main():
+    lr = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    sc = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    dev = torch.device("cuda:0")
+    hu = wu = lr * sc
+    net = M.MetaSR().to(dev).eval()
+    feat = torch.from_numpy(synth.encoder_features(123, 1, lr, lr)).to(dev)
+    packed = D.pack_metasr_state_dict(net.imnet.state_dict(), prefix="").to(dev)
+    ws = torch.empty(lr * lr * 576, device=dev)
+    out = torch.empty((1, 3, hu, wu), device=dev)
+
+    def ours():
+        D.metasr_decode_features(feat, packed, (hu, wu), out=out, workspace=ws)
+
+    coord = make_coord((hu, wu), dev).view(1, -1, 2)
+    cell = torch.ones_like(coord)
+    cell[:, :, 0] *= 2 / hu
+    cell[:, :, 1] *= 2 / wu
+
+    @torch.no_grad()
+    def eager():
+        return torch.cat([eager_query(net.imnet, feat, coord[:, ql:ql + 30000], cell[:, ql:ql + 30000])
+                          for ql in range(0, coord.shape[1], 30000)], dim=1)
+
+    with torch.no_grad():
+        ref = eager().view(1, hu, wu, 3).permute(0, 3, 1, 2)
+        ours()
+        err = float((out - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    for name, fn, n in (("HIP path", ours, 10), ("eager ops", eager, 2)):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        print(f"MetaSR decode {lr}x{lr} x{sc} ({hu * wu} px) {name:10s}: {ms:9.2f} ms  {hu * wu / ms / 1e3:8.2f} Mpix/s")
+    print(f"max|HIP - eager| / max|ref| = {err:.2e}")
+
+
+if __name__ == "__main__":
+    main()
