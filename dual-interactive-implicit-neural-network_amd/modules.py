@@ -104,27 +104,20 @@ def make_rdn(G0=64, RDNkSize=3, RDNconfig="B", scale=2, no_upsampling=True):
 # ---------------------------------------------------------------------------
 # model assemblies
 # ---------------------------------------------------------------------------
-class DIINN(nn.Module):
-    """Reference diinn.py:8-19: ``decoder(encoder(x), size, bsize)``.
-
-    ``graphs=True`` (inference only) replays the whole forward -- 148 encoder convolutions plus the
-    two decoder kernels -- from a hipGraph captured per (input shape, output size).  Small inputs are
-    launch-bound in the encoder (48x48: ~7 ms eager, ~150 launches); the graph removes that.  The
-    decoder's C-ABI launches never allocate or synchronise, so they capture as they are."""
+class _GraphReplay:
+    """hipGraph replay of a whole inference forward (encoder convolutions + decoder kernels), one graph per
+    (input shape, output size, parameter versions).  Small inputs are launch-bound in the encoder (48x48:
+    ~7 ms eager for ~150 launches); the graph removes that.  The decoder's C-ABI launches never allocate
+    or synchronise, so they capture as they are."""
 
     MAX_GRAPHS = 8
 
-    def __init__(self, mode, init_q, graphs: bool = False):
-        super().__init__()
-        self.encoder = make_rdn()
-        self.decoder = ImplicitDecoder(mode=mode, init_q=init_q)
+    def _init_graphs(self, graphs: bool):
         self.graphs = graphs
         self._graph_cache: Dict[Any, Any] = {}
 
-    def forward(self, x, size, bsize=None):
-        if self.graphs and x.is_cuda and not torch.is_grad_enabled():
-            return self._forward_graphed(x, size, bsize)
-        return self.decoder(self.encoder(x), size, bsize)
+    def _use_graph(self, x) -> bool:
+        return self.graphs and x.is_cuda and not torch.is_grad_enabled()
 
     def _forward_graphed(self, x, size, bsize):
         key = (tuple(x.shape), x.dtype, x.device, int(size[0]), int(size[1]),
@@ -138,17 +131,36 @@ class DIINN(nn.Module):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                      # warm-up outside capture (MIOpen find, weight packing)
                 for _ in range(2):
-                    self.decoder(self.encoder(static_x), size, bsize)
+                    self._forward_eager(static_x, size, bsize)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                static_y = self.decoder(self.encoder(static_x), size, bsize)
+                static_y = self._forward_eager(static_x, size, bsize)
             entry = (graph, static_x, static_y)
             self._graph_cache[key] = entry
         graph, static_x, static_y = entry
         static_x.copy_(x)
         graph.replay()
         return static_y.clone()
+
+
+class DIINN(nn.Module, _GraphReplay):
+    """Reference diinn.py:8-19: ``decoder(encoder(x), size, bsize)``.  ``graphs=True`` (inference only)
+    replays the whole forward from a hipGraph (see ``_GraphReplay``)."""
+
+    def __init__(self, mode, init_q, graphs: bool = False):
+        super().__init__()
+        self.encoder = make_rdn()
+        self.decoder = ImplicitDecoder(mode=mode, init_q=init_q)
+        self._init_graphs(graphs)
+
+    def _forward_eager(self, x, size, bsize=None):
+        return self.decoder(self.encoder(x), size, bsize)
+
+    def forward(self, x, size, bsize=None):
+        if self._use_graph(x):
+            return self._forward_graphed(x, size, bsize)
+        return self._forward_eager(x, size, bsize)
 
 
 class MLP(nn.Module):
@@ -167,15 +179,16 @@ class MLP(nn.Module):
         return self.layers(x.reshape(-1, x.shape[-1])).view(*x.shape[:-1], -1)
 
 
-class LIIF(nn.Module):
+class LIIF(nn.Module, _GraphReplay):
     """The LIIF comparison model (reference liif.py:9-155; Chen et al. 2021) behind the same
     ``forward(inp, size, bsize=None)`` boundary: RDN encoder (PyTorch-ROCm) + the implicit MLP decoder on
     the HIP path (``liif_kernel``).  Constructor defaults only (local ensemble, feature unfolding, cell
     decoding -- what ``make_net('liif')`` builds, sr_module.py:45-46); inference only.  ``bsize`` is the
     reference's query-chunk size, a memory knob: accepted and ignored."""
 
-    def __init__(self, local_ensemble=True, feat_unfold=True, cell_decode=True):
+    def __init__(self, local_ensemble=True, feat_unfold=True, cell_decode=True, graphs: bool = False):
         super().__init__()
+        self._init_graphs(graphs)
         if not (local_ensemble and feat_unfold and cell_decode):
             raise NotImplementedError("the HIP path implements LIIF with local_ensemble, feat_unfold and cell_decode on")
         self.local_ensemble, self.feat_unfold, self.cell_decode = local_ensemble, feat_unfold, cell_decode
@@ -195,21 +208,27 @@ class LIIF(nn.Module):
             self._packed_key = key
         return self._packed
 
-    def forward(self, inp, size, bsize=None):
+    def _forward_eager(self, inp, size, bsize=None):
         from .decoder import liif_decode_features
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("diinn_amd: LIIF runs on the HIP path for inference only; call under torch.no_grad()")
         feat = self.gen_feat(inp)
         return liif_decode_features(feat, self._packed_weights(feat.device), size)
 
+    def forward(self, inp, size, bsize=None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("diinn_amd: LIIF runs on the HIP path for inference only; call under torch.no_grad()")
+        if self._use_graph(inp):
+            return self._forward_graphed(inp, size, bsize)
+        return self._forward_eager(inp, size, bsize)
 
-class MetaSR(nn.Module):
+
+class MetaSR(nn.Module, _GraphReplay):
     """The MetaSR comparison model (reference metasr.py:22-135; Hu et al. 2019 as re-implemented by LIIF)
     behind ``forward(inp, size, bsize=None)``: RDN encoder (PyTorch-ROCm) + the meta-upscale decoder on the
     HIP path (``metasr_kernel``).  Inference only; ``bsize`` accepted and ignored."""
 
-    def __init__(self):
+    def __init__(self, graphs: bool = False):
         super().__init__()
+        self._init_graphs(graphs)
         self.encoder = make_rdn()
         self.imnet = MLP(3, self.encoder.out_dim * 9 * 3, [256])
         self._packed = None
@@ -227,12 +246,17 @@ class MetaSR(nn.Module):
             self._packed_key = key
         return self._packed
 
-    def forward(self, inp, size, bsize=None):
+    def _forward_eager(self, inp, size, bsize=None):
         from .decoder import metasr_decode_features
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("diinn_amd: MetaSR runs on the HIP path for inference only; call under torch.no_grad()")
         feat = self.gen_feat(inp)
         return metasr_decode_features(feat, self._packed_weights(feat.device), size)
+
+    def forward(self, inp, size, bsize=None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("diinn_amd: MetaSR runs on the HIP path for inference only; call under torch.no_grad()")
+        if self._use_graph(inp):
+            return self._forward_graphed(inp, size, bsize)
+        return self._forward_eager(inp, size, bsize)
 
 
 class BICUBIC_NET(nn.Module):

@@ -5,7 +5,7 @@ output sizes 48*s, s in {2, 3, 4, 6, 8} -- the reference's runtime comparison (r
 
 The reference times whole models (encoder included) with torch.utils.benchmark and leaves autograd on;
 inference on the HIP path runs under torch.no_grad().  ``--lr N`` changes the input size, ``--graphs`` replays
-DIINN from a hipGraph (launch-bound at 48x48)."""
+the three networks from hipGraphs (a 48x48 input is launch-bound in the encoder)."""
 import os
 import sys
 from argparse import ArgumentParser
@@ -28,8 +28,8 @@ def main():
     dev = torch.device("cuda:0")
     models = {
         "bicubic": BICUBIC_NET().to(dev),
-        "metasr": MetaSR().to(dev).eval(),
-        "liif": LIIF().to(dev).eval(),
+        "metasr": MetaSR(graphs=args.graphs).to(dev).eval(),
+        "liif": LIIF(graphs=args.graphs).to(dev).eval(),
         "diinn": DIINN(3, False, graphs=args.graphs).to(dev).eval(),
     }
     x = torch.rand(1, 3, args.lr, args.lr, device=dev)

@@ -57,8 +57,8 @@ def test_bicubic_and_unknown_arch():
     import diinn_amd.modules as M
     y = M.SRLitModule(arch="bicubic")(torch.rand(1, 3, 8, 8), (16, 12))
     assert y.shape == (1, 3, 16, 12)
-    with pytest.raises(NotImplementedError):
-        M.make_net("liif", 1, False)
+    assert isinstance(M.make_net("liif", 1, False), M.LIIF) and isinstance(M.make_net("metasr", 1, False), M.MetaSR)
+    assert M.make_net("no-such-arch", 1, False) is None      # the reference's make_net falls through (sr_module.py:42-50)
 
 
 @pytest.mark.gpu
