@@ -1030,13 +1030,15 @@ struct PlaneGemmParams {
     int M, Nc, ldc, tiles_per_split, with_rowsum;
 };
 
+template <int NB>
 __global__ __launch_bounds__(256, 1) void plane_gemm_kernel(const PlaneGemmParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
-    const int nblk = p.Nc / 256;
+    constexpr int WGN = 2 * NB * 32;                          // output columns per workgroup
+    const int nblk = p.Nc / WGN;
     const int m0 = (blockIdx.x / nblk) * 128 + (wave & 1) * 64;
-    const int n0 = (blockIdx.x % nblk) * 256 + (wave >> 1) * 128;
+    const int n0 = (blockIdx.x % nblk) * WGN + (wave >> 1) * (NB * 32);
     const int ks = blockIdx.y;
     const long long ntiles = (p.npix + PLANE_TILE - 1) / PLANE_TILE;
     const long long t0 = (long long)ks * p.tiles_per_split;
@@ -1053,16 +1055,16 @@ __global__ __launch_bounds__(256, 1) void plane_gemm_kernel(const PlaneGemmParam
     const unsigned voff = (unsigned)j * PLANE_ROW_BYTES + 16u * h;
     constexpr unsigned MFMA_ROWS = 32u * PLANE_ROW_BYTES;        // one 32-row MFMA panel: 4 KiB
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][NB];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     float rs[2] = {0.0f, 0.0f};
 
-    f32x4 fa[2][2][4], fb[2][4][4];                              // [buffer][panel][t]: 4 pixels each
+    f32x4 fa[2][2][4], fb[2][NB][4];                              // [buffer][panel][t]: 4 pixels each
     auto load = [&](int buf, int t) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1071,7 +1073,7 @@ __global__ __launch_bounds__(256, 1) void plane_gemm_kernel(const PlaneGemmParam
                 fa[buf][a][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                     ra, (int)voff, (int)(t * a_pitch + a * MFMA_ROWS + 32u * q), 0));
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < NB; ++b)
                 fb[buf][b][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                     rb, (int)voff, (int)(t * b_pitch + b * MFMA_ROWS + 32u * q), 0));
         }
@@ -1087,7 +1089,7 @@ __global__ __launch_bounds__(256, 1) void plane_gemm_kernel(const PlaneGemmParam
 #pragma unroll
                     for (int a = 0; a < 2; ++a) fa[buf][a][q][e] = in ? fa[buf][a][q][e] : 0.0f;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) fb[buf][b][q][e] = in ? fb[buf][b][q][e] : 0.0f;
+                    for (int b = 0; b < NB; ++b) fb[buf][b][q][e] = in ? fb[buf][b][q][e] : 0.0f;
                 }
         }
 #pragma unroll
@@ -1097,7 +1099,7 @@ __global__ __launch_bounds__(256, 1) void plane_gemm_kernel(const PlaneGemmParam
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[a][b] = MFMA32(fa[buf][a][q][e], fb[buf][b][q][e], acc[a][b]);
+                    for (int b = 0; b < NB; ++b) acc[a][b] = MFMA32(fa[buf][a][q][e], fb[buf][b][q][e], acc[a][b]);
                     rs[a] += fa[buf][a][q][e];
                 }
             }
@@ -1119,7 +1121,7 @@ __global__ __launch_bounds__(256, 1) void plane_gemm_kernel(const PlaneGemmParam
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -1727,7 +1729,7 @@ int diinn_plane_gemm_nt(void* stream, const float* A_dev, int a_rows, int a_row0
         return DIINN_ERR_INVALID_ARG;
     const int stp = check_npix(npix);
     if (stp) return stp;
-    if (M % 128 || Nc % 256) return DIINN_ERR_UNSUPPORTED;
+    if (M % 128 || Nc % 128) return DIINN_ERR_UNSUPPORTED;
     if (ksplit > 65535) return DIINN_ERR_TOO_LARGE;
     PlaneGemmParams p;
     p.A = A_dev; p.Bm = B_dev; p.part = part_dev; p.npix = npix;
@@ -1740,7 +1742,13 @@ int diinn_plane_gemm_nt(void* stream, const float* A_dev, int a_rows, int a_row0
     // offsets inside one split are 32-bit: tiles_per_split * rows * 128 bytes must stay below 2 GiB
     if (per * (long long)(a_rows > b_rows ? a_rows : b_rows) * PLANE_ROW_BYTES >= 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;
     p.tiles_per_split = (int)per;
-    hipLaunchKernelGGL(plane_gemm_kernel, dim3((M / 128) * (Nc / 256), ksplit), dim3(256), 0, (hipStream_t)stream, p);
+#ifndef PLANE_GEMM_NB
+#define PLANE_GEMM_NB 4
+#endif
+    if (PLANE_GEMM_NB == 4 && Nc % 256 == 0)
+        hipLaunchKernelGGL(plane_gemm_kernel<4>, dim3((M / 128) * (Nc / 256), ksplit), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(plane_gemm_kernel<2>, dim3((M / 128) * (Nc / 128), ksplit), dim3(256), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
 

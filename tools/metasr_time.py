@@ -45,8 +45,10 @@ def eager_query(imnet, feat, coord, cell):
 
 
 def main():
-    lr = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    sc = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    only_ours = "--only-ours" in sys.argv             # for profiling: skip the eager comparison
+    argv = [a for a in sys.argv if not a.startswith("--")]
+    lr = int(argv[1]) if len(argv) > 1 else 256
+    sc = int(argv[2]) if len(argv) > 2 else 4
     dev = torch.device("cuda:0")
     hu = wu = lr * sc
     net = M.MetaSR().to(dev).eval()
@@ -58,6 +60,11 @@ def main():
     def ours():
         D.metasr_decode_features(feat, packed, (hu, wu), out=out, workspace=ws)
 
+    if only_ours:
+        for _ in range(5):
+            ours()
+        torch.cuda.synchronize()
+        return
     coord = make_coord((hu, wu), dev).view(1, -1, 2)
     cell = torch.ones_like(coord)
     cell[:, :, 0] *= 2 / hu
