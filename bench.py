@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--sin", choices=["accurate", "hw", "hw_reduced"], default=os.environ.get("DIINN_SIN", "default"),
                     help="sine evaluation of the synthesis branch (default: the library default, hw_reduced)")
-    ap.add_argument("--compute", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--compute", choices=["f32", "bf16", "bf16_full"], default="f32",
                     help="arithmetic of the per-pixel layers; f32 is the reference's precision and the only "
                          "valid headline (bf16 is BASELINE config 5's optional path, 2e-3 relative)")
     ap.add_argument("--dist-mode", choices=["halo", "bcast"], default="halo")
@@ -162,8 +162,9 @@ def main():
         local = feat
         if world > 1:
             local = S.distribute_features(feat, shape, need, src=0, mode=args.dist_mode, device=dev, buf=feat_buf)
-        N.check(lib.diinn_precompute_P(C.c_void_p(stream), C.c_void_p(local.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                       C.c_void_p(workspace.data_ptr()), 1, H, W, r0, r1), "diinn_precompute_P")
+        N.check(lib.diinn_precompute_P_ex(C.c_void_p(stream), C.c_void_p(local.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                          C.c_void_p(workspace.data_ptr()), 1, H, W, r0, r1, N.COMPUTE[args.compute]),
+                "diinn_precompute_P_ex")
         if i is not None:
             ev[i][0].record()
         N.check(lib.diinn_decode_band_ex(C.c_void_p(stream), C.c_void_p(workspace.data_ptr()),
@@ -222,7 +223,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "decode_kernel" if args.compute == "f32" else "decode_bf16_kernel",
+                "kernel": "decode_kernel" if args.compute == "f32" else "decode_bf16x2_kernel",
                 "achieved": round(achieved, 3),
                 "peak": PEAK_F32_MFMA_TFLOPS if args.compute == "f32" else PEAK_BF16_MFMA_TFLOPS,
                 "unit": "TFLOP/s",

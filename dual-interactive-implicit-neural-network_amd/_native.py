@@ -26,7 +26,8 @@ ABI_VERSION = 1
 COMPUTE_F32 = 0
 COMPUTE_BF16 = 1
 COMPUTE_F32_QONLY = 2
-COMPUTE = {"f32": COMPUTE_F32, "fp32": COMPUTE_F32, "bf16": COMPUTE_BF16}
+COMPUTE_BF16_FULL = 3
+COMPUTE = {"f32": COMPUTE_F32, "fp32": COMPUTE_F32, "bf16": COMPUTE_BF16, "bf16_full": COMPUTE_BF16_FULL}
 
 _f = C.POINTER(C.c_float)
 _i32 = C.POINTER(C.c_int32)
@@ -49,6 +50,8 @@ SIGNATURES = {
     "diinn_lr_rows_for_band": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip]),
     "diinn_precompute_P": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "diinn_precompute_P_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_decode_band": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

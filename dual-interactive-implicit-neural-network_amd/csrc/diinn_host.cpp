@@ -83,9 +83,9 @@ size_t diinn_metasr_workspace_bytes(int B, int H, int W) {
 }
 
 int diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats) {
-    static const size_t off[9] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT};
-    static const size_t sz[9]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT};
-    if (section < 0 || section > 8 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
+    static const size_t off[10] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT, OFF_WPB};
+    static const size_t sz[10]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT, SZ_WPB};
+    if (section < 0 || section > 9 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
     *offset_floats = off[section];
     *size_floats = sz[section];
     return DIINN_OK;
@@ -198,6 +198,25 @@ int diinn_pack_weights(const float* K0w, const float* K0b,
                         }
                     }
                 }
+    // WPB: [mp][ks][t][lane][j] bf16
+    uint16_t* wpb = reinterpret_cast<uint16_t*>(packed + OFF_WPB);
+    for (int mo = 0; mo < 32; ++mo) {
+        const int i = mo >> 3;
+        const float* w = (i == 0) ? K0w : Kw[i - 1];
+        const size_t ld = (i == 0) ? (size_t)UNF : (size_t)(HID + UNF);
+        const size_t col0 = (i == 0) ? 0 : (size_t)HID;
+        for (int ks = 0; ks < WPB_KS; ++ks) {
+            uint16_t* dst = wpb + ((((size_t)(mo >> 1) * WPB_KS + ks) * 2) + (mo & 1)) * (64 * 8);
+            const int tap = ks >> 2, cg = ks & 3;
+            for (int lane = 0; lane < 64; ++lane) {
+                const int ch = 32 * (mo & 7) + (lane & 31);
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 16 * cg + 8 * (lane >> 5) + j;
+                    dst[lane * 8 + j] = f32_to_bf16(w[(size_t)ch * ld + col0 + (size_t)c * 9 + tap]);
+                }
+            }
+        }
+    }
     return DIINN_OK;
 }
 

@@ -1351,6 +1351,225 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_kernel(const DecodeParams 
 }
 
 // ---------------------------------------------------------------------------------
+// decode_bf16x2_kernel: the bf16 decode with TWO pixel tiles (2 x 32 pixels) per wave.  The single-tile
+// kernel above is bound by its weight stream (1 KiB per 32-cycle MFMA per wave through a 64 B/clk L1);
+// here every weight fragment feeds two MFMAs, which halves the bytes per MFMA.  To fit two tiles in the
+// register file the next layer's activation is parked in a wave-private LDS slab (32 KiB per wave: each
+// lane writes and later re-reads only its own 16-byte fragments, so no barrier is involved) and the RGB
+// head is accumulated inside the last layer's epilogue instead of from an fp32 copy of the activation.
+// A workgroup covers 16 x 16 HR pixels: wave w owns the 8x4 tile of decode_kernel's mapping and the one
+// 8 rows below it.
+// ---------------------------------------------------------------------------------
+#ifndef DECODE_BF16X2_PREFETCH
+#define DECODE_BF16X2_PREFETCH 4
+#endif
+
+template <int SIN_MODE>
+__global__ __launch_bounds__(256, 1) void decode_bf16x2_kernel(const DecodeParams p) {
+    __shared__ __attribute__((aligned(16))) bf16x8 park[4][2][16][64];     // [wave][tile][fragment][lane] = 128 KiB
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int x = blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
+    const int yb = p.y0 + blockIdx.y * (2 * TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
+    const int b = blockIdx.z;
+    int y[2];
+    bool valid[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        y[t] = yb + t * (TILE_H * WG_TILES_Y);
+        valid[t] = (x < p.Wu) && (y[t] < p.y1);
+    }
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid[0] || valid[1]) == 0ull))) return;
+    const int xc = x < p.Wu ? x : p.Wu - 1;
+    int ix;
+    float relw;
+    axis_eval(p.aw, xc, ix, relw);
+    const float* __restrict__ Wt = p.Wt;
+    const float* __restrict__ Pc[2];
+    float relh[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int yc = y[t] < p.y1 ? y[t] : p.y1 - 1;
+        int iy;
+        axis_eval(p.ah, yc, iy, relh[t]);
+        Pc[t] = p.P + (((size_t)b * p.H + iy) * p.W + ix) * PCH + 4 * h;
+    }
+
+    // ---- layer 0 (fp32), packed to bf16 fragments: register r = 4g+e of tile m -> qb[2m + (r>>3)][r&7]
+    bf16x8 qb[2][16];
+    {
+        const float* __restrict__ Q0 = Wt + OFF_Q0 + 4 * h;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * m + 8 * g;
+                const f32x4 wh = *(const f32x4*)(Q0 + 0 * HID + c0);
+                const f32x4 ww = *(const f32x4*)(Q0 + 1 * HID + c0);
+                const f32x4 wr = *(const f32x4*)(Q0 + 2 * HID + c0);
+                const f32x4 bq = *(const f32x4*)(Q0 + 3 * HID + c0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x4 pv = *(const f32x4*)(Pc[t] + c0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a = __builtin_fmaf(wr[e], p.ratio, bq[e]);
+                        a = __builtin_fmaf(ww[e], relw, a);
+                        a = __builtin_fmaf(wh[e], relh[t], a);
+                        qb[t][2 * m + (g >> 1)][4 * (g & 1) + e] = (__bf16)(relu0(pv[e]) * dsin<SIN_MODE>(a));
+                    }
+                }
+            }
+        }
+    }
+
+    constexpr int PF = DECODE_BF16X2_PREFETCH;
+    static_assert(16 % PF == 0, "ring index must be static");
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);
+    const int lane_off = lane * 16;
+    int wp = (int)(OFF_WLB * sizeof(float));
+    f32x4 rk[PF], rq[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        rk[d] = ld_piece(wrs, lane_off, wp + (2 * d + 0) * PIECE_BYTES);
+        rq[d] = ld_piece(wrs, lane_off, wp + (2 * d + 1) * PIECE_BYTES);
+    }
+    f32x4 sk[2][4], sq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        sk[0][g] = *(const f32x4*)(Pc[0] + HID + 8 * g);
+        sk[1][g] = *(const f32x4*)(Pc[1] + HID + 8 * g);
+        sq[g] = *(const f32x4*)(Wt + OFF_BQ + 4 * h + 8 * g);
+    }
+    float o[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    bf16x8 (*mine)[16][64] = park[wave];
+
+    // the layer loop is fully unrolled (a bf16 layer is 512 MFMAs): LAST is a compile-time constant per copy and
+    // fuses the RGB head (diinn.py:138) into the epilogue, on the unrounded activation
+#pragma unroll
+    for (int layer = 0; layer < 3; ++layer) {
+        const bool LAST = layer == 2;
+        const int nl = layer < 2 ? layer + 1 : 2;
+        const float* __restrict__ Bq = Wt + OFF_BQ + layer * HID + 4 * h;
+        const float* __restrict__ Bn = Wt + OFF_BQ + nl * HID + 4 * h;
+        const float* __restrict__ L = Wt + OFF_L + 4 * h;
+        f32x16 pk[2], ps[2];
+        bf16x8 frag[2];
+        f32x4 l0[4], l1[4], l2[4];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            f32x16 ak[2], as[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ak[t][4 * g + e] = sk[t][g][e];
+                        as[t][4 * g + e] = sq[g][e];
+                    }
+            if (LAST && m > 0) {                                  // head rows of the tile being finished
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    l0[g] = *(const f32x4*)(L + 0 * HID + 32 * (m - 1) + 8 * g);
+                    l1[g] = *(const f32x4*)(L + 1 * HID + 32 * (m - 1) + 8 * g);
+                    l2[g] = *(const f32x4*)(L + 2 * HID + 32 * (m - 1) + 8 * g);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int s = m * 16 + ks;
+                const bf16x8 wk = __builtin_bit_cast(bf16x8, rk[s % PF]);
+                const bf16x8 wq = __builtin_bit_cast(bf16x8, rq[s % PF]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    ak[t] = MFMA_BF16(wk, qb[t][ks], ak[t]);
+                    as[t] = MFMA_BF16(wq, qb[t][ks], as[t]);
+                }
+                rk[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF) + 0) * PIECE_BYTES);
+                rq[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF) + 1) * PIECE_BYTES);
+                if (ks == 2) {
+                    const int ln = layer + 1;                     // P slot of this layer; next layer's for the last tile
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            sk[t][g] = *(const f32x4*)(Pc[t] + (m < 7 ? ln * HID + 32 * (m + 1) : (nl + 1) * HID) + 8 * g);
+                        sq[g] = *(const f32x4*)((m < 7 ? Bq + 32 * (m + 1) : Bn) + 8 * g);
+                    }
+                }
+                if (m > 0) {                                      // one epilogue element of tile m-1 per k-step, both pixel tiles
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const float v = relu0(pk[t][ks]) * dsin<SIN_MODE>(ps[t][ks]);
+                        if (LAST) {
+                            o[t][0] = __builtin_fmaf(l0[ks >> 2][ks & 3], v, o[t][0]);
+                            o[t][1] = __builtin_fmaf(l1[ks >> 2][ks & 3], v, o[t][1]);
+                            o[t][2] = __builtin_fmaf(l2[ks >> 2][ks & 3], v, o[t][2]);
+                        } else {
+                            frag[t][ks & 7] = (__bf16)v;
+                            if ((ks & 7) == 7) mine[t][2 * (m - 1) + (ks >> 3)][lane] = frag[t];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                pk[t] = ak[t];
+                ps[t] = as[t];
+            }
+        }
+        if (LAST) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                l0[g] = *(const f32x4*)(L + 0 * HID + 32 * 7 + 8 * g);
+                l1[g] = *(const f32x4*)(L + 1 * HID + 32 * 7 + 8 * g);
+                l2[g] = *(const f32x4*)(L + 2 * HID + 32 * 7 + 8 * g);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = relu0(pk[t][r]) * dsin<SIN_MODE>(ps[t][r]);
+                if (LAST) {
+                    o[t][0] = __builtin_fmaf(l0[r >> 2][r & 3], v, o[t][0]);
+                    o[t][1] = __builtin_fmaf(l1[r >> 2][r & 3], v, o[t][1]);
+                    o[t][2] = __builtin_fmaf(l2[r >> 2][r & 3], v, o[t][2]);
+                } else {
+                    frag[t][r & 7] = (__bf16)v;
+                    if ((r & 7) == 7) mine[t][14 + (r >> 3)][lane] = frag[t];
+                }
+            }
+        }
+        if (!LAST) {                                              // the parked activation becomes the next layer's B operand
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) qb[t][i] = mine[t][i][lane];
+        }
+        wp += (int)(WLB_LAYER * sizeof(float));
+    }
+
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float o0 = o[t][0], o1 = o[t][1], o2 = o[t][2];
+        o0 += __shfl_xor(o0, 32);
+        o1 += __shfl_xor(o1, 32);
+        o2 += __shfl_xor(o2, 32);
+        if (valid[t] && h == 0) {
+            const size_t plane = (size_t)p.Hu * p.Wu;
+            float* op = p.out + (size_t)b * 3 * plane + (size_t)y[t] * p.Wu + x;
+            op[0] = o0 + Wt[OFF_BL + 0];
+            op[plane] = o1 + Wt[OFF_BL + 1];
+            op[2 * plane] = o2 + Wt[OFF_BL + 2];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // P kernel: P[b,y,x, i*256+ch] = sum_{c,ky,kx} Wx_i[ch,c,ky,kx] * feat[b,c,y+ky-1,x+kx-1] + bK_i[ch]
 // (zero padding; diinn.py:168 unfold + the feature columns of K[i], diinn.py:133,136)
 // An implicit-im2col GEMM [cells x 576] . [576 x 1024] on v_mfma_f32_32x32x2_f32.
@@ -1481,6 +1700,115 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
 }
 
 // ---------------------------------------------------------------------------------
+// precompute_P_bf16_kernel (DIINN_COMPUTE_BF16_FULL): the hoisted 3x3 conv on v_mfma_f32_32x32x16_bf16.
+// Same tiling as precompute_P_kernel (4 x 32 cells per workgroup, a wave per cell row, two M-tiles
+// advancing together), with the feature halo tile converted to bf16 while it is staged and laid out
+// channel-innermost in LDS: [6 x 34 pixels][64 channels + 8 pad] -> the B fragment of a k-step (16
+// channels of one tap, 8 per lane-half) is one ds_read_b128, and the 144-byte pixel pitch spreads the
+// 32 lanes of a row over all banks.  Accumulation, bias seeds and the stored P stay fp32.
+// Bound: the bf16 weight stream through L1 (1 KiB per MFMA per wave) and the 4 KiB/cell store of P.
+// ---------------------------------------------------------------------------------
+constexpr int PB_PITCH = C_IN + 8;                        // bf16 elements per staged pixel (144 bytes)
+constexpr int PB_LDS = PT_CH * PB_PITCH;                  // 14,688 bf16 = 29,376 B
+constexpr int PB_ITEMS = PT_CH * (C_IN / 2);              // staged as channel pairs: 6,528 32-bit items
+
+__global__ __launch_bounds__(256, 2) void precompute_P_bf16_kernel(const PParams p) {
+    __shared__ __attribute__((aligned(16))) __bf16 tile[PB_LDS];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int b = blockIdx.z / p.msplit;
+    const int part = blockIdx.z - b * p.msplit;
+    const int mp_count = p.mp_total / p.msplit, mp_begin = part * mp_count;
+    const int x0 = blockIdx.x * PT_COLS;
+    const int y0 = p.r0 + blockIdx.y * PT_ROWS;
+
+    const float* __restrict__ fb = p.feat + (size_t)b * C_IN * p.H * p.W;
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll 13
+    for (int it = 0; it < (PB_ITEMS + 255) / 256; ++it) {
+        const int idx = it * 256 + threadIdx.x;                   // (channel pair, pixel), pixel fastest
+        const int cp = idx / PT_CH;
+        const int pix = idx - cp * PT_CH;
+        const int ly = pix / PT_LC, lx = pix - ly * PT_LC;
+        const int yy = y0 + ly - 1, xx = x0 + lx - 1;
+        const bool ok = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W) && (idx < PB_ITEMS);
+        const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+        const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
+        const int cc = cp < C_IN / 2 ? cp : C_IN / 2 - 1;         // last iteration runs past the item count
+        const float v0 = fb[((size_t)(2 * cc) * p.H + yc) * p.W + xc];
+        const float v1 = fb[((size_t)(2 * cc + 1) * p.H + yc) * p.W + xc];
+        bf16x2 pk;
+        pk[0] = (__bf16)(ok ? v0 : 0.0f);
+        pk[1] = (__bf16)(ok ? v1 : 0.0f);
+        if (idx < PB_ITEMS) *(bf16x2*)(tile + pix * PB_PITCH + 2 * cp) = pk;
+    }
+    __syncthreads();
+
+    const int x = x0 + j, y = y0 + wave;
+    const bool store = (x < p.W) && (y < p.r1);
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(store) == 0ull))) return;
+
+    // B fragment of k-step ks = 4*tap + cg: tile[((wave + ky) * 34 + j + kx) * 72 + 16cg + 8h .. +7]
+    const int tb_off = (wave * PT_LC + j) * PB_PITCH + 8 * h;
+
+    constexpr int PF = P_PREFETCH;
+    static_assert(WPB_KS % PF == 0, "ring index must be static");
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);   // reads past the end return 0
+    const int lane_off = lane * 16;
+    int wp = (int)(OFF_WPB * sizeof(float)) + mp_begin * (WPB_KS * 2 * PIECE_BYTES);
+    const float* __restrict__ Bk = p.Wt + OFF_BK + 4 * h;
+    float* __restrict__ Pout = p.P + (((size_t)b * p.H + (y < p.H ? y : p.H - 1)) * p.W + (x < p.W ? x : p.W - 1)) * PCH + 4 * h;
+    f32x4 r0v[PF], r1v[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        r0v[d] = ld_piece(wrs, lane_off, wp + (2 * d + 0) * PIECE_BYTES);
+        r1v[d] = ld_piece(wrs, lane_off, wp + (2 * d + 1) * PIECE_BYTES);
+    }
+#pragma unroll 1
+    for (int mp = mp_begin; mp < mp_begin + mp_count; ++mp) {
+        int off = tb_off;                                         // hide the base from LICM (see precompute_P_kernel)
+        asm volatile("" : "+v"(off));
+        const __bf16* tbm = tile + off;
+        f32x16 a0, a1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 s0 = *(const f32x4*)(Bk + 64 * mp + 8 * g);
+            const f32x4 s1 = *(const f32x4*)(Bk + 64 * mp + 32 + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a0[4 * g + e] = s0[e];
+                a1[4 * g + e] = s1[e];
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < WPB_KS; ++ks) {
+            const int t = ks >> 2, cg = ks & 3;
+            const bf16x8 bv = *(const bf16x8*)(tbm + ((t / 3) * PT_LC + (t % 3)) * PB_PITCH + 16 * cg);
+            a0 = MFMA_BF16(__builtin_bit_cast(bf16x8, r0v[ks % PF]), bv, a0);
+            a1 = MFMA_BF16(__builtin_bit_cast(bf16x8, r1v[ks % PF]), bv, a1);
+            r0v[ks % PF] = ld_piece(wrs, lane_off, wp + (2 * (ks + PF) + 0) * PIECE_BYTES);
+            r1v[ks % PF] = ld_piece(wrs, lane_off, wp + (2 * (ks + PF) + 1) * PIECE_BYTES);
+        }
+        if (store) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v0, v1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v0[e] = a0[4 * g + e];
+                    v1[e] = a1[4 * g + e];
+                }
+                *(f32x4*)(Pout + 64 * mp + 8 * g) = v0;
+                *(f32x4*)(Pout + 64 * mp + 32 + 8 * g) = v1;
+            }
+        }
+        wp += WPB_KS * 2 * PIECE_BYTES;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // sine kernel (tests): the device sine of each mode, elementwise
 // ---------------------------------------------------------------------------------
 template <int MODE>
@@ -1549,15 +1877,23 @@ static int check_dims(int B, int H, int W) {
 }
 
 static int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,
-                    int B, int H, int W, int r0, int r1, int mp_total);
+                    int B, int H, int W, int r0, int r1, int mp_total, bool bf16 = false);
 
 int diinn_precompute_P(void* stream, const float* feat_dev, const float* packed_dev,
                        float* P_dev, int B, int H, int W, int r0, int r1) {
     return launch_P(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, 16);
 }
 
+int diinn_precompute_P_ex(void* stream, const float* feat_dev, const float* packed_dev,
+                          float* P_dev, int B, int H, int W, int r0, int r1, int compute) {
+    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY &&
+        compute != DIINN_COMPUTE_BF16_FULL)
+        return DIINN_ERR_UNSUPPORTED;
+    return launch_P(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, 16, compute == DIINN_COMPUTE_BF16_FULL);
+}
+
 static int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,
-                    int B, int H, int W, int r0, int r1, int mp_total) {
+                    int B, int H, int W, int r0, int r1, int mp_total, bool bf16) {
     if (!feat_dev || !packed_dev || !P_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
     if (st) return st;
@@ -1570,7 +1906,10 @@ static int launch_P(void* stream, const float* feat_dev, const float* packed_dev
     if ((long long)B * msplit > 65535) return DIINN_ERR_TOO_LARGE;
     PParams p{feat_dev, packed_dev, P_dev, B, H, W, r0, r1, msplit, mp_total};
     const dim3 grid((W + PT_COLS - 1) / PT_COLS, (r1 - r0 + PT_ROWS - 1) / PT_ROWS, B * msplit);
-    hipLaunchKernelGGL(precompute_P_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (bf16)
+        hipLaunchKernelGGL(precompute_P_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(precompute_P_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
 
@@ -1607,7 +1946,8 @@ int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
 int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_dev,
                          float* out_dev, int B, int H, int W, int Hu, int Wu,
                          int y0, int y1, int sin_mode, int compute) {
-    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY)
+    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY &&
+        compute != DIINN_COMPUTE_BF16_FULL)
         return DIINN_ERR_UNSUPPORTED;
     if (!P_dev || !packed_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
@@ -1630,13 +1970,26 @@ int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_d
     p.ah = make_axis(H, Hu, small);
     p.aw = make_axis(W, Wu, small);
     const dim3 grid(gx, gy, gz);
-    if (compute == DIINN_COMPUTE_BF16) {
-        if (sin_mode == DIINN_SIN_HW)
-            hipLaunchKernelGGL(decode_bf16_kernel<DIINN_SIN_HW>, grid, dim3(blk), 0, (hipStream_t)stream, p);
-        else if (sin_mode == DIINN_SIN_HW_REDUCED)
-            hipLaunchKernelGGL(decode_bf16_kernel<DIINN_SIN_HW_REDUCED>, grid, dim3(blk), 0, (hipStream_t)stream, p);
-        else
-            hipLaunchKernelGGL(decode_bf16_kernel<DIINN_SIN_ACCURATE>, grid, dim3(blk), 0, (hipStream_t)stream, p);
+    if (compute == DIINN_COMPUTE_BF16 || compute == DIINN_COMPUTE_BF16_FULL) {
+        // two pixel tiles per wave (half the weight bytes per MFMA) once the launch still fills the chip;
+        // small images keep one tile per wave (twice the workgroups)
+        const dim3 grid2(gx, (y1 - y0 + 2 * TILE_H * WG_TILES_Y - 1) / (2 * TILE_H * WG_TILES_Y), gz);   // 16 x 16 pixels per workgroup
+        const bool two_tiles = (long long)grid2.x * grid2.y * grid2.z >= 512;
+        if (!two_tiles) {
+            if (sin_mode == DIINN_SIN_HW)
+                hipLaunchKernelGGL(decode_bf16_kernel<DIINN_SIN_HW>, grid, dim3(blk), 0, (hipStream_t)stream, p);
+            else if (sin_mode == DIINN_SIN_HW_REDUCED)
+                hipLaunchKernelGGL(decode_bf16_kernel<DIINN_SIN_HW_REDUCED>, grid, dim3(blk), 0, (hipStream_t)stream, p);
+            else
+                hipLaunchKernelGGL(decode_bf16_kernel<DIINN_SIN_ACCURATE>, grid, dim3(blk), 0, (hipStream_t)stream, p);
+        } else {
+            if (sin_mode == DIINN_SIN_HW)
+                hipLaunchKernelGGL(decode_bf16x2_kernel<DIINN_SIN_HW>, grid2, dim3(blk), 0, (hipStream_t)stream, p);
+            else if (sin_mode == DIINN_SIN_HW_REDUCED)
+                hipLaunchKernelGGL(decode_bf16x2_kernel<DIINN_SIN_HW_REDUCED>, grid2, dim3(blk), 0, (hipStream_t)stream, p);
+            else
+                hipLaunchKernelGGL(decode_bf16x2_kernel<DIINN_SIN_ACCURATE>, grid2, dim3(blk), 0, (hipStream_t)stream, p);
+        }
         return hip_status(hipGetLastError());
     }
     if (compute == DIINN_COMPUTE_F32_QONLY) {
@@ -1837,7 +2190,7 @@ int diinn_decode_ex(void* stream, const float* feat_dev, const float* packed_dev
     int r0, r1;
     int st = diinn_lr_rows_for_band(H, Hu, Wu, y0, y1, &r0, &r1);
     if (st) return st;
-    st = diinn_precompute_P(stream, feat_dev, packed_dev, workspace_dev, B, H, W, r0, r1);
+    st = diinn_precompute_P_ex(stream, feat_dev, packed_dev, workspace_dev, B, H, W, r0, r1, compute);
     if (st) return st;
     if (compute == DIINN_COMPUTE_F32_QONLY) {                   // modes 1 and 2: per-cell modulation chain
         st = diinn_cell_chain(stream, workspace_dev, packed_dev, B, H, W, r0, r1);

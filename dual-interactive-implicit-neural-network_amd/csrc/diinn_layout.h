@@ -60,7 +60,13 @@ constexpr size_t SZ_WLB     = 3 * WLB_LAYER;               // 196,608 floats = 7
 //     indices swapped: value = W_part[ out = chan_of(4kg+e, lane>>5) ][ in = 32m + (lane&31) ].
 constexpr size_t OFF_WLT    = OFF_WLB + SZ_WLB;
 constexpr size_t SZ_WLT     = SZ_WL;
-constexpr size_t PACKED_FLOATS = OFF_WLT + SZ_WLT;         // 1,576,452
+// WPB: the hoisted 3x3 conv as bf16 A operands of v_mfma_f32_32x32x16_bf16 (DIINN_COMPUTE_BF16_FULL).
+//     [mp 16][ks 36][t 2][lane 64][j 8] bf16, M-tile mo = 2mp+t; k-step ks = 4*tap + cg covers channels
+//     16cg .. 16cg+15 of tap = ky*3+kx;  value = bf16(Wx[ o = 32mo + (lane&31) ][ c = 16cg + 8(lane>>5) + j ][ky][kx]).
+constexpr int    WPB_KS     = 36;
+constexpr size_t OFF_WPB    = OFF_WLT + SZ_WLT;
+constexpr size_t SZ_WPB     = (size_t)16 * WPB_KS * 2 * WL_PIECE;    // 294,912 floats
+constexpr size_t PACKED_FLOATS = OFF_WPB + SZ_WPB;         // 1,871,364
 
 // channel held by activation register (m, r) of lane-half h
 DIINN_HD int chan_of(int kk /* = 16*m + r */, int h) {

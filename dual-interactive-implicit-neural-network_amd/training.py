@@ -79,8 +79,9 @@ def pack_gather_index() -> torch.Tensor:
     packed = pack_state_dict(sd, mode=3).numpy()
     idx = np.rint(packed).astype(np.int64) - 1
     off, size = C.c_size_t(), C.c_size_t()
-    _native.check(lib.diinn_packed_section(7, C.byref(off), C.byref(size)), "diinn_packed_section")
-    idx[off.value:off.value + size.value] = -1          # bf16 copy: rounded values, not a permutation
+    for section in (7, 9):                              # bf16 copies: rounded values, not a permutation
+        _native.check(lib.diinn_packed_section(section, C.byref(off), C.byref(size)), "diinn_packed_section")
+        idx[off.value:off.value + size.value] = -1
     if idx.max() >= total or idx.min() < -1:
         raise RuntimeError("packed image is not a permutation of the reference tensors")
     used = np.zeros(total, bool)
@@ -92,7 +93,7 @@ def pack_gather_index() -> torch.Tensor:
     return _gather_index_cpu
 
 
-_packed_cache: Tuple[Optional[tuple], Optional[torch.Tensor]] = (None, None)
+_packed_cache: tuple = (None, None, None)          # (key, packed image, the parameter tensors the key describes)
 
 
 def pack_on_device(params: Sequence[torch.Tensor]) -> torch.Tensor:
@@ -104,7 +105,8 @@ def pack_on_device(params: Sequence[torch.Tensor]) -> torch.Tensor:
     if _packed_cache[0] == key:
         return _packed_cache[1]
     packed = _pack_on_device(params)
-    _packed_cache = (key, packed)
+    # the entry keeps the tensors alive: their addresses cannot be handed to other weights while the key is cached
+    _packed_cache = (key, packed, tuple(p.detach() for p in params))
     return packed
 
 

@@ -58,6 +58,9 @@ extern "C" {
 #define DIINN_COMPUTE_BF16 1   /* v_mfma_f32_32x32x16_bf16: bf16 weights/activations, fp32 accumulate;
                                   parity restated to 2e-3 * max|ref| (BASELINE config 5)                     */
 
+#define DIINN_COMPUTE_BF16_FULL 3  /* DIINN_COMPUTE_BF16 plus the hoisted 3x3 conv (P) on bf16 operands too (features and
+                                   weights rounded to bf16, fp32 accumulate): ~1.6e-3 relative at default-init
+                                   weights; the fastest path, BASELINE config 5 */
 #define DIINN_COMPUTE_F32_QONLY 2 /* decoder modes 1 and 2 (diinn.py:116-131): fp32, synthesis GEMM only; the
                                   workspace slots 1..3 hold the per-cell modulation k_i (>= 0) produced by
                                   diinn_cell_chain from P (diinn_decode_ex runs P, the chain and the decode) */
@@ -83,9 +86,9 @@ int         diinn_last_hip_error(void);
 size_t diinn_packed_weight_floats(void);
 /* Sections of the packed image (offset and size in floats): 0 WL stacked per-pixel layers, 1 WP the
  * hoisted 3x3 conv, 2 bK, 3 Q0 (+bQ0), 4 bQ1..3, 5 L, 6 bL, 7 WLB (bf16 copy of WL), 8 WLT (WL transposed,
- * read by the backward pass).  Every section but 7 is a pure permutation (plus zero padding) of the
- * reference tensors, so a training loop can re-pack on the device with one gather; section 7 holds
- * rounded values and is only read by DIINN_COMPUTE_BF16. */
+ * read by the backward pass), 9 WPB (bf16 copy of WP).  Every section but 7 and 9 is a pure permutation
+ * (plus zero padding) of the reference tensors, so a training loop can re-pack on the device with one
+ * gather; sections 7 and 9 hold rounded values and are only read by the bf16 compute modes. */
 int    diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats);
 int    diinn_pack_weights(const float* K0w, const float* K0b,
                           const float* const Kw[3], const float* const Kb[3],
@@ -130,6 +133,10 @@ int    diinn_lr_rows_for_band(int H, int Hu, int Wu, int y0, int y1, int* r0, in
  * diinn_decode        = precompute_P on the rows the band needs, then decode_band. */
 int diinn_precompute_P(void* stream, const float* feat_dev, const float* packed_dev,
                        float* P_dev, int B, int H, int W, int r0, int r1);
+/* the same with an explicit arithmetic: DIINN_COMPUTE_BF16_FULL runs the conv on bf16 operands (section 9 of the
+ * packed image); every other mode is the fp32 conv above. */
+int diinn_precompute_P_ex(void* stream, const float* feat_dev, const float* packed_dev,
+                          float* P_dev, int B, int H, int W, int r0, int r1, int compute);
 int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
                       float* out_dev, int B, int H, int W, int Hu, int Wu,
                       int y0, int y1, int sin_mode);

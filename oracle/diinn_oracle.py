@@ -239,14 +239,16 @@ def _bf16_round(t: torch.Tensor) -> torch.Tensor:
 
 
 @torch.no_grad()
-def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = False) -> torch.Tensor:
+def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = False, bf16_p: bool = False) -> torch.Tensor:
     """Same function evaluated the way the HIP kernels do: per-cell P, then the
     per-pixel 256->512 stacked layers.  Not reference-faithful in summation
     order; agrees with decode_reference_form to ~1e-7.
 
     ``bf16_operands=True`` emulates the optional bf16 path (BASELINE config 5): the weights and
     the activation entering layers 1..3 are rounded to bf16, products accumulate in fp32;
-    P, biases, sine, layer 0 and the head (on the unrounded last activation) stay fp32."""
+    P, biases, sine, layer 0 and the head (on the unrounded last activation) stay fp32.
+    ``bf16_p=True`` additionally rounds the features and the 3x3 conv weights of P to bf16 (fp32 accumulate,
+    fp32 bias): the DIINN_COMPUTE_BF16_FULL mode."""
     sw = split_weights(sd)
     feat = _as_t(feat)
     b, c, h, w = feat.shape
@@ -254,7 +256,11 @@ def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = Fal
     small = uses_small_output_kernel(hu, wu)
     idx_h, rel_h = axis_tables(h, hu, small)
     idx_w, rel_w = axis_tables(w, wu, small)
-    p = precompute_P(sd, feat)  # [B,H,W,1024]
+    if bf16_p:
+        p = F.conv2d(_bf16_round(feat), _bf16_round(sw["Wx"].view(4 * HIDDEN, IN_CHANNELS, 3, 3)), None, padding=1)
+        p = (p + sw["bK"].view(1, -1, 1, 1)).permute(0, 2, 3, 1).contiguous()
+    else:
+        p = precompute_P(sd, feat)  # [B,H,W,1024]
     pp = p[:, torch.from_numpy(idx_h.astype(np.int64))][:, :, torch.from_numpy(idx_w.astype(np.int64))]
     pp = pp.view(b, hu, wu, 4, HIDDEN)
     syn = torch.empty((hu, wu, 3))

@@ -86,7 +86,7 @@ def test_packed_image_layout(lib):
     import diinn_amd.decoder as D
     sd = synth.decoder_state_dict(11)
     packed = D.pack_state_dict(sd).numpy()
-    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608 + 393_216
+    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608 + 393_216 + 294_912
     lane = np.arange(64)
     out_l, h_l = lane & 31, lane >> 5
     # WL section
@@ -123,12 +123,23 @@ def test_packed_image_layout(lib):
     off += 768
     assert np.array_equal(packed[off: off + 3], sd["last_layer.bias"])
     # WLT section (backward pass): WL with the two channel indices swapped
-    WLT = packed[986_628 + 196_608:].reshape(3, 8, 32, 2, 64, 4)
+    WLT = packed[986_628 + 196_608:986_628 + 196_608 + 393_216].reshape(3, 8, 32, 2, 64, 4)
     for _ in range(200):
         i, m, kg, part, l, e = (int(rng.integers(n)) for n in (3, 8, 32, 2, 64, 4))
         cin, o = 32 * m + (l & 31), _chan_of(4 * kg + e, l >> 5)
         w = sd[f"K.{i + 1}.0.weight"][o, cin, 0, 0] if part == 0 else sd[f"Q.{i + 1}.0.weight"][o, cin, 0, 0]
         assert WLT[i, m, kg, part, l, e] == w
+    # WPB section (bf16 copy of the 3x3 conv): [mp][ks][t][lane][j], k-step = 4*tap + channel group of 16
+    WPB = packed[986_628 + 196_608 + 393_216:].view(np.uint16).reshape(16, 36, 2, 64, 8)
+    for _ in range(200):
+        mo, ks, l, jj = (int(rng.integers(n)) for n in (32, 36, 64, 8))
+        i, ch = mo >> 3, 32 * (mo & 7) + (l & 31)
+        tap, c = ks >> 2, 16 * (ks & 3) + 8 * (l >> 5) + jj
+        col = c * 9 + tap + (0 if i == 0 else 256)
+        w = np.float32(sd[f"K.{i}.0.weight"][ch, col, 0, 0])
+        u = int(w.view(np.uint32))
+        bf = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF            # round to nearest even
+        assert int(WPB[mo >> 1, ks, mo & 1, l, jj]) == bf
     # every channel appears exactly once per lane-half in the activation register order
     seen = sorted(_chan_of(kk, h) for kk in range(128) for h in range(2))
     assert seen == list(range(256))

@@ -237,6 +237,47 @@ def test_bf16_path_restated_tolerance(golden, dev):
         print(f"bf16 {name}: max|ref| {scale:.3f}  vs fp32 reference {err:.2e} ({err/scale:.1e} rel)  vs emulation {err2:.2e}")
 
 
+
+def test_bf16_full_path(golden, dev):
+    """DIINN_COMPUTE_BF16_FULL: bf16 operands in the hoisted 3x3 conv as well (precompute_P_bf16_kernel).
+    (1) P itself against the oracle's bf16-operand convolution: products of bf16 values are exact in fp32,
+        so only the summation order differs -> tight bound;
+    (2) the decode against the fp32 reference with the tolerance restated for this mode, 3e-3 * max|ref| at
+        default-init weights (emulated: 1.6e-3), 5e-2 on the x3 stress set (emulated: 2.3e-2);
+    (3) against the emulation of the same roundings."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.decoder as D
+    import diinn_oracle as orc
+    import torch.nn.functional as F
+    lib = N.load()
+    for name, b, h, w, hu, wu, gain in golden_cases(golden):
+        sd = synth.decoder_state_dict(123, gain)
+        feat = synth.encoder_features(123, b, h, w)
+        packed = D.pack_state_dict(sd).to(dev)
+        f = torch.from_numpy(feat).to(dev)
+        ws = torch.full((b * h * w * 1024,), float("nan"), device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        N.check(lib.diinn_precompute_P_ex(stream, C.c_void_p(f.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                          C.c_void_p(ws.data_ptr()), b, h, w, 0, h, N.COMPUTE_BF16_FULL), "P bf16")
+        torch.cuda.synchronize()
+        sw = orc.split_weights(sd)
+        p_emu = F.conv2d(orc._bf16_round(torch.from_numpy(feat)), orc._bf16_round(sw["Wx"].view(1024, 64, 3, 3)), None, padding=1)
+        p_emu = (p_emu + sw["bK"].view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+        p_got = ws.view(b, h, w, 1024).cpu()
+        assert torch.isfinite(p_got).all()
+        assert float((p_got - p_emu).abs().max()) <= 2e-5 * max(1.0, float(p_emu.abs().max())), name
+        got = _decode(sd, feat, (hu, wu), dev, compute="bf16_full")
+        ref = golden[f"out/{name}"]
+        scale = float(np.abs(ref).max())
+        err = float(np.abs(got - ref).max())
+        rel = 3e-3 if gain == 1.0 else 5e-2
+        assert err <= rel * scale + 1e-6, f"{name}: bf16_full vs fp32 reference {err:.3e} (max|ref| {scale:.3e})"
+        emu = orc.decode_hoisted_form(sd, feat, (hu, wu), bf16_operands=True, bf16_p=True).numpy()
+        err2 = float(np.abs(got - emu).max())
+        assert err2 <= rel * scale + 1e-6, f"{name}: bf16_full kernel vs emulation {err2:.3e}"
+        print(f"bf16_full {name}: vs fp32 reference {err/scale:.1e} rel  vs emulation {err2/scale:.1e} rel")
+
 def test_random_shapes_vs_oracle(dev):
     """Fuzz: random LR/HR shapes, batch sizes and scales (up- and down-scaling, tile edges that do
     not divide the 16x8 workgroup block or the 4x32 cell block) against the oracle."""
