@@ -19,8 +19,12 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_NAME = "libdiinn_hip.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 
-SOURCES = ["diinn_kernels.hip", "diinn_host.cpp"]
-DEPS = SOURCES + ["diinn_layout.h", os.path.join("..", "..", "include", "diinn_hip.h")]
+# one gfx950 translation unit per kernel family (shared definitions: diinn_device.h) + the host-only half of the ABI
+HIP_SOURCES = ["diinn_decode.hip", "diinn_precompute.hip", "diinn_bf16.hip", "diinn_training.hip",
+               "diinn_baselines.hip", "diinn_misc.hip"]
+HOST_SOURCES = ["diinn_host.cpp"]
+SOURCES = HIP_SOURCES + HOST_SOURCES
+DEPS = SOURCES + ["diinn_device.h", "diinn_layout.h", os.path.join("..", "..", "include", "diinn_hip.h")]
 
 # -ffp-contract=off: the coordinate formulas must round every fp32 op separately
 # (diinn_layout.h axis_eval); the kernels spell out fmaf where fusion is wanted.
@@ -43,27 +47,44 @@ def needs_build() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile the shared library if sources are newer; return its path."""
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = True, extra_flags=(), out: str = LIB_PATH, jobs: int = 4) -> str:
+    """Compile the shared library if sources are newer; return its path.  Objects that are newer than
+    every dependency are reused; the translation units compile ``jobs`` at a time.  ``extra_flags`` / ``out``
+    serve kernel A/B experiments (tools/build_variant.sh)."""
+    if not force and not extra_flags and out == LIB_PATH and not needs_build():
         return LIB_PATH
     hipcc = find_hipcc()
-    tmp = LIB_PATH + ".tmp"
-    objdir = os.path.join(PKG_DIR, "build")
+    tmp = out + ".tmp"
+    objdir = os.path.join(PKG_DIR, "build") if out == LIB_PATH and not extra_flags else out + ".obj"
     os.makedirs(objdir, exist_ok=True)
-    k_obj = os.path.join(objdir, "diinn_kernels.o")
-    h_obj = os.path.join(objdir, "diinn_host.o")
-    cmds = [
-        [hipcc, *HIPCC_FLAGS, "-c", os.path.join(CSRC, "diinn_kernels.hip"), "-o", k_obj],
-        [hipcc, *HOST_FLAGS, "-c", os.path.join(CSRC, "diinn_host.cpp"), "-o", h_obj],
-        [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, k_obj, h_obj],
-    ]
+    newest_header = max(os.path.getmtime(os.path.join(CSRC, d)) for d in DEPS if not d.endswith((".hip", ".cpp")))
+    cmds, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        src_path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(newest_header, os.path.getmtime(src_path)):
+            continue
+        flags = [*HIPCC_FLAGS, *extra_flags] if src in HIP_SOURCES else HOST_FLAGS
+        cmds.append([hipcc, *flags, "-c", src_path, "-o", obj])
+    running = []
     for cmd in cmds:
         if verbose:
             print("[diinn_amd.build]", " ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True, cwd=CSRC)
-    os.replace(tmp, LIB_PATH)
-    return LIB_PATH
+        running.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+        if len(running) >= jobs:
+            c, pr = running.pop(0)
+            if pr.wait():
+                raise subprocess.CalledProcessError(pr.returncode, c)
+    for c, pr in running:
+        if pr.wait():
+            raise subprocess.CalledProcessError(pr.returncode, c)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
+    if verbose:
+        print("[diinn_amd.build]", " ".join(link), flush=True)
+    subprocess.run(link, check=True, cwd=CSRC)
+    os.replace(tmp, out)
+    return out
 
 
 if __name__ == "__main__":

@@ -1,0 +1,473 @@
+// diinn_decode.hip -- gfx950 (MI355X, CDNA4): the fp32 decode kernel of the DIINN implicit decoder and the
+// decode entry points of the C ABI (include/diinn_hip.h).  Sibling translation units: see diinn_device.h.
+//
+// Reference path replaced: ImplicitDecoder.forward, mode 3
+//   /root/reference/src/models/components/diinn.py:163-173 (+ :94-110, :132-139, :149-160)
+//
+// Kernels (DESIGN.md has the derivation, the roofline and the measurements of each):
+//   precompute_P_kernel : per LR cell, P_i = Wx_i . unfold3x3(feat) + bK_i, i=0..3
+//                         (implicit-im2col GEMM 576 -> 1024 on v_mfma_f32_32x32x2_f32,
+//                         feature halo tile in LDS); precompute_P_bf16_kernel: bf16 operands
+//   decode_kernel       : per HR pixel, the dual-branch MLP.  One wave owns 32 pixels
+//                         and keeps their 256-channel activation in registers for the
+//                         whole network: the accumulator layout of one layer IS the
+//                         B-operand layout of the next (diinn_layout.h), so activations
+//                         never touch LDS or HBM.  Weights stream from the packed image.
+//                         <KPART=false>: decoder modes 1/2 (with cell_chain_kernel);
+//                         <SAVE>: training forward, also writes k_i, s_i as tiled planes
+//   decode_bf16_kernel, decode_bf16x2_kernel : bf16 operands in layers 1..3 (optional paths)
+//   bwd_head_kernel, bwd_layer_kernel, plane_gemm_kernel, plane_rowdot_kernel, cell_sum_kernel :
+//                         backward pass of the decoder (training)
+//   liif_kernel; unfold_cells_kernel + metasr_kernel : the LIIF and MetaSR comparison decoders
+//   axis_tables_kernel, sin_kernel : the device coordinate / sine code, exposed for tests.
+// Compile-time hooks that never ship enabled: ABL_* (timing ablations, wrong results),
+// DIINN_STAMPS (s_memtime stamps for tools/stamp_report.py).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (explicit fmaf where wanted)
+#include "diinn_device.h"
+
+template <int SIN_MODE, bool KPART = true, bool SAVE = false>
+__global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform (scalar offsets)
+    const int h = lane >> 5, j = lane & 31;
+
+    int x, y, b;
+    const long long ptile = (long long)blockIdx.x * 4 + wave;   // SAVE: plane tile of this wave
+    if constexpr (SAVE) {                                        // 32 consecutive flattened pixels
+        const long long pix = ptile * PLANE_TILE + j;
+        const long long pc = pix < p.npix ? pix : p.npix - 1;    // lanes past the end compute on the last pixel
+        const int hw = p.Hu * p.Wu;
+        b = (int)(pc / hw);
+        const int rem = (int)(pc - (long long)b * hw);
+        y = rem / p.Wu;
+        x = pix < p.npix ? rem - y * p.Wu : p.Wu;                // ... and are marked invalid below
+    } else {
+        x = blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
+        y = p.y0 + blockIdx.y * (TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
+        b = blockIdx.z;
+    }
+    const bool valid = (x < p.Wu) && (y < p.y1);
+    // whole wave outside the band/image: nothing to do (wave-uniform, no barriers in this kernel)
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
+    const int xc = x < p.Wu ? x : p.Wu - 1;
+    const int yc = y < p.y1 ? y : p.y1 - 1;
+
+    int iy, ix;
+    float relh, relw;
+    axis_eval(p.ah, yc, iy, relh);
+    axis_eval(p.aw, xc, ix, relw);
+
+#ifdef DIINN_STAMPS
+    const size_t stamp_base = ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    if (p.stamps && lane == 0) {
+        unsigned long long rt;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+        p.stamps[stamp_base + 7] = rt;
+    }
+#endif
+    STAMP(0);
+    const float* __restrict__ Wt = p.Wt;
+    const float* __restrict__ Pc = p.P + (((size_t)b * p.H + iy) * p.W + ix) * PCH + 4 * h;
+
+    // saved-activation planes (SAVE): one buffer descriptor per layer covering this wave's plane tile
+    // (512 rows x 32 pixels); a lane's offset is its pixel inside the row of channel 4h, the channel
+    // row is a compile-time scalar offset.  Lanes past the end carry an offset outside the
+    // descriptor's range: the store is dropped.
+    const long long act_tiles = (p.npix + PLANE_TILE - 1) / PLANE_TILE;
+    const unsigned act_voff = (SAVE && valid) ? 4u * j + 4u * h * PLANE_ROW_BYTES : 0xFFFFFFF0u;
+    auto act_rsrc = [&](int layer) {
+        return tile_rsrc(p.acts + (size_t)layer * act_tiles * ACT_ROWS * PLANE_TILE, ptile, ACT_ROWS);
+    };
+
+    // ---- layer 0: q0 = relu(P_0[cell]) * sin(Q0 . (rel_h, rel_w, ratio) + bQ0)   (diinn.py:133-134)
+    float q[128];
+    {
+        const float* __restrict__ Q0 = Wt + OFF_Q0 + 4 * h;
+        const __amdgpu_buffer_rsrc_t ar0 = act_rsrc(0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * m + 8 * g;
+                const f32x4 pv = *(const f32x4*)(Pc + c0);
+                const f32x4 wh = *(const f32x4*)(Q0 + 0 * HID + c0);
+                const f32x4 ww = *(const f32x4*)(Q0 + 1 * HID + c0);
+                const f32x4 wr = *(const f32x4*)(Q0 + 2 * HID + c0);
+                const f32x4 bq = *(const f32x4*)(Q0 + 3 * HID + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = __builtin_fmaf(wr[e], p.ratio, bq[e]);
+                    a = __builtin_fmaf(ww[e], relw, a);
+                    a = __builtin_fmaf(wh[e], relh, a);
+                    const float kv = relu0(pv[e]);
+                    q[16 * m + 4 * g + e] = kv * dsin<SIN_MODE>(a);
+                    if constexpr (SAVE) {
+                        st_act(ar0, act_voff, (unsigned)(c0 + e) * PLANE_ROW_BYTES, kv);
+                        st_act(ar0, act_voff, (unsigned)(HID + c0 + e) * PLANE_ROW_BYTES, a);
+                    }
+                }
+            }
+        }
+    }
+
+    STAMP(1);
+    // ---- layers 1..3: [k;s] = [Wq_i;Qw_i] . q + [P_i[cell]; bQ_i];  q = relu(k) * sin(s)   (diinn.py:135-137)
+    // Software pipeline, spelled out in program order (the loops below are fully unrolled):
+    //   * weight pieces are fetched PF steps (8 MFMAs = 512 cycles each) ahead into a register ring
+    //     that is carried across tiles and layers (the packed image is contiguous in step order);
+    //   * the accumulator seeds of tile m+1 (P_i[cell], bQ_i) are fetched during tile m;
+    //   * the VALU epilogue (relu * sin) of tile m-1 is spread over the MFMA stream of tile m.
+    constexpr int PF = DECODE_PREFETCH;
+    static_assert(WL_KG % PF == 0, "ring index must be static");
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);   // reads past the end return 0
+    const int lane_off = lane * 16;
+    int wp = (int)(OFF_WL * sizeof(float));                      // byte offset; advances one layer per iteration
+    f32x4 rk[PF], rq[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        if constexpr (KPART) rk[d] = ld_piece(wrs, lane_off, wp + (2 * d + 0) * PIECE_BYTES);
+        rq[d] = ld_piece(wrs, lane_off, wp + (2 * d + 1) * PIECE_BYTES);
+    }
+    f32x4 sk[4], sq[4];                                          // seeds of the next tile
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        sk[g] = *(const f32x4*)(Pc + HID + 8 * g);
+        sq[g] = *(const f32x4*)(Wt + OFF_BQ + 4 * h + 8 * g);
+    }
+#pragma unroll 1
+    for (int layer = 0; layer < DECODE_RUN_LAYERS; ++layer) {
+        const int nl = layer < 2 ? layer + 1 : 2;                // seeds of the next layer's tile 0 (clamped)
+        const float* __restrict__ Pl = Pc + (layer + 1) * HID;
+        const float* __restrict__ Bq = Wt + OFF_BQ + layer * HID + 4 * h;
+        const float* __restrict__ Pn = Pc + (nl + 1) * HID;
+        const float* __restrict__ Bn = Wt + OFF_BQ + nl * HID + 4 * h;
+        float qn[128];
+        f32x16 pk, ps;                                           // finished accumulators of the previous tile
+        const __amdgpu_buffer_rsrc_t arl = act_rsrc(layer + 1);
+        (void)arl;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            f32x16 ak, as;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ak[4 * g + e] = sk[g][e];
+                    as[4 * g + e] = sq[g][e];
+                }
+            }
+#pragma unroll
+            for (int kg = 0; kg < WL_KG; ++kg) {
+                const int s = m * WL_KG + kg;
+                const f32x4 wq = rq[s % PF];
+                if constexpr (KPART) {
+                    const f32x4 wk = rk[s % PF];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ak = MFMA32(wk[e], q[4 * kg + e], ak);
+                        as = MFMA32(wq[e], q[4 * kg + e], as);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) as = MFMA32(wq[e], q[4 * kg + e], as);
+                }
+                // refill the ring slot just consumed with the piece PF steps ahead
+                if constexpr (KPART) rk[s % PF] = ld_piece(wrs, lane_off, wp + (2 * ABL_STEP(s + PF) + 0) * PIECE_BYTES);
+                rq[s % PF] = ld_piece(wrs, lane_off, wp + (2 * ABL_STEP(s + PF) + 1) * PIECE_BYTES);
+                if (kg == 4) {                                    // seeds for the next tile
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        sk[g] = *(const f32x4*)((m < 7 ? Pl + 32 * (m + 1) : Pn) + 8 * g);
+                        sq[g] = *(const f32x4*)((m < 7 ? Bq + 32 * (m + 1) : Bn) + 8 * g);
+                    }
+                }
+                if (m > 0 && (kg & 1) == 0) {                     // one epilogue element of tile m-1 every 16 MFMAs
+                    const int r = kg >> 1;
+                    const float kv = relu0(pk[r]);
+                    qn[16 * (m - 1) + r] = kv * ABL_SIN(ps[r]);
+                    if constexpr (SAVE) {                        // register r of tile m-1 = channel 32(m-1) + (r&3) + 8(r>>2) + 4h
+                        const unsigned so = (unsigned)(32 * (m - 1) + (r & 3) + 8 * (r >> 2)) * PLANE_ROW_BYTES;
+                        st_act(arl, act_voff, so, kv);
+                        st_act(arl, act_voff, so + HID * PLANE_ROW_BYTES, ps[r]);
+                    }
+                }
+            }
+            pk = ak;
+            ps = as;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float kv = relu0(pk[r]);
+            qn[16 * 7 + r] = kv * dsin<SIN_MODE>(ps[r]);
+            if constexpr (SAVE) {
+                const unsigned so = (unsigned)(32 * 7 + (r & 3) + 8 * (r >> 2)) * PLANE_ROW_BYTES;
+                st_act(arl, act_voff, so, kv);
+                st_act(arl, act_voff, so + HID * PLANE_ROW_BYTES, ps[r]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 128; ++i) q[i] = qn[i];
+        wp += (int)(WL_LAYER * sizeof(float));
+#ifdef DIINN_STAMPS
+        if (layer == 0) STAMP(2); else if (layer == 1) STAMP(3); else STAMP(4);
+#endif
+    }
+
+    // ---- head: out = L . q3 + bL   (diinn.py:138)
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+    {
+        const float* __restrict__ L = Wt + OFF_L + 4 * h;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * m + 8 * g;
+                const f32x4 l0 = *(const f32x4*)(L + 0 * HID + c0);
+                const f32x4 l1 = *(const f32x4*)(L + 1 * HID + c0);
+                const f32x4 l2 = *(const f32x4*)(L + 2 * HID + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = q[16 * m + 4 * g + e];
+                    o0 = __builtin_fmaf(l0[e], v, o0);
+                    o1 = __builtin_fmaf(l1[e], v, o1);
+                    o2 = __builtin_fmaf(l2[e], v, o2);
+                }
+            }
+        }
+    }
+    o0 += __shfl_xor(o0, 32);
+    o1 += __shfl_xor(o1, 32);
+    o2 += __shfl_xor(o2, 32);
+    if (valid && h == 0) {
+        const size_t plane = (size_t)p.Hu * p.Wu;
+        float* o = p.out + (size_t)b * 3 * plane + (size_t)y * p.Wu + x;
+        o[0] = o0 + Wt[OFF_BL + 0];
+        o[plane] = o1 + Wt[OFF_BL + 1];
+        o[2 * plane] = o2 + Wt[OFF_BL + 2];
+    }
+    STAMP(5);
+}
+
+
+
+// ---------------------------------------------------------------------------------
+// cell_chain_kernel (decoder modes 1 and 2, diinn.py:116-131): the modulation chain depends on the
+// LR cell only: k_0 = relu(P_0), k_i = relu(K_i^k k_{i-1} + P_i), i = 1..3.  Same register-resident
+// scheme as decode_kernel with LR cells in place of HR pixels and the modulation half of the
+// stacked weights alone (part 0 of the WL image holds K.i[:, :256] in A-operand order already).
+// k_i overwrites the P_i slot of the workspace; decode_kernel<SIN, KPART=false> then reads it as
+// the multiplier of the synthesis branch.
+// ---------------------------------------------------------------------------------
+struct ChainParams {
+    float* P;            // [B,H,W,1024], slots 1..3 updated in place for rows [r0,r1)
+    const float* Wt;
+    int B, H, W, r0, r1;
+};
+
+__global__ __launch_bounds__(256, 1) void cell_chain_kernel(const ChainParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int x = blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
+    const int y = p.r0 + blockIdx.y * (TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
+    const int b = blockIdx.z;
+    const bool valid = (x < p.W) && (y < p.r1);
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
+    const int xc = x < p.W ? x : p.W - 1;
+    const int yc = y < p.r1 ? y : p.r1 - 1;
+    float* __restrict__ Pc = p.P + (((size_t)b * p.H + yc) * p.W + xc) * PCH + 4 * h;
+
+    float k[128];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const f32x4 pv = *(const f32x4*)(Pc + 8 * i);             // channels 32m + 8g + 4h .., i = 4m + g
+#pragma unroll
+        for (int e = 0; e < 4; ++e) k[4 * i + e] = relu0(pv[e]);
+    }
+
+    constexpr int PF = DECODE_PREFETCH;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);
+    const int lane_off = lane * 16;
+    int wp = (int)(OFF_WL * sizeof(float));
+    f32x4 rk[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) rk[d] = ld_piece(wrs, lane_off, wp + (2 * d) * PIECE_BYTES);
+#pragma unroll 1
+    for (int layer = 0; layer < 3; ++layer) {
+        float* __restrict__ Pl = Pc + (layer + 1) * HID;
+        float kn[128];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            f32x16 ak;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 pv = *(const f32x4*)(Pl + 32 * m + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ak[4 * g + e] = pv[e];
+            }
+#pragma unroll
+            for (int kg = 0; kg < WL_KG; ++kg) {
+                const int s = m * WL_KG + kg;
+                const f32x4 wk = rk[s % PF];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ak = MFMA32(wk[e], k[4 * kg + e], ak);
+                rk[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF)) * PIECE_BYTES);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = relu0(ak[4 * g + e]);
+                    kn[16 * m + 4 * g + e] = v[e];
+                }
+                if (valid) *(f32x4*)(Pl + 32 * m + 8 * g) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 128; ++i) k[i] = kn[i];
+        wp += (int)(WL_LAYER * sizeof(float));
+    }
+}
+
+
+extern "C" {
+
+int diinn_cell_chain(void* stream, float* P_dev, const float* packed_dev, int B, int H, int W, int r0, int r1) {
+    if (!P_dev || !packed_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (r0 < 0 || r1 > H || r0 >= r1) return DIINN_ERR_INVALID_ARG;
+    ChainParams p{P_dev, packed_dev, B, H, W, r0, r1};
+    const dim3 grid((W + TILE_W * WG_TILES_X - 1) / (TILE_W * WG_TILES_X),
+                    (r1 - r0 + TILE_H * WG_TILES_Y - 1) / (TILE_H * WG_TILES_Y), B);
+    if (grid.y > 65535) return DIINN_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(cell_chain_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,
+                             int* grid_x, int* grid_y, int* grid_z, int* block) {
+    if (B <= 0 || Hu <= 0 || Wu <= 0 || y0 < 0 || y1 > Hu || y0 >= y1) return DIINN_ERR_INVALID_ARG;
+    if (grid_x) *grid_x = (Wu + TILE_W * WG_TILES_X - 1) / (TILE_W * WG_TILES_X);
+    if (grid_y) *grid_y = (y1 - y0 + TILE_H * WG_TILES_Y - 1) / (TILE_H * WG_TILES_Y);
+    if (grid_z) *grid_z = B;
+    if (block) *block = 256;
+    return DIINN_OK;
+}
+
+int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
+                      float* out_dev, int B, int H, int W, int Hu, int Wu,
+                      int y0, int y1, int sin_mode) {
+    return diinn_decode_band_ex(stream, P_dev, packed_dev, out_dev, B, H, W, Hu, Wu, y0, y1, sin_mode,
+                                DIINN_COMPUTE_F32);
+}
+
+int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_dev,
+                         float* out_dev, int B, int H, int W, int Hu, int Wu,
+                         int y0, int y1, int sin_mode, int compute) {
+    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY &&
+        compute != DIINN_COMPUTE_BF16_FULL)
+        return DIINN_ERR_UNSUPPORTED;
+    if (!P_dev || !packed_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (Hu <= 0 || Wu <= 0 || y0 < 0 || y1 > Hu || y0 >= y1) return DIINN_ERR_INVALID_ARG;
+    if ((double)Hu * Wu >= 2.0e9) return DIINN_ERR_TOO_LARGE;
+    if (sin_mode < DIINN_SIN_ACCURATE || sin_mode > DIINN_SIN_HW_REDUCED) return DIINN_ERR_UNSUPPORTED;
+    int gx, gy, gz, blk;
+    diinn_decode_launch_info(B, Hu, Wu, y0, y1, &gx, &gy, &gz, &blk);
+    if (gy > 65535 || gz > 65535) return DIINN_ERR_TOO_LARGE;   // HIP grid.y / grid.z limits
+    DecodeParams p;
+    p.P = P_dev; p.Wt = packed_dev; p.out = out_dev;
+    p.B = B; p.H = H; p.W = W; p.Hu = Hu; p.Wu = Wu; p.y0 = y0; p.y1 = y1;
+    p.ratio = (float)(((double)H * (double)W) / ((double)Hu * (double)Wu));
+    p.acts = nullptr; p.npix = 0;
+#ifdef DIINN_STAMPS
+    p.stamps = g_stamps;
+#endif
+    const int small = diinn_uses_small_output_kernel(Hu, Wu);
+    p.ah = make_axis(H, Hu, small);
+    p.aw = make_axis(W, Wu, small);
+    const dim3 grid(gx, gy, gz);
+    if (compute == DIINN_COMPUTE_BF16 || compute == DIINN_COMPUTE_BF16_FULL)
+        return launch_decode_bf16(stream, p, gx, gy, gz, sin_mode);
+    if (compute == DIINN_COMPUTE_F32_QONLY) {
+        if (sin_mode == DIINN_SIN_HW)
+            hipLaunchKernelGGL((decode_kernel<DIINN_SIN_HW, false>), grid, dim3(blk), 0, (hipStream_t)stream, p);
+        else if (sin_mode == DIINN_SIN_HW_REDUCED)
+            hipLaunchKernelGGL((decode_kernel<DIINN_SIN_HW_REDUCED, false>), grid, dim3(blk), 0, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL((decode_kernel<DIINN_SIN_ACCURATE, false>), grid, dim3(blk), 0, (hipStream_t)stream, p);
+        return hip_status(hipGetLastError());
+    }
+    if (sin_mode == DIINN_SIN_HW)
+        hipLaunchKernelGGL(decode_kernel<DIINN_SIN_HW>, grid, dim3(blk), 0, (hipStream_t)stream, p);
+    else if (sin_mode == DIINN_SIN_HW_REDUCED)
+        hipLaunchKernelGGL(decode_kernel<DIINN_SIN_HW_REDUCED>, grid, dim3(blk), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(decode_kernel<DIINN_SIN_ACCURATE>, grid, dim3(blk), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed_dev, float* out_dev,
+                           float* acts_dev, int B, int H, int W, int Hu, int Wu, int sin_mode) {
+    if (!P_dev || !packed_dev || !out_dev || !acts_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (Hu <= 0 || Wu <= 0) return DIINN_ERR_INVALID_ARG;
+    if (sin_mode < DIINN_SIN_ACCURATE || sin_mode > DIINN_SIN_HW_REDUCED) return DIINN_ERR_UNSUPPORTED;
+    if ((double)Hu * Wu >= 2.0e9) return DIINN_ERR_TOO_LARGE;
+    const long long npix = (long long)B * Hu * Wu;
+    st = check_npix(npix);
+    if (st) return st;
+    const dim3 grid((unsigned)((npix + 4 * PLANE_TILE - 1) / (4 * PLANE_TILE)));
+    DecodeParams p;
+    p.P = P_dev; p.Wt = packed_dev; p.out = out_dev;
+    p.B = B; p.H = H; p.W = W; p.Hu = Hu; p.Wu = Wu; p.y0 = 0; p.y1 = Hu;
+    p.ratio = (float)(((double)H * (double)W) / ((double)Hu * (double)Wu));
+    p.acts = acts_dev; p.npix = npix;
+#ifdef DIINN_STAMPS
+    p.stamps = nullptr;
+#endif
+    const int small = diinn_uses_small_output_kernel(Hu, Wu);
+    p.ah = make_axis(H, Hu, small);
+    p.aw = make_axis(W, Wu, small);
+    if (sin_mode == DIINN_SIN_HW)
+        hipLaunchKernelGGL((decode_kernel<DIINN_SIN_HW, true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (sin_mode == DIINN_SIN_HW_REDUCED)
+        hipLaunchKernelGGL((decode_kernel<DIINN_SIN_HW_REDUCED, true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((decode_kernel<DIINN_SIN_ACCURATE, true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+int diinn_decode(void* stream, const float* feat_dev, const float* packed_dev,
+                 float* workspace_dev, float* out_dev,
+                 int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode) {
+    return diinn_decode_ex(stream, feat_dev, packed_dev, workspace_dev, out_dev, B, H, W, Hu, Wu, y0, y1,
+                           sin_mode, DIINN_COMPUTE_F32);
+}
+
+int diinn_decode_ex(void* stream, const float* feat_dev, const float* packed_dev,
+                    float* workspace_dev, float* out_dev,
+                    int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode, int compute) {
+    if (!workspace_dev) return DIINN_ERR_INVALID_ARG;
+
+    int r0, r1;
+    int st = diinn_lr_rows_for_band(H, Hu, Wu, y0, y1, &r0, &r1);
+    if (st) return st;
+    st = diinn_precompute_P_ex(stream, feat_dev, packed_dev, workspace_dev, B, H, W, r0, r1, compute);
+    if (st) return st;
+    if (compute == DIINN_COMPUTE_F32_QONLY) {                   // modes 1 and 2: per-cell modulation chain
+        st = diinn_cell_chain(stream, workspace_dev, packed_dev, B, H, W, r0, r1);
+        if (st) return st;
+    }
+    return diinn_decode_band_ex(stream, workspace_dev, packed_dev, out_dev, B, H, W, Hu, Wu, y0, y1, sin_mode,
+                                compute);
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+// diinn_device.h -- what the gfx950 translation units of libdiinn_hip.so share: vector types, the
+// sine variants, the weight-stream load, tile geometry, the tiled-plane helpers of the training
+// path, and the small host-side helpers of the C ABI launch functions.
+//
+// Translation units (all built with hipcc --offload-arch=gfx950 -O3 -ffp-contract=off):
+//   diinn_decode.hip      decode_kernel (+ modes 1/2 chain, training forward) and the decode entry points
+//   diinn_precompute.hip  precompute_P_kernel, precompute_P_bf16_kernel
+//   diinn_bf16.hip        decode_bf16_kernel, decode_bf16x2_kernel
+//   diinn_training.hip    backward pass: bwd_head/bwd_layer, plane_gemm, plane_rowdot, cell_sum
+//   diinn_baselines.hip   LIIF and MetaSR comparison decoders
+//   diinn_misc.hip        device sine / axis-table test hooks, error state
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/diinn_hip.h"
+#include "diinn_layout.h"
+
+using namespace diinn;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// ---------------------------------------------------------------------------------
+// sine (reference: torch.sin via SineAct, diinn.py:21-26)
+// ---------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ float dsin(float x);
+
+// Cody-Waite reduction to [-pi/2, pi/2] by multiples of pi, odd minimax polynomial.
+// Absolute error <= ~2.5e-7 for |x| <= 1e4 (arguments here are O(1)..O(100)).
+template <>
+__device__ __forceinline__ float dsin<DIINN_SIN_ACCURATE>(float x) {
+    const float k = __builtin_rintf(x * 0.31830988618379067154f);
+    float r = __builtin_fmaf(k, -3.14159274101257324219f, x);      // pi, fp32 head
+    r = __builtin_fmaf(k, 8.74227765734758577309e-08f, r);          // -(pi - head)
+    const float s = r * r;
+    // flip sign for odd k: (-1)^k
+    const int ki = (int)k;
+    r = __builtin_bit_cast(float, __builtin_bit_cast(int, r) ^ (ki << 31));
+    float u = 2.6083159809786593541503e-06f;
+    u = __builtin_fmaf(u, s, -0.0001981069071916863322258f);
+    u = __builtin_fmaf(u, s, 0.00833307858556509017944336f);
+    u = __builtin_fmaf(u, s, -0.166666597127914428710938f);
+    return __builtin_fmaf(s, u * r, r);
+}
+
+// v_sin_f32 takes revolutions; fract keeps it inside the instruction's valid domain.
+// The product x/(2 pi) is rounded to fp32 before the reduction, so the absolute error grows
+// like |x| * 6e-8: fine for O(1)..O(100) arguments, the fastest form (3 VALU ops).
+template <>
+__device__ __forceinline__ float dsin<DIINN_SIN_HW>(float x) {
+    return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.15915494309189533577f));
+}
+
+// Reduction done in revolutions, Cody-Waite style: t = x * c with c = 1/(2 pi) split into an fp32
+// head and tail; r = fma(x, c_hi, -rint(t)) is the exact head product minus an integer, the tail
+// adds the rest.  Then v_sin_f32 on r in [-0.5, 0.5]: 5 VALU ops, error independent of |x|
+// (measured max abs error ~4e-7 for |x| <= 1e4).
+template <>
+__device__ __forceinline__ float dsin<DIINN_SIN_HW_REDUCED>(float x) {
+    constexpr float C_HI = 0.15915494309189533577f;                  // fp32(1/(2 pi)) = 0.159154936671257019...
+    constexpr float C_LO = 6.4206383650924e-09f;                     // 1/(2 pi) - C_HI
+    const float k = __builtin_rintf(x * C_HI);
+    float r = __builtin_fmaf(x, C_HI, -k);
+    r = __builtin_fmaf(x, C_LO, r);
+    return __builtin_amdgcn_sinf(r);
+}
+
+// ---------------------------------------------------------------------------------
+// decode kernel
+// ---------------------------------------------------------------------------------
+struct DecodeParams {
+    const float* P;        // [B,H,W,1024]
+    const float* Wt;       // packed image
+    float* out;            // [B,3,Hu,Wu]
+    int B, H, W, Hu, Wu, y0, y1;
+    float ratio;           // fp32(H*W / (Hu*Wu))   (diinn.py:166)
+    Axis ah, aw;
+    float* acts;           // training forward only (SAVE): saved activations, tiled planes [4 layers][ntiles][512][32]
+    long long npix;        // SAVE: B*Hu*Wu
+#ifdef DIINN_STAMPS
+    unsigned long long* stamps;   // diagnostic build only: 8 x u64 per wave (never in the shipped library)
+#endif
+};
+
+#ifdef DIINN_STAMPS
+// In-kernel stamps (cdna_hip_programming.md section 7): one asm statement, fenced, values go to a
+// buffer nothing else reads.  STAMP(i) records s_memtime; slot 7 records s_memrealtime (100 MHz).
+#define STAMP(i)                                                                              \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (p.stamps && lane == 0) p.stamps[stamp_base + (i)] = t_;                           \
+    } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
+constexpr int TILE_W = 8, TILE_H = 4;           // one wave: 8x4 HR pixels
+// timing-ablation hooks (wrong results when defined; never in the shipped build)
+#ifdef ABL_WSTREAM
+#define ABL_STEP(x) ((x) & 3)
+#else
+#define ABL_STEP(x) (x)
+#endif
+#ifdef ABL_NOSIN
+#define ABL_SIN(x) (x)
+#else
+#define ABL_SIN(x) dsin<SIN_MODE>(x)
+#endif
+#ifndef DECODE_RUN_LAYERS
+#define DECODE_RUN_LAYERS 3                     // < 3 only in timing-ablation builds (wrong results)
+#endif
+#ifndef WSTREAM_AUX
+#define WSTREAM_AUX 0                           // cache-policy bits of the weight-stream loads (sc0=1, nt=2, sc1=16)
+#endif
+#ifndef P_PREFETCH
+#define P_PREFETCH 4
+#endif
+#ifndef DECODE_PREFETCH
+#define DECODE_PREFETCH 4                       // weight ring depth, in steps of 8 MFMAs
+#endif
+
+// relu without the canonicalising v_max that fmaxf(x, 0) emits for an MFMA result
+__device__ __forceinline__ float relu0(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));     // one VALU op (fmaxf adds a canonicalising v_max)
+    return r;
+}
+
+// Weight-stream loads go through a buffer descriptor: address = SGPR descriptor base + SGPR byte
+// offset (scalar unit) + one constant per-lane VGPR offset, so the stream costs no VALU address
+// arithmetic.  That matters here: on gfx950 the fp32 MFMA shares its issue/datapath with the VALU
+// (tools/ubench/mfma_rate.hip: every VALU op between MFMAs costs ~3.2 cycles of MFMA time).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld_piece(__amdgpu_buffer_rsrc_t rsrc, int lane_off, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, WSTREAM_AUX));
+}
+constexpr int PIECE_BYTES = (int)(WL_PIECE * sizeof(float));
+constexpr int WG_TILES_X = 2, WG_TILES_Y = 2;   // 4 waves -> 16x8 HR pixels per workgroup
+
+// KPART = false (decoder modes 1 and 2, diinn.py:116-131): the modulation chain k_i depends on the LR
+// cell only, so the caller leaves k_i[cell] (already rectified) in the workspace slot of P_i and the
+// per-pixel layers run the synthesis GEMM alone: half the MFMAs, half the weight stream.
+//
+// SAVE = true (training forward, reference step() under autograd: diinn.py:132-139 called with
+// bsize=None from sr_module.py:127-129): the same network, and every layer's rectified modulation
+// k_i and sine argument s_i are written to p.acts for the backward pass.  One wave then owns 32
+// consecutive pixels of the flattened (b, y, x) index -- one PLANE TILE.
+//
+// Training planes are stored tiled: a group of C channel rows over npix pixels is
+// [ceil(npix/32) tiles][C rows][32 pixels], element (c, pix) at ((pix >> 5) * C + c) * 32 + (pix & 31).
+// Everything a wave touches for its 32 pixels is one contiguous block (64 KiB for C = 512), every
+// row segment is a full 128-byte line, and the weight-gradient GEMM over the pixel axis reads
+// contiguous [rows][32] panels (with plain [C][npix] planes each of its loads touched 32 rows
+// megabytes apart: 1.6x slower, measured).
+constexpr int PLANE_TILE = 32;
+constexpr int ACT_ROWS = 2 * HID;                               // rows 0..255: k_i (or g_a,i); 256..511: s_i (or g_s,i)
+constexpr unsigned PLANE_ROW_BYTES = PLANE_TILE * sizeof(float);   // 128
+__device__ __forceinline__ void st_act(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, (int)soff, 0);
+}
+// descriptor of one tile (rows x 32 floats) of a tiled plane group
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* group, long long tile, int rows) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(group + (size_t)tile * rows * PLANE_TILE), 0,
+                                             rows * (int)PLANE_ROW_BYTES, 0x00020000);
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// ---------------------------------------------------------------------------------
+// host side of the launch functions
+// ---------------------------------------------------------------------------------
+__attribute__((visibility("hidden"))) extern thread_local int g_last_hip_error;       // diinn_misc.hip
+#ifdef DIINN_STAMPS
+extern unsigned long long* g_stamps;            // diinn_misc.hip
+#endif
+
+static inline int hip_status(hipError_t e) {
+    if (e == hipSuccess) return DIINN_OK;
+    g_last_hip_error = (int)e;
+    return DIINN_ERR_HIP;
+}
+
+static inline int check_dims(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return DIINN_ERR_INVALID_ARG;
+    if ((double)B * H * W * PCH >= 9.0e18 || B > 65535 || H > 65535) return DIINN_ERR_TOO_LARGE;
+    return DIINN_OK;
+}
+
+static inline int check_npix(long long npix) {
+    if (npix <= 0) return DIINN_ERR_INVALID_ARG;
+    if (npix > DIINN_TRAIN_MAX_PIXELS) return DIINN_ERR_TOO_LARGE;
+    return DIINN_OK;
+}
+
+// diinn_precompute.hip: the hoisted conv for mp_total M-tile pairs (16 = all 1024 channels), fp32 or bf16 operands
+__attribute__((visibility("hidden")))
+int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,
+             int B, int H, int W, int r0, int r1, int mp_total, bool bf16 = false);
+// diinn_bf16.hip: the bf16 decode of HR rows [p.y0, p.y1) (grid of the one-tile kernel: gx, gy, gz)
+__attribute__((visibility("hidden")))
+int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int gz, int sin_mode);

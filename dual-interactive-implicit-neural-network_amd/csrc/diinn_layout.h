@@ -1,5 +1,5 @@
 // diinn_layout.h -- packed-weight image layout and the coordinate formulas shared
-// by the host packer (diinn_host.cpp) and the gfx950 kernels (diinn_kernels.hip).
+// by the host packer (diinn_host.cpp) and the gfx950 kernels (diinn_*.hip via diinn_device.h).
 //
 // The decode kernel keeps the 256-channel activation q of 32 HR pixels in the
 // registers of one wave, in the accumulator layout of v_mfma_f32_32x32x2_f32:

@@ -1,0 +1,58 @@
+// diinn_misc.hip -- error state of the launch functions and the device sine / axis-table test hooks
+// (part of libdiinn_hip.so; shared definitions in diinn_device.h, layout in diinn_layout.h)
+#include "diinn_device.h"
+
+// ---------------------------------------------------------------------------------
+// sine kernel (tests): the device sine of each mode, elementwise
+// ---------------------------------------------------------------------------------
+template <int MODE>
+__global__ void sin_kernel(const float* x, float* y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = dsin<MODE>(x[i]);
+}
+
+// ---------------------------------------------------------------------------------
+// tables kernel (tests): the device evaluation of axis_eval
+// ---------------------------------------------------------------------------------
+__global__ void axis_tables_kernel(Axis a, int n_out, int32_t* idx, float* rel) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_out) return;
+    int id;
+    float r;
+    axis_eval(a, j, id, r);
+    if (idx) idx[j] = id;
+    if (rel) rel[j] = r;
+}
+
+thread_local int g_last_hip_error = 0;
+#ifdef DIINN_STAMPS
+unsigned long long* g_stamps = nullptr;
+extern "C" int diinn_debug_set_stamp_buffer(void* dev_ptr) { g_stamps = (unsigned long long*)dev_ptr; return 0; }
+#endif
+
+extern "C" {
+
+int diinn_last_hip_error(void) { return g_last_hip_error; }
+
+int diinn_make_axis_tables_device(void* stream, int n_in, int n_out, int small_output,
+                                  int32_t* idx_dev, float* rel_dev) {
+    if (n_in <= 0 || n_out <= 0) return DIINN_ERR_INVALID_ARG;
+    const Axis a = make_axis(n_in, n_out, small_output ? 1 : 0);
+    hipLaunchKernelGGL(axis_tables_kernel, dim3((n_out + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, a, n_out, idx_dev, rel_dev);
+    return hip_status(hipGetLastError());
+}
+
+int diinn_eval_sin_device(void* stream, int sin_mode, const float* x_dev, float* y_dev, int n) {
+    if (!x_dev || !y_dev || n <= 0) return DIINN_ERR_INVALID_ARG;
+    const dim3 grid((n + 255) / 256), blk(256);
+    switch (sin_mode) {
+        case DIINN_SIN_ACCURATE: hipLaunchKernelGGL(sin_kernel<DIINN_SIN_ACCURATE>, grid, blk, 0, (hipStream_t)stream, x_dev, y_dev, n); break;
+        case DIINN_SIN_HW: hipLaunchKernelGGL(sin_kernel<DIINN_SIN_HW>, grid, blk, 0, (hipStream_t)stream, x_dev, y_dev, n); break;
+        case DIINN_SIN_HW_REDUCED: hipLaunchKernelGGL(sin_kernel<DIINN_SIN_HW_REDUCED>, grid, blk, 0, (hipStream_t)stream, x_dev, y_dev, n); break;
+        default: return DIINN_ERR_UNSUPPORTED;
+    }
+    return hip_status(hipGetLastError());
+}
+
+}  // extern "C"

@@ -1,0 +1,280 @@
+// diinn_precompute.hip -- the hoisted 3x3 convolution P = Wx . unfold3x3(feat) + bK (fp32 and bf16 operands)
+// (part of libdiinn_hip.so; shared definitions in diinn_device.h, layout in diinn_layout.h)
+#include "diinn_device.h"
+
+// ---------------------------------------------------------------------------------
+// P kernel: P[b,y,x, i*256+ch] = sum_{c,ky,kx} Wx_i[ch,c,ky,kx] * feat[b,c,y+ky-1,x+kx-1] + bK_i[ch]
+// (zero padding; diinn.py:168 unfold + the feature columns of K[i], diinn.py:133,136)
+// An implicit-im2col GEMM [cells x 576] . [576 x 1024] on v_mfma_f32_32x32x2_f32.
+// Workgroup = 4 waves = a 4-row x 32-column block of LR cells; its 6 x 34 x 64 feature halo
+// tile is staged once in LDS (zero padded), and each wave (one row of 32 cells) streams the
+// whole packed WP image past it two M-tiles at a time: A operands from the packed image
+// (identical for the 4 waves -> one L1 fill), B operands by ds_read_b32 at an immediate
+// offset per (tap, channel).  Few registers -> 2 workgroups per CU hide each other's waits.
+// ---------------------------------------------------------------------------------
+struct PParams {
+    const float* feat;   // [B,64,H,W]
+    const float* Wt;
+    float* P;            // [B,H,W,1024]
+    int B, H, W, r0, r1;
+    int msplit;          // the M-tile pairs are divided over `msplit` workgroups (blockIdx.z = b*msplit + part)
+    int mp_total;        // M-tile pairs (64 channels each) to compute: 16 = all 1024 channels; LIIF needs the first 4
+};
+
+constexpr int PT_ROWS = 4, PT_COLS = 32;                 // cells per workgroup: 4 x 32
+constexpr int PT_LR = PT_ROWS + 2, PT_LC = PT_COLS + 2;  // with the 3x3 halo: 6 x 34
+constexpr int PT_CH = PT_LR * PT_LC;                     // 204 floats per channel
+constexpr int PT_LDS_FLOATS = C_IN * PT_CH;              // 13,056 floats = 52,224 B
+
+__global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
+    __shared__ __attribute__((aligned(16))) float tile[PT_LDS_FLOATS];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int b = blockIdx.z / p.msplit;
+    const int part = blockIdx.z - b * p.msplit;
+    const int mp_count = p.mp_total / p.msplit, mp_begin = part * mp_count;
+    const int x0 = blockIdx.x * PT_COLS;
+    const int y0 = p.r0 + blockIdx.y * PT_ROWS;
+
+    // stage feat[b, :, y0-1 .. y0+4, x0-1 .. x0+32] (zeros outside the map)
+    const float* __restrict__ fb = p.feat + (size_t)b * C_IN * p.H * p.W;
+    static_assert(PT_LDS_FLOATS % 256 == 0, "staging loop has a fixed trip count");
+    // fixed trip count, unrolled in batches so that many loads are in flight (a rolled loop would pay
+    // one memory latency per element)
+#pragma unroll 17
+    for (int it = 0; it < PT_LDS_FLOATS / 256; ++it) {
+        const int idx = it * 256 + threadIdx.x;
+        const int c = idx / PT_CH;
+        const int rem = idx - c * PT_CH;
+        const int ly = rem / PT_LC, lx = rem - ly * PT_LC;
+        const int yy = y0 + ly - 1, xx = x0 + lx - 1;
+        const bool ok = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
+        // unconditional load from a clamped address, then select: a load under `ok ? .. : 0` compiles
+        // to a branch and a vmcnt(0) per element (51 serial memory round trips per workgroup)
+        const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+        const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
+        const float v = fb[((size_t)c * p.H + yc) * p.W + xc];
+        tile[idx] = ok ? v : 0.0f;
+    }
+    __syncthreads();
+
+    const int x = x0 + j, y = y0 + wave;
+    const bool store = (x < p.W) && (y < p.r1);
+    // a wave whose row is past the band still runs (cheap at the band edge) -- no barrier follows,
+    // so it may simply leave.
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(store) == 0ull))) return;
+
+    // B operand of k-step kk = 32*t + cp (tap t = ky*3+kx, channel 2*cp + h):
+    //   tile[(2cp + h) * PT_CH + (wave + ky) * PT_LC + j + kx]
+    const int tb_off = h * PT_CH + wave * PT_LC + j;
+
+    constexpr int PF = P_PREFETCH;
+    static_assert(WP_KG % PF == 0, "ring index must be static");
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);   // reads past the end return 0
+    const int lane_off = lane * 16;
+    int wp = (int)(OFF_WP * sizeof(float)) + mp_begin * (WP_KG * 2 * PIECE_BYTES);   // advances one M-tile pair per iteration
+    const float* __restrict__ Bk = p.Wt + OFF_BK + 4 * h;
+    float* __restrict__ Pout = p.P + (((size_t)b * p.H + (y < p.H ? y : p.H - 1)) * p.W + (x < p.W ? x : p.W - 1)) * PCH + 4 * h;
+    f32x4 r0v[PF], r1v[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        r0v[d] = ld_piece(wrs, lane_off, wp + (2 * d + 0) * PIECE_BYTES);
+        r1v[d] = ld_piece(wrs, lane_off, wp + (2 * d + 1) * PIECE_BYTES);
+    }
+#pragma unroll 1
+    for (int mp = mp_begin; mp < mp_begin + mp_count; ++mp) {
+        // the B operands do not depend on mp: hide the base from LICM, or all 288 LDS reads are
+        // hoisted out of this loop and live (spilled) across it
+        int off = tb_off;
+        asm volatile("" : "+v"(off));
+        const float* tbm = tile + off;          // still an LDS (ds_read) address
+        f32x16 a0, a1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 s0 = *(const f32x4*)(Bk + 64 * mp + 8 * g);
+            const f32x4 s1 = *(const f32x4*)(Bk + 64 * mp + 32 + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a0[4 * g + e] = s0[e];
+                a1[4 * g + e] = s1[e];
+            }
+        }
+#pragma unroll
+        for (int kg = 0; kg < WP_KG; ++kg) {
+            const f32x4 u0 = r0v[kg % PF], u1 = r1v[kg % PF];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = 4 * kg + e;
+                const int t = kk >> 5, cp = kk & 31;
+                const float bv = tbm[(2 * cp) * PT_CH + (t / 3) * PT_LC + (t % 3)];
+                a0 = MFMA32(u0[e], bv, a0);
+                a1 = MFMA32(u1[e], bv, a1);
+            }
+            r0v[kg % PF] = ld_piece(wrs, lane_off, wp + (2 * (kg + PF) + 0) * PIECE_BYTES);
+            r1v[kg % PF] = ld_piece(wrs, lane_off, wp + (2 * (kg + PF) + 1) * PIECE_BYTES);
+        }
+        if (store) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v0, v1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v0[e] = a0[4 * g + e];
+                    v1[e] = a1[4 * g + e];
+                }
+                *(f32x4*)(Pout + 64 * mp + 8 * g) = v0;
+                *(f32x4*)(Pout + 64 * mp + 32 + 8 * g) = v1;
+            }
+        }
+        wp += WP_KG * 2 * PIECE_BYTES;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// precompute_P_bf16_kernel (DIINN_COMPUTE_BF16_FULL): the hoisted 3x3 conv on v_mfma_f32_32x32x16_bf16.
+// Same tiling as precompute_P_kernel (4 x 32 cells per workgroup, a wave per cell row, two M-tiles
+// advancing together), with the feature halo tile converted to bf16 while it is staged and laid out
+// channel-innermost in LDS: [6 x 34 pixels][64 channels + 8 pad] -> the B fragment of a k-step (16
+// channels of one tap, 8 per lane-half) is one ds_read_b128, and the 144-byte pixel pitch spreads the
+// 32 lanes of a row over all banks.  Accumulation, bias seeds and the stored P stay fp32.
+// Bound: the bf16 weight stream through L1 (1 KiB per MFMA per wave) and the 4 KiB/cell store of P.
+// ---------------------------------------------------------------------------------
+constexpr int PB_PITCH = C_IN + 8;                        // bf16 elements per staged pixel (144 bytes)
+constexpr int PB_LDS = PT_CH * PB_PITCH;                  // 14,688 bf16 = 29,376 B
+constexpr int PB_ITEMS = PT_CH * (C_IN / 2);              // staged as channel pairs: 6,528 32-bit items
+
+__global__ __launch_bounds__(256, 2) void precompute_P_bf16_kernel(const PParams p) {
+    __shared__ __attribute__((aligned(16))) __bf16 tile[PB_LDS];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int b = blockIdx.z / p.msplit;
+    const int part = blockIdx.z - b * p.msplit;
+    const int mp_count = p.mp_total / p.msplit, mp_begin = part * mp_count;
+    const int x0 = blockIdx.x * PT_COLS;
+    const int y0 = p.r0 + blockIdx.y * PT_ROWS;
+
+    const float* __restrict__ fb = p.feat + (size_t)b * C_IN * p.H * p.W;
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll 13
+    for (int it = 0; it < (PB_ITEMS + 255) / 256; ++it) {
+        const int idx = it * 256 + threadIdx.x;                   // (channel pair, pixel), pixel fastest
+        const int cp = idx / PT_CH;
+        const int pix = idx - cp * PT_CH;
+        const int ly = pix / PT_LC, lx = pix - ly * PT_LC;
+        const int yy = y0 + ly - 1, xx = x0 + lx - 1;
+        const bool ok = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W) && (idx < PB_ITEMS);
+        const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+        const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
+        const int cc = cp < C_IN / 2 ? cp : C_IN / 2 - 1;         // last iteration runs past the item count
+        const float v0 = fb[((size_t)(2 * cc) * p.H + yc) * p.W + xc];
+        const float v1 = fb[((size_t)(2 * cc + 1) * p.H + yc) * p.W + xc];
+        bf16x2 pk;
+        pk[0] = (__bf16)(ok ? v0 : 0.0f);
+        pk[1] = (__bf16)(ok ? v1 : 0.0f);
+        if (idx < PB_ITEMS) *(bf16x2*)(tile + pix * PB_PITCH + 2 * cp) = pk;
+    }
+    __syncthreads();
+
+    const int x = x0 + j, y = y0 + wave;
+    const bool store = (x < p.W) && (y < p.r1);
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(store) == 0ull))) return;
+
+    // B fragment of k-step ks = 4*tap + cg: tile[((wave + ky) * 34 + j + kx) * 72 + 16cg + 8h .. +7]
+    const int tb_off = (wave * PT_LC + j) * PB_PITCH + 8 * h;
+
+    constexpr int PF = P_PREFETCH;
+    static_assert(WPB_KS % PF == 0, "ring index must be static");
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);   // reads past the end return 0
+    const int lane_off = lane * 16;
+    int wp = (int)(OFF_WPB * sizeof(float)) + mp_begin * (WPB_KS * 2 * PIECE_BYTES);
+    const float* __restrict__ Bk = p.Wt + OFF_BK + 4 * h;
+    float* __restrict__ Pout = p.P + (((size_t)b * p.H + (y < p.H ? y : p.H - 1)) * p.W + (x < p.W ? x : p.W - 1)) * PCH + 4 * h;
+    f32x4 r0v[PF], r1v[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        r0v[d] = ld_piece(wrs, lane_off, wp + (2 * d + 0) * PIECE_BYTES);
+        r1v[d] = ld_piece(wrs, lane_off, wp + (2 * d + 1) * PIECE_BYTES);
+    }
+#pragma unroll 1
+    for (int mp = mp_begin; mp < mp_begin + mp_count; ++mp) {
+        int off = tb_off;                                         // hide the base from LICM (see precompute_P_kernel)
+        asm volatile("" : "+v"(off));
+        const __bf16* tbm = tile + off;
+        f32x16 a0, a1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 s0 = *(const f32x4*)(Bk + 64 * mp + 8 * g);
+            const f32x4 s1 = *(const f32x4*)(Bk + 64 * mp + 32 + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a0[4 * g + e] = s0[e];
+                a1[4 * g + e] = s1[e];
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < WPB_KS; ++ks) {
+            const int t = ks >> 2, cg = ks & 3;
+            const bf16x8 bv = *(const bf16x8*)(tbm + ((t / 3) * PT_LC + (t % 3)) * PB_PITCH + 16 * cg);
+            a0 = MFMA_BF16(__builtin_bit_cast(bf16x8, r0v[ks % PF]), bv, a0);
+            a1 = MFMA_BF16(__builtin_bit_cast(bf16x8, r1v[ks % PF]), bv, a1);
+            r0v[ks % PF] = ld_piece(wrs, lane_off, wp + (2 * (ks + PF) + 0) * PIECE_BYTES);
+            r1v[ks % PF] = ld_piece(wrs, lane_off, wp + (2 * (ks + PF) + 1) * PIECE_BYTES);
+        }
+        if (store) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v0, v1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v0[e] = a0[4 * g + e];
+                    v1[e] = a1[4 * g + e];
+                }
+                *(f32x4*)(Pout + 64 * mp + 8 * g) = v0;
+                *(f32x4*)(Pout + 64 * mp + 32 + 8 * g) = v1;
+            }
+        }
+        wp += WPB_KS * 2 * PIECE_BYTES;
+    }
+}
+
+int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,
+                    int B, int H, int W, int r0, int r1, int mp_total, bool bf16) {
+    if (!feat_dev || !packed_dev || !P_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (r0 < 0 || r1 > H || r0 >= r1) return DIINN_ERR_INVALID_ARG;
+    // Small maps: split the 1024 output channels over up to 16 workgroups per cell block so the
+    // launch still fills the chip (2 workgroups/CU resident -> aim for >= 2 rounds of 512).
+    const long long blocks = (long long)((W + PT_COLS - 1) / PT_COLS) * ((r1 - r0 + PT_ROWS - 1) / PT_ROWS) * B;
+    int msplit = 1;
+    while (msplit < mp_total && blocks * msplit < 1024) msplit *= 2;
+    if ((long long)B * msplit > 65535) return DIINN_ERR_TOO_LARGE;
+    PParams p{feat_dev, packed_dev, P_dev, B, H, W, r0, r1, msplit, mp_total};
+    const dim3 grid((W + PT_COLS - 1) / PT_COLS, (r1 - r0 + PT_ROWS - 1) / PT_ROWS, B * msplit);
+    if (bf16)
+        hipLaunchKernelGGL(precompute_P_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(precompute_P_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+extern "C" {
+
+int diinn_precompute_P(void* stream, const float* feat_dev, const float* packed_dev,
+                       float* P_dev, int B, int H, int W, int r0, int r1) {
+    return launch_P(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, 16);
+}
+
+int diinn_precompute_P_ex(void* stream, const float* feat_dev, const float* packed_dev,
+                          float* P_dev, int B, int H, int W, int r0, int r1, int compute) {
+    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY &&
+        compute != DIINN_COMPUTE_BF16_FULL)
+        return DIINN_ERR_UNSUPPORTED;
+    return launch_P(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, 16, compute == DIINN_COMPUTE_BF16_FULL);
+}
+
+}  // extern "C"

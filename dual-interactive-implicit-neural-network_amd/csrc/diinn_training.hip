@@ -1,0 +1,478 @@
+// diinn_training.hip -- backward pass of the decoder (training): per-pixel chain, weight-gradient GEMMs, per-cell sums
+// (part of libdiinn_hip.so; shared definitions in diinn_device.h, layout in diinn_layout.h)
+#include "diinn_device.h"
+
+// ---------------------------------------------------------------------------------
+// backward pass of the per-pixel layers (training; reference: autograd through step(), diinn.py:132-139)
+//
+// With q_i = k_i * sin(s_i) and the planes k_i, s_i saved by decode_kernel<SAVE>:
+//     g_a,i = g_q,i * sin(s_i) * [k_i > 0]      (gradient at the modulation pre-activation)
+//     g_s,i = g_q,i * k_i * cos(s_i)            (gradient at the sine argument)
+//     g_q,i-1 = Wq_i^T g_a,i + Qw_i^T g_s,i     (stacked [256 x 512] GEMM per pixel)
+// bwd_head_kernel  : g_q,3 = L^T g_out, gates of layer 3 (elementwise, HBM-bound).
+// bwd_layer_kernel : one launch per layer i = 3, 2, 1.  A wave owns one plane tile (32 pixels), loads
+//                    their 512 gate gradients G_i = (g_a,i ; g_s,i) into registers as the MFMA B operand
+//                    (the rows are read in accumulator order, so no shuffle is needed), streams the
+//                    transposed weights (WLT section) exactly like the forward kernel streams WL, and
+//                    its epilogue applies the gates of layer i-1 and writes G_{i-1} and q_{i-1}.
+// plane_gemm_kernel / plane_rowdot_kernel : the parameter gradients, GEMMs over the pixel axis of the
+//                    planes written here (dW_i = G_i q_{i-1}^T ...).
+// All planes are tiled (see PLANE_TILE above): acts, G [4][ntiles][512][32]; Q [4][ntiles][256][32].
+// ---------------------------------------------------------------------------------
+struct BwdParams {
+    const float* Wt;         // packed image
+    const float* acts;       // k_i (rows 0..255), s_i (rows 256..511)
+    const float* gout;       // [3][npix] plain planes: d loss / d out
+    float* G;                // g_a,i (rows 0..255), g_s,i (rows 256..511)
+    float* Q;                // q_i
+    long long npix, ntiles;
+    int layer;               // bwd_layer_kernel: consumes G_layer, produces G_{layer-1}, Q_{layer-1}
+};
+
+__device__ __forceinline__ void dsincos(float x, float& sn, float& cs) {
+    constexpr float C_HI = 0.15915494309189533577f;
+    constexpr float C_LO = 6.4206383650924e-09f;
+    const float k = __builtin_rintf(x * C_HI);
+    float r = __builtin_fmaf(x, C_HI, -k);
+    r = __builtin_fmaf(x, C_LO, r);
+    sn = __builtin_amdgcn_sinf(r);
+    cs = __builtin_amdgcn_cosf(r);
+}
+
+__device__ __forceinline__ float ld_act(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
+}
+
+__global__ __launch_bounds__(256) void bwd_head_kernel(const BwdParams p) {
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= p.npix) return;
+    const size_t np = (size_t)p.npix;
+    const float g0 = p.gout[pix], g1 = p.gout[np + pix], g2 = p.gout[2 * np + pix];
+    const float* __restrict__ L = p.Wt + OFF_L;
+    const size_t tile = (size_t)(pix >> 5), lane = (size_t)(pix & 31);
+    const size_t a0 = ((size_t)3 * p.ntiles + tile) * ACT_ROWS * PLANE_TILE + lane;   // layer 3 tile, row 0
+    const size_t q0 = ((size_t)3 * p.ntiles + tile) * HID * PLANE_TILE + lane;
+    const int c0 = blockIdx.y * 16;
+#pragma unroll 4
+    for (int c = c0; c < c0 + 16; ++c) {
+        float g = L[c] * g0;
+        g = __builtin_fmaf(L[HID + c], g1, g);
+        g = __builtin_fmaf(L[2 * HID + c], g2, g);
+        const float kv = p.acts[a0 + (size_t)c * PLANE_TILE];
+        const float sv = p.acts[a0 + (size_t)(HID + c) * PLANE_TILE];
+        float sn, cs;
+        dsincos(sv, sn, cs);
+        p.G[a0 + (size_t)c * PLANE_TILE] = kv > 0.0f ? g * sn : 0.0f;
+        p.G[a0 + (size_t)(HID + c) * PLANE_TILE] = g * kv * cs;
+        p.Q[q0 + (size_t)c * PLANE_TILE] = kv * sn;
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const long long tile = (long long)blockIdx.x * 4 + wave;
+    if (tile >= p.ntiles) return;                                // wave-uniform
+    const bool valid = tile * PLANE_TILE + j < p.npix;
+
+    const int li = p.layer;                                     // 1..3
+    const size_t agroup = (size_t)p.ntiles * ACT_ROWS * PLANE_TILE;     // floats per layer of acts / G
+    const size_t qgroup = (size_t)p.ntiles * HID * PLANE_TILE;
+    // lanes past the end: offset outside the descriptor, loads return 0 and stores are dropped
+    const unsigned voff = valid ? 4u * j + 4u * h * PLANE_ROW_BYTES : 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t inG = tile_rsrc(p.G + (size_t)li * agroup, tile, ACT_ROWS);
+    const __amdgpu_buffer_rsrc_t act = tile_rsrc(p.acts + (size_t)(li - 1) * agroup, tile, ACT_ROWS);
+    const __amdgpu_buffer_rsrc_t outG = tile_rsrc(p.G + (size_t)(li - 1) * agroup, tile, ACT_ROWS);
+    const __amdgpu_buffer_rsrc_t outQ = tile_rsrc(p.Q + (size_t)(li - 1) * qgroup, tile, HID);
+
+    // B operand: register kk = 16m + r of lane-half h holds channel chan_of(kk, h) of this lane's pixel.
+    // Only the first BLD k-groups are fetched up front; the rest stream in BLD groups ahead of the
+    // MFMAs of the first output tile (which walks all 32 k-groups), so the 64 KiB a wave reads
+    // hide behind its own arithmetic instead of in front of it.
+    constexpr int BLD = 8;
+    float ga[128], gs[128];
+    auto load_group = [&](int kg) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int kk = 4 * kg + e;
+            const unsigned so = (unsigned)(32 * (kk >> 4) + (kk & 3) + 8 * ((kk & 15) >> 2)) * PLANE_ROW_BYTES;
+            ga[kk] = ld_act(inG, voff, so);
+            gs[kk] = ld_act(inG, voff, so + HID * PLANE_ROW_BYTES);
+        }
+    };
+#pragma unroll
+    for (int kg = 0; kg < BLD; ++kg) load_group(kg);
+
+    constexpr int PF = DECODE_PREFETCH;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);   // reads past the end return 0
+    const int lane_off = lane * 16;
+    const int wp = (int)((OFF_WLT + (size_t)(li - 1) * WL_LAYER) * sizeof(float));
+    f32x4 rk[PF], rq[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        rk[d] = ld_piece(wrs, lane_off, wp + (2 * d + 0) * PIECE_BYTES);
+        rq[d] = ld_piece(wrs, lane_off, wp + (2 * d + 1) * PIECE_BYTES);
+    }
+
+    // gates of layer li-1 for one finished element: g = d loss / d q_{li-1}[channel, pixel]
+    auto gate_store = [&](int mt, int r, float g, float kv, float sv) {
+        const unsigned so = (unsigned)(32 * mt + (r & 3) + 8 * (r >> 2)) * PLANE_ROW_BYTES;
+        float sn, cs;
+        dsincos(sv, sn, cs);
+        st_act(outG, voff, so, kv > 0.0f ? g * sn : 0.0f);
+        st_act(outG, voff, so + HID * PLANE_ROW_BYTES, g * kv * cs);
+        st_act(outQ, voff, so, kv * sn);
+    };
+
+    f32x16 pg;                                                   // finished g_q tile (sum of the two accumulators)
+    float kt[16], st[16];                                        // saved k, s of the tile being finished
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x16 ak, as;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ak[r] = 0.0f; as[r] = 0.0f; }
+#pragma unroll
+        for (int kg = 0; kg < WL_KG; ++kg) {
+            const int s = m * WL_KG + kg;
+            const f32x4 wk = rk[s % PF];
+            const f32x4 wq = rq[s % PF];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ak = MFMA32(wk[e], ga[4 * kg + e], ak);
+                as = MFMA32(wq[e], gs[4 * kg + e], as);
+            }
+            rk[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF) + 0) * PIECE_BYTES);
+            rq[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF) + 1) * PIECE_BYTES);
+            if (m == 0 && kg + BLD < WL_KG) load_group(kg + BLD); // rest of the B operand, BLD groups ahead
+            if (m > 0 && kg == 0) {                               // saved planes of tile m-1, used from kg = 8 on
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned so = (unsigned)(32 * (m - 1) + (r & 3) + 8 * (r >> 2)) * PLANE_ROW_BYTES;
+                    kt[r] = ld_act(act, voff, so);
+                    st[r] = ld_act(act, voff, so + HID * PLANE_ROW_BYTES);
+                }
+            }
+            if (m > 0 && kg >= 8 && kg < 24) {                    // one epilogue element of tile m-1 every 8 MFMAs
+                const int r = kg - 8;
+                gate_store(m - 1, r, pg[r], kt[r], st[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pg[r] = ak[r] + as[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned so = (unsigned)(32 * 7 + (r & 3) + 8 * (r >> 2)) * PLANE_ROW_BYTES;
+        kt[r] = ld_act(act, voff, so);
+        st[r] = ld_act(act, voff, so + HID * PLANE_ROW_BYTES);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gate_store(7, r, pg[r], kt[r], st[r]);
+}
+
+// ---------------------------------------------------------------------------------
+// cell_sum_kernel (training backward): dP_i[b, ch, cy, cx] = sum of g_a,i over the HR pixels whose
+// nearest LR cell is (cy, cx) -- the adjoint of the nearest-exact replication (diinn.py:168).  The
+// index tables are monotone, so a cell's pixels are the rectangle [seg_h[cy], seg_h[cy+1]) x
+// [seg_w[cx], seg_w[cx+1]).  One thread per output element, cx fastest: neighbouring lanes read
+// neighbouring column segments of the same HR rows.  Fixed summation order (no atomics).  Output is
+// NCHW [B][1024][H][W], channel = 256 i + ch: the layout the 3x3 convolution's weight/input
+// gradients are taken in.  HBM-bound (reads the g_a rows of G once).
+// ---------------------------------------------------------------------------------
+struct CellSumParams {
+    const float* G;          // tiled [4][ntiles][512][32]; rows 0..255 (g_a) are summed
+    float* dP;               // [B][1024][H][W]
+    const int* seg_h;        // [H+1] first HR row of every LR row (seg_h[H] = Hu)
+    const int* seg_w;        // [W+1]
+    int B, H, W, Hu, Wu;
+    long long ntiles;
+};
+
+__global__ __launch_bounds__(256) void cell_sum_kernel(const CellSumParams p) {
+    const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int hb = (p.H + 3) / 4;
+    const int b = blockIdx.y / hb;
+    const int cy = (blockIdx.y - b * hb) * 4 + (threadIdx.x >> 6);
+    if (cx >= p.W || cy >= p.H) return;
+    const int plane = blockIdx.z;                                    // 256 i + ch
+    const float* __restrict__ src = p.G + ((size_t)(plane >> 8) * p.ntiles * ACT_ROWS + (plane & 255)) * PLANE_TILE;
+    const int y0 = p.seg_h[cy], y1 = p.seg_h[cy + 1];
+    const int x0 = p.seg_w[cx], x1 = p.seg_w[cx + 1];
+    float acc = 0.0f;
+    for (int y = y0; y < y1; ++y) {
+        const long long rowpix = ((long long)b * p.Hu + y) * p.Wu;
+        float r = 0.0f;
+        for (int x = x0; x < x1; ++x) {
+            const long long pix = rowpix + x;
+            r += src[(size_t)(pix >> 5) * (ACT_ROWS * PLANE_TILE) + (size_t)(pix & 31)];
+        }
+        acc += r;
+    }
+    p.dP[(((size_t)b * PCH + plane) * p.H + cy) * p.W + cx] = acc;
+}
+
+// ---------------------------------------------------------------------------------
+// plane_gemm_kernel (training backward, weight gradients): C[M x Nc] = A[M x npix] . B[Nc x npix]^T, A and B
+// being rows [a_row0, a_row0+M) / [b_row0, b_row0+Nc) of tiled plane groups, i.e. a GEMM whose reduction
+// axis is the pixel axis.  Split-K: workgroup (block, ks) reduces the plane tiles of chunk ks for a
+// 128 x 256 output block and writes its partial product to part[ks]; the caller adds the ksplit
+// partials (fixed order, no atomics).  4 waves = 2 (M) x 2 (N), wave tile 64 x 128 = 2 x 4 MFMA tiles
+// (128 accumulator registers).  Operand fragments go global -> registers directly: with tiled planes a
+// 32-row x 32-pixel MFMA panel is one contiguous 4 KiB block; lane (row = l&31, half = l>>5) reads
+// 16 bytes of its row per load, four loads cover the row's whole 128-byte line.  The MFMA k-pair
+// (pixel e, pixel 4+e) is the same for A and B, and the sum over pixels does not care about the order.
+// Optional extra column Nc: row sums of A (bias gradients).
+// ---------------------------------------------------------------------------------
+struct PlaneGemmParams {
+    const float* A;          // tiled group, a_rows rows per tile; rows [a_row0, a_row0 + M) are used
+    const float* Bm;         // tiled group, b_rows rows per tile; rows [b_row0, b_row0 + Nc)
+    float* part;             // [ksplit][M][ldc]
+    long long npix;
+    int a_rows, a_row0, b_rows, b_row0;
+    int M, Nc, ldc, tiles_per_split, with_rowsum;
+};
+
+template <int NB>
+__global__ __launch_bounds__(256, 1) void plane_gemm_kernel(const PlaneGemmParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    constexpr int WGN = 2 * NB * 32;                          // output columns per workgroup
+    const int nblk = p.Nc / WGN;
+    const int m0 = (blockIdx.x / nblk) * 128 + (wave & 1) * 64;
+    const int n0 = (blockIdx.x % nblk) * WGN + (wave >> 1) * (NB * 32);
+    const int ks = blockIdx.y;
+    const long long ntiles = (p.npix + PLANE_TILE - 1) / PLANE_TILE;
+    const long long t0 = (long long)ks * p.tiles_per_split;
+    long long t1 = t0 + p.tiles_per_split;
+    if (t1 > ntiles) t1 = ntiles;
+    const int nt = t1 > t0 ? (int)(t1 - t0) : 0;                 // tiles this workgroup reduces
+
+    // descriptors start at this split's first tile (offsets inside a split stay far below 4 GiB)
+    const unsigned a_pitch = (unsigned)p.a_rows * PLANE_ROW_BYTES, b_pitch = (unsigned)p.b_rows * PLANE_ROW_BYTES;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.A + ((size_t)t0 * p.a_rows + p.a_row0 + m0) * PLANE_TILE), 0, (int)(nt * a_pitch), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.Bm + ((size_t)t0 * p.b_rows + p.b_row0 + n0) * PLANE_TILE), 0, (int)(nt * b_pitch), 0x00020000);
+    const unsigned voff = (unsigned)j * PLANE_ROW_BYTES + 16u * h;
+    constexpr unsigned MFMA_ROWS = 32u * PLANE_ROW_BYTES;        // one 32-row MFMA panel: 4 KiB
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float rs[2] = {0.0f, 0.0f};
+
+    f32x4 fa[2][2][4], fb[2][NB][4];                              // [buffer][panel][t]: 4 pixels each
+    auto load = [&](int buf, int t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                fa[buf][a][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    ra, (int)voff, (int)(t * a_pitch + a * MFMA_ROWS + 32u * q), 0));
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                fb[buf][b][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rb, (int)voff, (int)(t * b_pitch + b * MFMA_ROWS + 32u * q), 0));
+        }
+    };
+    auto compute = [&](int buf, int t) {
+        const long long pix0 = (t0 + t) * PLANE_TILE;
+        if (pix0 + PLANE_TILE > p.npix) {                        // ragged last tile: its padding was never written
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = pix0 + 8 * q + 4 * h + e < p.npix;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) fa[buf][a][q][e] = in ? fa[buf][a][q][e] : 0.0f;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) fb[buf][b][q][e] = in ? fb[buf][b][q][e] : 0.0f;
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) acc[a][b] = MFMA32(fa[buf][a][q][e], fb[buf][b][q][e], acc[a][b]);
+                    rs[a] += fa[buf][a][q][e];
+                }
+            }
+    };
+
+    if (nt > 0) {
+        load(0, 0);
+        for (int t = 0; t < nt; t += 2) {
+            if (t + 1 < nt) load(1, t + 1);
+            compute(0, t);
+            if (t + 1 < nt) {
+                if (t + 2 < nt) load(0, t + 2);
+                compute(1, t + 1);
+            }
+        }
+    }
+
+    float* __restrict__ dst = p.part + (size_t)ks * p.M * p.ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                dst[(size_t)row * p.ldc + n0 + 32 * b + j] = acc[a][b][r];
+            }
+    if (p.with_rowsum && n0 == 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float v = rs[a] + __shfl_xor(rs[a], 32);
+            if (h == 0) dst[(size_t)(m0 + 32 * a + j) * p.ldc + p.Nc] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// plane_rowdot_kernel (training backward, the two skinny products): C[M x 4] = A[M x npix] . S[4 x npix]^T
+// with A rows of a tiled group (M = 256 or 512) and S a tiled 4-row group.  Used for
+//   layer 0: (g_a,0 ; g_s,0) . (rel_h, rel_w, ratio, 1)^T  -> dbK_0, dQ0, dbQ0          (diinn.py:133-134,165-167)
+//   head   : q_3 . (g_out0, g_out1, g_out2, 0)^T            -> d last_layer.weight      (diinn.py:138)
+// HBM-bound (reads A once); split over the tiles like plane_gemm_kernel, partials added by the caller.
+// ---------------------------------------------------------------------------------
+struct RowDotParams {
+    const float* A;          // tiled, a_rows per tile, rows [0, M)
+    const float* S;          // tiled [ntiles][4][32]
+    float* part;             // [splits][M][4]
+    long long npix;
+    int a_rows, M, tiles_per_split;
+};
+
+__global__ __launch_bounds__(256) void plane_rowdot_kernel(const RowDotParams p) {
+    const long long ntiles = (p.npix + PLANE_TILE - 1) / PLANE_TILE;
+    const long long t0 = (long long)blockIdx.x * p.tiles_per_split;
+    long long t1 = t0 + p.tiles_per_split;
+    if (t1 > ntiles) t1 = ntiles;
+    for (int row = threadIdx.x; row < p.M; row += 256) {
+        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+        for (long long t = t0; t < t1; ++t) {
+            const f32x4* __restrict__ a = (const f32x4*)(p.A + ((size_t)t * p.a_rows + row) * PLANE_TILE);
+            const f32x4* __restrict__ s = (const f32x4*)(p.S + (size_t)t * 4 * PLANE_TILE);
+            const int left = (int)(p.npix - t * PLANE_TILE < PLANE_TILE ? p.npix - t * PLANE_TILE : PLANE_TILE);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                f32x4 av = a[q];
+                if (left < PLANE_TILE) {                          // ragged last tile: padding was never written
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[e] = 4 * q + e < left ? av[e] : 0.0f;
+                }
+                const f32x4 s0 = s[q], s1 = s[8 + q], s2 = s[16 + q], s3 = s[24 + q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    c0 = __builtin_fmaf(av[e], s0[e], c0);
+                    c1 = __builtin_fmaf(av[e], s1[e], c1);
+                    c2 = __builtin_fmaf(av[e], s2[e], c2);
+                    c3 = __builtin_fmaf(av[e], s3[e], c3);
+                }
+            }
+        }
+        float* __restrict__ dst = p.part + ((size_t)blockIdx.x * p.M + row) * 4;
+        dst[0] = c0; dst[1] = c1; dst[2] = c2; dst[3] = c3;
+    }
+}
+
+extern "C" {
+
+long long diinn_training_plane_floats(long long npix, int rows) {
+    if (npix <= 0 || rows <= 0 || npix > DIINN_TRAIN_MAX_PIXELS) return -1;
+    return (npix + PLANE_TILE - 1) / PLANE_TILE * rows * PLANE_TILE;
+}
+
+int diinn_backward_data(void* stream, const float* gout_planes_dev, const float* acts_dev,
+                        const float* packed_dev, float* G_dev, float* Q_dev, long long npix) {
+    if (!gout_planes_dev || !acts_dev || !packed_dev || !G_dev || !Q_dev) return DIINN_ERR_INVALID_ARG;
+    const int stp = check_npix(npix);
+    if (stp) return stp;
+    BwdParams p;
+    p.Wt = packed_dev; p.acts = acts_dev; p.gout = gout_planes_dev; p.G = G_dev; p.Q = Q_dev;
+    p.npix = npix; p.ntiles = (npix + PLANE_TILE - 1) / PLANE_TILE; p.layer = 0;
+    hipLaunchKernelGGL(bwd_head_kernel, dim3((unsigned)((npix + 255) / 256), HID / 16), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_status(e);
+    const unsigned blocks = (unsigned)((p.ntiles + 3) / 4);
+    for (int layer = 3; layer >= 1; --layer) {
+        p.layer = layer;
+        hipLaunchKernelGGL(bwd_layer_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_status(e);
+    }
+    return DIINN_OK;
+}
+
+int diinn_plane_gemm_nt(void* stream, const float* A_dev, int a_rows, int a_row0, const float* B_dev, int b_rows,
+                        int b_row0, float* part_dev, int M, int Nc, long long npix, int ksplit, int with_rowsum) {
+    if (!A_dev || !B_dev || !part_dev || M <= 0 || Nc <= 0 || ksplit <= 0 || a_row0 < 0 || b_row0 < 0 ||
+        a_row0 + M > a_rows || b_row0 + Nc > b_rows)
+        return DIINN_ERR_INVALID_ARG;
+    const int stp = check_npix(npix);
+    if (stp) return stp;
+    if (M % 128 || Nc % 128) return DIINN_ERR_UNSUPPORTED;
+    if (ksplit > 65535) return DIINN_ERR_TOO_LARGE;
+    PlaneGemmParams p;
+    p.A = A_dev; p.Bm = B_dev; p.part = part_dev; p.npix = npix;
+    p.a_rows = a_rows; p.a_row0 = a_row0; p.b_rows = b_rows; p.b_row0 = b_row0;
+    p.M = M; p.Nc = Nc;
+    p.ldc = Nc + (with_rowsum ? 1 : 0);
+    p.with_rowsum = with_rowsum ? 1 : 0;
+    const long long ntiles = (npix + PLANE_TILE - 1) / PLANE_TILE;
+    const long long per = (ntiles + ksplit - 1) / ksplit;
+    // offsets inside one split are 32-bit: tiles_per_split * rows * 128 bytes must stay below 2 GiB
+    if (per * (long long)(a_rows > b_rows ? a_rows : b_rows) * PLANE_ROW_BYTES >= 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;
+    p.tiles_per_split = (int)per;
+#ifndef PLANE_GEMM_NB
+#define PLANE_GEMM_NB 4
+#endif
+    if (PLANE_GEMM_NB == 4 && Nc % 256 == 0)
+        hipLaunchKernelGGL(plane_gemm_kernel<4>, dim3((M / 128) * (Nc / 256), ksplit), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(plane_gemm_kernel<2>, dim3((M / 128) * (Nc / 128), ksplit), dim3(256), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+int diinn_plane_rowdot(void* stream, const float* A_dev, int a_rows, const float* S_dev, float* part_dev,
+                       int M, long long npix, int splits) {
+    if (!A_dev || !S_dev || !part_dev || M <= 0 || M > a_rows || splits <= 0) return DIINN_ERR_INVALID_ARG;
+    const int stp = check_npix(npix);
+    if (stp) return stp;
+    RowDotParams p;
+    p.A = A_dev; p.S = S_dev; p.part = part_dev; p.npix = npix; p.a_rows = a_rows; p.M = M;
+    const long long ntiles = (npix + PLANE_TILE - 1) / PLANE_TILE;
+    p.tiles_per_split = (int)((ntiles + splits - 1) / splits);
+    hipLaunchKernelGGL(plane_rowdot_kernel, dim3(splits), dim3(256), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+int diinn_backward_cell_sum(void* stream, const float* G_dev, const int32_t* seg_h_dev, const int32_t* seg_w_dev,
+                            float* dP_dev, int B, int H, int W, int Hu, int Wu) {
+    if (!G_dev || !seg_h_dev || !seg_w_dev || !dP_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (Hu <= 0 || Wu <= 0) return DIINN_ERR_INVALID_ARG;
+    const long long npix = (long long)B * Hu * Wu;
+    st = check_npix(npix);
+    if (st) return st;
+    if ((long long)((H + 3) / 4) * B > 65535) return DIINN_ERR_TOO_LARGE;
+    CellSumParams p{G_dev, dP_dev, seg_h_dev, seg_w_dev, B, H, W, Hu, Wu, (npix + PLANE_TILE - 1) / PLANE_TILE};
+    hipLaunchKernelGGL(cell_sum_kernel, dim3((W + 63) / 64, ((H + 3) / 4) * B, PCH), dim3(256), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+}  // extern "C"
