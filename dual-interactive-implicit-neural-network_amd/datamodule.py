@@ -227,9 +227,10 @@ class SRDataModule:
         if self.data_train is not None or self.data_test is not None:
             return
         hp = self.hparams
-        train = ConcatDataset([self._dataset(n, s, hp.train_scales, hp.patch_size, True, self.DIV2K_TRAIN)
-                               for n, s in hp.trainsets])
-        self.data_train = ConcatDataset([train] * hp.trainsets_repeat)
+        if hp.trainsets:                                          # evaluation-only callers pass no training set
+            train = ConcatDataset([self._dataset(n, s, hp.train_scales, hp.patch_size, True, self.DIV2K_TRAIN)
+                                   for n, s in hp.trainsets])
+            self.data_train = ConcatDataset([train] * hp.trainsets_repeat)
         self.data_test = [self._dataset(n, s, hp.test_scales, 0, False, self.DIV2K_HELD_OUT) for n, s in hp.testsets]
         self.data_val = self._dataset("DIV2K", "train", hp.train_scales, 0, False, self.DIV2K_HELD_OUT)
 

@@ -49,7 +49,7 @@ def test_demo2_and_benchmarks_run_end_to_end(tmp_path, golden):
     assert out.exists()
     assert Image.open(out).size == (61, 50)
     # benchmarks.py: a one-image "Set5"
-    hr_dir = tmp_path / "data" / "Set5" / "HR"
+    hr_dir = tmp_path / "data" / "benchmark" / "Set5" / "HR"
     hr_dir.mkdir(parents=True)
     Image.fromarray(rng.integers(0, 255, (64, 72, 3), dtype=np.uint8)).save(hr_dir / "a.png")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "benchmarks.py"), "--ckpt_path", str(ckpt),
