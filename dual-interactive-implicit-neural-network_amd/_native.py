@@ -68,6 +68,13 @@ SIGNATURES = {
     "diinn_metasr_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_metasr_make_axis_tables": (C.c_int, [C.c_int, C.c_int, _i32, _f, _f]),
+    "diinn_conv_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
+                                   C.c_int, C.c_int, C.c_int, C.c_int]),
+    "diinn_rdn_packed_floats": (C.c_size_t, []),
+    "diinn_rdn_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "diinn_rdn_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int]),
     "diinn_liif_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_liif_make_axis_tables": (C.c_int, [C.c_int, C.c_int, C.c_int, _i32, _f, _f]),

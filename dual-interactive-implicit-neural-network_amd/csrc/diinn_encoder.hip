@@ -1,0 +1,222 @@
+// diinn_encoder.hip -- RDN encoder convolutions for SMALL feature maps.
+// (part of libdiinn_hip.so; shared definitions in diinn_device.h, layout in diinn_layout.h)
+//
+// Reference: src/models/components/rdn.py:9-105 (RDB_Conv, RDB, RDN config 'B': 16 blocks x 8 dense 3x3 convs,
+// growth 64, 1x1 local / global feature fusion).  On a 48x48 input -- the size of the reference's
+// runtime_test.py and of its training patches -- a 64-output convolution has only 72 MFMA pixel tiles:
+// a library convolution launches a few dozen workgroups and runs at launch/latency cost (~35 us per
+// layer, 5 ms per forward for 1e11 FLOP).  conv_small_kernel splits the reduction instead of the output:
+// a workgroup owns one (32-pixel tile, 32-output half) and its 8 waves each reduce 1/8 of the input
+// channels (their own slice of the 3x3 halo tile staged privately in LDS: no barrier while computing),
+// then the 8 partial accumulators are summed through LDS and the epilogue (bias, ReLU, residual, up to
+// two destinations: the dense buffer slice and the global-fusion input) is applied once.
+// diinn_rdn_forward runs the whole trunk (everything after SFENet1) as 147 launches from C++.
+#include "diinn_device.h"
+
+constexpr int CS_WAVES = 8;                       // K-split: waves per workgroup, each 1/8 of the input channels
+constexpr int CS_TW = 8, CS_TH = 4;               // pixel tile 8 x 4 = 32 = one MFMA N-tile
+constexpr int CS_HALO = (CS_TH + 2) * (CS_TW + 2);   // 60 staged pixels per channel for a 3x3 convolution
+constexpr int CS_STAGE_FLOATS = 4096;             // per-wave LDS slice: 64 channels x 60 (3x3) or 128 channels x 32 (1x1)
+
+struct ConvSmallParams {
+    const float* in;         // input channel planes: in + b*in_bs + c*H*W
+    const float* w;          // packed: [half 2][wave 8][tap][channel group of 8][lane 64][4]
+    const float* bias;       // [64]
+    const float* res;        // optional residual [B,64,H,W] (batch stride res_bs), added after bias (no ReLU with it)
+    float* out0;             // destination 0: out0 + b*out0_bs + co*H*W
+    float* out1;             // optional destination 1
+    long long in_bs, out0_bs, out1_bs, res_bs;
+    int Cin, B, H, W, relu;
+};
+
+template <int TAPS>
+__global__ __launch_bounds__(512) void conv_small_kernel(const ConvSmallParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[CS_WAVES * CS_STAGE_FLOATS];   // 128 KiB: staging, then the partial sums
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int tiles_x = (p.W + CS_TW - 1) / CS_TW, tiles_y = (p.H + CS_TH - 1) / CS_TH;
+    int t = blockIdx.x;
+    const int b = t / (tiles_x * tiles_y);
+    t -= b * tiles_x * tiles_y;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int half = blockIdx.y;
+    const int y0 = ty * CS_TH, x0 = tx * CS_TW;
+    const int cw = p.Cin / CS_WAVES;                             // channels reduced by this wave
+    const size_t plane = (size_t)p.H * p.W;
+    const float* __restrict__ src = p.in + (size_t)b * p.in_bs + (size_t)(wave * cw) * plane;
+    float* __restrict__ mine = lds + wave * CS_STAGE_FLOATS;
+
+    // A pieces (weights) of one tap: up to GMAX groups of 8 channels, all in flight at once; the next tap's pieces
+    // are fetched while this tap's MFMAs run (pieces of consecutive taps are contiguous in the packed image).
+    constexpr int GMAX = TAPS == 9 ? 8 : 16;                     // Cin <= 512 for 3x3 layers, <= 1024 for 1x1 layers
+    const int groups = cw / 8;                                   // pieces (4 k-steps = 8 channels) per tap
+    const float* __restrict__ wbase = p.w + ((size_t)(half * CS_WAVES + wave) * TAPS * groups) * WL_PIECE + lane * 4;
+    f32x4 acur[GMAX], anext[GMAX];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g)
+        if (g < groups) acur[g] = *(const f32x4*)(wbase + (size_t)g * WL_PIECE);
+
+    // ---- stage this wave's channels of the tile (3x3: with the halo, zero outside the map); wave-private.
+    // Unrolled so that 8 independent loads are in flight (a rolled loop pays one memory latency per element).
+    constexpr int PIX = TAPS == 9 ? CS_HALO : CS_TW * CS_TH;
+    constexpr int LW = TAPS == 9 ? CS_TW + 2 : CS_TW;
+    constexpr int OFF = TAPS == 9 ? 1 : 0;
+    const int total = cw * PIX;
+    for (int base = 0; base < total; base += 8 * 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 64 + lane;
+            const int ic = idx < total ? idx : total - 1;
+            const int c = ic / PIX, pp = ic - c * PIX;
+            const int ly = pp / LW, lx = pp - ly * LW;
+            const int yy = y0 + ly - OFF, xx = x0 + lx - OFF;
+            const bool ok = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
+            const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+            const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
+            const float t = src[(size_t)c * plane + (size_t)yc * p.W + xc];
+            v[u] = ok ? t : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 64 + lane;
+            if (idx < total) mine[idx] = v[u];
+        }
+    }
+
+    // ---- this wave's share of the reduction: k-step = (tap, channel pair)
+    const int pix_off = (j / CS_TW) * LW + (j % CS_TW);          // this lane's pixel inside the staged tile (tap (0,0))
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+        if (tap + 1 < TAPS) {
+#pragma unroll
+            for (int g = 0; g < GMAX; ++g)
+                if (g < groups) anext[g] = *(const f32x4*)(wbase + ((size_t)(tap + 1) * groups + g) * WL_PIECE);
+        }
+        const int toff = TAPS == 9 ? (tap / 3) * LW + (tap % 3) : 0;
+        const float* __restrict__ bsrc = mine + h * PIX + pix_off + toff;
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) {
+            if (g < groups) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = MFMA32(acur[g][e], bsrc[(8 * g + 2 * e) * PIX], acc);   // channel 8g + 2e + h
+            }
+        }
+        if (tap + 1 < TAPS) {
+#pragma unroll
+            for (int g = 0; g < GMAX; ++g) acur[g] = anext[g];
+        }
+    }
+
+    // ---- sum the 8 partial tiles through LDS, then the epilogue
+    __syncthreads();                                             // every wave is done reading its staged slice
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    const int y = y0 + j / CS_TW, x = x0 + j % CS_TW;
+    const bool inside = (y < p.H) && (x < p.W);
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {                             // wave w finishes accumulator registers 2w, 2w+1
+        const int r = 2 * wave + rr;
+        float v = 0.0f;
+#pragma unroll
+        for (int w8 = 0; w8 < CS_WAVES; ++w8) v += lds[(w8 * 16 + r) * 64 + lane];
+        const int co = 32 * half + (r & 3) + 8 * (r >> 2) + 4 * h;
+        v += p.bias[co];
+        if (p.relu) v = v > 0.0f ? v : 0.0f;
+        if (inside) {
+            const size_t o = (size_t)co * plane + (size_t)y * p.W + x;
+            if (p.res) v += p.res[(size_t)b * p.res_bs + o];
+            p.out0[(size_t)b * p.out0_bs + o] = v;
+            if (p.out1) p.out1[(size_t)b * p.out1_bs + o] = v;
+        }
+    }
+}
+
+static int launch_conv_small(void* stream, const ConvSmallParams& p, int taps) {
+    const int tiles = ((p.W + CS_TW - 1) / CS_TW) * ((p.H + CS_TH - 1) / CS_TH) * p.B;
+    const dim3 grid(tiles, 2);
+    if (taps == 9)
+        hipLaunchKernelGGL(conv_small_kernel<9>, grid, dim3(512), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(conv_small_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+extern "C" {
+
+int diinn_conv_small(void* stream, const float* in_dev, long long in_batch_stride, int Cin, int taps,
+                     const float* packed_w_dev, const float* bias_dev,
+                     const float* res_dev, long long res_batch_stride,
+                     float* out0_dev, long long out0_batch_stride, float* out1_dev, long long out1_batch_stride,
+                     int relu, int B, int H, int W) {
+    if (!in_dev || !packed_w_dev || !bias_dev || !out0_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (taps != 9 && taps != 1) return DIINN_ERR_UNSUPPORTED;
+    if (Cin <= 0 || Cin % 64) return DIINN_ERR_UNSUPPORTED;
+    if ((taps == 9 ? CS_HALO : CS_TW * CS_TH) * (Cin / CS_WAVES) > CS_STAGE_FLOATS) return DIINN_ERR_TOO_LARGE;
+    if ((long long)((W + CS_TW - 1) / CS_TW) * ((H + CS_TH - 1) / CS_TH) * B > 2147483647LL) return DIINN_ERR_TOO_LARGE;
+    ConvSmallParams p;
+    p.in = in_dev; p.w = packed_w_dev; p.bias = bias_dev; p.res = res_dev; p.out0 = out0_dev; p.out1 = out1_dev;
+    p.in_bs = in_batch_stride; p.out0_bs = out0_batch_stride; p.out1_bs = out1_batch_stride; p.res_bs = res_batch_stride;
+    p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0;
+    return launch_conv_small(stream, p, taps);
+}
+
+size_t diinn_rdn_packed_floats(void) {
+    // SFENet2 64*64*9; 16 x [8 dense convs 64*(64..512)*9 + LFF 64*576]; GFF 64*1024 + 64*64*9
+    size_t n = (size_t)64 * 64 * 9;
+    for (int c = 0; c < 8; ++c) n += (size_t)16 * 64 * (64 + 64 * c) * 9;
+    n += (size_t)16 * 64 * 576 + (size_t)64 * 1024 + (size_t)64 * 64 * 9;
+    return n;
+}
+
+size_t diinn_rdn_workspace_floats(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * H * W * (2 * 576 + 1024 + 64);
+}
+
+int diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packed_dev, const float* biases_dev,
+                      float* workspace_dev, float* out_dev, int B, int H, int W) {
+    if (!sfe1_dev || !packed_dev || !biases_dev || !workspace_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    const long long hw = (long long)H * W;
+    float* buf[2] = {workspace_dev, workspace_dev + (size_t)B * 576 * hw};     // dense buffers [B,576,H,W]
+    float* gff_in = workspace_dev + (size_t)2 * B * 576 * hw;                    // [B,1024,H,W]
+    float* tmp = gff_in + (size_t)B * 1024 * hw;                                 // [B,64,H,W]
+    const float* w = packed_dev;
+    const float* bias = biases_dev;
+    auto conv = [&](const float* in, long long in_bs, int cin, int taps, const float* res, long long res_bs,
+                    float* o0, long long o0_bs, float* o1, long long o1_bs, int relu) {
+        const int s = diinn_conv_small(stream, in, in_bs, cin, taps, w, bias, res, res_bs, o0, o0_bs, o1, o1_bs, relu, B, H, W);
+        w += (size_t)64 * cin * taps;
+        bias += 64;
+        return s;
+    };
+    // SFENet2: 64 -> 64 into channels [0,64) of the first dense buffer (rdn.py:97)
+    st = conv(sfe1_dev, 64 * hw, 64, 9, nullptr, 0, buf[0], 576 * hw, nullptr, 0, 0);
+    if (st) return st;
+    for (int d = 0; d < 16; ++d) {
+        float* cur = buf[d & 1];
+        float* nxt = buf[(d + 1) & 1];
+        for (int c = 0; c < 8; ++c) {                            // dense 3x3 convs: read channels [0, 64(c+1)), append 64 (rdn.py:15-17)
+            st = conv(cur, 576 * hw, 64 * (c + 1), 9, nullptr, 0, cur + (size_t)64 * (c + 1) * hw, 576 * hw, nullptr, 0, 1);
+            if (st) return st;
+        }
+        // LFF 1x1 576 -> 64 plus the block input (rdn.py:34): next block's input and the d-th slice of the global fusion input
+        st = conv(cur, 576 * hw, 576, 1, cur, 576 * hw, nxt, 576 * hw, gff_in + (size_t)64 * d * hw, 1024 * hw, 0);
+        if (st) return st;
+    }
+    // GFF: 1x1 1024 -> 64, then 3x3 64 -> 64, plus the shallow features (rdn.py:100-103)
+    st = conv(gff_in, 1024 * hw, 1024, 1, nullptr, 0, tmp, 64 * hw, nullptr, 0, 0);
+    if (st) return st;
+    return conv(tmp, 64 * hw, 64, 9, sfe1_dev, 64 * hw, out_dev, 64 * hw, nullptr, 0, 0);
+}
+
+}  // extern "C"

@@ -70,8 +70,27 @@ class RDB(nn.Module):
         return self.LFF(buf) + x
 
 
+def pack_conv_small(weight: torch.Tensor) -> torch.Tensor:
+    """Conv weight [64, Cin, kh, kw] (Cin % 64 == 0; 3x3 or 1x1) -> the layout ``diinn_conv_small`` reads
+    (include/diinn_hip.h): [half 2][wave 8][tap][group][lane 64][4] with cout = 32 half + (lane & 31) and
+    input channel = wave*Cin/8 + 8 group + 2 e + (lane >> 5)."""
+    co, cin, kh, kw = weight.shape
+    if co != 64 or cin % 64 or (kh, kw) not in ((3, 3), (1, 1)):
+        raise ValueError(f"unsupported convolution shape {tuple(weight.shape)}")
+    taps, groups = kh * kw, cin // 64
+    w = weight.detach().to(torch.float32).reshape(2, 32, 8, groups, 4, 2, taps)     # [half, i, wave, g, e, h, tap]
+    return w.permute(0, 2, 6, 3, 5, 1, 4).reshape(-1)                               # [half, wave, tap, g, h, i, e]
+
+
 class RDN(nn.Module):
     _CONFIGS = {"A": (20, 6, 32), "B": (16, 8, 64)}
+    # Inference on feature maps of up to this many pixels (batch included) runs the trunk on conv_small_kernel
+    # (C ABI diinn_rdn_forward): a 64-output convolution on a 48x48 map has 72 MFMA tiles, far too few for a
+    # library convolution's output-parallel launch, so the HIP path splits the reduction over 8 waves per tile
+    # instead: 3.2 ms vs 6.9 ms (MIOpen eager) / 4.6 ms (MIOpen in a hipGraph) at 48x48, 3.3 vs 6.9 / 6.3 at
+    # 64x64; from 96x96 on (9.4 vs 7.7 ms) MIOpen wins and keeps the job (tools/enc_small_time.py).
+    # None disables the HIP trunk.
+    hip_trunk_max_pixels: Optional[int] = 72 * 72
 
     def __init__(self, G0: int = 64, RDNkSize: int = 3, RDNconfig: str = "B", n_colors: int = 3):
         super().__init__()
@@ -84,9 +103,47 @@ class RDN(nn.Module):
         self.out_dim = G0
         self.args = SimpleNamespace(G0=G0, RDNkSize=RDNkSize, RDNconfig=RDNconfig, scale=[2],
                                     no_upsampling=True, n_colors=n_colors)
+        self._hip_ok = (RDNconfig == "B" and G0 == 64 and RDNkSize == 3)
+        self._hip_pack = None
+        self._hip_key = None
+
+    def _trunk_layers(self):
+        """The 147 convolutions after SFENet1 in execution order (rdn.py:97-103)."""
+        layers = [self.SFENet2]
+        for rdb in self.RDBs:
+            layers += [c.conv[0] for c in rdb.convs] + [rdb.LFF]
+        return layers + [self.GFF[0], self.GFF[1]]
+
+    def _hip_packed(self, device):
+        layers = self._trunk_layers()
+        key = (str(device),) + tuple((l.weight.data_ptr(), l.weight._version, l.bias._version) for l in layers)
+        if self._hip_pack is None or self._hip_key != key:
+            w = torch.cat([pack_conv_small(l.weight) for l in layers]).to(device)
+            b = torch.cat([l.bias.detach().to(torch.float32) for l in layers]).to(device)
+            self._hip_pack, self._hip_key = (w, b), key
+        return self._hip_pack
+
+    def _forward_hip_trunk(self, shallow):
+        import ctypes as C
+        from . import _native
+        lib = _native.load()
+        b, _, h, w = shallow.shape
+        shallow = shallow.contiguous()
+        packed, biases = self._hip_packed(shallow.device)
+        ws = torch.empty(lib.diinn_rdn_workspace_floats(b, h, w), dtype=torch.float32, device=shallow.device)
+        out = torch.empty_like(shallow)
+        with torch.cuda.device(shallow.device):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _native.check(lib.diinn_rdn_forward(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                                C.c_void_p(biases.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                                C.c_void_p(out.data_ptr()), b, h, w), "diinn_rdn_forward")
+        return out
 
     def forward(self, x):
         shallow = self.SFENet1(x)
+        if (self._hip_ok and self.hip_trunk_max_pixels is not None and x.is_cuda and not torch.is_grad_enabled()
+                and x.dtype == torch.float32 and x.shape[0] * x.shape[-2] * x.shape[-1] <= self.hip_trunk_max_pixels):
+            return self._forward_hip_trunk(shallow)
         x = self.SFENet2(shallow)
         blocks = []
         for rdb in self.RDBs:
