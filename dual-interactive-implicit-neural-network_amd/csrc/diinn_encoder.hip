@@ -62,26 +62,27 @@ __global__ __launch_bounds__(512) void conv_small_kernel(const ConvSmallParams p
     constexpr int PIX = TAPS == 9 ? CS_HALO : CS_TW * CS_TH;
     constexpr int LW = TAPS == 9 ? CS_TW + 2 : CS_TW;
     constexpr int OFF = TAPS == 9 ? 1 : 0;
-    const int total = cw * PIX;
-    for (int base = 0; base < total; base += 8 * 64) {
-        float v[8];
+    // A lane keeps one staged position for the whole loop (3x3: lanes 0..59 = the 6 x 10 halo of one channel per
+    // iteration; 1x1: 32 pixels x 2 channels per iteration), so the loop body is one load and one LDS store.
+    {
+        constexpr int CPI = TAPS == 9 ? 1 : 2;                   // channels staged per iteration
+        const int pp = TAPS == 9 ? (lane < PIX ? lane : PIX - 1) : (lane & 31);
+        const int csel = TAPS == 9 ? 0 : (lane >> 5);
+        const int ly = pp / LW, lx = pp - ly * LW;
+        const int yy = y0 + ly - OFF, xx = x0 + lx - OFF;
+        const bool ok = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
+        const bool mine_lane = TAPS == 9 ? lane < PIX : true;
+        const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+        const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
+        const float* __restrict__ lsrc = src + (size_t)csel * plane + (size_t)yc * p.W + xc;
+        float* __restrict__ ldst = mine + csel * PIX + pp;
+        for (int c0 = 0; c0 < cw; c0 += 8) {                     // cw is a multiple of 8; 8 (3x3) or 4 (1x1) independent loads in flight
+            float v[8 / CPI];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * 64 + lane;
-            const int ic = idx < total ? idx : total - 1;
-            const int c = ic / PIX, pp = ic - c * PIX;
-            const int ly = pp / LW, lx = pp - ly * LW;
-            const int yy = y0 + ly - OFF, xx = x0 + lx - OFF;
-            const bool ok = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
-            const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
-            const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
-            const float t = src[(size_t)c * plane + (size_t)yc * p.W + xc];
-            v[u] = ok ? t : 0.0f;
-        }
+            for (int u = 0; u < 8 / CPI; ++u) v[u] = lsrc[(size_t)(c0 + u * CPI) * plane];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * 64 + lane;
-            if (idx < total) mine[idx] = v[u];
+            for (int u = 0; u < 8 / CPI; ++u)
+                if (mine_lane) ldst[(c0 + u * CPI) * PIX] = ok ? v[u] : 0.0f;
         }
     }
 
