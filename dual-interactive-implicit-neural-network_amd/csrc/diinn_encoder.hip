@@ -16,7 +16,7 @@
 constexpr int CS_WAVES = 8;                       // K-split: waves per workgroup, each 1/8 of the input channels
 constexpr int CS_TW = 8, CS_TH = 4;               // pixel tile 8 x 4 = 32 = one MFMA N-tile
 constexpr int CS_HALO = (CS_TH + 2) * (CS_TW + 2);   // 60 staged pixels per channel for a 3x3 convolution
-constexpr int CS_STAGE_FLOATS = 4096;             // per-wave LDS slice: 64 channels x 60 (3x3) or 128 channels x 32 (1x1)
+constexpr int CS_STAGE_FLOATS = 2048;             // per-wave LDS slice (8 KiB): a chunk of 32 channels x 60 (3x3) or 64 channels x 32 (1x1)
 
 struct ConvSmallParams {
     const float* in;         // input channel planes: in + b*in_bs + c*H*W
@@ -30,8 +30,8 @@ struct ConvSmallParams {
 };
 
 template <int TAPS>
-__global__ __launch_bounds__(512) void conv_small_kernel(const ConvSmallParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[CS_WAVES * CS_STAGE_FLOATS];   // 128 KiB: staging, then the partial sums
+__global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[CS_WAVES * CS_STAGE_FLOATS];   // 64 KiB: staging, then the partial sums
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
@@ -47,69 +47,80 @@ __global__ __launch_bounds__(512) void conv_small_kernel(const ConvSmallParams p
     const float* __restrict__ src = p.in + (size_t)b * p.in_bs + (size_t)(wave * cw) * plane;
     float* __restrict__ mine = lds + wave * CS_STAGE_FLOATS;
 
-    // A pieces (weights) of one tap: up to GMAX groups of 8 channels, all in flight at once; the next tap's pieces
-    // are fetched while this tap's MFMAs run (pieces of consecutive taps are contiguous in the packed image).
-    constexpr int GMAX = TAPS == 9 ? 8 : 16;                     // Cin <= 512 for 3x3 layers, <= 1024 for 1x1 layers
-    const int groups = cw / 8;                                   // pieces (4 k-steps = 8 channels) per tap
-    const float* __restrict__ wbase = p.w + ((size_t)(half * CS_WAVES + wave) * TAPS * groups) * WL_PIECE + lane * 4;
-    f32x4 acur[GMAX], anext[GMAX];
-#pragma unroll
-    for (int g = 0; g < GMAX; ++g)
-        if (g < groups) acur[g] = *(const f32x4*)(wbase + (size_t)g * WL_PIECE);
-
-    // ---- stage this wave's channels of the tile (3x3: with the halo, zero outside the map); wave-private.
-    // Unrolled so that 8 independent loads are in flight (a rolled loop pays one memory latency per element).
+    // The wave's channels go through its 8 KiB LDS slice in chunks of CH channels (two workgroups fit a CU, so one's
+    // staging overlaps the other's MFMAs).  A pieces (weights) of one (chunk, tap): up to GQ groups of 8 channels, all
+    // in flight at once; the next (chunk, tap)'s pieces are fetched while this one's MFMAs run.
     constexpr int PIX = TAPS == 9 ? CS_HALO : CS_TW * CS_TH;
     constexpr int LW = TAPS == 9 ? CS_TW + 2 : CS_TW;
     constexpr int OFF = TAPS == 9 ? 1 : 0;
-    // A lane keeps one staged position for the whole loop (3x3: lanes 0..59 = the 6 x 10 halo of one channel per
-    // iteration; 1x1: 32 pixels x 2 channels per iteration), so the loop body is one load and one LDS store.
+    constexpr int CH = TAPS == 9 ? 32 : 64;                      // 32 x 60 / 64 x 32 floats <= CS_STAGE_FLOATS
+    constexpr int GQ = CH / 8;
+    static_assert(CH * PIX <= CS_STAGE_FLOATS, "chunk must fit the wave's LDS slice");
+    const int groups = cw / 8;                                   // pieces (4 k-steps = 8 channels) per tap
+    const float* __restrict__ wbase = p.w + ((size_t)(half * CS_WAVES + wave) * TAPS * groups) * WL_PIECE + lane * 4;
+    f32x4 acur[GQ], anext[GQ];
     {
-        constexpr int CPI = TAPS == 9 ? 1 : 2;                   // channels staged per iteration
-        const int pp = TAPS == 9 ? (lane < PIX ? lane : PIX - 1) : (lane & 31);
-        const int csel = TAPS == 9 ? 0 : (lane >> 5);
-        const int ly = pp / LW, lx = pp - ly * LW;
-        const int yy = y0 + ly - OFF, xx = x0 + lx - OFF;
-        const bool ok = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
-        const bool mine_lane = TAPS == 9 ? lane < PIX : true;
-        const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
-        const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
-        const float* __restrict__ lsrc = src + (size_t)csel * plane + (size_t)yc * p.W + xc;
-        float* __restrict__ ldst = mine + csel * PIX + pp;
-        for (int c0 = 0; c0 < cw; c0 += 8) {                     // cw is a multiple of 8; 8 (3x3) or 4 (1x1) independent loads in flight
+        const int g0n = groups < GQ ? groups : GQ;
+#pragma unroll
+        for (int g = 0; g < GQ; ++g)
+            if (g < g0n) acur[g] = *(const f32x4*)(wbase + (size_t)g * WL_PIECE);
+    }
+
+    // a lane keeps one staged position for the whole kernel (3x3: lanes 0..59 = the 6 x 10 halo of one channel per
+    // load; 1x1: 32 pixels x 2 channels per load), so staging is one load and one LDS store per element
+    constexpr int CPI = TAPS == 9 ? 1 : 2;                       // channels staged per load instruction
+    const int pp = TAPS == 9 ? (lane < PIX ? lane : PIX - 1) : (lane & 31);
+    const int csel = TAPS == 9 ? 0 : (lane >> 5);
+    const int ly = pp / LW, lx = pp - ly * LW;
+    const int yy = y0 + ly - OFF, xx = x0 + lx - OFF;
+    const bool ok = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
+    const bool mine_lane = TAPS == 9 ? lane < PIX : true;
+    const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+    const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
+    const float* __restrict__ lsrc = src + (size_t)csel * plane + (size_t)yc * p.W + xc;
+    float* __restrict__ ldst = mine + csel * PIX + pp;
+    const int pix_off = (j / CS_TW) * LW + (j % CS_TW);          // this lane's pixel inside the staged tile (tap (0,0))
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int cbase = 0; cbase < cw; cbase += CH) {
+        const int cc = cw - cbase < CH ? cw - cbase : CH;        // channels in this chunk (multiple of 8)
+        const int gcount = cc / 8, gbase = cbase / 8;
+        const int nc = cw - cbase - CH;                          // channels left after this chunk
+        const int gnext = nc <= 0 ? 0 : (nc < CH ? nc / 8 : GQ);
+        // ---- stage the chunk (wave-private; the previous chunk's LDS reads were issued earlier in program order)
+        for (int c0 = 0; c0 < cc; c0 += 8) {                     // 8 (3x3) or 4 (1x1) independent loads in flight
             float v[8 / CPI];
 #pragma unroll
-            for (int u = 0; u < 8 / CPI; ++u) v[u] = lsrc[(size_t)(c0 + u * CPI) * plane];
+            for (int u = 0; u < 8 / CPI; ++u) v[u] = lsrc[(size_t)(cbase + c0 + u * CPI) * plane];
 #pragma unroll
             for (int u = 0; u < 8 / CPI; ++u)
                 if (mine_lane) ldst[(c0 + u * CPI) * PIX] = ok ? v[u] : 0.0f;
         }
-    }
-
-    // ---- this wave's share of the reduction: k-step = (tap, channel pair)
-    const int pix_off = (j / CS_TW) * LW + (j % CS_TW);          // this lane's pixel inside the staged tile (tap (0,0))
-    f32x16 acc;
+        // ---- this chunk's share of the reduction: k-step = (tap, channel pair)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int tap = 0; tap < TAPS; ++tap) {
+            if (tap + 1 < TAPS) {
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-        if (tap + 1 < TAPS) {
+                for (int g = 0; g < GQ; ++g)
+                    if (g < gcount) anext[g] = *(const f32x4*)(wbase + ((size_t)(tap + 1) * groups + gbase + g) * WL_PIECE);
+            } else {                                             // last tap: tap 0 of the next chunk
 #pragma unroll
-            for (int g = 0; g < GMAX; ++g)
-                if (g < groups) anext[g] = *(const f32x4*)(wbase + ((size_t)(tap + 1) * groups + g) * WL_PIECE);
-        }
-        const int toff = TAPS == 9 ? (tap / 3) * LW + (tap % 3) : 0;
-        const float* __restrict__ bsrc = mine + h * PIX + pix_off + toff;
-#pragma unroll
-        for (int g = 0; g < GMAX; ++g) {
-            if (g < groups) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc = MFMA32(acur[g][e], bsrc[(8 * g + 2 * e) * PIX], acc);   // channel 8g + 2e + h
+                for (int g = 0; g < GQ; ++g)
+                    if (g < gnext) anext[g] = *(const f32x4*)(wbase + (size_t)(gbase + GQ + g) * WL_PIECE);
             }
-        }
-        if (tap + 1 < TAPS) {
+            const int toff = TAPS == 9 ? (tap / 3) * LW + (tap % 3) : 0;
+            const float* __restrict__ bsrc = mine + h * PIX + pix_off + toff;
 #pragma unroll
-            for (int g = 0; g < GMAX; ++g) acur[g] = anext[g];
+            for (int g = 0; g < GQ; ++g) {
+                if (g < gcount) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = MFMA32(acur[g][e], bsrc[(8 * g + 2 * e) * PIX], acc);   // channel cbase + 8g + 2e + h
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < GQ; ++g) acur[g] = anext[g];
         }
     }
 
@@ -160,7 +171,6 @@ int diinn_conv_small(void* stream, const float* in_dev, long long in_batch_strid
     if (st) return st;
     if (taps != 9 && taps != 1) return DIINN_ERR_UNSUPPORTED;
     if (Cin <= 0 || Cin % 64) return DIINN_ERR_UNSUPPORTED;
-    if ((taps == 9 ? CS_HALO : CS_TW * CS_TH) * (Cin / CS_WAVES) > CS_STAGE_FLOATS) return DIINN_ERR_TOO_LARGE;
     if ((long long)((W + CS_TW - 1) / CS_TW) * ((H + CS_TH - 1) / CS_TH) * B > 2147483647LL) return DIINN_ERR_TOO_LARGE;
     ConvSmallParams p;
     p.in = in_dev; p.w = packed_w_dev; p.bias = bias_dev; p.res = res_dev; p.out0 = out0_dev; p.out1 = out1_dev;
