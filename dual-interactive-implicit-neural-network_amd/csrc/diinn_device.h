@@ -165,6 +165,9 @@ constexpr unsigned PLANE_ROW_BYTES = PLANE_TILE * sizeof(float);   // 128
 __device__ __forceinline__ void st_act(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, (int)soff, 0);
 }
+__device__ __forceinline__ float ld_act(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
+}
 // descriptor of one tile (rows x 32 floats) of a tiled plane group
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* group, long long tile, int rows) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)(group + (size_t)tile * rows * PLANE_TILE), 0,

@@ -50,35 +50,49 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallParam
     // The wave's channels go through its 8 KiB LDS slice in chunks of CH channels (two workgroups fit a CU, so one's
     // staging overlaps the other's MFMAs).  A pieces (weights) of one (chunk, tap): up to GQ groups of 8 channels, all
     // in flight at once; the next (chunk, tap)'s pieces are fetched while this one's MFMAs run.
-    constexpr int PIX = TAPS == 9 ? CS_HALO : CS_TW * CS_TH;
-    constexpr int LW = TAPS == 9 ? CS_TW + 2 : CS_TW;
+    // LDS layout of a staged channel: 3x3: 6 halo rows at a pitch of 16 floats, channel pitch 104; 1x1: 32 pixels.
+    // An MFMA B read takes, for lane-half h, channel 2s+h at the lane's pixel: with these pitches the 32 lanes
+    // of h = 0 fall on banks {0-7, 16-23, 32-39, 48-55} (+ the tap's column shift) and h = 1, 104 = 40 (mod 64)
+    // floats further, on the other 32 banks: conflict-free (a dense 6 x 10 tile made every read 2-way conflicted).
+    constexpr int NPOS = TAPS == 9 ? CS_HALO : CS_TW * CS_TH;    // staged positions per channel (lanes that stage)
+    constexpr int LW = TAPS == 9 ? 16 : CS_TW;
+    constexpr int PIX = TAPS == 9 ? 104 : CS_TW * CS_TH;         // channel pitch in floats
     constexpr int OFF = TAPS == 9 ? 1 : 0;
-    constexpr int CH = TAPS == 9 ? 32 : 64;                      // 32 x 60 / 64 x 32 floats <= CS_STAGE_FLOATS
+    constexpr int CH = TAPS == 9 ? 16 : 64;                      // 16 x 104 / 64 x 32 floats <= CS_STAGE_FLOATS
     constexpr int GQ = CH / 8;
     static_assert(CH * PIX <= CS_STAGE_FLOATS, "chunk must fit the wave's LDS slice");
     const int groups = cw / 8;                                   // pieces (4 k-steps = 8 channels) per tap
-    const float* __restrict__ wbase = p.w + ((size_t)(half * CS_WAVES + wave) * TAPS * groups) * WL_PIECE + lane * 4;
+    // weight pieces and staged features are fetched through buffer descriptors: descriptor base + scalar byte offset
+    // + one constant per-lane offset, i.e. no per-load VALU address arithmetic (the fp32 MFMA shares its issue slot
+    // with the VALU; this kernel ran 4.7 VALU instructions per MFMA with plain pointers)
+    const int wbytes = TAPS * groups * PIECE_BYTES;              // this wave's slice of the packed weight
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.w + ((size_t)(half * CS_WAVES + wave) * TAPS * groups) * WL_PIECE), 0, wbytes, 0x00020000);
+    const int lane_off = lane * 16;
     f32x4 acur[GQ], anext[GQ];
     {
         const int g0n = groups < GQ ? groups : GQ;
 #pragma unroll
         for (int g = 0; g < GQ; ++g)
-            if (g < g0n) acur[g] = *(const f32x4*)(wbase + (size_t)g * WL_PIECE);
+            if (g < g0n) acur[g] = ld_piece(wrs, lane_off, g * PIECE_BYTES);
     }
 
     // a lane keeps one staged position for the whole kernel (3x3: lanes 0..59 = the 6 x 10 halo of one channel per
     // load; 1x1: 32 pixels x 2 channels per load), so staging is one load and one LDS store per element
     constexpr int CPI = TAPS == 9 ? 1 : 2;                       // channels staged per load instruction
-    const int pp = TAPS == 9 ? (lane < PIX ? lane : PIX - 1) : (lane & 31);
+    const int pp = TAPS == 9 ? (lane < NPOS ? lane : NPOS - 1) : (lane & 31);
     const int csel = TAPS == 9 ? 0 : (lane >> 5);
-    const int ly = pp / LW, lx = pp - ly * LW;
+    const int ly = TAPS == 9 ? pp / (CS_TW + 2) : pp / CS_TW;
+    const int lx = TAPS == 9 ? pp - ly * (CS_TW + 2) : pp - ly * CS_TW;
     const int yy = y0 + ly - OFF, xx = x0 + lx - OFF;
     const bool ok = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
-    const bool mine_lane = TAPS == 9 ? lane < PIX : true;
+    const bool mine_lane = TAPS == 9 ? lane < NPOS : true;
     const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
     const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
-    const float* __restrict__ lsrc = src + (size_t)csel * plane + (size_t)yc * p.W + xc;
-    float* __restrict__ ldst = mine + csel * PIX + pp;
+    const unsigned plane_b = (unsigned)(plane * sizeof(float));
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)((unsigned)cw * plane_b), 0x00020000);
+    const unsigned lsrc_off = (unsigned)csel * plane_b + (unsigned)(yc * p.W + xc) * 4u;
+    float* __restrict__ ldst = mine + csel * PIX + (TAPS == 9 ? ly * LW + lx : pp);
     const int pix_off = (j / CS_TW) * LW + (j % CS_TW);          // this lane's pixel inside the staged tile (tap (0,0))
 
     f32x16 acc;
@@ -93,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallParam
         for (int c0 = 0; c0 < cc; c0 += 8) {                     // 8 (3x3) or 4 (1x1) independent loads in flight
             float v[8 / CPI];
 #pragma unroll
-            for (int u = 0; u < 8 / CPI; ++u) v[u] = lsrc[(size_t)(cbase + c0 + u * CPI) * plane];
+            for (int u = 0; u < 8 / CPI; ++u) v[u] = ld_act(irs, lsrc_off, (unsigned)(cbase + c0 + u * CPI) * plane_b);
 #pragma unroll
             for (int u = 0; u < 8 / CPI; ++u)
                 if (mine_lane) ldst[(c0 + u * CPI) * PIX] = ok ? v[u] : 0.0f;
@@ -104,11 +118,11 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallParam
             if (tap + 1 < TAPS) {
 #pragma unroll
                 for (int g = 0; g < GQ; ++g)
-                    if (g < gcount) anext[g] = *(const f32x4*)(wbase + ((size_t)(tap + 1) * groups + gbase + g) * WL_PIECE);
+                    if (g < gcount) anext[g] = ld_piece(wrs, lane_off, ((tap + 1) * groups + gbase + g) * PIECE_BYTES);
             } else {                                             // last tap: tap 0 of the next chunk
 #pragma unroll
                 for (int g = 0; g < GQ; ++g)
-                    if (g < gnext) anext[g] = *(const f32x4*)(wbase + (size_t)(gbase + GQ + g) * WL_PIECE);
+                    if (g < gnext) anext[g] = ld_piece(wrs, lane_off, (gbase + GQ + g) * PIECE_BYTES);
             }
             const int toff = TAPS == 9 ? (tap / 3) * LW + (tap % 3) : 0;
             const float* __restrict__ bsrc = mine + h * PIX + pix_off + toff;

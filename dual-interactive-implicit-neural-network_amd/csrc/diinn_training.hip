@@ -39,9 +39,6 @@ __device__ __forceinline__ void dsincos(float x, float& sn, float& cs) {
     cs = __builtin_amdgcn_cosf(r);
 }
 
-__device__ __forceinline__ float ld_act(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
-}
 
 __global__ __launch_bounds__(256) void bwd_head_kernel(const BwdParams p) {
     const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;

@@ -87,10 +87,10 @@ class RDN(nn.Module):
     # Inference on feature maps of up to this many pixels (batch included) runs the trunk on conv_small_kernel
     # (C ABI diinn_rdn_forward): a 64-output convolution on a 48x48 map has 72 MFMA tiles, far too few for a
     # library convolution's output-parallel launch, so the HIP path splits the reduction over 8 waves per tile
-    # instead: 2.5 ms vs 6.8 ms (MIOpen eager) / 4.6 ms (MIOpen in a hipGraph) at 48x48, 2.7 vs 6.7 / 6.4 at
-    # 64x64, 6.8 vs 7.6 at 96x96; at 128x128 (9.5 vs 7.9 ms) MIOpen wins and keeps the job (tools/enc_small_time.py).
-    # None disables the HIP trunk.
-    hip_trunk_max_pixels: Optional[int] = 104 * 104
+    # instead.  Measured (tools/enc_small_time.py, HIP vs MIOpen eager): 2.3 vs 6.8 ms at 48x48, 6.0 vs 7.6-8.6
+    # at 96x96, 8.5 vs 7.7-9.8 at 128x128, 18.2 vs 20.2-20.6 at 192x192, 32.7 vs 28.3-31.1 at 256x256: MIOpen
+    # keeps the large maps.  None disables the HIP trunk.
+    hip_trunk_max_pixels: Optional[int] = 192 * 192
 
     def __init__(self, G0: int = 64, RDNkSize: int = 3, RDNconfig: str = "B", n_colors: int = 3):
         super().__init__()

@@ -39,12 +39,17 @@ def graphed(fn):
 
 def main():
     dev = torch.device("cuda:0")
-    sizes = [int(a) for a in sys.argv[1:]] or [24, 48, 64, 96, 128, 192, 256]
+    only_hip = "--only-hip" in sys.argv                      # for profiling: HIP trunk alone, eager
+    sizes = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [24, 48, 64, 96, 128, 192, 256]
     enc = M.make_rdn().to(dev).eval()
     print(f"{'LR':>9s} {'MIOpen ms':>10s} {'MIOpen graph':>13s} {'HIP trunk ms':>13s} {'HIP graph':>10s} {'max diff':>9s}")
     with torch.no_grad():
         for lr in sizes:
             x = torch.rand(1, 3, lr, lr, device=dev)
+            if only_hip:
+                enc.hip_trunk_max_pixels = 1 << 30
+                print(f"{lr:4d}x{lr:<4d} HIP trunk {t_ms(lambda: enc(x)):10.3f} ms", flush=True)
+                continue
             enc.hip_trunk_max_pixels = None
             ref = enc(x)
             t_mi = t_ms(lambda: enc(x))
