@@ -68,7 +68,7 @@ SIGNATURES = {
     "diinn_metasr_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_metasr_make_axis_tables": (C.c_int, [C.c_int, C.c_int, _i32, _f, _f]),
-    "diinn_conv_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+    "diinn_conv_ksplit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
                                    C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_rdn_packed_floats": (C.c_size_t, []),

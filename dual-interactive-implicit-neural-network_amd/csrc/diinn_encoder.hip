@@ -1,15 +1,19 @@
-// diinn_encoder.hip -- RDN encoder convolutions for SMALL feature maps.
+// diinn_encoder.hip -- the RDN encoder trunk on gfx950.
 // (part of libdiinn_hip.so; shared definitions in diinn_device.h, layout in diinn_layout.h)
 //
 // Reference: src/models/components/rdn.py:9-105 (RDB_Conv, RDB, RDN config 'B': 16 blocks x 8 dense 3x3 convs,
-// growth 64, 1x1 local / global feature fusion).  On a 48x48 input -- the size of the reference's
-// runtime_test.py and of its training patches -- a 64-output convolution has only 72 MFMA pixel tiles:
-// a library convolution launches a few dozen workgroups and runs at launch/latency cost (~35 us per
-// layer, 5 ms per forward for 1e11 FLOP).  conv_small_kernel splits the reduction instead of the output:
-// a workgroup owns one (32-pixel tile, 32-output half) and its 8 waves each reduce 1/8 of the input
-// channels (their own slice of the 3x3 halo tile staged privately in LDS: no barrier while computing),
-// then the 8 partial accumulators are summed through LDS and the epilogue (bias, ReLU, residual, up to
-// two destinations: the dense buffer slice and the global-fusion input) is applied once.
+// growth 64, 1x1 local / global feature fusion).  Every convolution of the trunk has 64 outputs and 64..1024
+// inputs: a short M, a long K.  conv_ksplit_kernel splits the REDUCTION inside the workgroup instead of only
+// the output across workgroups: a workgroup owns one 32-pixel tile (8 x 4) and its 8 waves each reduce 1/8 of
+// the input channels from a slice of the 3x3 halo tile they stage privately in LDS (8 KiB per wave, refilled
+// in chunks; no barrier while computing; two workgroups per CU so one's staging overlaps the other's MFMAs),
+// then the 8 partial accumulators are summed through LDS and the epilogue (bias, ReLU, residual, up to two
+// destinations: the dense-buffer slice and the global-fusion input) is applied once.
+//   * small maps (48x48: the reference's runtime_test.py and training patches, 72 tiles): a workgroup per
+//     (tile, 32-output half) -- a library convolution is launch/latency-bound there (~35 us per layer);
+//   * maps with >= 512 tiles: both output halves per workgroup (half the staging and LDS reads per MFMA).
+// Measured against MIOpen (PyTorch-ROCm), whole encoder: 2.1 vs 6.8 ms at 48x48, 25.1 vs 28.1 ms at 256x256
+// (115 TFLOP/s), 99.7 vs 108.4 ms at 512x512 (tools/enc_trunk_time.py).
 // diinn_rdn_forward runs the whole trunk (everything after SFENet1) as 147 launches from C++.
 #include "diinn_device.h"
 
@@ -18,7 +22,10 @@ constexpr int CS_TW = 8, CS_TH = 4;               // pixel tile 8 x 4 = 32 = one
 constexpr int CS_HALO = (CS_TH + 2) * (CS_TW + 2);   // 60 staged pixels per channel for a 3x3 convolution
 constexpr int CS_STAGE_FLOATS = 2048;             // per-wave LDS slice (8 KiB): a chunk of 32 channels x 60 (3x3) or 64 channels x 32 (1x1)
 
-struct ConvSmallParams {
+struct TagFalse { static constexpr bool value = false; };
+struct TagTrue { static constexpr bool value = true; };
+
+struct ConvKsplitParams {
     const float* in;         // input channel planes: in + b*in_bs + c*H*W
     const float* w;          // packed: [half 2][wave 8][tap][channel group of 8][lane 64][4]
     const float* bias;       // [64]
@@ -29,8 +36,12 @@ struct ConvSmallParams {
     int Cin, B, H, W, relu;
 };
 
-template <int TAPS>
-__global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallParams p) {
+// NH = 1: a workgroup computes one 32-output half (blockIdx.y) -- twice the workgroups, for maps with few tiles.
+// NH = 2: both halves from the same staged features (half the staging and half the LDS reads per MFMA), for maps
+//         with enough tiles to fill the chip anyway.
+template <int TAPS, int NH>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))      // two workgroups of 8 waves per CU: <= 128 VGPRs
+void conv_ksplit_kernel(const ConvKsplitParams p) {
     __shared__ __attribute__((aligned(16))) float lds[CS_WAVES * CS_STAGE_FLOATS];   // 64 KiB: staging, then the partial sums
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -40,7 +51,7 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallParam
     const int b = t / (tiles_x * tiles_y);
     t -= b * tiles_x * tiles_y;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
-    const int half = blockIdx.y;
+    const int half = NH == 1 ? (int)blockIdx.y : 0;
     const int y0 = ty * CS_TH, x0 = tx * CS_TW;
     const int cw = p.Cin / CS_WAVES;                             // channels reduced by this wave
     const size_t plane = (size_t)p.H * p.W;
@@ -58,7 +69,8 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallParam
     constexpr int LW = TAPS == 9 ? 16 : CS_TW;
     constexpr int PIX = TAPS == 9 ? 104 : CS_TW * CS_TH;         // channel pitch in floats
     constexpr int OFF = TAPS == 9 ? 1 : 0;
-    constexpr int CH = TAPS == 9 ? 16 : 64;                      // 16 x 104 / 64 x 32 floats <= CS_STAGE_FLOATS
+    constexpr int CH = TAPS == 9 ? 16 : (NH == 2 ? 32 : 64);     // 16 x 104 / 64 x 32 floats <= CS_STAGE_FLOATS; NH = 2 holds
+                                                                 // weights of both halves: fewer groups per chunk to stay in 128 VGPRs
     constexpr int GQ = CH / 8;
     static_assert(CH * PIX <= CS_STAGE_FLOATS, "chunk must fit the wave's LDS slice");
     const int groups = cw / 8;                                   // pieces (4 k-steps = 8 channels) per tap
@@ -67,14 +79,18 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallParam
     // with the VALU; this kernel ran 4.7 VALU instructions per MFMA with plain pointers)
     const int wbytes = TAPS * groups * PIECE_BYTES;              // this wave's slice of the packed weight
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.w + ((size_t)(half * CS_WAVES + wave) * TAPS * groups) * WL_PIECE), 0, wbytes, 0x00020000);
+        (void*)(p.w + ((size_t)(half * CS_WAVES + wave) * TAPS * groups) * WL_PIECE), 0,
+        NH == 1 ? wbytes : CS_WAVES * wbytes + wbytes, 0x00020000);
     const int lane_off = lane * 16;
-    f32x4 acur[GQ], anext[GQ];
+    const int half_bytes = CS_WAVES * wbytes;                    // distance to the same wave's slice of the other output half
+    f32x4 a[2][NH][GQ];
     {
         const int g0n = groups < GQ ? groups : GQ;
 #pragma unroll
-        for (int g = 0; g < GQ; ++g)
-            if (g < g0n) acur[g] = ld_piece(wrs, lane_off, g * PIECE_BYTES);
+        for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+            for (int g = 0; g < GQ; ++g)
+                if (g < g0n) a[0][hh][g] = ld_piece(wrs, lane_off, hh * half_bytes + g * PIECE_BYTES);
     }
 
     // a lane keeps one staged position for the whole kernel (3x3: lanes 0..59 = the 6 x 10 halo of one channel per
@@ -95,9 +111,11 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallParam
     float* __restrict__ ldst = mine + csel * PIX + (TAPS == 9 ? ly * LW + lx : pp);
     const int pix_off = (j / CS_TW) * LW + (j % CS_TW);          // this lane's pixel inside the staged tile (tap (0,0))
 
-    f32x16 acc;
+    f32x16 acc[NH];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[hh][r] = 0.0f;
     for (int cbase = 0; cbase < cw; cbase += CH) {
         const int cc = cw - cbase < CH ? cw - cbase : CH;        // channels in this chunk (multiple of 8)
         const int gcount = cc / 8, gbase = cbase / 8;
@@ -112,46 +130,70 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallParam
             for (int u = 0; u < 8 / CPI; ++u)
                 if (mine_lane) ldst[(c0 + u * CPI) * PIX] = ok ? v[u] : 0.0f;
         }
-        // ---- this chunk's share of the reduction: k-step = (tap, channel pair)
+        // ---- this chunk's share of the reduction: k-step = (tap, channel pair).  The pieces of tap t sit in
+        // a[t & 1] and tap t+1's are fetched into the other buffer meanwhile (static indices: no register copies
+        // inside a chunk); FULL chunks (all GQ groups present, the common case) run without per-group branches.
+        auto taps = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            if (tap + 1 < TAPS) {
+            for (int tap = 0; tap < TAPS; ++tap) {
+                f32x4 (&cur)[NH][GQ] = a[tap & 1];
+                f32x4 (&nxt)[NH][GQ] = a[(tap + 1) & 1];
 #pragma unroll
-                for (int g = 0; g < GQ; ++g)
-                    if (g < gcount) anext[g] = ld_piece(wrs, lane_off, ((tap + 1) * groups + gbase + g) * PIECE_BYTES);
-            } else {                                             // last tap: tap 0 of the next chunk
+                for (int hh = 0; hh < NH; ++hh) {
+                    if (tap + 1 < TAPS) {
 #pragma unroll
-                for (int g = 0; g < GQ; ++g)
-                    if (g < gnext) anext[g] = ld_piece(wrs, lane_off, (gbase + GQ + g) * PIECE_BYTES);
-            }
-            const int toff = TAPS == 9 ? (tap / 3) * LW + (tap % 3) : 0;
-            const float* __restrict__ bsrc = mine + h * PIX + pix_off + toff;
+                        for (int g = 0; g < GQ; ++g)
+                            if (FULL || g < gcount)
+                                nxt[hh][g] = ld_piece(wrs, lane_off, hh * half_bytes + ((tap + 1) * groups + gbase + g) * PIECE_BYTES);
+                    } else {                                     // last tap: tap 0 of the next chunk
 #pragma unroll
-            for (int g = 0; g < GQ; ++g) {
-                if (g < gcount) {
+                        for (int g = 0; g < GQ; ++g)
+                            if (g < gnext) nxt[hh][g] = ld_piece(wrs, lane_off, hh * half_bytes + (gbase + GQ + g) * PIECE_BYTES);
+                    }
+                }
+                const int toff = TAPS == 9 ? (tap / 3) * LW + (tap % 3) : 0;
+                const float* __restrict__ bsrc = mine + h * PIX + pix_off + toff;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = MFMA32(acur[g][e], bsrc[(8 * g + 2 * e) * PIX], acc);   // channel cbase + 8g + 2e + h
+                for (int g = 0; g < GQ; ++g) {
+                    if (FULL || g < gcount) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float bv = bsrc[(8 * g + 2 * e) * PIX];                                // channel cbase + 8g + 2e + h
+#pragma unroll
+                            for (int hh = 0; hh < NH; ++hh) acc[hh] = MFMA32(cur[hh][g][e], bv, acc[hh]);
+                        }
+                    }
                 }
             }
+        };
+        if (gcount == GQ) taps(TagTrue{});
+        else taps(TagFalse{});
+        if ((TAPS & 1) != 0) {                                   // odd tap count: the next chunk's tap 0 landed in a[1]
 #pragma unroll
-            for (int g = 0; g < GQ; ++g) acur[g] = anext[g];
+            for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+                for (int g = 0; g < GQ; ++g) a[0][hh][g] = a[1][hh][g];
         }
     }
 
     // ---- sum the 8 partial tiles through LDS, then the epilogue
     __syncthreads();                                             // every wave is done reading its staged slice
 #pragma unroll
-    for (int r = 0; r < 16; ++r) lds[(wave * 16 + r) * 64 + lane] = acc[r];
+    for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds[((wave * NH + hh) * 16 + r) * 64 + lane] = acc[hh][r];
     __syncthreads();
     const int y = y0 + j / CS_TW, x = x0 + j % CS_TW;
     const bool inside = (y < p.H) && (x < p.W);
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {                             // wave w finishes accumulator registers 2w, 2w+1
-        const int r = 2 * wave + rr;
+    for (int rr = 0; rr < 2 * NH; ++rr) {                        // wave w finishes 2 NH of the 16 NH accumulator rows
+        const int row = 2 * NH * wave + rr;
+        const int hh = row / 16, r = row % 16;
         float v = 0.0f;
 #pragma unroll
-        for (int w8 = 0; w8 < CS_WAVES; ++w8) v += lds[(w8 * 16 + r) * 64 + lane];
-        const int co = 32 * half + (r & 3) + 8 * (r >> 2) + 4 * h;
+        for (int w8 = 0; w8 < CS_WAVES; ++w8) v += lds[((w8 * NH + hh) * 16 + r) * 64 + lane];
+        const int co = 32 * (NH == 1 ? half : hh) + (r & 3) + 8 * (r >> 2) + 4 * h;
         v += p.bias[co];
         if (p.relu) v = v > 0.0f ? v : 0.0f;
         if (inside) {
@@ -163,19 +205,24 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallParam
     }
 }
 
-static int launch_conv_small(void* stream, const ConvSmallParams& p, int taps) {
+static int launch_conv_ksplit(void* stream, const ConvKsplitParams& p, int taps) {
     const int tiles = ((p.W + CS_TW - 1) / CS_TW) * ((p.H + CS_TH - 1) / CS_TH) * p.B;
-    const dim3 grid(tiles, 2);
-    if (taps == 9)
-        hipLaunchKernelGGL(conv_small_kernel<9>, grid, dim3(512), 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(conv_small_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
+    // both output halves per workgroup once the tiles alone give every CU two workgroups; otherwise one half each
+    const bool both = tiles >= 512;
+    const dim3 grid(tiles, both ? 1 : 2);
+    if (taps == 9) {
+        if (both) hipLaunchKernelGGL((conv_ksplit_kernel<9, 2>), grid, dim3(512), 0, (hipStream_t)stream, p);
+        else      hipLaunchKernelGGL((conv_ksplit_kernel<9, 1>), grid, dim3(512), 0, (hipStream_t)stream, p);
+    } else {
+        if (both) hipLaunchKernelGGL((conv_ksplit_kernel<1, 2>), grid, dim3(512), 0, (hipStream_t)stream, p);
+        else      hipLaunchKernelGGL((conv_ksplit_kernel<1, 1>), grid, dim3(512), 0, (hipStream_t)stream, p);
+    }
     return hip_status(hipGetLastError());
 }
 
 extern "C" {
 
-int diinn_conv_small(void* stream, const float* in_dev, long long in_batch_stride, int Cin, int taps,
+int diinn_conv_ksplit(void* stream, const float* in_dev, long long in_batch_stride, int Cin, int taps,
                      const float* packed_w_dev, const float* bias_dev,
                      const float* res_dev, long long res_batch_stride,
                      float* out0_dev, long long out0_batch_stride, float* out1_dev, long long out1_batch_stride,
@@ -186,11 +233,11 @@ int diinn_conv_small(void* stream, const float* in_dev, long long in_batch_strid
     if (taps != 9 && taps != 1) return DIINN_ERR_UNSUPPORTED;
     if (Cin <= 0 || Cin % 64) return DIINN_ERR_UNSUPPORTED;
     if ((long long)((W + CS_TW - 1) / CS_TW) * ((H + CS_TH - 1) / CS_TH) * B > 2147483647LL) return DIINN_ERR_TOO_LARGE;
-    ConvSmallParams p;
+    ConvKsplitParams p;
     p.in = in_dev; p.w = packed_w_dev; p.bias = bias_dev; p.res = res_dev; p.out0 = out0_dev; p.out1 = out1_dev;
     p.in_bs = in_batch_stride; p.out0_bs = out0_batch_stride; p.out1_bs = out1_batch_stride; p.res_bs = res_batch_stride;
     p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0;
-    return launch_conv_small(stream, p, taps);
+    return launch_conv_ksplit(stream, p, taps);
 }
 
 size_t diinn_rdn_packed_floats(void) {
@@ -219,7 +266,7 @@ int diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packed_d
     const float* bias = biases_dev;
     auto conv = [&](const float* in, long long in_bs, int cin, int taps, const float* res, long long res_bs,
                     float* o0, long long o0_bs, float* o1, long long o1_bs, int relu) {
-        const int s = diinn_conv_small(stream, in, in_bs, cin, taps, w, bias, res, res_bs, o0, o0_bs, o1, o1_bs, relu, B, H, W);
+        const int s = diinn_conv_ksplit(stream, in, in_bs, cin, taps, w, bias, res, res_bs, o0, o0_bs, o1, o1_bs, relu, B, H, W);
         w += (size_t)64 * cin * taps;
         bias += 64;
         return s;

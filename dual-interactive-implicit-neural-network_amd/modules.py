@@ -70,8 +70,8 @@ class RDB(nn.Module):
         return self.LFF(buf) + x
 
 
-def pack_conv_small(weight: torch.Tensor) -> torch.Tensor:
-    """Conv weight [64, Cin, kh, kw] (Cin % 64 == 0; 3x3 or 1x1) -> the layout ``diinn_conv_small`` reads
+def pack_conv_ksplit(weight: torch.Tensor) -> torch.Tensor:
+    """Conv weight [64, Cin, kh, kw] (Cin % 64 == 0; 3x3 or 1x1) -> the layout ``diinn_conv_ksplit`` reads
     (include/diinn_hip.h): [half 2][wave 8][tap][group][lane 64][4] with cout = 32 half + (lane & 31) and
     input channel = wave*Cin/8 + 8 group + 2 e + (lane >> 5)."""
     co, cin, kh, kw = weight.shape
@@ -84,13 +84,13 @@ def pack_conv_small(weight: torch.Tensor) -> torch.Tensor:
 
 class RDN(nn.Module):
     _CONFIGS = {"A": (20, 6, 32), "B": (16, 8, 64)}
-    # Inference on feature maps of up to this many pixels (batch included) runs the trunk on conv_small_kernel
-    # (C ABI diinn_rdn_forward): a 64-output convolution on a 48x48 map has 72 MFMA tiles, far too few for a
-    # library convolution's output-parallel launch, so the HIP path splits the reduction over 8 waves per tile
-    # instead.  Measured (tools/enc_small_time.py, HIP vs MIOpen eager): 2.3 vs 6.8 ms at 48x48, 6.0 vs 7.6-8.6
-    # at 96x96, 8.5 vs 7.7-9.8 at 128x128, 18.2 vs 20.2-20.6 at 192x192, 32.7 vs 28.3-31.1 at 256x256: MIOpen
-    # keeps the large maps.  None disables the HIP trunk.
-    hip_trunk_max_pixels: Optional[int] = 192 * 192
+    # Inference (no autograd, fp32, config 'B') runs the trunk -- everything after SFENet1 -- on conv_ksplit_kernel
+    # (C ABI diinn_rdn_forward, csrc/diinn_encoder.hip): workgroups split the reduction over their 8 waves, which
+    # suits convolutions with 64 outputs and up to 1024 inputs at every map size.  Measured (tools/enc_trunk_time.py,
+    # HIP vs MIOpen eager): 2.1 vs 6.8 ms at 48x48, 5.9 vs 7.6 at 96x96, 7.0 vs 7.9 at 128x128, 16.1 vs 20.2 at
+    # 192x192, 25.1 vs 28.1 at 256x256, 55.4 vs 60.2 at 384x384, 99.7 vs 108.4 at 512x512.  The attribute caps the
+    # batch*H*W that takes this path (workspace: 2,240 floats per pixel); None disables it (MIOpen everywhere).
+    hip_trunk_max_pixels: Optional[int] = 2048 * 2048
 
     def __init__(self, G0: int = 64, RDNkSize: int = 3, RDNconfig: str = "B", n_colors: int = 3):
         super().__init__()
@@ -118,7 +118,7 @@ class RDN(nn.Module):
         layers = self._trunk_layers()
         key = (str(device),) + tuple((l.weight.data_ptr(), l.weight._version, l.bias._version) for l in layers)
         if self._hip_pack is None or self._hip_key != key:
-            w = torch.cat([pack_conv_small(l.weight) for l in layers]).to(device)
+            w = torch.cat([pack_conv_ksplit(l.weight) for l in layers]).to(device)
             b = torch.cat([l.bias.detach().to(torch.float32) for l in layers]).to(device)
             self._hip_pack, self._hip_key = (w, b), key
         return self._hip_pack

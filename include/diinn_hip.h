@@ -240,11 +240,11 @@ int    diinn_metasr_decode(void* stream, const float* feat_dev, const float* pac
                            float* out_dev, int B, int H, int W, int Hu, int Wu);
 int    diinn_metasr_make_axis_tables(int n_in, int n_out, int32_t* idx, float* rel, float* r_rev);
 
-/* ---- RDN encoder trunk for small feature maps --------------
+/* ---- RDN encoder trunk ------------------------------------
  * Replaces: RDN.forward after SFENet1 (rdn.py:95-105), config 'B' (16 RDBs x 8 dense 3x3 convs, growth 64,
- * 1x1 local/global fusion), for maps where a library convolution is launch/latency-bound (48x48: the
- * reference's runtime_test.py and training patches).
- * diinn_conv_small: one 64-output convolution (taps = 9: 3x3 zero-padded, 1: 1x1) over Cin % 64 == 0 input
+ * 1x1 local/global fusion), inference.  Split-K convolution kernel (csrc/diinn_encoder.hip): faster than the
+ * library convolution from 48x48 (3x: launch/latency-bound there) to 512x512 (1.09x) feature maps.
+ * diinn_conv_ksplit: one 64-output convolution (taps = 9: 3x3 zero-padded, 1: 1x1) over Cin % 64 == 0 input
  *   channel planes at in_dev + b*in_batch_stride + c*H*W; epilogue = + bias, optional ReLU, optional
  *   + residual, written to one or two destinations (element strides in floats).  packed_w_dev holds the
  *   weight W[64][Cin][taps] as [half 2][wave 8][tap][group Cin/64][lane 64][4]:
@@ -253,7 +253,7 @@ int    diinn_metasr_make_axis_tables(int n_in, int n_out, int32_t* idx, float* r
  *   caller), packed_dev = the 147 packed weights in execution order (SFENet2; per block: 8 dense convs, LFF;
  *   GFF.0, GFF.1), biases_dev = their 147 x 64 biases, workspace_dev = diinn_rdn_workspace_floats floats,
  *   out_dev [B,64,H,W]. */
-int    diinn_conv_small(void* stream, const float* in_dev, long long in_batch_stride, int Cin, int taps,
+int    diinn_conv_ksplit(void* stream, const float* in_dev, long long in_batch_stride, int Cin, int taps,
                         const float* packed_w_dev, const float* bias_dev,
                         const float* res_dev, long long res_batch_stride,
                         float* out0_dev, long long out0_batch_stride, float* out1_dev, long long out1_batch_stride,

@@ -1,5 +1,5 @@
-"""RDN encoder trunk on conv_small_kernel: packing layout on CPU; on the GPU, single
-convolutions and the whole trunk against the same network on PyTorch-ROCm / MIOpen."""
+"""RDN encoder trunk on conv_ksplit_kernel: packing layout on CPU; on the GPU, single
+convolutions (both kernel variants) and the whole trunk against the same network on PyTorch-ROCm / MIOpen."""
 import numpy as np
 import pytest
 import torch
@@ -8,12 +8,12 @@ import torch.nn.functional as F
 import diinn_amd.synth as synth
 
 
-def test_pack_conv_small_layout():
+def test_pack_conv_ksplit_layout():
     import diinn_amd.modules as M
     rng = np.random.default_rng(0)
     for cin, k in ((64, 3), (192, 3), (576, 1)):
         w = torch.from_numpy(rng.standard_normal((64, cin, k, k)).astype(np.float32))
-        packed = M.pack_conv_small(w).numpy()
+        packed = M.pack_conv_ksplit(w).numpy()
         taps, groups, cw = k * k, cin // 64, cin // 8
         assert packed.size == 64 * cin * taps
         pk = packed.reshape(2, 8, taps, groups, 64, 4)
@@ -22,12 +22,12 @@ def test_pack_conv_small_layout():
             co, ch = 32 * half + (lane & 31), wave * cw + 8 * g + 2 * e + (lane >> 5)
             assert pk[half, wave, tap, g, lane, e] == w[co, ch, tap // k, tap % k]
     with pytest.raises(ValueError):
-        M.pack_conv_small(torch.zeros(64, 3, 3, 3))
+        M.pack_conv_ksplit(torch.zeros(64, 3, 3, 3))
 
 
 @pytest.mark.gpu
-def test_conv_small_kernel_matches_torch():
-    """diinn_conv_small: 3x3 / 1x1, ReLU, residual, two destinations, strided channel-plane views, ragged maps."""
+def test_conv_ksplit_kernel_matches_torch():
+    """diinn_conv_ksplit: 3x3 / 1x1, ReLU, residual, two destinations, strided channel-plane views, ragged maps."""
     import ctypes as C
     import diinn_amd._native as N
     import diinn_amd.modules as M
@@ -38,7 +38,9 @@ def test_conv_small_kernel_matches_torch():
     ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
     for (b, cin, k, h, w, relu, use_res, two) in [(1, 64, 3, 48, 48, 1, 0, 0), (2, 320, 3, 13, 21, 1, 0, 1),
                                                   (1, 576, 1, 48, 48, 0, 1, 1), (1, 1024, 1, 9, 7, 0, 0, 0),
-                                                  (1, 512, 3, 5, 3, 0, 1, 0)]:
+                                                  (1, 512, 3, 5, 3, 0, 1, 0),
+                                                  # >= 512 tiles: the both-output-halves variant of the kernel
+                                                  (1, 192, 3, 128, 136, 1, 0, 1), (2, 576, 1, 70, 61, 0, 1, 0)]:
         total = max(cin, 64) + 64
         buf = torch.randn((b, total, h, w), device=dev, generator=gen)          # input = first cin planes of a larger buffer
         wt = torch.randn((64, cin, k, k), device=dev, generator=gen) / (cin * k * k) ** 0.5
@@ -46,8 +48,8 @@ def test_conv_small_kernel_matches_torch():
         res = torch.randn((b, 64, h, w), device=dev, generator=gen) if use_res else None
         out0 = torch.full((b, 64, h, w), float("nan"), device=dev)
         out1 = torch.full((b, 96, h, w), float("nan"), device=dev) if two else None
-        packed = M.pack_conv_small(wt).to(dev)
-        st = lib.diinn_conv_small(stream, ptr(buf), total * h * w, cin, k * k, ptr(packed), ptr(bias),
+        packed = M.pack_conv_ksplit(wt).to(dev)
+        st = lib.diinn_conv_ksplit(stream, ptr(buf), total * h * w, cin, k * k, ptr(packed), ptr(bias),
                                   ptr(res) if use_res else None, 64 * h * w, ptr(out0), 64 * h * w,
                                   ptr(out1[:, 32:]) if two else None, 96 * h * w, relu, b, h, w)
         assert st == 0
@@ -61,7 +63,7 @@ def test_conv_small_kernel_matches_torch():
         assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (cin, k, h, w, err)
         if two:
             assert torch.equal(out1[:, 32:96], out0) and torch.isnan(out1[:, :32]).all()
-    assert lib.diinn_conv_small(stream, ptr(buf), 1, 96, 9, ptr(packed), ptr(bias), None, 0, ptr(out0), 1, None, 0, 0, 1, 4, 4) == N.ERR_UNSUPPORTED
+    assert lib.diinn_conv_ksplit(stream, ptr(buf), 1, 96, 9, ptr(packed), ptr(bias), None, 0, ptr(out0), 1, None, 0, 0, 1, 4, 4) == N.ERR_UNSUPPORTED
 
 
 @pytest.mark.gpu
@@ -73,7 +75,7 @@ def test_rdn_hip_trunk_matches_miopen():
     shapes = {k: list(v.shape) for k, v in enc.state_dict().items()}
     enc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_for(shapes, 123, "enc.").items()})
     enc = enc.to(dev).eval()
-    for (b, h, w) in [(1, 48, 48), (2, 20, 33)]:
+    for (b, h, w) in [(1, 48, 48), (2, 20, 33), (1, 160, 112)]:          # the last one has >= 512 tiles (both-halves kernels)
         x = torch.from_numpy(synth.uniform(7, f"img:{b}x{h}x{w}", (b, 3, h, w), 0.5) + np.float32(0.5)).to(dev)
         with torch.no_grad():
             got = enc(x)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""RDN encoder forward: HIP trunk (conv_small_kernel, C ABI diinn_rdn_forward) vs PyTorch-ROCm/MIOpen, eager and
+"""RDN encoder forward: HIP trunk (conv_ksplit_kernel, C ABI diinn_rdn_forward) vs PyTorch-ROCm/MIOpen, eager and
 hipGraph-replayed, over input sizes -- locates the cross-over behind RDN.hip_trunk_max_pixels.
-usage: enc_small_time.py [SIZE ...]"""
+usage: enc_trunk_time.py [SIZE ...]"""
 import os
 import sys
 
