@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIINN_ABI_VERSION 1
+#define DIINN_ABI_VERSION 2   /* 2: training, LIIF/MetaSR, encoder-trunk entry points; packed image sections 8-9 */
 
 /* status codes */
 #define DIINN_OK                 0
