@@ -233,6 +233,7 @@ int diinn_conv_ksplit(void* stream, const float* in_dev, long long in_batch_stri
     if (taps != 9 && taps != 1) return DIINN_ERR_UNSUPPORTED;
     if (Cin <= 0 || Cin % 64) return DIINN_ERR_UNSUPPORTED;
     if ((long long)((W + CS_TW - 1) / CS_TW) * ((H + CS_TH - 1) / CS_TH) * B > 2147483647LL) return DIINN_ERR_TOO_LARGE;
+    if ((long long)(Cin / CS_WAVES) * H * W * 4 > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;   // a wave's channel slice is addressed with 32-bit byte offsets
     ConvKsplitParams p;
     p.in = in_dev; p.w = packed_w_dev; p.bias = bias_dev; p.res = res_dev; p.out0 = out0_dev; p.out1 = out1_dev;
     p.in_bs = in_batch_stride; p.out0_bs = out0_batch_stride; p.out1_bs = out1_batch_stride; p.res_bs = res_batch_stride;

@@ -90,7 +90,7 @@ class RDN(nn.Module):
     # HIP vs MIOpen eager): 2.1 vs 6.8 ms at 48x48, 5.9 vs 7.6 at 96x96, 7.0 vs 7.9 at 128x128, 16.1 vs 20.2 at
     # 192x192, 25.1 vs 28.1 at 256x256, 55.4 vs 60.2 at 384x384, 99.7 vs 108.4 at 512x512.  The attribute caps the
     # batch*H*W that takes this path (workspace: 2,240 floats per pixel); None disables it (MIOpen everywhere).
-    hip_trunk_max_pixels: Optional[int] = 2048 * 2048
+    hip_trunk_max_pixels: Optional[int] = 1024 * 1024          # byte offsets of a wave's channel slice stay far below 2^31
 
     def __init__(self, G0: int = 64, RDNkSize: int = 3, RDNconfig: str = "B", n_colors: int = 3):
         super().__init__()
