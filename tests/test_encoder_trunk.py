@@ -86,3 +86,23 @@ def test_rdn_hip_trunk_matches_miopen():
         assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (b, h, w, err)
     y = enc(x)                                               # grad enabled: the autograd (PyTorch) path
     assert y.requires_grad
+
+
+@pytest.mark.gpu
+def test_rdn_hip_trunk_odd_shapes():
+    """Degenerate and ragged maps (single pixel, single row / column, sizes that are not multiples of the 8x4 tile,
+    batch > 1) through the whole HIP trunk against MIOpen."""
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    enc = M.make_rdn().to(dev).eval()
+    for (b, h, w) in [(1, 1, 1), (1, 1, 13), (1, 11, 1), (2, 3, 2), (1, 37, 5), (3, 9, 10), (1, 4, 8), (1, 5, 9)]:
+        x = torch.rand(b, 3, h, w, device=dev)
+        with torch.no_grad():
+            got = enc(x)
+            enc.hip_trunk_max_pixels = None
+            ref = enc(x)
+            enc.hip_trunk_max_pixels = M.RDN.hip_trunk_max_pixels
+        assert got.shape == ref.shape == (b, 64, h, w)
+        err = float((got - ref).abs().max())
+        assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (b, h, w, err)
