@@ -12,8 +12,8 @@
 //   * small maps (48x48: the reference's runtime_test.py and training patches, 72 tiles): a workgroup per
 //     (tile, 32-output half) -- a library convolution is launch/latency-bound there (~35 us per layer);
 //   * maps with >= 512 tiles: both output halves per workgroup (half the staging and LDS reads per MFMA).
-// Measured against MIOpen (PyTorch-ROCm), whole encoder: 2.1 vs 6.8 ms at 48x48, 25.1 vs 28.1 ms at 256x256
-// (115 TFLOP/s), 99.7 vs 108.4 ms at 512x512 (tools/enc_trunk_time.py).
+// Measured against MIOpen (PyTorch-ROCm), whole encoder: 2.1 vs 6.8 ms at 48x48, 23.9 vs 28.1 ms at 256x256
+// (120 TFLOP/s), 96.9 vs 108.4 ms at 512x512 (tools/enc_trunk_time.py).
 // diinn_rdn_forward runs the whole trunk (everything after SFENet1) as 147 launches from C++.
 #include "diinn_device.h"
 
@@ -40,9 +40,11 @@ struct ConvKsplitParams {
 // NH = 2: both halves from the same staged features (half the staging and half the LDS reads per MFMA), for maps
 //         with enough tiles to fill the chip anyway.
 template <int TAPS, int NH>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))      // two workgroups of 8 waves per CU: <= 128 VGPRs
-void conv_ksplit_kernel(const ConvKsplitParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[CS_WAVES * CS_STAGE_FLOATS];   // 64 KiB: staging, then the partial sums
+__device__ __forceinline__ void conv_ksplit_body(const ConvKsplitParams& p) {
+    // staging slices of the 8 waves, then (one output half at a time) their partial sums: 3x3 layers stage 8 channels
+    // at a time (32 KiB per workgroup: three workgroups per CU), 1x1 layers 32 or 64 (64 KiB)
+    constexpr int SLICE = TAPS == 9 ? 1024 : CS_STAGE_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[CS_WAVES * SLICE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
@@ -56,7 +58,7 @@ void conv_ksplit_kernel(const ConvKsplitParams p) {
     const int cw = p.Cin / CS_WAVES;                             // channels reduced by this wave
     const size_t plane = (size_t)p.H * p.W;
     const float* __restrict__ src = p.in + (size_t)b * p.in_bs + (size_t)(wave * cw) * plane;
-    float* __restrict__ mine = lds + wave * CS_STAGE_FLOATS;
+    float* __restrict__ mine = lds + wave * SLICE;
 
     // The wave's channels go through its 8 KiB LDS slice in chunks of CH channels (two workgroups fit a CU, so one's
     // staging overlaps the other's MFMAs).  A pieces (weights) of one (chunk, tap): up to GQ groups of 8 channels, all
@@ -83,8 +85,9 @@ void conv_ksplit_kernel(const ConvKsplitParams p) {
         NH == 1 ? wbytes : CS_WAVES * wbytes + wbytes, 0x00020000);
     const int lane_off = lane * 16;
     const int half_bytes = CS_WAVES * wbytes;                    // distance to the same wave's slice of the other output half
+    constexpr bool PIPE = TAPS == 9;                             // 3x3 layers: the fully pipelined path below
     f32x4 a[2][NH][GQ];
-    {
+    if constexpr (!PIPE) {
         const int g0n = groups < GQ ? groups : GQ;
 #pragma unroll
         for (int hh = 0; hh < NH; ++hh)
@@ -116,6 +119,46 @@ void conv_ksplit_kernel(const ConvKsplitParams p) {
     for (int hh = 0; hh < NH; ++hh)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[hh][r] = 0.0f;
+    if constexpr (PIPE) {
+        // 3x3 layers, everything prefetched.  A chunk is 8 channels = one weight piece per (tap, half):
+        //  * weight pieces live in a ring of 3 taps and are requested two taps (16 NH MFMAs) before use; 9 taps per
+        //    chunk keep the ring phase equal from chunk to chunk, so every index is static and nothing is copied;
+        //  * the next chunk's 8 feature values per lane are requested before this chunk's MFMAs and stored to LDS
+        //    after them.
+        // Requests past the wave's slice are harmless: the descriptors' range checks return 0 / other slices' data
+        // that is never used.
+        f32x4 ring[3][NH];
+        float vpre[8];
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            ring[0][hh] = ld_piece(wrs, lane_off, hh * half_bytes + (0 * groups + 0) * PIECE_BYTES);
+            ring[1][hh] = ld_piece(wrs, lane_off, hh * half_bytes + (1 * groups + 0) * PIECE_BYTES);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vpre[u] = ld_act(irs, lsrc_off, (unsigned)u * plane_b);
+        for (int chunk = 0; chunk < groups; ++chunk) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (mine_lane) ldst[u * PIX] = ok ? vpre[u] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vpre[u] = ld_act(irs, lsrc_off, (unsigned)(8 * (chunk + 1) + u) * plane_b);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int nt = tap + 2;                          // tap fetched now: (chunk, nt) or (chunk + 1, nt - 9)
+#pragma unroll
+                for (int hh = 0; hh < NH; ++hh)
+                    ring[nt % 3][hh] = ld_piece(wrs, lane_off, hh * half_bytes +
+                                                ((nt < 9 ? nt : nt - 9) * groups + (nt < 9 ? chunk : chunk + 1)) * PIECE_BYTES);
+                const float* __restrict__ bsrc = mine + h * PIX + pix_off + (tap / 3) * LW + (tap % 3);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float bv = bsrc[(2 * e) * PIX];        // channel 8 chunk + 2e + h
+#pragma unroll
+                    for (int hh = 0; hh < NH; ++hh) acc[hh] = MFMA32(ring[tap % 3][hh][e], bv, acc[hh]);
+                }
+            }
+        }
+    } else
     for (int cbase = 0; cbase < cw; cbase += CH) {
         const int cc = cw - cbase < CH ? cw - cbase : CH;        // channels in this chunk (multiple of 8)
         const int gcount = cc / 8, gbase = cbase / 8;
@@ -177,33 +220,43 @@ void conv_ksplit_kernel(const ConvKsplitParams p) {
         }
     }
 
-    // ---- sum the 8 partial tiles through LDS, then the epilogue
-    __syncthreads();                                             // every wave is done reading its staged slice
-#pragma unroll
-    for (int hh = 0; hh < NH; ++hh)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) lds[((wave * NH + hh) * 16 + r) * 64 + lane] = acc[hh][r];
-    __syncthreads();
+    // ---- sum the 8 partial tiles through LDS (one output half per pass: 32 KiB), then the epilogue
     const int y = y0 + j / CS_TW, x = x0 + j % CS_TW;
     const bool inside = (y < p.H) && (x < p.W);
 #pragma unroll
-    for (int rr = 0; rr < 2 * NH; ++rr) {                        // wave w finishes 2 NH of the 16 NH accumulator rows
-        const int row = 2 * NH * wave + rr;
-        const int hh = row / 16, r = row % 16;
-        float v = 0.0f;
+    for (int hh = 0; hh < NH; ++hh) {
+        __syncthreads();                                         // every wave is done with the LDS contents of the previous phase
 #pragma unroll
-        for (int w8 = 0; w8 < CS_WAVES; ++w8) v += lds[((w8 * NH + hh) * 16 + r) * 64 + lane];
-        const int co = 32 * (NH == 1 ? half : hh) + (r & 3) + 8 * (r >> 2) + 4 * h;
-        v += p.bias[co];
-        if (p.relu) v = v > 0.0f ? v : 0.0f;
-        if (inside) {
-            const size_t o = (size_t)co * plane + (size_t)y * p.W + x;
-            if (p.res) v += p.res[(size_t)b * p.res_bs + o];
-            p.out0[(size_t)b * p.out0_bs + o] = v;
-            if (p.out1) p.out1[(size_t)b * p.out1_bs + o] = v;
+        for (int r = 0; r < 16; ++r) lds[(wave * 16 + r) * 64 + lane] = acc[hh][r];
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {                         // wave w finishes accumulator rows 2w, 2w+1 of this half
+            const int r = 2 * wave + rr;
+            float v = 0.0f;
+#pragma unroll
+            for (int w8 = 0; w8 < CS_WAVES; ++w8) v += lds[(w8 * 16 + r) * 64 + lane];
+            const int co = 32 * (NH == 1 ? half : hh) + (r & 3) + 8 * (r >> 2) + 4 * h;
+            v += p.bias[co];
+            if (p.relu) v = v > 0.0f ? v : 0.0f;
+            if (inside) {
+                const size_t o = (size_t)co * plane + (size_t)y * p.W + x;
+                if (p.res) v += p.res[(size_t)b * p.res_bs + o];
+                p.out0[(size_t)b * p.out0_bs + o] = v;
+                if (p.out1) p.out1[(size_t)b * p.out1_bs + o] = v;
+            }
         }
     }
 }
+
+// 3x3 layers: 32 KiB of LDS and <= 80 VGPRs -> three workgroups (6 waves per SIMD) share a CU, which covers one
+// workgroup's prologue and reduction phases with the others' MFMAs; 1x1 layers: two workgroups per CU.
+template <int NH>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6)))
+void conv_ksplit_kernel_3x3(const ConvKsplitParams p) { conv_ksplit_body<9, NH>(p); }
+
+template <int NH>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
+void conv_ksplit_kernel_1x1(const ConvKsplitParams p) { conv_ksplit_body<1, NH>(p); }
 
 static int launch_conv_ksplit(void* stream, const ConvKsplitParams& p, int taps) {
     const int tiles = ((p.W + CS_TW - 1) / CS_TW) * ((p.H + CS_TH - 1) / CS_TH) * p.B;
@@ -211,11 +264,11 @@ static int launch_conv_ksplit(void* stream, const ConvKsplitParams& p, int taps)
     const bool both = tiles >= 512;
     const dim3 grid(tiles, both ? 1 : 2);
     if (taps == 9) {
-        if (both) hipLaunchKernelGGL((conv_ksplit_kernel<9, 2>), grid, dim3(512), 0, (hipStream_t)stream, p);
-        else      hipLaunchKernelGGL((conv_ksplit_kernel<9, 1>), grid, dim3(512), 0, (hipStream_t)stream, p);
+        if (both) hipLaunchKernelGGL(conv_ksplit_kernel_3x3<2>, grid, dim3(512), 0, (hipStream_t)stream, p);
+        else      hipLaunchKernelGGL(conv_ksplit_kernel_3x3<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
     } else {
-        if (both) hipLaunchKernelGGL((conv_ksplit_kernel<1, 2>), grid, dim3(512), 0, (hipStream_t)stream, p);
-        else      hipLaunchKernelGGL((conv_ksplit_kernel<1, 1>), grid, dim3(512), 0, (hipStream_t)stream, p);
+        if (both) hipLaunchKernelGGL(conv_ksplit_kernel_1x1<2>, grid, dim3(512), 0, (hipStream_t)stream, p);
+        else      hipLaunchKernelGGL(conv_ksplit_kernel_1x1<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
     }
     return hip_status(hipGetLastError());
 }

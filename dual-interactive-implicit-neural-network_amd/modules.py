@@ -87,8 +87,8 @@ class RDN(nn.Module):
     # Inference (no autograd, fp32, config 'B') runs the trunk -- everything after SFENet1 -- on conv_ksplit_kernel
     # (C ABI diinn_rdn_forward, csrc/diinn_encoder.hip): workgroups split the reduction over their 8 waves, which
     # suits convolutions with 64 outputs and up to 1024 inputs at every map size.  Measured (tools/enc_trunk_time.py,
-    # HIP vs MIOpen eager): 2.1 vs 6.8 ms at 48x48, 5.9 vs 7.6 at 96x96, 7.0 vs 7.9 at 128x128, 16.1 vs 20.2 at
-    # 192x192, 25.1 vs 28.1 at 256x256, 55.4 vs 60.2 at 384x384, 99.7 vs 108.4 at 512x512.  The attribute caps the
+    # HIP vs MIOpen eager): 2.1 vs 6.8 ms at 48x48, 5.0 vs 7.6 at 96x96, 6.5 vs 7.9 at 128x128, 14.7 vs 20.2 at
+    # 192x192, 23.9 vs 28.1 at 256x256, 53.5 vs 60.2 at 384x384, 96.9 vs 108.4 at 512x512.  The attribute caps the
     # batch*H*W that takes this path (workspace: 2,240 floats per pixel); None disables it (MIOpen everywhere).
     hip_trunk_max_pixels: Optional[int] = 1024 * 1024          # byte offsets of a wave's channel slice stay far below 2^31
 
