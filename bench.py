@@ -5,15 +5,22 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N > 1 is launched by the driver as
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1], "c2"): 256x256 LR encoder features, x4 decode
--> 1024x1024 HR, fp32, synthetic features (seeded N(0,1)) and synthetic weights
-drawn from the reference decoder's default-init distribution (synth.py).
-A *step* is one full pass of the hot path over one batch: P precompute (hoisted
-3x3 conv) + fused decode kernel, inputs already resident in HBM.
-N GPUs (weak scaling): the LR map grows to (256*N) x 256 and the HR grid
-(1024*N) x 1024 is sharded into N row bands, one per rank; each step first hands
-every rank its feature rows (+1-row halo) point-to-point from rank 0 over
-RCCL/xGMI, then decodes its band.  Outputs stay sharded (no gather).
+Default workload (BASELINE.json configs[1], "c2"): 256x256 LR encoder features, x4 decode
+-> 1024x1024 HR, fp32, synthetic features (seeded N(0,1)) and synthetic weights drawn from the
+reference decoder's default-init distribution (synth.py).  A *step* is one full pass of the hot
+path over one batch: feature hand-off (N>1) + P precompute (hoisted 3x3 conv) + fused decode
+kernel, inputs already resident in HBM on the rank that holds the encoder output.
+
+--workload {c1,c2,c3,tgt,c4,c5} selects another BASELINE config (tgt = the north-star target
+1024^2 -> 4096^2).  --scaling weak (default): every GPU decodes one whole workload image (the LR
+map grows to (H*N) x W, one row band per rank).  --scaling strong: ONE workload image is split
+into N row bands (BASELINE configs c3/c4: "tiled across 2 then 4", "8 GPUs tile-sharded").
+Either way each rank holds band-sized buffers only and receives its feature rows (+1-row halo)
+point-to-point from rank 0 over RCCL/xGMI; with one rank the same code path runs with an empty
+exchange.  Outputs stay sharded; --gather additionally times assembling the image on rank 0.
+
+After the timed loop the output that was timed is compared with the CPU oracle on a few HR row
+bands ("checked"); the run fails if that is out of tolerance.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -23,6 +30,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -33,12 +41,21 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-LR = 256           # per-GPU LR band height and LR width
-SCALE = 4
+# BASELINE.json configs (LR map, HR size); "tgt" is the north_star target shape
+WORKLOADS = {
+    "c1": ((48, 48), (96, 96), "c1: 48x48 LR, x2 decode -> 96x96 HR"),
+    "c2": ((256, 256), (1024, 1024), "c2: 256x256 LR encoder features, x4 decode -> 1024x1024 HR"),
+    "c3": ((512, 512), (2048, 2048), "c3: 512x512 LR, x4 decode -> 2048x2048 HR"),
+    "tgt": ((1024, 1024), (4096, 4096), "north-star target: 1024x1024 LR, x4 decode -> 4096x4096 HR"),
+    "c4": ((1024, 1024), (8192, 8192), "c4: 1024x1024 LR, x8 decode -> 8192x8192 HR"),
+    "c5": ((720, 1280), (2376, 4224), "c5: 720x1280 LR, x3.3 decode -> 2376x4224 HR"),
+}
 FLOP_DECODE_PER_PX = 789_504.0        # 3 stacked 512x256 layers + Q0 + head, 2*MAC
 FLOP_P_PER_CELL = 1_179_648.0         # hoisted 3x3 conv 64 -> 1024, 2*MAC
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (only for --compute bf16)
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (only for --compute bf16*)
+# parity bound of the post-run check: f32 = north_star's 1e-4; bf16 restated (SURVEY §8 d4 / DESIGN §4.3)
+CHECK_TOL = {"f32": (1e-4, True), "bf16": (2e-3, False), "bf16_full": (3e-3, False)}
 
 
 def parse():
@@ -46,13 +63,19 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: one workload image per GPU; strong: one image split into N row bands")
     ap.add_argument("--sin", choices=["accurate", "hw", "hw_reduced"], default=os.environ.get("DIINN_SIN", "default"),
                     help="sine evaluation of the synthesis branch (default: the library default, hw_reduced)")
     ap.add_argument("--compute", choices=["f32", "bf16", "bf16_full"], default="f32",
                     help="arithmetic of the per-pixel layers; f32 is the reference's precision and the only "
                          "valid headline (bf16 is BASELINE config 5's optional path, 2e-3 relative)")
     ap.add_argument("--dist-mode", choices=["halo", "bcast"], default="halo")
+    ap.add_argument("--gather", action="store_true", help="also time assembling the image on rank 0 (reported "
+                                                           "as gather_ms, never part of value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
     return ap.parse_args()
 
 
@@ -73,30 +96,82 @@ def effective_cores() -> int:
     return cores
 
 
-def cpu_baseline(sd, feat_np, size):
-    """Reference-faithful CPU decode (oracle/) timed on this host, bounded sample of the same workload."""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import diinn_oracle as orc
+    return orc
+
+
+def cpu_baseline(sd, feat_cpu, size, wl_name):
+    """Reference-faithful CPU decode (oracle/) timed on this host: a bounded sample of the benchmarked
+    workload on all usable cores (the headline `value`), plus the SURVEY §8 d7 / BASELINE.md §3 legs:
+    one thread, config 1 (48^2 -> 96^2) and 128^2 -> 512^2."""
+    orc = _oracle()
+    import diinn_amd.synth as synth
     cores = effective_cores()
-    torch.set_num_threads(cores)
     hu, wu = size
-    # probe: 64 HR rows; then the reported sample is sized for roughly 10-20 s of CPU work
-    t0 = time.perf_counter()
-    orc.decode_reference_form(sd, feat_np, size, 30000, row_range=(0, 64))
-    t_probe = time.perf_counter() - t0
-    rows = int(min(hu, max(64, (12.0 / max(t_probe, 1e-3)) * 64)))
-    rows -= rows % 64
-    rows = max(rows, 64)
-    t0 = time.perf_counter()
-    orc.decode_reference_form(sd, feat_np, size, 30000, row_range=(0, rows))
-    t = time.perf_counter() - t0
+    h = feat_cpu.shape[2]
+
+    def band(rows, threads):
+        torch.set_num_threads(threads)
+        idx, _ = orc.axis_tables(h, hu, orc.uses_small_output_kernel(hu, wu))
+        a1 = min(int(idx[rows - 1]) + 2, h)
+        crop = feat_cpu[:, :, :a1].contiguous()
+        t0 = time.perf_counter()
+        orc.decode_reference_form(sd, crop, size, 30000, row_range=(0, rows), feat_row0=0, full_h=h)
+        return time.perf_counter() - t0
+
+    def sized(threads, budget_s):
+        probe_rows = min(hu, 16)
+        t_probe = band(probe_rows, threads)
+        rows = int(min(hu, max(probe_rows, budget_s / max(t_probe, 1e-3) * probe_rows)))
+        if rows > 64:
+            rows -= rows % 64
+        t = band(rows, threads)
+        return rows, t
+
+    rows_n, t_n = sized(cores, 8.0)
+    rows_1, t_1 = sized(1, 3.0)
+
+    def whole(hw, out, threads, reps):
+        torch.set_num_threads(threads)
+        f = synth.encoder_features(123, 1, hw, hw)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            orc.decode_reference_form(sd, f, (out, out), 30000)
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
+    t_c1_n = whole(48, 96, cores, 7)
+    t_c1_1 = whole(48, 96, 1, 3)
+    t_128 = whole(128, 512, cores, 2)
+    torch.set_num_threads(cores)
     return {
-        "value": round(rows * wu / t / 1e6, 5),
+        "value": round(rows_n * wu / t_n / 1e6, 5),
         "unit": "Mpixels/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"c2 workload, HR rows 0..{rows} of {hu} ({rows * wu} px), reference-form torch-CPU oracle "
-                  f"(unfold -> nearest-exact -> 9 conv1x1 + cat + sin, bsize=30000), {t:.2f} s",
+        "cpu_model": cpu_model(),
+        "sample": f"{wl_name} workload, HR rows 0..{rows_n} of {hu} ({rows_n * wu} px), reference-form torch-CPU oracle "
+                  f"(unfold -> nearest-exact -> 9 conv1x1 + cat + sin, bsize=30000), {cores} threads, {t_n:.2f} s",
+        "one_thread": {"value": round(rows_1 * wu / t_1 / 1e6, 5), "cores": 1,
+                       "sample": f"same workload, HR rows 0..{rows_1}, {t_1:.2f} s"},
+        "c1_48x48_x2": {"value": round(96 * 96 / t_c1_n / 1e6, 5), "cores": cores, "ms": round(t_c1_n * 1e3, 2),
+                        "one_thread_value": round(96 * 96 / t_c1_1 / 1e6, 5), "one_thread_ms": round(t_c1_1 * 1e3, 2),
+                        "sample": "whole image, bsize=30000, median of 7 (n threads) / 3 (1 thread)"},
+        "lr128_x4": {"value": round(512 * 512 / t_128 / 1e6, 5), "cores": cores, "ms": round(t_128 * 1e3, 1),
+                     "sample": "128x128 -> 512x512 whole image, bsize=30000, median of 2"},
     }
 
 
@@ -110,14 +185,39 @@ def load_traffic():
         return None
 
 
+def check_band_rows(sd, feat_win_cpu, feat_row0, full_h, size, out_band_cpu, band_y0, rows_list, compute):
+    """max error of the timed output against the oracle on the given HR row ranges (inside this rank's band)."""
+    orc = _oracle()
+    tol_rel, floor_one = CHECK_TOL[compute]
+    worst, ok = 0.0, True
+    for (y0, y1) in rows_list:
+        ref = orc.decode_reference_form(sd, feat_win_cpu, size, 30000, row_range=(y0, y1),
+                                        feat_row0=feat_row0, full_h=full_h).numpy()
+        got = out_band_cpu[:, :, y0 - band_y0:y1 - band_y0].numpy()
+        err = float(abs(got - ref).max())
+        scale = float(abs(ref).max())
+        tol = tol_rel * (max(1.0, scale) if floor_one else scale)
+        worst = max(worst, err)
+        ok = ok and (err <= tol) and bool((got == got).all())
+    return worst, ok
+
+
+def pct(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    i = min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))
+    return xs[i]
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run, one rank "
+                         f"per GPU, and pass the same N as --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the DIINN decode path has no CPU implementation")
     torch.cuda.set_device(local_rank)
@@ -138,41 +238,47 @@ def main():
     sin_mode = {"accurate": N.SIN_ACCURATE, "hw": N.SIN_HW, "hw_reduced": N.SIN_HW_REDUCED,
                 "default": N.SIN_DEFAULT}[args.sin]
     sin_name = {N.SIN_ACCURATE: "accurate", N.SIN_HW: "hw", N.SIN_HW_REDUCED: "hw_reduced"}[sin_mode]
+    comp = N.COMPUTE[args.compute]
     sd = synth.decoder_state_dict(123)
     packed = D.pack_state_dict(sd).to(dev)
 
-    H, W = LR * world, LR
-    HU, WU = H * SCALE, W * SCALE
+    (h1, w1), (hu1, wu1), wl_label = WORKLOADS[args.workload]
+    mult = world if args.scaling == "weak" else 1
+    H, W, HU, WU = h1 * mult, w1, hu1 * mult, wu1
     shape = (1, 64, H, W)
+    # every rank draws the same map (same seed, same device type): rank 0's copy is the encoder output that is
+    # handed off, the others keep theirs only to verify what they received
     gen = torch.Generator(device=dev)
     gen.manual_seed(123)
-    feat = torch.randn(shape, device=dev, generator=gen) if rank == 0 else None
-    feat_buf = torch.zeros(shape, device=dev) if rank != 0 else None
-    workspace = torch.empty(H * W * 1024, device=dev)
-    out = torch.zeros((1, 3, HU, WU), device=dev)
+    feat_all = torch.randn(shape, device=dev, generator=gen)
+    feat = feat_all if rank == 0 else None
 
-    bands = S.all_bands(HU, world)
-    y0, y1 = bands[rank]
-    need = [S.feature_rows_for_band(H, D.lr_rows_for_band(H, HU, WU, a, b)) for (a, b) in bands]
-    r0, r1 = D.lr_rows_for_band(H, HU, WU, y0, y1)
+    dec = S.BandDecoder(shape, (HU, WU), packed, src=0, mode=args.dist_mode, sin_mode=sin_mode, compute=args.compute)
+    bd = dec.band
+    if bd.empty:
+        raise SystemExit("more ranks than HR rows")
     stream = torch.cuda.current_stream().cuda_stream
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    mk = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
+    ev = [(mk(), mk(), mk(), mk()) for _ in range(args.steps)]
 
     def step(i=None):
-        local = feat
-        if world > 1:
-            local = S.distribute_features(feat, shape, need, src=0, mode=args.dist_mode, device=dev, buf=feat_buf)
-        N.check(lib.diinn_precompute_P_ex(C.c_void_p(stream), C.c_void_p(local.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                          C.c_void_p(workspace.data_ptr()), 1, H, W, r0, r1, N.COMPUTE[args.compute]),
-                "diinn_precompute_P_ex")
         if i is not None:
             ev[i][0].record()
-        N.check(lib.diinn_decode_band_ex(C.c_void_p(stream), C.c_void_p(workspace.data_ptr()),
-                                         C.c_void_p(packed.data_ptr()), C.c_void_p(out.data_ptr()),
-                                         1, H, W, HU, WU, y0, y1, sin_mode, N.COMPUTE[args.compute]),
-                "diinn_decode_band_ex")
+        win, row0 = dec.handoff(feat)
         if i is not None:
             ev[i][1].record()
+        N.check(lib.diinn_precompute_P_win(C.c_void_p(stream), C.c_void_p(win.data_ptr()), row0, win.shape[2],
+                                           C.c_void_p(packed.data_ptr()), C.c_void_p(dec.p_win.data_ptr()),
+                                           bd.r0, bd.r1 - bd.r0, 1, H, W, bd.r0, bd.r1, comp), "diinn_precompute_P_win")
+        if i is not None:
+            ev[i][2].record()
+        N.check(lib.diinn_decode_band_win(C.c_void_p(stream), C.c_void_p(dec.p_win.data_ptr()), bd.r0, bd.r1 - bd.r0,
+                                          C.c_void_p(packed.data_ptr()), C.c_void_p(dec.out_band.data_ptr()),
+                                          bd.y0, bd.y1 - bd.y0, 1, H, W, HU, WU, bd.y0, bd.y1, sin_mode, comp),
+                "diinn_decode_band_win")
+        if i is not None:
+            ev[i][3].record()
+        return win, row0
 
     for _ in range(args.warmup):
         step()
@@ -182,7 +288,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        win, row0 = step(i)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -193,14 +299,65 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant kernel: decode_kernel, HIP-event duration on the launch stream (rank 0's band)
-    k_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
-    px_launch = (y1 - y0) * WU
+    # per-step HIP-event durations on the launch stream (this rank)
+    step_ms = [e[0].elapsed_time(e[3]) for e in ev]
+    hand_ms = [e[0].elapsed_time(e[1]) for e in ev]
+    p_ms = [e[1].elapsed_time(e[2]) for e in ev]
+    k_ms_all = [e[2].elapsed_time(e[3]) for e in ev]
+    k_ms = sum(k_ms_all) / max(len(k_ms_all), 1)
+    px_launch = (bd.y1 - bd.y0) * WU
     achieved = FLOP_DECODE_PER_PX * px_launch / (k_ms * 1e-3) / 1e12
+    p_mean = sum(p_ms) / max(len(p_ms), 1)
+    p_tflops = FLOP_P_PER_CELL * (bd.r1 - bd.r0) * W / (p_mean * 1e-3) / 1e12
+
+    # ---- the output that was timed, against the oracle (outside the timed region)
+    checked = None
+    if not args.no_check:
+        handoff_ok = True
+        if rank != 0:
+            handoff_ok = bool(torch.equal(win, feat_all[:, :, row0:row0 + win.shape[2]]))
+        nrows = min(4, bd.y1 - bd.y0)
+        mid = (bd.y0 + bd.y1) // 2
+        starts = sorted({bd.y0, max(bd.y0, min(bd.y1 - nrows, mid)), bd.y1 - nrows})
+        rows_list = [(s, s + nrows) for s in starts]
+        win_cpu = feat_all[:, :, bd.a0:bd.a1].cpu()
+        out_cpu = dec.out_band.cpu()
+        torch.set_num_threads(effective_cores())
+        err, ok = check_band_rows(sd, win_cpu, bd.a0, H, (HU, WU), out_cpu, bd.y0, rows_list, args.compute)
+        ok = ok and handoff_ok
+        if use_dist:
+            t = torch.tensor([err, 0.0 if ok else 1.0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            err, ok = float(t[0].item()), float(t[1].item()) == 0.0
+        checked = {"rows": [list(r) for r in rows_list], "rows_of": "rank 0's band; every rank checks its own",
+                   "max_err": err, "tol": f"{CHECK_TOL[args.compute][0]:g} x max(1,|ref|)" if CHECK_TOL[args.compute][1]
+                   else f"{CHECK_TOL[args.compute][0]:g} x max|ref|", "handoff_exact": handoff_ok, "ok": ok}
+
+    gather_ms = None
+    if args.gather:
+        full = torch.empty((1, 3, HU, WU), device=dev) if rank == 0 else None
+        for _ in range(2):
+            dec.gather(dec.out_band, dst=0, out=full)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        tg = time.perf_counter()
+        for _ in range(5):
+            dec.gather(dec.out_band, dst=0, out=full)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        gather_ms = (time.perf_counter() - tg) / 5 * 1e3
 
     if rank == 0:
         total_px = HU * WU
         ms_per_step = elapsed / args.steps * 1e3
+        bf = args.compute != "f32"
+        peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
+        if args.scaling == "weak":
+            wl = (f"{wl_label} per GPU, {HU}x{WU} HR total ({world} row band(s) of {hu1}x{WU}), B=1, mode=3")
+        else:
+            wl = (f"{wl_label}, split into {world} HR row band(s) of ~{HU // world}x{WU}, B=1, mode=3")
         res = {
             "metric": "decoded Mpixels/sec (DIINN implicit decoder, x4 on 256^2 LR)",
             "value": round(total_px * args.steps / elapsed / 1e6, 3),
@@ -210,34 +367,46 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.compute,
             "data": "synthetic",
             "config": {
-                "workload": f"c2: {LR}x{LR} LR encoder features per GPU, x{SCALE} decode -> "
-                            f"{HU}x{WU} HR total ({world} row band(s) of {LR * SCALE}x{WU}), B=1, mode=3",
+                "workload": wl, "name": args.workload,
                 "lr": [H, W], "hr": [HU, WU], "sin": sin_name,
                 "parallelism": f"hr-row-bands x{world}" + (f" ({args.dist_mode} feature hand-off)" if world > 1 else ""),
-                "step": "feature hand-off (N>1) + precompute_P + decode_kernel",
+                "step": "feature hand-off (N>1) + precompute_P + decode_kernel, band-sized buffers",
             },
+            "step_ms": {"min": round(min(step_ms), 4), "median": round(statistics.median(step_ms), 4),
+                        "p90": round(pct(step_ms, 0.9), 4), "mean_wall": round(ms_per_step, 4),
+                        "handoff_median": round(statistics.median(hand_ms), 4), "of": "rank 0, HIP events"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "decode_kernel" if args.compute == "f32" else "decode_bf16x2_kernel",
+                "kernel": "decode_kernel" if not bf else "decode_bf16 kernel",
                 "achieved": round(achieved, 3),
-                "peak": PEAK_F32_MFMA_TFLOPS if args.compute == "f32" else PEAK_BF16_MFMA_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": round(achieved / (PEAK_F32_MFMA_TFLOPS if args.compute == "f32" else PEAK_BF16_MFMA_TFLOPS), 4),
+                "frac": round(achieved / peak, 4),
                 "kernel_ms": round(k_ms, 4),
+                "kernel_ms_min": round(min(k_ms_all), 4),
                 "flop_per_launch": FLOP_DECODE_PER_PX * px_launch,
-                "traffic": load_traffic() if args.compute == "f32" else None,
+                "traffic": load_traffic() if (not bf and args.workload == "c2" and world == 1) else None,
+                "p_kernel": {"ms": round(p_mean, 4), "ms_min": round(min(p_ms), 4), "tflops": round(p_tflops, 2),
+                             "frac": round(p_tflops / (PEAK_BF16_MFMA_TFLOPS if args.compute == "bf16_full"
+                                                       else PEAK_F32_MFMA_TFLOPS), 4)},
             },
         }
+        if checked is not None:
+            res["checked"] = checked
+        if gather_ms is not None:
+            res["gather_ms"] = round(gather_ms, 4)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sd, feat.cpu().numpy(), (HU, WU))
+            res["cpu_baseline"] = cpu_baseline(sd, feat_all.cpu(), (HU, WU), args.workload)
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if checked is not None and not checked["ok"]:
+        raise SystemExit(f"bench.py: timed output failed the oracle check: {checked}")
 
 
 if __name__ == "__main__":

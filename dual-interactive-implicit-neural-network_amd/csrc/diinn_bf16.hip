@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_kernel(const DecodeParams 
     axis_eval(p.ah, yc, iy, relh);
     axis_eval(p.aw, xc, ix, relw);
     const float* __restrict__ Wt = p.Wt;
-    const float* __restrict__ Pc = p.P + (((size_t)b * p.H + iy) * p.W + ix) * PCH + 4 * h;
+    const float* __restrict__ Pc = p.P + (((size_t)b * p.Prows + (iy - p.Prow0)) * p.W + ix) * PCH + 4 * h;
 
     // ---- layer 0 (fp32), packed to bf16 fragments: register r = 4g+e of tile m -> qb[2m + (r>>3)][r&7]
     bf16x8 qb[16];
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_kernel(const DecodeParams 
     o1 += __shfl_xor(o1, 32);
     o2 += __shfl_xor(o2, 32);
     if (valid && h == 0) {
-        const size_t plane = (size_t)p.Hu * p.Wu;
-        float* o = p.out + (size_t)b * 3 * plane + (size_t)y * p.Wu + x;
+        const size_t plane = (size_t)p.Orows * p.Wu;
+        float* o = p.out + (size_t)b * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
         o[0] = o0 + Wt[OFF_BL + 0];
         o[plane] = o1 + Wt[OFF_BL + 1];
         o[2 * plane] = o2 + Wt[OFF_BL + 2];
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x2_kernel(const DecodeParam
         const int yc = y[t] < p.y1 ? y[t] : p.y1 - 1;
         int iy;
         axis_eval(p.ah, yc, iy, relh[t]);
-        Pc[t] = p.P + (((size_t)b * p.H + iy) * p.W + ix) * PCH + 4 * h;
+        Pc[t] = p.P + (((size_t)b * p.Prows + (iy - p.Prow0)) * p.W + ix) * PCH + 4 * h;
     }
 
     // ---- layer 0 (fp32), packed to bf16 fragments: register r = 4g+e of tile m -> qb[2m + (r>>3)][r&7]
@@ -376,8 +376,8 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x2_kernel(const DecodeParam
         o1 += __shfl_xor(o1, 32);
         o2 += __shfl_xor(o2, 32);
         if (valid[t] && h == 0) {
-            const size_t plane = (size_t)p.Hu * p.Wu;
-            float* op = p.out + (size_t)b * 3 * plane + (size_t)y[t] * p.Wu + x;
+            const size_t plane = (size_t)p.Orows * p.Wu;
+            float* op = p.out + (size_t)b * 3 * plane + (size_t)(y[t] - p.Orow0) * p.Wu + x;
             op[0] = o0 + Wt[OFF_BL + 0];
             op[plane] = o1 + Wt[OFF_BL + 1];
             op[2 * plane] = o2 + Wt[OFF_BL + 2];

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
 #endif
     STAMP(0);
     const float* __restrict__ Wt = p.Wt;
-    const float* __restrict__ Pc = p.P + (((size_t)b * p.H + iy) * p.W + ix) * PCH + 4 * h;
+    const float* __restrict__ Pc = p.P + (((size_t)b * p.Prows + (iy - p.Prow0)) * p.W + ix) * PCH + 4 * h;
 
     // saved-activation planes (SAVE): one buffer descriptor per layer covering this wave's plane tile
     // (512 rows x 32 pixels); a lane's offset is its pixel inside the row of channel 4h, the channel
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     o1 += __shfl_xor(o1, 32);
     o2 += __shfl_xor(o2, 32);
     if (valid && h == 0) {
-        const size_t plane = (size_t)p.Hu * p.Wu;
-        float* o = p.out + (size_t)b * 3 * plane + (size_t)y * p.Wu + x;
+        const size_t plane = (size_t)p.Orows * p.Wu;
+        float* o = p.out + (size_t)b * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
         o[0] = o0 + Wt[OFF_BL + 0];
         o[plane] = o1 + Wt[OFF_BL + 1];
         o[2 * plane] = o2 + Wt[OFF_BL + 2];
@@ -261,9 +261,9 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
 // the multiplier of the synthesis branch.
 // ---------------------------------------------------------------------------------
 struct ChainParams {
-    float* P;            // [B,H,W,1024], slots 1..3 updated in place for rows [r0,r1)
+    float* P;            // [B,Prows,W,1024] = LR rows [Prow0, Prow0+Prows); slots 1..3 updated in place for rows [r0,r1)
     const float* Wt;
-    int B, H, W, r0, r1;
+    int B, H, W, r0, r1, Prow0, Prows;
 };
 
 __global__ __launch_bounds__(256, 1) void cell_chain_kernel(const ChainParams p) {
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void cell_chain_kernel(const ChainParams p)
     if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
     const int xc = x < p.W ? x : p.W - 1;
     const int yc = y < p.r1 ? y : p.r1 - 1;
-    float* __restrict__ Pc = p.P + (((size_t)b * p.H + yc) * p.W + xc) * PCH + 4 * h;
+    float* __restrict__ Pc = p.P + (((size_t)b * p.Prows + (yc - p.Prow0)) * p.W + xc) * PCH + 4 * h;
 
     float k[128];
 #pragma unroll
@@ -334,14 +334,15 @@ __global__ __launch_bounds__(256, 1) void cell_chain_kernel(const ChainParams p)
 }
 
 
-extern "C" {
-
-int diinn_cell_chain(void* stream, float* P_dev, const float* packed_dev, int B, int H, int W, int r0, int r1) {
+static int cell_chain_impl(void* stream, float* P_dev, const float* packed_dev, int B, int H, int W, int r0, int r1,
+                           RowWin pw) {
     if (!P_dev || !packed_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
     if (st) return st;
     if (r0 < 0 || r1 > H || r0 >= r1) return DIINN_ERR_INVALID_ARG;
-    ChainParams p{P_dev, packed_dev, B, H, W, r0, r1};
+    st = check_window(pw.row0, pw.rows, H, r0, r1);
+    if (st) return st;
+    ChainParams p{P_dev, packed_dev, B, H, W, r0, r1, pw.row0, pw.rows};
     const dim3 grid((W + TILE_W * WG_TILES_X - 1) / (TILE_W * WG_TILES_X),
                     (r1 - r0 + TILE_H * WG_TILES_Y - 1) / (TILE_H * WG_TILES_Y), B);
     if (grid.y > 65535) return DIINN_ERR_TOO_LARGE;
@@ -349,26 +350,9 @@ int diinn_cell_chain(void* stream, float* P_dev, const float* packed_dev, int B,
     return hip_status(hipGetLastError());
 }
 
-int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,
-                             int* grid_x, int* grid_y, int* grid_z, int* block) {
-    if (B <= 0 || Hu <= 0 || Wu <= 0 || y0 < 0 || y1 > Hu || y0 >= y1) return DIINN_ERR_INVALID_ARG;
-    if (grid_x) *grid_x = (Wu + TILE_W * WG_TILES_X - 1) / (TILE_W * WG_TILES_X);
-    if (grid_y) *grid_y = (y1 - y0 + TILE_H * WG_TILES_Y - 1) / (TILE_H * WG_TILES_Y);
-    if (grid_z) *grid_z = B;
-    if (block) *block = 256;
-    return DIINN_OK;
-}
-
-int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
-                      float* out_dev, int B, int H, int W, int Hu, int Wu,
-                      int y0, int y1, int sin_mode) {
-    return diinn_decode_band_ex(stream, P_dev, packed_dev, out_dev, B, H, W, Hu, Wu, y0, y1, sin_mode,
-                                DIINN_COMPUTE_F32);
-}
-
-int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_dev,
-                         float* out_dev, int B, int H, int W, int Hu, int Wu,
-                         int y0, int y1, int sin_mode, int compute) {
+static int decode_band_impl(void* stream, const float* P_dev, const float* packed_dev,
+                            float* out_dev, int B, int H, int W, int Hu, int Wu,
+                            int y0, int y1, int sin_mode, int compute, RowWin pw, RowWin ow) {
     if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY &&
         compute != DIINN_COMPUTE_BF16_FULL)
         return DIINN_ERR_UNSUPPORTED;
@@ -377,6 +361,15 @@ int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_d
     if (st) return st;
     if (Hu <= 0 || Wu <= 0 || y0 < 0 || y1 > Hu || y0 >= y1) return DIINN_ERR_INVALID_ARG;
     if ((double)Hu * Wu >= 2.0e9) return DIINN_ERR_TOO_LARGE;
+    {
+        int r0, r1;
+        st = diinn_lr_rows_for_band(H, Hu, Wu, y0, y1, &r0, &r1);
+        if (st) return st;
+        st = check_window(pw.row0, pw.rows, H, r0, r1);
+        if (st) return st;
+        st = check_window(ow.row0, ow.rows, Hu, y0, y1);
+        if (st) return st;
+    }
     if (sin_mode < DIINN_SIN_ACCURATE || sin_mode > DIINN_SIN_HW_REDUCED) return DIINN_ERR_UNSUPPORTED;
     int gx, gy, gz, blk;
     diinn_decode_launch_info(B, Hu, Wu, y0, y1, &gx, &gy, &gz, &blk);
@@ -385,6 +378,7 @@ int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_d
     p.P = P_dev; p.Wt = packed_dev; p.out = out_dev;
     p.B = B; p.H = H; p.W = W; p.Hu = Hu; p.Wu = Wu; p.y0 = y0; p.y1 = y1;
     p.ratio = (float)(((double)H * (double)W) / ((double)Hu * (double)Wu));
+    p.Prow0 = pw.row0; p.Prows = pw.rows; p.Orow0 = ow.row0; p.Orows = ow.rows;
     p.acts = nullptr; p.npix = 0;
 #ifdef DIINN_STAMPS
     p.stamps = g_stamps;
@@ -413,6 +407,66 @@ int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_d
     return hip_status(hipGetLastError());
 }
 
+static int decode_impl(void* stream, const float* feat_dev, const float* packed_dev,
+                       float* workspace_dev, float* out_dev,
+                       int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode, int compute,
+                       RowWin fw, RowWin pw, RowWin ow) {
+    if (!workspace_dev) return DIINN_ERR_INVALID_ARG;
+
+    int r0, r1;
+    int st = diinn_lr_rows_for_band(H, Hu, Wu, y0, y1, &r0, &r1);
+    if (st) return st;
+    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY &&
+        compute != DIINN_COMPUTE_BF16_FULL)
+        return DIINN_ERR_UNSUPPORTED;
+    st = launch_P(stream, feat_dev, packed_dev, workspace_dev, B, H, W, r0, r1, 16, compute == DIINN_COMPUTE_BF16_FULL,
+                  &fw, &pw);
+    if (st) return st;
+    if (compute == DIINN_COMPUTE_F32_QONLY) {                   // modes 1 and 2: per-cell modulation chain
+        st = cell_chain_impl(stream, workspace_dev, packed_dev, B, H, W, r0, r1, pw);
+        if (st) return st;
+    }
+    return decode_band_impl(stream, workspace_dev, packed_dev, out_dev, B, H, W, Hu, Wu, y0, y1, sin_mode,
+                            compute, pw, ow);
+}
+
+extern "C" {
+
+int diinn_cell_chain(void* stream, float* P_dev, const float* packed_dev, int B, int H, int W, int r0, int r1) {
+    return cell_chain_impl(stream, P_dev, packed_dev, B, H, W, r0, r1, RowWin{0, H});
+}
+
+int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,
+                             int* grid_x, int* grid_y, int* grid_z, int* block) {
+    if (B <= 0 || Hu <= 0 || Wu <= 0 || y0 < 0 || y1 > Hu || y0 >= y1) return DIINN_ERR_INVALID_ARG;
+    if (grid_x) *grid_x = (Wu + TILE_W * WG_TILES_X - 1) / (TILE_W * WG_TILES_X);
+    if (grid_y) *grid_y = (y1 - y0 + TILE_H * WG_TILES_Y - 1) / (TILE_H * WG_TILES_Y);
+    if (grid_z) *grid_z = B;
+    if (block) *block = 256;
+    return DIINN_OK;
+}
+
+int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
+                      float* out_dev, int B, int H, int W, int Hu, int Wu,
+                      int y0, int y1, int sin_mode) {
+    return diinn_decode_band_ex(stream, P_dev, packed_dev, out_dev, B, H, W, Hu, Wu, y0, y1, sin_mode,
+                                DIINN_COMPUTE_F32);
+}
+
+int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_dev,
+                         float* out_dev, int B, int H, int W, int Hu, int Wu,
+                         int y0, int y1, int sin_mode, int compute) {
+    return decode_band_impl(stream, P_dev, packed_dev, out_dev, B, H, W, Hu, Wu, y0, y1, sin_mode, compute,
+                            RowWin{0, H}, RowWin{0, Hu});
+}
+
+int diinn_decode_band_win(void* stream, const float* P_win_dev, int p_row0, int p_rows, const float* packed_dev,
+                          float* out_win_dev, int out_row0, int out_rows,
+                          int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode, int compute) {
+    return decode_band_impl(stream, P_win_dev, packed_dev, out_win_dev, B, H, W, Hu, Wu, y0, y1, sin_mode, compute,
+                            RowWin{p_row0, p_rows}, RowWin{out_row0, out_rows});
+}
+
 int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed_dev, float* out_dev,
                            float* acts_dev, int B, int H, int W, int Hu, int Wu, int sin_mode) {
     if (!P_dev || !packed_dev || !out_dev || !acts_dev) return DIINN_ERR_INVALID_ARG;
@@ -429,6 +483,7 @@ int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed
     p.P = P_dev; p.Wt = packed_dev; p.out = out_dev;
     p.B = B; p.H = H; p.W = W; p.Hu = Hu; p.Wu = Wu; p.y0 = 0; p.y1 = Hu;
     p.ratio = (float)(((double)H * (double)W) / ((double)Hu * (double)Wu));
+    p.Prow0 = 0; p.Prows = H; p.Orow0 = 0; p.Orows = Hu;
     p.acts = acts_dev; p.npix = npix;
 #ifdef DIINN_STAMPS
     p.stamps = nullptr;
@@ -455,19 +510,16 @@ int diinn_decode(void* stream, const float* feat_dev, const float* packed_dev,
 int diinn_decode_ex(void* stream, const float* feat_dev, const float* packed_dev,
                     float* workspace_dev, float* out_dev,
                     int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode, int compute) {
-    if (!workspace_dev) return DIINN_ERR_INVALID_ARG;
+    return decode_impl(stream, feat_dev, packed_dev, workspace_dev, out_dev, B, H, W, Hu, Wu, y0, y1, sin_mode, compute,
+                       RowWin{0, H}, RowWin{0, H}, RowWin{0, Hu});
+}
 
-    int r0, r1;
-    int st = diinn_lr_rows_for_band(H, Hu, Wu, y0, y1, &r0, &r1);
-    if (st) return st;
-    st = diinn_precompute_P_ex(stream, feat_dev, packed_dev, workspace_dev, B, H, W, r0, r1, compute);
-    if (st) return st;
-    if (compute == DIINN_COMPUTE_F32_QONLY) {                   // modes 1 and 2: per-cell modulation chain
-        st = diinn_cell_chain(stream, workspace_dev, packed_dev, B, H, W, r0, r1);
-        if (st) return st;
-    }
-    return diinn_decode_band_ex(stream, workspace_dev, packed_dev, out_dev, B, H, W, Hu, Wu, y0, y1, sin_mode,
-                                compute);
+int diinn_decode_win(void* stream, const float* feat_win_dev, int feat_row0, int feat_rows,
+                     const float* packed_dev, float* P_win_dev, int p_row0, int p_rows,
+                     float* out_win_dev, int out_row0, int out_rows,
+                     int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode, int compute) {
+    return decode_impl(stream, feat_win_dev, packed_dev, P_win_dev, out_win_dev, B, H, W, Hu, Wu, y0, y1, sin_mode,
+                       compute, RowWin{feat_row0, feat_rows}, RowWin{p_row0, p_rows}, RowWin{out_row0, out_rows});
 }
 
 }  // extern "C"

@@ -77,6 +77,9 @@ struct DecodeParams {
     const float* Wt;       // packed image
     float* out;            // [B,3,Hu,Wu]
     int B, H, W, Hu, Wu, y0, y1;
+    // row windows (include/diinn_hip.h "row windows"): P holds LR rows [Prow0, Prow0+Prows), out holds HR rows
+    // [Orow0, Orow0+Orows); the full-buffer entry points pass (0, H) and (0, Hu)
+    int Prow0, Prows, Orow0, Orows;
     float ratio;           // fp32(H*W / (Hu*Wu))   (diinn.py:166)
     Axis ah, aw;
     float* acts;           // training forward only (SAVE): saved activations, tiled planes [4 layers][ntiles][512][32]
@@ -197,6 +200,13 @@ static inline int check_dims(int B, int H, int W) {
     return DIINN_OK;
 }
 
+// the window [row0, row0+rows) must lie inside [0, full) and contain [need0, need1)
+static inline int check_window(int row0, int rows, int full, int need0, int need1) {
+    if (row0 < 0 || rows <= 0 || row0 > full - rows) return DIINN_ERR_INVALID_ARG;
+    if (need0 < row0 || need1 > row0 + rows) return DIINN_ERR_INVALID_ARG;
+    return DIINN_OK;
+}
+
 static inline int check_npix(long long npix) {
     if (npix <= 0) return DIINN_ERR_INVALID_ARG;
     if (npix > DIINN_TRAIN_MAX_PIXELS) return DIINN_ERR_TOO_LARGE;
@@ -204,9 +214,11 @@ static inline int check_npix(long long npix) {
 }
 
 // diinn_precompute.hip: the hoisted conv for mp_total M-tile pairs (16 = all 1024 channels), fp32 or bf16 operands
+struct RowWin { int row0, rows; };             // rows [row0, row0+rows) of a full-size tensor, stored on their own
 __attribute__((visibility("hidden")))
 int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,
-             int B, int H, int W, int r0, int r1, int mp_total, bool bf16 = false);
+             int B, int H, int W, int r0, int r1, int mp_total, bool bf16 = false,
+             const RowWin* feat_win = nullptr, const RowWin* p_win = nullptr);
 // diinn_bf16.hip: the bf16 decode of HR rows [p.y0, p.y1) (grid of the one-tile kernel: gx, gy, gz)
 __attribute__((visibility("hidden")))
 int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int gz, int sin_mode);

@@ -251,4 +251,17 @@ int diinn_lr_rows_for_band(int H, int Hu, int Wu, int y0, int y1, int* r0, int* 
     return DIINN_OK;
 }
 
+int diinn_window_rows(int H, int Hu, int Wu, int y0, int y1,
+                      int* feat_row0, int* feat_rows, int* p_row0, int* p_rows) {
+    int r0, r1;
+    const int st = diinn_lr_rows_for_band(H, Hu, Wu, y0, y1, &r0, &r1);
+    if (st) return st;
+    const int a0 = r0 > 0 ? r0 - 1 : 0, a1 = r1 < H ? r1 + 1 : H;     // + the 3x3 halo, clipped to the map
+    if (feat_row0) *feat_row0 = a0;
+    if (feat_rows) *feat_rows = a1 - a0;
+    if (p_row0) *p_row0 = r0;
+    if (p_rows) *p_rows = r1 - r0;
+    return DIINN_OK;
+}
+
 }  // extern "C"

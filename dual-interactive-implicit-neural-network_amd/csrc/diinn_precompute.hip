@@ -13,10 +13,11 @@
 // offset per (tap, channel).  Few registers -> 2 workgroups per CU hide each other's waits.
 // ---------------------------------------------------------------------------------
 struct PParams {
-    const float* feat;   // [B,64,H,W]
+    const float* feat;   // [B,64,Frows,W] = LR rows [Frow0, Frow0+Frows) of the [B,64,H,W] map (full map: 0, H)
     const float* Wt;
-    float* P;            // [B,H,W,1024]
+    float* P;            // [B,Prows,W,1024] = LR rows [Prow0, Prow0+Prows) of [B,H,W,1024]
     int B, H, W, r0, r1;
+    int Frow0, Frows, Prow0, Prows;
     int msplit;          // the M-tile pairs are divided over `msplit` workgroups (blockIdx.z = b*msplit + part)
     int mp_total;        // M-tile pairs (64 channels each) to compute: 16 = all 1024 channels; LIIF needs the first 4
 };
@@ -38,7 +39,8 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
     const int y0 = p.r0 + blockIdx.y * PT_ROWS;
 
     // stage feat[b, :, y0-1 .. y0+4, x0-1 .. x0+32] (zeros outside the map)
-    const float* __restrict__ fb = p.feat + (size_t)b * C_IN * p.H * p.W;
+    const float* __restrict__ fb = p.feat + (size_t)b * C_IN * p.Frows * p.W;
+    const int fy_hi = p.Frow0 + p.Frows - 1;              // rows of the map the feature window holds: [Frow0, fy_hi]
     static_assert(PT_LDS_FLOATS % 256 == 0, "staging loop has a fixed trip count");
     // fixed trip count, unrolled in batches so that many loads are in flight (a rolled loop would pay
     // one memory latency per element)
@@ -52,9 +54,10 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
         const bool ok = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W);
         // unconditional load from a clamped address, then select: a load under `ok ? .. : 0` compiles
         // to a branch and a vmcnt(0) per element (51 serial memory round trips per workgroup)
-        const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+        // rows of the map outside the window are only ever read for cells past the band (never stored)
+        const int yc = (yy < p.Frow0 ? p.Frow0 : (yy > fy_hi ? fy_hi : yy)) - p.Frow0;
         const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
-        const float v = fb[((size_t)c * p.H + yc) * p.W + xc];
+        const float v = fb[((size_t)c * p.Frows + yc) * p.W + xc];
         tile[idx] = ok ? v : 0.0f;
     }
     __syncthreads();
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
     const int lane_off = lane * 16;
     int wp = (int)(OFF_WP * sizeof(float)) + mp_begin * (WP_KG * 2 * PIECE_BYTES);   // advances one M-tile pair per iteration
     const float* __restrict__ Bk = p.Wt + OFF_BK + 4 * h;
-    float* __restrict__ Pout = p.P + (((size_t)b * p.H + (y < p.H ? y : p.H - 1)) * p.W + (x < p.W ? x : p.W - 1)) * PCH + 4 * h;
+    float* __restrict__ Pout = p.P + (((size_t)b * p.Prows + ((y < p.r1 ? y : p.r1 - 1) - p.Prow0)) * p.W + (x < p.W ? x : p.W - 1)) * PCH + 4 * h;
     f32x4 r0v[PF], r1v[PF];
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
@@ -156,7 +159,8 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_kernel(const PParams
     const int x0 = blockIdx.x * PT_COLS;
     const int y0 = p.r0 + blockIdx.y * PT_ROWS;
 
-    const float* __restrict__ fb = p.feat + (size_t)b * C_IN * p.H * p.W;
+    const float* __restrict__ fb = p.feat + (size_t)b * C_IN * p.Frows * p.W;
+    const int fy_hi = p.Frow0 + p.Frows - 1;
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll 13
     for (int it = 0; it < (PB_ITEMS + 255) / 256; ++it) {
@@ -166,11 +170,11 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_kernel(const PParams
         const int ly = pix / PT_LC, lx = pix - ly * PT_LC;
         const int yy = y0 + ly - 1, xx = x0 + lx - 1;
         const bool ok = (yy >= 0) && (yy < p.H) && (xx >= 0) && (xx < p.W) && (idx < PB_ITEMS);
-        const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+        const int yc = (yy < p.Frow0 ? p.Frow0 : (yy > fy_hi ? fy_hi : yy)) - p.Frow0;
         const int xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
         const int cc = cp < C_IN / 2 ? cp : C_IN / 2 - 1;         // last iteration runs past the item count
-        const float v0 = fb[((size_t)(2 * cc) * p.H + yc) * p.W + xc];
-        const float v1 = fb[((size_t)(2 * cc + 1) * p.H + yc) * p.W + xc];
+        const float v0 = fb[((size_t)(2 * cc) * p.Frows + yc) * p.W + xc];
+        const float v1 = fb[((size_t)(2 * cc + 1) * p.Frows + yc) * p.W + xc];
         bf16x2 pk;
         pk[0] = (__bf16)(ok ? v0 : 0.0f);
         pk[1] = (__bf16)(ok ? v1 : 0.0f);
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_kernel(const PParams
     const int lane_off = lane * 16;
     int wp = (int)(OFF_WPB * sizeof(float)) + mp_begin * (WPB_KS * 2 * PIECE_BYTES);
     const float* __restrict__ Bk = p.Wt + OFF_BK + 4 * h;
-    float* __restrict__ Pout = p.P + (((size_t)b * p.H + (y < p.H ? y : p.H - 1)) * p.W + (x < p.W ? x : p.W - 1)) * PCH + 4 * h;
+    float* __restrict__ Pout = p.P + (((size_t)b * p.Prows + ((y < p.r1 ? y : p.r1 - 1) - p.Prow0)) * p.W + (x < p.W ? x : p.W - 1)) * PCH + 4 * h;
     f32x4 r0v[PF], r1v[PF];
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
@@ -242,18 +246,25 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_kernel(const PParams
 }
 
 int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,
-                    int B, int H, int W, int r0, int r1, int mp_total, bool bf16) {
+             int B, int H, int W, int r0, int r1, int mp_total, bool bf16, const RowWin* feat_win, const RowWin* p_win) {
     if (!feat_dev || !packed_dev || !P_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
     if (st) return st;
     if (r0 < 0 || r1 > H || r0 >= r1) return DIINN_ERR_INVALID_ARG;
+    const RowWin fw = feat_win ? *feat_win : RowWin{0, H};
+    const RowWin pw = p_win ? *p_win : RowWin{0, H};
+    // the feature window must hold the band's rows and their 3x3 halo (clipped to the map: zero padding beyond)
+    st = check_window(fw.row0, fw.rows, H, r0 > 0 ? r0 - 1 : 0, r1 < H ? r1 + 1 : H);
+    if (st) return st;
+    st = check_window(pw.row0, pw.rows, H, r0, r1);
+    if (st) return st;
     // Small maps: split the 1024 output channels over up to 16 workgroups per cell block so the
     // launch still fills the chip (2 workgroups/CU resident -> aim for >= 2 rounds of 512).
     const long long blocks = (long long)((W + PT_COLS - 1) / PT_COLS) * ((r1 - r0 + PT_ROWS - 1) / PT_ROWS) * B;
     int msplit = 1;
     while (msplit < mp_total && blocks * msplit < 1024) msplit *= 2;
     if ((long long)B * msplit > 65535) return DIINN_ERR_TOO_LARGE;
-    PParams p{feat_dev, packed_dev, P_dev, B, H, W, r0, r1, msplit, mp_total};
+    PParams p{feat_dev, packed_dev, P_dev, B, H, W, r0, r1, fw.row0, fw.rows, pw.row0, pw.rows, msplit, mp_total};
     const dim3 grid((W + PT_COLS - 1) / PT_COLS, (r1 - r0 + PT_ROWS - 1) / PT_ROWS, B * msplit);
     if (bf16)
         hipLaunchKernelGGL(precompute_P_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -275,6 +286,17 @@ int diinn_precompute_P_ex(void* stream, const float* feat_dev, const float* pack
         compute != DIINN_COMPUTE_BF16_FULL)
         return DIINN_ERR_UNSUPPORTED;
     return launch_P(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, 16, compute == DIINN_COMPUTE_BF16_FULL);
+}
+
+int diinn_precompute_P_win(void* stream, const float* feat_win_dev, int feat_row0, int feat_rows,
+                           const float* packed_dev, float* P_win_dev, int p_row0, int p_rows,
+                           int B, int H, int W, int r0, int r1, int compute) {
+    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY &&
+        compute != DIINN_COMPUTE_BF16_FULL)
+        return DIINN_ERR_UNSUPPORTED;
+    const RowWin fw{feat_row0, feat_rows}, pw{p_row0, p_rows};
+    return launch_P(stream, feat_win_dev, packed_dev, P_win_dev, B, H, W, r0, r1, 16, compute == DIINN_COMPUTE_BF16_FULL,
+                    &fw, &pw);
 }
 
 }  // extern "C"

@@ -162,6 +162,63 @@ def decode_features(feat: torch.Tensor, packed: torch.Tensor, size: Sequence[int
     return out
 
 
+def window_rows(h: int, hu: int, wu: int, y0: int, y1: int) -> Tuple[Tuple[int, int], Tuple[int, int]]:
+    """((feat_row0, feat_rows), (p_row0, p_rows)): the LR feature rows (cells + 3x3 halo) and the P rows that
+    decoding HR rows [y0,y1) touches (C ABI ``diinn_window_rows``)."""
+    lib = _native.load()
+    a0, an, r0, rn = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    _native.check(lib.diinn_window_rows(h, hu, wu, y0, y1, C.byref(a0), C.byref(an), C.byref(r0), C.byref(rn)),
+                  "diinn_window_rows")
+    return (a0.value, an.value), (r0.value, rn.value)
+
+
+def decode_window(feat_win: torch.Tensor, feat_row0: int, full_h: int, packed: torch.Tensor, size: Sequence[int],
+                  rows: Tuple[int, int], p_win: Optional[torch.Tensor] = None, out_win: Optional[torch.Tensor] = None,
+                  sin_mode: int = _native.SIN_DEFAULT, compute: str = "f32", mode: int = 3) -> torch.Tensor:
+    """Decode HR rows ``rows=(y0,y1)`` from band-sized buffers (the multi-GPU row-band unit).
+
+    ``feat_win`` [B,64,fr,W] holds LR rows [feat_row0, feat_row0+fr) of a map of height ``full_h`` and must
+    cover the band's cells plus the 3x3 halo (``window_rows``).  ``p_win`` is a workspace of at least
+    B*p_rows*W*1024 floats and ``out_win`` [B,3,y1-y0,Wu] the band of the output (both allocated if None).
+    Bit-identical to the same rows of ``decode_features`` on the full map.  C ABI: ``diinn_decode_win``."""
+    lib = _native.load()
+    _require_cuda(feat_win, "feat_win")
+    _require_cuda(packed, "packed weights")
+    if feat_win.dtype != torch.float32 or feat_win.dim() != 4 or feat_win.shape[1] != IN_CHANNELS \
+            or not feat_win.is_contiguous():
+        raise ValueError(f"feat_win must be contiguous fp32 [B,{IN_CHANNELS},rows,W], got {feat_win.dtype} "
+                         f"{tuple(feat_win.shape)}")
+    hu, wu = size
+    hu, wu = int(hu), int(wu)
+    y0, y1 = int(rows[0]), int(rows[1])
+    b, _, fr, w = feat_win.shape
+    (_, _), (r0, rn) = window_rows(int(full_h), hu, wu, y0, y1)
+    need = b * rn * w * P_CHANNELS
+    if p_win is None:
+        p_win = torch.empty(need, dtype=torch.float32, device=feat_win.device)
+    elif p_win.numel() < need or p_win.dtype != torch.float32 or not p_win.is_contiguous() \
+            or p_win.device != feat_win.device:
+        raise ValueError(f"p_win must be a contiguous fp32 buffer of >= {need} floats on feat_win's device")
+    if out_win is None:
+        out_win = torch.empty((b, 3, y1 - y0, wu), dtype=torch.float32, device=feat_win.device)
+    elif out_win.shape != (b, 3, y1 - y0, wu) or out_win.dtype != torch.float32 or not out_win.is_contiguous() \
+            or out_win.device != feat_win.device:
+        raise ValueError("out_win must be a contiguous fp32 [B,3,y1-y0,Wu] tensor on feat_win's device")
+    if mode not in (1, 2, 3):
+        raise NotImplementedError(f"mode {mode}: the HIP path covers modes 1-3")
+    if mode != 3 and compute != "f32":
+        raise ValueError("modes 1 and 2 run in fp32 only")
+    comp = _native.COMPUTE[compute] if mode == 3 else _native.COMPUTE_F32_QONLY
+    with torch.cuda.device(feat_win.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        st = lib.diinn_decode_win(C.c_void_p(stream), C.c_void_p(feat_win.data_ptr()), int(feat_row0), fr,
+                                  C.c_void_p(packed.data_ptr()), C.c_void_p(p_win.data_ptr()), r0, rn,
+                                  C.c_void_p(out_win.data_ptr()), y0, y1 - y0,
+                                  b, int(full_h), w, hu, wu, y0, y1, int(sin_mode), comp)
+    _native.check(st, "diinn_decode_win")
+    return out_win
+
+
 # ---------------------------------------------------------------------------
 # LIIF comparison decoder (reference liif.py; SURVEY.md §8 row f4)
 # ---------------------------------------------------------------------------
@@ -362,9 +419,16 @@ class ImplicitDecoder(nn.Module):
             return decode_with_grad(self, x, size)
         b, c, h, w = x.shape
         need = b * h * w * P_CHANNELS
-        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != x.device:
-            self._workspace = torch.empty(need, dtype=torch.float32, device=x.device)
+        if torch.cuda.is_current_stream_capturing():
+            # hipGraph capture (modules._GraphReplay): the captured kernels keep the workspace pointer for the
+            # graph's lifetime, so it must come from the graph's private pool -- the cached workspace below is
+            # replaced (and its block recycled) as soon as a larger input arrives
+            workspace = None
+        else:
+            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != x.device:
+                self._workspace = torch.empty(need, dtype=torch.float32, device=x.device)
+            workspace = self._workspace
         with torch.no_grad():
             packed = self.packed_weights(x.device)
-            return decode_features(x, packed, size, workspace=self._workspace, sin_mode=self.sin_mode,
+            return decode_features(x, packed, size, workspace=workspace, sin_mode=self.sin_mode,
                                    compute=self.compute, mode=self.mode)

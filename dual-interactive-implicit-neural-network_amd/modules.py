@@ -176,9 +176,19 @@ class _GraphReplay:
     def _use_graph(self, x) -> bool:
         return self.graphs and x.is_cuda and not torch.is_grad_enabled()
 
+    def _graph_key(self, x, size):
+        """Everything that decides which kernels a capture records and which buffers they read: input geometry,
+        output size, the identity and version of every parameter (a re-assigned ``param.data`` changes the
+        pointer, an in-place update the version), and the knobs that switch code paths."""
+        dec = getattr(self, "decoder", None)
+        enc = getattr(self, "encoder", None)
+        return (tuple(x.shape), x.dtype, x.device, int(size[0]), int(size[1]),
+                tuple((p.data_ptr(), p._version) for p in self.parameters()),
+                getattr(dec, "sin_mode", None), getattr(dec, "compute", None), getattr(dec, "mode", None),
+                getattr(enc, "hip_trunk_max_pixels", None))
+
     def _forward_graphed(self, x, size, bsize):
-        key = (tuple(x.shape), x.dtype, x.device, int(size[0]), int(size[1]),
-               tuple(p._version for p in self.parameters()))
+        key = self._graph_key(x, size)
         entry = self._graph_cache.get(key)
         if entry is None:
             if len(self._graph_cache) >= self.MAX_GRAPHS:
@@ -192,10 +202,14 @@ class _GraphReplay:
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
+                # every buffer the captured kernels touch is either allocated inside the capture (the graph's
+                # private pool: workspaces, activations, the result) or kept alive by the entry below (packed
+                # weight images, which live in module caches that a later call may replace)
                 static_y = self._forward_eager(static_x, size, bsize)
-            entry = (graph, static_x, static_y)
+            keep = [getattr(m, a, None) for m in self.modules() for a in ("_packed", "_hip_pack")]
+            entry = (graph, static_x, static_y, keep)
             self._graph_cache[key] = entry
-        graph, static_x, static_y = entry
+        graph, static_x, static_y = entry[:3]
         static_x.copy_(x)
         graph.replay()
         return static_y.clone()
@@ -411,7 +425,16 @@ class SRLitModule(nn.Module):
     def load_from_checkpoint(cls, checkpoint_path: str, map_location=None, strict: bool = True, **overrides):
         """Lightning checkpoint dict: ``hyper_parameters`` (ctor kwargs saved by save_hyperparameters,
         sr_module.py:91) and ``state_dict`` (keys ``net.encoder.*``, ``net.decoder.*``, ``sub``, ``div``)."""
-        ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+        # plain tensors + a dict of primitives load under weights_only=True; a checkpoint that pickles other
+        # classes (Lightning's AttributeDict, callbacks) executes code on load and needs an explicit opt-in
+        try:
+            ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=True)
+        except Exception as e:
+            import os
+            import pickle
+            if not isinstance(e, pickle.UnpicklingError) or os.environ.get("DIINN_TRUST_CKPT") != "1":
+                raise
+            ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
         hp = dict(ckpt.get("hyper_parameters", {}))
         hp.update(overrides)
         known = ("arch", "mode", "init_q", "lr", "lr_gamma", "lr_step", "eval_bsize")

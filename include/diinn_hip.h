@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define DIINN_ABI_VERSION 2   /* 2: training, LIIF/MetaSR, encoder-trunk entry points; packed image sections 8-9 */
+#define DIINN_ABI_VERSION 3   /* 2: training, LIIF/MetaSR, encoder-trunk entry points; packed image sections 8-9
+                                 3: row-window entry points (band-sized buffers for the multi-GPU row-band split) */
 
 /* status codes */
 #define DIINN_OK                 0
@@ -151,6 +152,32 @@ int diinn_decode_band_ex(void* stream, const float* P_dev, const float* packed_d
 int diinn_decode_ex(void* stream, const float* feat_dev, const float* packed_dev,
                     float* workspace_dev, float* out_dev,
                     int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode, int compute);
+
+/* ---- row windows (multi-GPU row bands) --------------------
+ * Under the row-band split a rank holds only the slice of each buffer its band touches.  A WINDOW is a
+ * contiguous range of rows of a full-size tensor stored as a tensor of its own:
+ *   features  feat_win_dev [B,64,feat_rows,W]   = LR rows [feat_row0, feat_row0+feat_rows) of [B,64,H,W]
+ *   workspace P_win_dev    [B,p_rows,W,1024]    = LR rows [p_row0, p_row0+p_rows)        of [B,H,W,1024]
+ *   output    out_win_dev  [B,3,out_rows,Wu]    = HR rows [out_row0, out_row0+out_rows)  of [B,3,Hu,Wu]
+ * Row numbers (r0,r1,y0,y1) stay those of the full tensors, so results are bit-identical to the
+ * full-buffer entry points.  Requirements (else DIINN_ERR_INVALID_ARG): the feature window holds rows
+ * [max(r0-1,0), min(r1+1,H)) (the band's cells plus the 3x3 halo; rows outside the map are the unfold's
+ * zero padding, diinn.py:168), the P window holds [r0,r1), the output window holds [y0,y1).
+ * diinn_window_rows reports all three for an HR band: what a rank must receive and allocate.
+ * Replaces (per band) the same reference lines as diinn_precompute_P_ex / diinn_decode_band_ex /
+ * diinn_decode_ex; the reference itself has no multi-GPU inference (benchmarks.py:13 devices=1). */
+int diinn_window_rows(int H, int Hu, int Wu, int y0, int y1,
+                      int* feat_row0, int* feat_rows, int* p_row0, int* p_rows);
+int diinn_precompute_P_win(void* stream, const float* feat_win_dev, int feat_row0, int feat_rows,
+                           const float* packed_dev, float* P_win_dev, int p_row0, int p_rows,
+                           int B, int H, int W, int r0, int r1, int compute);
+int diinn_decode_band_win(void* stream, const float* P_win_dev, int p_row0, int p_rows, const float* packed_dev,
+                          float* out_win_dev, int out_row0, int out_rows,
+                          int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode, int compute);
+int diinn_decode_win(void* stream, const float* feat_win_dev, int feat_row0, int feat_rows,
+                     const float* packed_dev, float* P_win_dev, int p_row0, int p_rows,
+                     float* out_win_dev, int out_row0, int out_rows,
+                     int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode, int compute);
 
 /* Modes 1 and 2 only: the modulation chain per LR cell, k_0 = relu(P_0), k_i = relu(K_i^k k_{i-1} + P_i)
  * (diinn.py:118-121,126-129), for LR rows [r0,r1); k_i overwrites the P_i slot (i = 1..3) of P_dev. */

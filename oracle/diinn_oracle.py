@@ -171,19 +171,30 @@ def decode_reference_form_f64(sd, feat, size: Sequence[int]) -> torch.Tensor:
 
 @torch.no_grad()
 def decode_reference_form(sd, feat, size: Sequence[int], bsize: Optional[int] = None,
-                          row_range: Optional[Tuple[int, int]] = None, mode: int = 3) -> torch.Tensor:
+                          row_range: Optional[Tuple[int, int]] = None, mode: int = 3,
+                          feat_row0: int = 0, full_h: Optional[int] = None) -> torch.Tensor:
     """Reference-faithful CPU decode: unfold -> nearest-exact replicate ->
     9 conv1x1 + 3 cat + 4 sin, optional column strips of ``bsize//Hu`` columns
     (diinn.py:149-160).  ``row_range=(y0,y1)`` restricts the output to an HR
     row band (what one GPU computes under tile sharding); the maths per pixel
-    is unchanged."""
+    is unchanged.
+
+    ``feat_row0`` / ``full_h``: ``feat`` holds only LR rows [feat_row0, feat_row0 + feat.shape[2]) of a map
+    of height ``full_h`` (for checking bands of maps too large to unfold whole on the CPU).  The crop must
+    contain the band's cells and their 3x3 halo, so that the unfold's zero padding only ever stands for
+    rows that are outside the full map as well."""
     sd = {k: _as_t(v) for k, v in sd.items()}
     feat = _as_t(feat)
-    b, c, h, w = feat.shape
+    b, c, hc, w = feat.shape
+    h = hc if full_h is None else int(full_h)
     hu, wu = int(size[0]), int(size[1])
     syn, idx_h, idx_w = make_syn_inp(b, h, w, hu, wu)
     y0, y1 = (0, hu) if row_range is None else row_range
-    ih = torch.from_numpy(idx_h[y0:y1].astype(np.int64))
+    rows = idx_h[y0:y1].astype(np.int64)
+    lo, hi = int(rows.min()), int(rows.max())
+    if not (feat_row0 <= max(lo - 1, 0) and min(hi + 1, h - 1) <= feat_row0 + hc - 1):
+        raise ValueError("feature crop does not cover the band's cells + halo")
+    ih = torch.from_numpy(rows - feat_row0)
     iw = torch.from_numpy(idx_w.astype(np.int64))
     u = unfold3x3(feat)
     x = u[:, :, ih][:, :, :, iw]  # nearest-exact replication through the tables
@@ -239,7 +250,9 @@ def _bf16_round(t: torch.Tensor) -> torch.Tensor:
 
 
 @torch.no_grad()
-def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = False, bf16_p: bool = False) -> torch.Tensor:
+def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = False, bf16_p: bool = False,
+                        row_range: Optional[Tuple[int, int]] = None, feat_row0: int = 0,
+                        full_h: Optional[int] = None) -> torch.Tensor:
     """Same function evaluated the way the HIP kernels do: per-cell P, then the
     per-pixel 256->512 stacked layers.  Not reference-faithful in summation
     order; agrees with decode_reference_form to ~1e-7.
@@ -248,23 +261,30 @@ def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = Fal
     the activation entering layers 1..3 are rounded to bf16, products accumulate in fp32;
     P, biases, sine, layer 0 and the head (on the unrounded last activation) stay fp32.
     ``bf16_p=True`` additionally rounds the features and the 3x3 conv weights of P to bf16 (fp32 accumulate,
-    fp32 bias): the DIINN_COMPUTE_BF16_FULL mode."""
+    fp32 bias): the DIINN_COMPUTE_BF16_FULL mode.
+    ``row_range`` / ``feat_row0`` / ``full_h``: an HR row band from a feature crop, as in decode_reference_form."""
     sw = split_weights(sd)
     feat = _as_t(feat)
-    b, c, h, w = feat.shape
+    b, c, hc, w = feat.shape
+    h = hc if full_h is None else int(full_h)
     hu, wu = int(size[0]), int(size[1])
     small = uses_small_output_kernel(hu, wu)
     idx_h, rel_h = axis_tables(h, hu, small)
     idx_w, rel_w = axis_tables(w, wu, small)
+    y0, y1 = (0, hu) if row_range is None else row_range
+    rows = idx_h[y0:y1].astype(np.int64)
+    if not (feat_row0 <= max(int(rows.min()) - 1, 0) and min(int(rows.max()) + 1, h - 1) <= feat_row0 + hc - 1):
+        raise ValueError("feature crop does not cover the band's cells + halo")
     if bf16_p:
         p = F.conv2d(_bf16_round(feat), _bf16_round(sw["Wx"].view(4 * HIDDEN, IN_CHANNELS, 3, 3)), None, padding=1)
         p = (p + sw["bK"].view(1, -1, 1, 1)).permute(0, 2, 3, 1).contiguous()
     else:
-        p = precompute_P(sd, feat)  # [B,H,W,1024]
-    pp = p[:, torch.from_numpy(idx_h.astype(np.int64))][:, :, torch.from_numpy(idx_w.astype(np.int64))]
-    pp = pp.view(b, hu, wu, 4, HIDDEN)
-    syn = torch.empty((hu, wu, 3))
-    syn[..., 0] = torch.from_numpy(rel_h)[:, None]
+        p = precompute_P(sd, feat)  # [B,hc,W,1024]
+    pp = p[:, torch.from_numpy(rows - feat_row0)][:, :, torch.from_numpy(idx_w.astype(np.int64))]
+    nh = y1 - y0
+    pp = pp.view(b, nh, wu, 4, HIDDEN)
+    syn = torch.empty((nh, wu, 3))
+    syn[..., 0] = torch.from_numpy(rel_h[y0:y1])[:, None]
     syn[..., 1] = torch.from_numpy(rel_w)[None, :]
     syn[..., 2] = float(scale_ratio(h, w, hu, wu))
     q = torch.relu(pp[:, :, :, 0]) * torch.sin(syn @ sw["Q0"].t() + sw["bQ"][0])

@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.diinn_abi_version() == 2
+    assert lib.diinn_abi_version() == 3
     assert lib.diinn_status_string(0) == b"ok"
     assert b"invalid" in lib.diinn_status_string(1)
 
@@ -159,3 +159,26 @@ def test_host_axis_tables_match_oracle_on_random_pairs(lib):
             oi, orl = orc.axis_tables(n_in, n_out, small)
             assert np.array_equal(idx, oi), (n_in, n_out, small)
             assert np.array_equal(rel.view(np.uint32), orl.view(np.uint32)), (n_in, n_out, small)
+
+
+def test_window_rows_and_window_validation(lib):
+    """diinn_window_rows (host) against the oracle's tables, and the window entry points refuse windows that
+    do not hold what the band reads -- checked before any launch, so this runs without a GPU."""
+    import diinn_amd._native as N
+    import diinn_amd.decoder as D
+    import diinn_oracle as orc
+    for (h, hu, wu, y0, y1) in [(256, 1024, 1024, 512, 640), (720, 2376, 4224, 0, 297), (1024, 8192, 8192, 7168, 8192),
+                                (5, 3, 9, 2, 3)]:
+        idx, _ = orc.axis_tables(h, hu, orc.uses_small_output_kernel(hu, wu))
+        (a0, an), (r0, rn) = D.window_rows(h, hu, wu, y0, y1)
+        assert r0 == idx[y0] and r0 + rn == idx[y1 - 1] + 1
+        assert a0 == max(r0 - 1, 0) and a0 + an == min(r0 + rn + 1, h)
+    fake = C.c_void_p(4096)          # never dereferenced: validation fails first
+    # P window [10,14) cannot serve HR rows 0..8 of a x4 decode (cells 0..1)
+    assert lib.diinn_decode_band_win(None, fake, 10, 4, fake, fake, 0, 8, 1, 64, 64, 256, 256, 0, 8, 2, 0) == N.ERR_INVALID_ARG
+    # output window must contain the band
+    assert lib.diinn_decode_band_win(None, fake, 0, 2, fake, fake, 4, 8, 1, 64, 64, 256, 256, 0, 8, 2, 0) == N.ERR_INVALID_ARG
+    # feature window without the halo row
+    assert lib.diinn_precompute_P_win(None, fake, 8, 8, fake, fake, 8, 8, 1, 64, 64, 8, 16, 0) == N.ERR_INVALID_ARG
+    # window outside the map
+    assert lib.diinn_precompute_P_win(None, fake, 60, 8, fake, fake, 61, 3, 1, 64, 64, 61, 64, 0) == N.ERR_INVALID_ARG

@@ -115,3 +115,35 @@ def test_graphed_forward_equals_eager():
     assert torch.allclose(e1, g1, atol=1e-5) and torch.allclose(e2, g2, atol=1e-5)
     assert torch.allclose(g1, g1b, atol=1e-5) and not torch.allclose(g1, g2, atol=1e-5)
     assert len(net._graph_cache) == 1
+
+
+@pytest.mark.gpu
+def test_graph_replay_survives_larger_shape_and_knob_changes():
+    """Replaying the graph of shape A after a LARGER shape B has run must not touch memory the caching
+    allocator has handed to someone else (the P workspace of a capture lives in the graph's private pool),
+    and changing a knob that selects other kernels (sine mode) must capture a new graph, not replay a stale one."""
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = M.DIINN(mode=3, init_q=False, graphs=True).to(dev).eval()
+    xa = torch.rand(1, 3, 16, 16, device=dev)
+    xb = torch.rand(1, 3, 40, 40, device=dev)
+    with torch.no_grad():
+        net.graphs = False
+        ea, eb = net(xa, (40, 40), 30000), net(xb, (100, 100), 30000)
+        net.graphs = True
+        ga = net(xa, (40, 40), 30000)          # captures A
+        gb = net(xb, (100, 100), 30000)        # larger: the decoder's cached eager workspace is replaced
+        held = gb.clone()
+        # churn the allocator so a recycled block would be handed out again
+        junk = [torch.full((n,), 7.0, device=dev) for n in (1 << 18, 1 << 20, 1 << 22)]
+        ga2 = net(xa, (40, 40), 30000)         # replays A
+        torch.cuda.synchronize()
+        assert torch.allclose(ga, ea, atol=1e-5) and torch.allclose(ga2, ea, atol=1e-5)
+        assert torch.allclose(gb, eb, atol=1e-5) and torch.equal(gb, held)
+        assert all(bool((j == 7.0).all()) for j in junk)
+        n_graphs = len(net._graph_cache)
+        net.decoder.sin_mode = N.SIN_ACCURATE
+        net(xa, (40, 40), 30000)
+        assert len(net._graph_cache) == n_graphs + 1

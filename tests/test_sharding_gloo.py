@@ -1,6 +1,6 @@
-"""CPU, world_size 2 over gloo: the multi-GPU plumbing (band partition + feature hand-off).
-The per-band decode itself is the HIP kernel (GPU tests); here the oracle stands in for it so the
-stitched result can be compared with the unsharded decode."""
+"""CPU, world_size 2 and 4 over gloo: the multi-GPU plumbing (band partition, feature hand-off into
+band-sized windows, output gather).  The per-band decode itself is the HIP kernel (GPU tests); here the
+oracle stands in for it so the stitched result can be compared with the unsharded decode."""
 import os
 import socket
 
@@ -31,6 +31,24 @@ def test_feature_rows_include_halo():
     assert S.feature_rows_for_band(256, (192, 256)) == (191, 256)
 
 
+def test_plan_bands_matches_index_tables():
+    """plan_bands (library index code) against the oracle's nearest-exact tables: every band's P rows are
+    exactly the cells its HR rows select, the feature rows add the clipped 3x3 halo."""
+    import diinn_oracle as orc
+    import diinn_amd.sharded as S
+    for (h, hu, wu, world) in [(24, 79, 66, 4), (256, 1024, 1024, 8), (720, 2376, 4224, 8), (1024, 8192, 8192, 8),
+                               (5, 3, 9, 4), (40, 132, 185, 3)]:
+        idx, _ = orc.axis_tables(h, hu, orc.uses_small_output_kernel(hu, wu))
+        bands = S.plan_bands(h, hu, wu, world)
+        assert len(bands) == world
+        for bd in bands:
+            if bd.empty:
+                continue
+            assert bd.r0 == idx[bd.y0] and bd.r1 == idx[bd.y1 - 1] + 1
+            assert bd.a0 == max(bd.r0 - 1, 0) and bd.a1 == min(bd.r1 + 1, h)
+        assert sum(1 for bd in bands if bd.empty) == max(0, world - hu)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -39,66 +57,90 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, q):
+def _worker(rank, world, port, mode, geom, q):
     import sys
     from conftest import ROOT
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import diinn_oracle as orc
-    import diinn_amd.decoder as D
     import diinn_amd.sharded as S
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(2)
-        b, h, w, hu, wu = 1, 24, 20, 79, 66
+        b, h, w, hu, wu = geom
         shape = (b, 64, h, w)
         sd = synth.decoder_state_dict(9)
         feat_np = synth.encoder_features(9, b, h, w)
         feat = torch.from_numpy(feat_np) if rank == 0 else None
-        bands = S.all_bands(hu, world)
-        need = [S.feature_rows_for_band(h, D.lr_rows_for_band(h, hu, wu, a, c)) for a, c in bands]
-        buf = torch.full(shape, float("nan")) if rank != 0 else None
-        local = S.distribute_features(feat, shape, need, src=0, mode=mode, device="cpu", buf=buf)
-        a0, a1 = need[rank]
-        ok_rows = bool(np.array_equal(local[:, :, a0:a1].numpy(), feat_np[:, :, a0:a1]))
-        # decode the band from ONLY the rows this rank holds (zero elsewhere) -> must equal the full decode
-        masked = torch.zeros(shape)
-        masked[:, :, a0:a1] = local[:, :, a0:a1]
-        y0, y1 = bands[rank]
-        band = orc.decode_reference_form(sd, masked, (hu, wu), None, row_range=(y0, y1))
-        outs = [None] * world
-        dist.all_gather_object(outs, (y0, y1, band.numpy()))
+        bands = S.plan_bands(h, hu, wu, world)
+        ex = S.BandExchange(shape, (hu, wu), bands, "cpu", src=0, mode=mode)
+        if ex.feat_win is not None:
+            ex.feat_win.fill_(float("nan"))
+        bd = ex.band
+        ok_rows, band = True, None
+        for it in range(2):                       # twice: the pre-allocated buffers are reused
+            win, row0 = ex.handoff(feat)
+            if bd.empty:
+                continue
+            if mode == "halo" and rank != 0:
+                assert win.shape[2] == bd.a1 - bd.a0 and row0 == bd.a0       # band-sized, not the whole map
+            lo = bd.a0 - row0
+            ok_rows = ok_rows and bool(np.array_equal(win[:, :, lo:lo + bd.a1 - bd.a0].numpy(), feat_np[:, :, bd.a0:bd.a1]))
+            # decode the band from ONLY the rows this rank holds -> must equal the same rows of the full decode
+            band = orc.decode_reference_form(sd, win[:, :, lo:lo + bd.a1 - bd.a0].contiguous(), (hu, wu), None,
+                                             row_range=(bd.y0, bd.y1), feat_row0=bd.a0, full_h=h)
+        img = ex.gather(band, dst=0)
         if rank == 0:
             full = orc.decode_reference_form(sd, feat_np, (hu, wu), None).numpy()
-            stitched = np.concatenate([o[2] for o in sorted(outs, key=lambda t: t[0])], axis=2)
-            q.put((ok_rows, float(np.abs(stitched - full).max())))
+            q.put((ok_rows, float(np.abs(img.numpy() - full).max())))
         else:
+            assert img is None
             q.put((ok_rows, 0.0))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["halo", "bcast"])
-def test_two_rank_feature_handoff_and_stitch(mode):
+def _run(world, mode, geom, target=_worker, timeout=300):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port, mode, geom, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
+    res = [q.get(timeout=timeout) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("mode", ["halo", "bcast"])
+def test_two_rank_feature_handoff_and_stitch(mode):
+    res = _run(2, mode, (1, 24, 20, 79, 66))
     assert all(r[0] for r in res)
     assert max(r[1] for r in res) <= 1e-6
 
 
-def _gpu_worker(rank, world, port, q):
-    """Two ranks sharing cuda:0 (the test box has one GPU): gloo carries the broadcast, the HIP
-    kernels decode each rank's band.  (RCCL refuses two ranks on one device; the halo P2P form is
-    covered on CPU above.)"""
+def test_four_ranks_uneven_bands_batch2():
+    """world_size 4, HR height 79 (bands of 20,20,20,19 rows), non-integer scale, batch 2."""
+    res = _run(4, "halo", (2, 24, 20, 79, 66))
+    assert all(r[0] for r in res)
+    assert max(r[1] for r in res) <= 1e-6
+
+
+def test_more_ranks_than_rows():
+    """4 ranks, 3 HR rows: the last rank's band is empty and it simply sits the exchange out."""
+    res = _run(4, "halo", (1, 5, 6, 3, 9))
+    assert all(r[0] for r in res)
+    assert max(r[1] for r in res) <= 1e-6
+
+
+def _gpu_worker(rank, world, port, mode, geom, q):
+    """Two ranks sharing cuda:0 (the test box has one GPU, and RCCL refuses two ranks on one device): the
+    hand-off and the gather travel over gloo on CPU buffers, each rank's band is decoded by the HIP
+    kernels from its band-sized window (diinn_decode_win) and compared bit-for-bit with the same rows of
+    an unsharded decode."""
     import diinn_amd.decoder as D
     import diinn_amd.sharded as S
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -106,19 +148,22 @@ def _gpu_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cuda:0")
-        b, h, w, hu, wu = 1, 40, 56, 132, 185
+        b, h, w, hu, wu = geom
         shape = (b, 64, h, w)
         packed = D.pack_state_dict(synth.decoder_state_dict(21)).to(dev)
-        feat = torch.from_numpy(synth.encoder_features(21, b, h, w)).to(dev) if rank == 0 else None
-        out, (y0, y1) = S.decode_sharded(feat, shape, packed, (hu, wu), src=0, mode="bcast")
+        feat_cpu = torch.from_numpy(synth.encoder_features(21, b, h, w))
+        bands = S.plan_bands(h, hu, wu, world)
+        ex = S.BandExchange(shape, (hu, wu), bands, "cpu", src=0, mode=mode)
+        win, row0 = ex.handoff(feat_cpu if rank == 0 else None)
+        bd = ex.band
+        if rank == 0:                              # the source holds the whole map: crop to its own window too
+            win, row0 = win[:, :, bd.a0:bd.a1].contiguous(), bd.a0
+        band = D.decode_window(win.to(dev), row0, h, packed, (hu, wu), (bd.y0, bd.y1))
         torch.cuda.synchronize()
-        band = out[:, :, y0:y1].cpu().numpy()
-        outs = [None] * world
-        dist.all_gather_object(outs, (y0, y1, band))
+        img = ex.gather(band.cpu(), dst=0)
         if rank == 0:
-            full = D.decode_features(feat, packed, (hu, wu)).cpu().numpy()
-            stitched = np.concatenate([o[2] for o in sorted(outs, key=lambda t: t[0])], axis=2)
-            q.put(bool(np.array_equal(stitched, full)))
+            full = D.decode_features(feat_cpu.to(dev), packed, (hu, wu)).cpu()
+            q.put(bool(torch.equal(img, full)))
         else:
             q.put(True)
     finally:
@@ -127,14 +172,5 @@ def _gpu_worker(rank, world, port, q):
 
 @pytest.mark.gpu
 def test_two_ranks_decode_bands_on_gpu():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    res = _run(2, "halo", (1, 40, 56, 132, 185), target=_gpu_worker, timeout=600)
     assert all(res)
