@@ -1,6 +1,7 @@
 // diinn_bf16.hip -- the optional bf16-operand decode kernels (DIINN_COMPUTE_BF16 / DIINN_COMPUTE_BF16_FULL)
 // (part of libdiinn_hip.so; shared definitions in diinn_device.h, layout in diinn_layout.h)
 #include "diinn_device.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------
 // decode kernel, bf16 operands (optional path, BASELINE config 5; tolerance restated in
@@ -75,16 +76,16 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_kernel(const DecodeParams 
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         sk[g] = *(const f32x4*)(Pc + HID + 8 * g);
-        sq[g] = *(const f32x4*)(Wt + OFF_BQ + 4 * h + 8 * g);
+        sq[g] = *(const f32x4*)(Wt + OFF_BQR + 4 * h + 8 * g);
     }
     float q3[128];                                               // fp32 copy of the last activation for the head
 #pragma unroll 1
     for (int layer = 0; layer < 3; ++layer) {
         const int nl = layer < 2 ? layer + 1 : 2;
         const float* __restrict__ Pl = Pc + (layer + 1) * HID;
-        const float* __restrict__ Bq = Wt + OFF_BQ + layer * HID + 4 * h;
+        const float* __restrict__ Bq = Wt + OFF_BQR + layer * HID + 4 * h;
         const float* __restrict__ Pn = Pc + (nl + 1) * HID;
-        const float* __restrict__ Bn = Wt + OFF_BQ + nl * HID + 4 * h;
+        const float* __restrict__ Bn = Wt + OFF_BQR + nl * HID + 4 * h;
         bf16x8 qn[16];
         f32x16 pk, ps;
 #pragma unroll
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_kernel(const DecodeParams 
                     }
                 }
                 if (m > 0) {                                      // one epilogue element of tile m-1 per k-step
-                    const float v = relu0(pk[ks]) * dsin<SIN_MODE>(ps[ks]);
+                    const float v = relu0(pk[ks]) * dsin_rev<SIN_MODE>(ps[ks]);
                     qn[2 * (m - 1) + (ks >> 3)][ks & 7] = (__bf16)v;
                     q3[16 * (m - 1) + ks] = v;
                 }
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_kernel(const DecodeParams 
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float v = relu0(pk[r]) * dsin<SIN_MODE>(ps[r]);
+            const float v = relu0(pk[r]) * dsin_rev<SIN_MODE>(ps[r]);
             qn[14 + (r >> 3)][r & 7] = (__bf16)v;
             q3[16 * 7 + r] = v;
         }
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x2_kernel(const DecodeParam
     for (int g = 0; g < 4; ++g) {
         sk[0][g] = *(const f32x4*)(Pc[0] + HID + 8 * g);
         sk[1][g] = *(const f32x4*)(Pc[1] + HID + 8 * g);
-        sq[g] = *(const f32x4*)(Wt + OFF_BQ + 4 * h + 8 * g);
+        sq[g] = *(const f32x4*)(Wt + OFF_BQR + 4 * h + 8 * g);
     }
     float o[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
     bf16x8 (*mine)[16][64] = park[wave];
@@ -268,8 +269,8 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x2_kernel(const DecodeParam
     for (int layer = 0; layer < 3; ++layer) {
         const bool LAST = layer == 2;
         const int nl = layer < 2 ? layer + 1 : 2;
-        const float* __restrict__ Bq = Wt + OFF_BQ + layer * HID + 4 * h;
-        const float* __restrict__ Bn = Wt + OFF_BQ + nl * HID + 4 * h;
+        const float* __restrict__ Bq = Wt + OFF_BQR + layer * HID + 4 * h;
+        const float* __restrict__ Bn = Wt + OFF_BQR + nl * HID + 4 * h;
         const float* __restrict__ L = Wt + OFF_L + 4 * h;
         f32x16 pk[2], ps[2];
         bf16x8 frag[2];
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x2_kernel(const DecodeParam
                 if (m > 0) {                                      // one epilogue element of tile m-1 per k-step, both pixel tiles
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        const float v = relu0(pk[t][ks]) * dsin<SIN_MODE>(ps[t][ks]);
+                        const float v = relu0(pk[t][ks]) * dsin_rev<SIN_MODE>(ps[t][ks]);
                         if (LAST) {
                             o[t][0] = __builtin_fmaf(l0[ks >> 2][ks & 3], v, o[t][0]);
                             o[t][1] = __builtin_fmaf(l1[ks >> 2][ks & 3], v, o[t][1]);
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x2_kernel(const DecodeParam
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = relu0(pk[t][r]) * dsin<SIN_MODE>(ps[t][r]);
+                const float v = relu0(pk[t][r]) * dsin_rev<SIN_MODE>(ps[t][r]);
                 if (LAST) {
                     o[t][0] = __builtin_fmaf(l0[r >> 2][r & 3], v, o[t][0]);
                     o[t][1] = __builtin_fmaf(l1[r >> 2][r & 3], v, o[t][1]);
@@ -385,6 +386,389 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x2_kernel(const DecodeParam
     }
 }
 
+// ---------------------------------------------------------------------------------
+// decode_bf16_coop_kernel: the bf16 decode with the four waves of a workgroup COOPERATING on one block of
+// 4 pixel tiles (16 x 8 HR pixels) instead of each owning pixels of its own.  Wave w owns 64 of the 256
+// channels of every layer (M-tiles 2w and 2w+1 of the modulation rows and of the synthesis rows, so
+// relu(k) * sin(s) stays register-local) for ALL pixels of the block:
+//   * weights: a wave reads only its own quarter of a layer (64 KiB) and keeps the 32 fragments of the current
+//     M-tile in registers, where each feeds 4 MFMAs (one per pixel tile): a quarter of the single-tile kernel's
+//     vector-memory instructions and L1 bytes per MFMA, with no sharing protocol between the waves;
+//   * activations: the layer input of the whole block lives in LDS as ready-made B fragments
+//     [tile][k-step][lane] x 16 B (written and read lane-linearly: conflict-free), one ds_read_b128 per two
+//     MFMAs; input and output images are double-buffered (2 x 64 KiB) and the epilogue stores straight into the
+//     other buffer;
+//   * accumulator seeds: the slice P_{layer+1} of the block's LR cells (<= 24 cells, the launch checks the scale)
+//     and the synthesis biases are staged in LDS once per layer by whole-row loads (1 KiB per cell per
+//     instruction) instead of four scattered 16-byte loads per pixel tile and M-tile;
+//   * the RGB head is accumulated in the last layer's epilogue (fp32, unrounded activation) and the four
+//     waves' partial sums meet in LDS.
+// At one wave per SIMD a wave can issue about 8 instructions per 32-cycle bf16 MFMA, the MFMA included
+// (tools + PMC: DESIGN.md section 4.3), so the instruction stream between two MFMAs is placed by hand
+// (sched_barrier): LDS read | MFMA | half an epilogue element | MFMA | the other half + refill loads.
+// Same products and the same k-order of accumulation as decode_bf16_kernel.
+// ---------------------------------------------------------------------------------
+constexpr int CO_TILES = 4;                                   // 2 x 2 tiles of 8 x 4 pixels = 16 x 8 HR pixels
+constexpr int CO_MT_BYTES = 16 * 2 * PIECE_BYTES;             // one M-tile of the WLB image: [ks 16][part 2] pieces
+constexpr int CO_SEED_CELLS = 24;                             // LR cells of a block's footprint the seed slab holds
+constexpr int CO_SEED_PITCH = HID + 4;                        // floats per staged cell row (+16 B: rotates the banks)
+constexpr int CO_BRING = 4;                                   // LDS read-ahead of the B fragments, in k-steps
+#define CO_SB() __builtin_amdgcn_sched_barrier(0)
+
+struct CoopTagFalse { static constexpr bool value = false; };
+struct CoopTagTrue { static constexpr bool value = true; };
+
+// the sine of the synthesis branch on revolutions, split so that its two halves can sit in different MFMA gaps
+template <int MODE> __device__ __forceinline__ float co_sin_prep(float x) { return x; }
+template <> __device__ __forceinline__ float co_sin_prep<DIINN_SIN_HW_REDUCED>(float x) { return __builtin_amdgcn_fractf(x); }
+template <int MODE> __device__ __forceinline__ float co_sin_fin(float y) { return __builtin_amdgcn_sinf(y); }
+template <> __device__ __forceinline__ float co_sin_fin<DIINN_SIN_ACCURATE>(float y) { return dsin_rev<DIINN_SIN_ACCURATE>(y); }
+
+#ifdef DIINN_STAMPS
+#define CO_STAMP(i)                                                                           \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (p.stamps && lane == 0) p.stamps[co_stamp_base + (i)] = t_;                        \
+    } while (0)
+#else
+#define CO_STAMP(i) do {} while (0)
+#endif
+
+template <int SIN_MODE>
+__global__ __launch_bounds__(256, 1) void decode_bf16_coop_kernel(const DecodeParams p) {
+    constexpr int TILES = CO_TILES;
+    __shared__ __attribute__((aligned(16))) bf16x8 qa[2][TILES][16][64];       // 128 KiB: B fragments, double-buffered
+    __shared__ __attribute__((aligned(16))) float seed[CO_SEED_CELLS * CO_SEED_PITCH];   // P slice of the block's cells
+    __shared__ __attribute__((aligned(16))) float bias[3 * HID];               // bQ1..3 in revolutions
+    float (*red)[TILES * 32][3] = reinterpret_cast<float (*)[TILES * 32][3]>(seed);   // partial RGB per (wave, lane half),
+    static_assert(sizeof(seed) >= 8 * TILES * 32 * 3 * sizeof(float), "red aliases the seed slab");   // after the last seed read
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int b = blockIdx.z;
+    const float* __restrict__ Wt = p.Wt;
+    const int ncx = p.seed_cols;                                  // cells per slab row (host: max over the launch)
+#ifdef DIINN_STAMPS
+    const size_t co_stamp_base = ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 16;
+#endif
+    CO_STAMP(0);
+
+    // pixel of this lane in tile t: x = bx*16 + (t&1)*8 + (j&7), y = y0 + by*8 + (t>>1)*4 + (j>>3)
+    const int x0 = blockIdx.x * (2 * TILE_W) + (j & (TILE_W - 1));
+    const int yb = p.y0 + blockIdx.y * (2 * TILE_H) + (j / TILE_W);
+    // first LR cell of the block (wave-uniform)
+    int ix0, iy0;
+    {
+        float rel;
+        const int xf = blockIdx.x * (2 * TILE_W), yf = p.y0 + blockIdx.y * (2 * TILE_H);
+        axis_eval(p.aw, xf < p.Wu ? xf : p.Wu - 1, ix0, rel);
+        axis_eval(p.ah, yf < p.y1 ? yf : p.y1 - 1, iy0, rel);
+        ix0 = __builtin_amdgcn_readfirstlane(ix0);
+        iy0 = __builtin_amdgcn_readfirstlane(iy0);
+    }
+    // slab row of every tile's pixel: byte offset of its cell's staged P row (+ this lane-half's 16 bytes)
+    int srow[TILES];
+    {
+        int ixs[2], iys[2];
+        float rel;
+#pragma unroll
+        for (int tx = 0; tx < 2; ++tx) {
+            const int x = x0 + tx * TILE_W;
+            axis_eval(p.aw, x < p.Wu ? x : p.Wu - 1, ixs[tx], rel);
+        }
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty) {
+            const int y = yb + ty * TILE_H;
+            axis_eval(p.ah, y < p.y1 ? y : p.y1 - 1, iys[ty], rel);
+        }
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+            srow[t] = (((iys[t >> 1] - iy0) * ncx + (ixs[t & 1] - ix0)) * CO_SEED_PITCH + 4 * h) * (int)sizeof(float);
+    }
+    // the cells this wave stages (slab rows wave, wave + 4, ...): element offset of their P rows, clamped into the window
+    size_t scell[CO_SEED_CELLS / 4];
+#pragma unroll
+    for (int i = 0; i < CO_SEED_CELLS / 4; ++i) {
+        const int c = wave + 4 * i;
+        int cy = iy0 + c / ncx, cx = ix0 + c % ncx;
+        const int ylast = p.Prow0 + p.Prows - 1;
+        cy = cy < ylast ? cy : ylast;
+        cx = cx < p.W - 1 ? cx : p.W - 1;
+        scell[i] = ((size_t)(b * p.Prows + (cy - p.Prow0)) * p.W + cx) * PCH + 4 * lane;
+    }
+    f32x4 st[CO_SEED_CELLS / 4];
+    auto stage_load = [&](const int slice) {                      // whole 1 KiB rows, one instruction per cell
+#pragma unroll
+        for (int i = 0; i < CO_SEED_CELLS / 4; ++i) st[i] = *(const f32x4*)(p.P + scell[i] + slice * HID);
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < CO_SEED_CELLS / 4; ++i)
+            *(f32x4*)(seed + (wave + 4 * i) * CO_SEED_PITCH + 4 * lane) = st[i];
+    };
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);
+    const int lane_off = lane * 16;
+    // piece pc (= 2 ks + part) of the M-tile at byte offset mt: 4 pieces share one scalar offset, the piece inside
+    // the 4 KiB goes into the instruction's immediate field
+    auto ld_w = [&](const int mt, const int pc) {
+        return ld_piece(wrs, lane_off + (pc & 3) * PIECE_BYTES, mt + (pc >> 2) * 4 * PIECE_BYTES);
+    };
+    // weight fragments of the current M-tile, [k-step] x {modulation, synthesis}; each is refilled with the next
+    // M-tile's fragment as soon as the last pixel tile has consumed it.  The first M-tile is requested here, ahead
+    // of the prologue, so that it arrives while layer 0 is computed.
+    f32x4 Ak[16], As[16];
+    int wp = (int)(OFF_WLB * sizeof(float)) + (2 * wave) * CO_MT_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        Ak[ks] = ld_w(wp, 2 * ks + 0);
+        As[ks] = ld_w(wp, 2 * ks + 1);
+    }
+    // ---- prologue: everything layer 0 reads is staged in LDS first (a vector-memory instruction blocks its wave
+    // for ~60 cycles; the 160 scattered loads a wave would need become 14 row loads).  The Q0 table and the P_0
+    // slice live in the second activation buffer, which is free until layer 1's epilogue starts writing it.
+    float* const q0tab = reinterpret_cast<float*>(&qa[1][0][0][0]);          // [4][256]: Q0h, Q0w, Q0r, bQ0 (revolutions)
+    float* const seed0 = q0tab + 4 * HID;                                      // P_0 rows of the block's cells
+    static_assert((4 * HID + CO_SEED_CELLS * CO_SEED_PITCH) * sizeof(float) <= sizeof(qa) / 2, "prologue tables fit in qa[1]");
+    {
+        f32x4 s0[CO_SEED_CELLS / 4];
+#pragma unroll
+        for (int i = 0; i < CO_SEED_CELLS / 4; ++i) s0[i] = *(const f32x4*)(p.P + scell[i]);
+        stage_load(1);
+        const f32x4 tq = *(const f32x4*)(Wt + OFF_Q0R + 4 * threadIdx.x);
+        f32x4 tb = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (threadIdx.x < 3 * HID / 4) tb = *(const f32x4*)(Wt + OFF_BQR + 4 * threadIdx.x);
+#pragma unroll
+        for (int i = 0; i < CO_SEED_CELLS / 4; ++i)
+            *(f32x4*)(seed0 + (wave + 4 * i) * CO_SEED_PITCH + 4 * lane) = s0[i];
+        stage_store();
+        *(f32x4*)(q0tab + 4 * threadIdx.x) = tq;
+        if (threadIdx.x < 3 * HID / 4) *(f32x4*)(bias + 4 * threadIdx.x) = tb;
+    }
+    const float bl0 = Wt[OFF_BL + 0], bl1 = Wt[OFF_BL + 1], bl2 = Wt[OFF_BL + 2];   // head bias, needed at the very end
+    __syncthreads();
+
+    // ---- layer 0 (fp32): wave w evaluates tile w for all 256 channels and writes its B fragments
+    {
+        const float* __restrict__ Q0 = q0tab + 4 * h;
+        const int t = wave;
+        const int x = x0 + (t & 1) * TILE_W, y = yb + (t >> 1) * TILE_H;
+        int ix, iy;
+        float relw, relh;
+        axis_eval(p.aw, x < p.Wu ? x : p.Wu - 1, ix, relw);
+        axis_eval(p.ah, y < p.y1 ? y : p.y1 - 1, iy, relh);
+        const float* __restrict__ Pc = seed0 + ((iy - iy0) * ncx + (ix - ix0)) * CO_SEED_PITCH + 4 * h;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            bf16x8 f[2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * m + 8 * g;
+                const f32x4 pv = *(const f32x4*)(Pc + c0);
+                const f32x4 wh = *(const f32x4*)(Q0 + 0 * HID + c0);
+                const f32x4 ww = *(const f32x4*)(Q0 + 1 * HID + c0);
+                const f32x4 wr = *(const f32x4*)(Q0 + 2 * HID + c0);
+                const f32x4 bq = *(const f32x4*)(Q0 + 3 * HID + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = __builtin_fmaf(wr[e], p.ratio, bq[e]);
+                    a = __builtin_fmaf(ww[e], relw, a);
+                    a = __builtin_fmaf(wh[e], relh, a);
+                    f[g >> 1][4 * (g & 1) + e] = (__bf16)(relu0(pv[e]) * dsin_rev<SIN_MODE>(a));
+                }
+            }
+            qa[0][t][2 * m][lane] = f[0];
+            qa[0][t][2 * m + 1][lane] = f[1];
+        }
+    }
+
+    float o[TILES][3];                                            // partial RGB of this wave's channels (last layer)
+    CO_STAMP(1);
+    __syncthreads();
+    CO_STAMP(2);
+
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    // seeds of (M-tile m, tile t): modulation rows from the staged P slice, synthesis rows from the bias table
+    auto seed_k = [&](const int t, const int m, const int gg) {
+        return *(const f32x4*)((const char*)seed + srow[t] + (32 * m + 8 * gg) * (int)sizeof(float));
+    };
+
+    // CUR = index of the LDS image holding the layer input (compile-time: the three layers are three copies)
+    auto layer_body = [&](auto last_tag, auto cur_tag, const int layer) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        constexpr int CUR = decltype(cur_tag)::value ? 1 : 0;
+        constexpr int NXT = 1 - CUR;
+        f32x4 hl[2][3][4];                                        // LAST: head rows of this wave's two M-tiles
+        if (LAST) {
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) o[t][0] = o[t][1] = o[t][2] = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        hl[g][k][gg] = *(const f32x4*)(Wt + OFF_L + k * HID + 32 * (2 * wave + g) + 4 * h + 8 * gg);
+        }
+        const float* __restrict__ bl = bias + layer * HID + 4 * h;
+        bf16x8 bq[CO_BRING];                                      // B fragments, read CO_BRING k-steps ahead
+#pragma unroll
+        for (int i = 0; i < CO_BRING; ++i) bq[i] = qa[CUR][0][i][lane];
+        f32x4 sk[4], sq[4];
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            sk[gg] = seed_k(0, 2 * wave, gg);
+            sq[gg] = *(const f32x4*)(bl + 32 * (2 * wave) + 8 * gg);
+        }
+        f32x16 pk, ps;                                            // finished accumulators of the previous unit
+        float kv = 0.0f, sr = 0.0f, v0 = 0.0f;
+        u32x4 fragw;
+        // units u = TILES*g + t: pixel tile t of M-tile 2w+g; the epilogue of unit u-1 runs under unit u's MFMAs,
+        // one element per k-step, split over the two MFMA gaps of the step
+#pragma unroll
+        for (int u = 0; u < 2 * TILES; ++u) {
+            const int g = u / TILES, t = u % TILES;
+            const int pg = (u - 1) / TILES, pt = (u - 1) % TILES;   // the unit whose epilogue runs now
+            f32x16 ak, as;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ak[4 * gg + e] = sk[gg][e];
+                    as[4 * gg + e] = sq[gg][e];
+                }
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int n = 16 * u + ks;                        // step number inside the layer
+                const bf16x8 bv = bq[ks % CO_BRING];
+                CO_SB();
+                if (n + CO_BRING < 32 * TILES)
+                    bq[ks % CO_BRING] = qa[CUR][((n + CO_BRING) >> 4) % TILES][(n + CO_BRING) & 15][lane];
+                CO_SB();
+                ak = MFMA_BF16(__builtin_bit_cast(bf16x8, Ak[ks]), bv, ak);
+                CO_SB();
+                if (u > 0) {                                      // first half of epilogue element ks of the previous unit
+                    kv = relu0(pk[ks]);
+                    sr = co_sin_prep<SIN_MODE>(ps[ks]);
+                }
+                if (ks >= 2 && ks < 6 && u + 1 < 2 * TILES) {     // seeds of the next unit, one read per step
+                    const int ng = (u + 1) / TILES, nt = (u + 1) % TILES, gg = ks - 2;
+                    sk[gg] = seed_k(nt, 2 * wave + ng, gg);
+                    if (nt == 0) sq[gg] = *(const f32x4*)(bl + 32 * (2 * wave + ng) + 8 * gg);
+                }
+                CO_SB();
+                as = MFMA_BF16(__builtin_bit_cast(bf16x8, As[ks]), bv, as);
+                CO_SB();
+                if (u > 0) {                                      // second half: q = relu(k) * sin(s), packed or folded into the head
+                    const float v = kv * co_sin_fin<SIN_MODE>(sr);
+                    if (LAST) {
+                        o[pt][0] = __builtin_fmaf(hl[pg][0][ks >> 2][ks & 3], v, o[pt][0]);
+                        o[pt][1] = __builtin_fmaf(hl[pg][1][ks >> 2][ks & 3], v, o[pt][1]);
+                        o[pt][2] = __builtin_fmaf(hl[pg][2][ks >> 2][ks & 3], v, o[pt][2]);
+                        // nothing but the final store uses these sums, so the optimiser would sink the whole
+                        // epilogue of the last layer past its MFMAs: an opaque use keeps it in this gap
+                        asm volatile("" : "+v"(o[pt][0]), "+v"(o[pt][1]), "+v"(o[pt][2]));
+                    } else if (ks & 1) {
+                        f32x2 pr = {v0, v};
+                        fragw[(ks >> 1) & 3] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2));
+                        if ((ks & 7) == 7)
+                            qa[NXT][pt][2 * (2 * wave + pg) + (ks >> 3)][lane] = __builtin_bit_cast(bf16x8, fragw);
+                    } else {
+                        v0 = v;
+                    }
+                }
+                if (t == TILES - 1 && !(LAST && g == 1)) {        // last use of this fragment: fetch the next M-tile's
+                    const int nwp = g == 0 ? wp + CO_MT_BYTES : wp + (int)(WLB_LAYER * sizeof(float));
+                    Ak[ks] = ld_w(nwp, 2 * ks + 0);
+                    As[ks] = ld_w(nwp, 2 * ks + 1);
+                }
+                if (!LAST && u == TILES && ks == 8) stage_load(layer + 2);   // next layer's P slice, into registers
+            }
+            pk = ak;
+            ps = as;
+        }
+        CO_SB();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                            // the last unit's epilogue has nothing to hide under
+            const float v = relu0(pk[r]) * co_sin_fin<SIN_MODE>(co_sin_prep<SIN_MODE>(ps[r]));
+            if (LAST) {
+                o[TILES - 1][0] = __builtin_fmaf(hl[1][0][r >> 2][r & 3], v, o[TILES - 1][0]);
+                o[TILES - 1][1] = __builtin_fmaf(hl[1][1][r >> 2][r & 3], v, o[TILES - 1][1]);
+                o[TILES - 1][2] = __builtin_fmaf(hl[1][2][r >> 2][r & 3], v, o[TILES - 1][2]);
+            } else if (r & 1) {
+                f32x2 pr = {v0, v};
+                fragw[(r >> 1) & 3] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2));
+                if ((r & 7) == 7)
+                    qa[NXT][TILES - 1][2 * (2 * wave + 1) + (r >> 3)][lane] = __builtin_bit_cast(bf16x8, fragw);
+            } else {
+                v0 = v;
+            }
+        }
+        CO_STAMP(3 + 3 * (LAST ? 2 : CUR));
+        __syncthreads();                                          // layer output complete; input and seed slab are free
+        CO_STAMP(4 + 3 * (LAST ? 2 : CUR));
+        if (!LAST) {
+            stage_store();
+            __syncthreads();
+        }
+        CO_STAMP(5 + 3 * (LAST ? 2 : CUR));
+    };
+
+    layer_body(CoopTagFalse{}, CoopTagFalse{}, 0);
+    wp += (int)(WLB_LAYER * sizeof(float));
+    layer_body(CoopTagFalse{}, CoopTagTrue{}, 1);
+    wp += (int)(WLB_LAYER * sizeof(float));
+    layer_body(CoopTagTrue{}, CoopTagFalse{}, 2);
+
+    // ---- head: the 8 partial sums of a pixel (4 waves x 2 lane halves) meet in LDS (diinn.py:138)
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) red[2 * wave + h][t * 32 + j][k] = o[t][k];
+    __syncthreads();
+    if (threadIdx.x < TILES * 32) {
+        const int t = threadIdx.x >> 5, jj = threadIdx.x & 31;    // one pixel per thread
+        const int x = blockIdx.x * (2 * TILE_W) + (t & 1) * TILE_W + (jj & (TILE_W - 1));
+        const int y = p.y0 + blockIdx.y * (2 * TILE_H) + (t >> 1) * TILE_H + (jj / TILE_W);
+        float acc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[k] += red[w8][threadIdx.x][k];
+        if (x < p.Wu && y < p.y1) {
+            const size_t plane = (size_t)p.Orows * p.Wu;
+            float* op = p.out + (size_t)b * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
+            op[0] = acc[0] + bl0;
+            op[plane] = acc[1] + bl1;
+            op[2 * plane] = acc[2] + bl2;
+        }
+    }
+    CO_STAMP(12);
+}
+
+// cells of the LR footprint of the widest 16 x 8 block of the launch: (columns, rows)
+static void coop_footprint(const DecodeParams& p, int& ncx, int& ncy) {
+    ncx = ncy = 1;
+    int a, b2;
+    float rel;
+    for (int x = 0; x < p.Wu; x += 2 * TILE_W) {
+        const int xl = x + 2 * TILE_W - 1 < p.Wu ? x + 2 * TILE_W - 1 : p.Wu - 1;
+        axis_eval(p.aw, x, a, rel);
+        axis_eval(p.aw, xl, b2, rel);
+        ncx = b2 - a + 1 > ncx ? b2 - a + 1 : ncx;
+    }
+    for (int y = p.y0; y < p.y1; y += 2 * TILE_H) {
+        const int yl = y + 2 * TILE_H - 1 < p.y1 ? y + 2 * TILE_H - 1 : p.y1 - 1;
+        axis_eval(p.ah, y, a, rel);
+        axis_eval(p.ah, yl, b2, rel);
+        ncy = b2 - a + 1 > ncy ? b2 - a + 1 : ncy;
+    }
+}
+
 int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int gz, int sin_mode) {
     const int y0 = p.y0, y1 = p.y1, blk = 256;
     const dim3 grid(gx, gy, gz);
@@ -393,7 +777,26 @@ int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int 
         // small images keep one tile per wave (twice the workgroups)
         const dim3 grid2(gx, (y1 - y0 + 2 * TILE_H * WG_TILES_Y - 1) / (2 * TILE_H * WG_TILES_Y), gz);   // 16 x 16 pixels per workgroup
         const bool two_tiles = (long long)grid2.x * grid2.y * grid2.z >= 512;
-        if (!two_tiles) {
+        // diagnostic override (tests / A-B timing): DIINN_BF16_KERNEL = 1 one tile per wave, 2 two tiles per wave,
+        // 4 cooperative; unset = pick by launch size and scale
+        const char* fenv = getenv("DIINN_BF16_KERNEL");
+        const int force = fenv ? atoi(fenv) : 0;
+        // the cooperative kernel stages the P rows of a block's LR footprint in LDS: needs the footprint to fit
+        // (scales from about x3 up), and >= 2 rounds of workgroups to be worth its prologue
+        DecodeParams pc = p;
+        int ncx, ncy;
+        coop_footprint(p, ncx, ncy);
+        pc.seed_cols = ncx;
+        const bool coop_ok = ncx * ncy <= CO_SEED_CELLS;
+        const bool coop = coop_ok && (force ? force == 4 : (long long)gx * gy * gz >= 1024);
+        if (coop) {                                               // 16 x 8 pixel blocks: the grid of the one-tile kernel
+            if (sin_mode == DIINN_SIN_HW)
+                hipLaunchKernelGGL(decode_bf16_coop_kernel<DIINN_SIN_HW>, grid, dim3(blk), 0, (hipStream_t)stream, pc);
+            else if (sin_mode == DIINN_SIN_HW_REDUCED)
+                hipLaunchKernelGGL(decode_bf16_coop_kernel<DIINN_SIN_HW_REDUCED>, grid, dim3(blk), 0, (hipStream_t)stream, pc);
+            else
+                hipLaunchKernelGGL(decode_bf16_coop_kernel<DIINN_SIN_ACCURATE>, grid, dim3(blk), 0, (hipStream_t)stream, pc);
+        } else if (!((force == 1 || force == 2) ? force == 2 : two_tiles)) {
             if (sin_mode == DIINN_SIN_HW)
                 hipLaunchKernelGGL(decode_bf16_kernel<DIINN_SIN_HW>, grid, dim3(blk), 0, (hipStream_t)stream, p);
             else if (sin_mode == DIINN_SIN_HW_REDUCED)

@@ -69,6 +69,23 @@ __device__ __forceinline__ float dsin<DIINN_SIN_HW_REDUCED>(float x) {
     return __builtin_amdgcn_sinf(r);
 }
 
+// The same three modes for an argument already in REVOLUTIONS (the bf16 kernels: synthesis weights and biases
+// are stored pre-divided by 2 pi, packed sections 7 / 10): HW is the bare instruction (valid for |x| <= 256
+// revolutions), HW_REDUCED adds the fract that makes it valid for any magnitude, ACCURATE converts back to
+// radians and runs the polynomial.
+template <int MODE>
+__device__ __forceinline__ float dsin_rev(float x);
+template <>
+__device__ __forceinline__ float dsin_rev<DIINN_SIN_HW>(float x) { return __builtin_amdgcn_sinf(x); }
+template <>
+__device__ __forceinline__ float dsin_rev<DIINN_SIN_HW_REDUCED>(float x) {
+    return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x));
+}
+template <>
+__device__ __forceinline__ float dsin_rev<DIINN_SIN_ACCURATE>(float x) {
+    return dsin<DIINN_SIN_ACCURATE>(x * 6.28318530717958647692f);
+}
+
 // ---------------------------------------------------------------------------------
 // decode kernel
 // ---------------------------------------------------------------------------------
@@ -80,6 +97,7 @@ struct DecodeParams {
     // row windows (include/diinn_hip.h "row windows"): P holds LR rows [Prow0, Prow0+Prows), out holds HR rows
     // [Orow0, Orow0+Orows); the full-buffer entry points pass (0, H) and (0, Hu)
     int Prow0, Prows, Orow0, Orows;
+    int seed_cols;         // decode_bf16_coop_kernel: LR columns of a block's footprint (row length of its LDS seed slab)
     float ratio;           // fp32(H*W / (Hu*Wu))   (diinn.py:166)
     Axis ah, aw;
     float* acts;           // training forward only (SAVE): saved activations, tiled planes [4 layers][ntiles][512][32]

@@ -10,6 +10,8 @@
 
 using namespace diinn;
 
+static const float INV_2PI = 0.15915494309189533577f;      // fp32(1 / (2 pi))
+
 // fp32 -> bf16, round to nearest even (weights are finite; NaN is kept a NaN)
 static inline uint16_t f32_to_bf16(float f) {
     uint32_t u;
@@ -83,9 +85,11 @@ size_t diinn_metasr_workspace_bytes(int B, int H, int W) {
 }
 
 int diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats) {
-    static const size_t off[10] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT, OFF_WPB};
-    static const size_t sz[10]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT, SZ_WPB};
-    if (section < 0 || section > 9 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
+    static const size_t off[12] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT, OFF_WPB, OFF_BQR,
+                                   OFF_Q0R};
+    static const size_t sz[12]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT, SZ_WPB, 3 * HID,
+                                   4 * HID};
+    if (section < 0 || section > 11 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
     *offset_floats = off[section];
     *size_floats = sz[section];
     return DIINN_OK;
@@ -177,6 +181,9 @@ int diinn_pack_weights(const float* K0w, const float* K0b,
         q0[3 * HID + ch] = Q0b[ch];
     }
     for (int i = 0; i < 3; ++i) std::memcpy(packed + OFF_BQ + i * HID, Qb[i], HID * sizeof(float));
+    for (int i = 0; i < 3; ++i)
+        for (int ch = 0; ch < HID; ++ch) packed[OFF_BQR + i * HID + ch] = Qb[i][ch] * INV_2PI;
+    for (int i = 0; i < 4 * HID; ++i) packed[OFF_Q0R + i] = q0[i] * INV_2PI;
     std::memcpy(packed + OFF_L, Lw, 3 * HID * sizeof(float));
     float* bl = packed + OFF_BL;
     bl[0] = Lb[0]; bl[1] = Lb[1]; bl[2] = Lb[2]; bl[3] = 0.0f;
@@ -192,8 +199,9 @@ int diinn_pack_weights(const float* K0w, const float* K0b,
                         const int h = lane >> 5;
                         for (int j = 0; j < 8; ++j) {
                             const int in = chan_of_bf16(ks, h, j);
+                            // synthesis rows in revolutions (one fp32 multiply, then the bf16 rounding)
                             const float w = part == 0 ? Kw[i][(size_t)out * (HID + UNF) + in]
-                                                      : Qw[i][(size_t)out * HID + in];
+                                                      : Qw[i][(size_t)out * HID + in] * INV_2PI;
                             dst[lane * 8 + j] = f32_to_bf16(w);
                         }
                     }

@@ -50,7 +50,8 @@ constexpr size_t OFF_L      = OFF_BQ + 3 * HID;            // L[3][256]
 constexpr size_t OFF_BL     = OFF_L + 3 * HID;             // bL[3] + pad
 // WLB: the per-pixel layers again, as bf16 A operands of v_mfma_f32_32x32x16_bf16 (optional
 //     reduced-precision path, BASELINE config 5).  [layer 3][m 8][ks 16][part 2][lane 64][j 8] bf16;
-//     value = bf16(W_part[ out = 32m + (lane&31) ][ in = chan_of_bf16(ks, lane>>5, j) ]), 16 B per lane.
+//     value = bf16(W_part[ out = 32m + (lane&31) ][ in = chan_of_bf16(ks, lane>>5, j) ]), 16 B per lane;
+//     part 1 (synthesis rows) is bf16(W * fp32(1/(2 pi))): see BQR below.
 constexpr size_t WLB_PIECE  = 64 * 4;                      // floats (= 64 lanes x 8 bf16) per piece = 1 KiB
 constexpr size_t WLB_LAYER  = (size_t)8 * 16 * 2 * WLB_PIECE;
 constexpr size_t OFF_WLB    = OFF_BL + 4;
@@ -66,7 +67,13 @@ constexpr size_t SZ_WLT     = SZ_WL;
 constexpr int    WPB_KS     = 36;
 constexpr size_t OFF_WPB    = OFF_WLT + SZ_WLT;
 constexpr size_t SZ_WPB     = (size_t)16 * WPB_KS * 2 * WL_PIECE;    // 294,912 floats
-constexpr size_t PACKED_FLOATS = OFF_WPB + SZ_WPB;         // 1,871,364
+// BQR: the synthesis biases of layers 1..3 in REVOLUTIONS, bQ_i / (2 pi), for the bf16 decode kernels: there the
+//     synthesis rows of WLB are stored pre-multiplied by 1/(2 pi) as well, so the accumulator already holds the
+//     argument v_sin_f32 wants (revolutions) and the epilogue needs no range-reduction arithmetic.
+constexpr size_t OFF_BQR    = OFF_WPB + SZ_WPB;
+// Q0R: the Q0 table (Q0h, Q0w, Q0r, bQ0; [4][256]) in revolutions as well, for the cooperative bf16 kernel
+constexpr size_t OFF_Q0R    = OFF_BQR + 3 * HID;
+constexpr size_t PACKED_FLOATS = OFF_Q0R + 4 * HID;        // 1,873,156
 
 // channel held by activation register (m, r) of lane-half h
 DIINN_HD int chan_of(int kk /* = 16*m + r */, int h) {

@@ -87,9 +87,11 @@ int         diinn_last_hip_error(void);
 size_t diinn_packed_weight_floats(void);
 /* Sections of the packed image (offset and size in floats): 0 WL stacked per-pixel layers, 1 WP the
  * hoisted 3x3 conv, 2 bK, 3 Q0 (+bQ0), 4 bQ1..3, 5 L, 6 bL, 7 WLB (bf16 copy of WL), 8 WLT (WL transposed,
- * read by the backward pass), 9 WPB (bf16 copy of WP).  Every section but 7 and 9 is a pure permutation
- * (plus zero padding) of the reference tensors, so a training loop can re-pack on the device with one
- * gather; sections 7 and 9 hold rounded values and are only read by the bf16 compute modes. */
+ * read by the backward pass), 9 WPB (bf16 copy of WP), 10 BQR (bQ1..3 / (2 pi): the bf16 kernels evaluate the
+ * sine on revolutions, and the synthesis rows inside section 7 are pre-multiplied by 1/(2 pi) to match), 11 Q0R
+ * (section 3 / (2 pi)).  Every section but 7 and 9..11 is a pure permutation (plus zero padding) of the reference
+ * tensors, so a training loop can re-pack on the device with one gather; sections 7 and 9..11 hold derived values
+ * and are only read by the bf16 compute modes. */
 int    diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats);
 int    diinn_pack_weights(const float* K0w, const float* K0b,
                           const float* const Kw[3], const float* const Kb[3],

@@ -289,10 +289,18 @@ def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = Fal
     syn[..., 2] = float(scale_ratio(h, w, hu, wu))
     q = torch.relu(pp[:, :, :, 0]) * torch.sin(syn @ sw["Q0"].t() + sw["bQ"][0])
     rnd = _bf16_round if bf16_operands else (lambda t: t)
+    inv_2pi = torch.tensor(0.15915494309189533577, dtype=torch.float32)
     for i in range(1, 4):
         qi = rnd(q)
         k = torch.relu(qi @ rnd(sw["Wq"][i - 1]).t() + pp[:, :, :, i])
-        q = k * torch.sin(qi @ rnd(sw["Qw"][i - 1]).t() + sw["bQ"][i])
+        if bf16_operands:
+            # the bf16 kernels keep the synthesis branch in REVOLUTIONS: weights are multiplied by fp32(1/(2 pi))
+            # before the bf16 rounding and the bias after it (packed sections 7 and 10, diinn_host.cpp), and the
+            # sine is taken of 2 pi x (here in float64, so that only the operand roundings are emulated)
+            rev = qi @ rnd(sw["Qw"][i - 1] * inv_2pi).t() + sw["bQ"][i] * inv_2pi
+            q = k * torch.sin(rev.double() * (2.0 * np.pi)).float()
+        else:
+            q = k * torch.sin(qi @ sw["Qw"][i - 1].t() + sw["bQ"][i])
     out = q @ sw["L"].t() + sw["bL"]
     return out.permute(0, 3, 1, 2).contiguous()
 

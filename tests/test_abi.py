@@ -86,7 +86,7 @@ def test_packed_image_layout(lib):
     import diinn_amd.decoder as D
     sd = synth.decoder_state_dict(11)
     packed = D.pack_state_dict(sd).numpy()
-    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608 + 393_216 + 294_912
+    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608 + 393_216 + 294_912 + 768 + 1024
     lane = np.arange(64)
     out_l, h_l = lane & 31, lane >> 5
     # WL section
@@ -130,7 +130,7 @@ def test_packed_image_layout(lib):
         w = sd[f"K.{i + 1}.0.weight"][o, cin, 0, 0] if part == 0 else sd[f"Q.{i + 1}.0.weight"][o, cin, 0, 0]
         assert WLT[i, m, kg, part, l, e] == w
     # WPB section (bf16 copy of the 3x3 conv): [mp][ks][t][lane][j], k-step = 4*tap + channel group of 16
-    WPB = packed[986_628 + 196_608 + 393_216:].view(np.uint16).reshape(16, 36, 2, 64, 8)
+    WPB = packed[986_628 + 196_608 + 393_216:986_628 + 196_608 + 393_216 + 294_912].view(np.uint16).reshape(16, 36, 2, 64, 8)
     for _ in range(200):
         mo, ks, l, jj = (int(rng.integers(n)) for n in (32, 36, 64, 8))
         i, ch = mo >> 3, 32 * (mo & 7) + (l & 31)
@@ -140,6 +140,26 @@ def test_packed_image_layout(lib):
         u = int(w.view(np.uint32))
         bf = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF            # round to nearest even
         assert int(WPB[mo >> 1, ks, mo & 1, l, jj]) == bf
+    # WLB section (bf16 copy of the per-pixel layers): [layer][m][ks][part][lane][j]; the synthesis rows (part 1) and
+    # the BQR table are in revolutions: multiplied by fp32(1/(2 pi)) (before the bf16 rounding for the weights)
+    def bf16_bits(w):
+        u = int(np.float32(w).view(np.uint32))
+        return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF
+    inv2pi = np.float32(0.15915494309189533577)
+    WLB = packed[986_628:986_628 + 196_608].view(np.uint16).reshape(3, 8, 16, 2, 64, 8)
+    for _ in range(300):
+        i, m, ks, part, l, jj = (int(rng.integers(n)) for n in (3, 8, 16, 2, 64, 8))
+        hh = l >> 5
+        o, cin = 32 * m + (l & 31), 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (jj >> 2) + 4 * hh + (jj & 3)
+        w = sd[f"K.{i + 1}.0.weight"][o, cin, 0, 0] if part == 0 else np.float32(sd[f"Q.{i + 1}.0.weight"][o, cin, 0, 0] * inv2pi)
+        assert int(WLB[i, m, ks, part, l, jj]) == bf16_bits(w)
+    BQR = packed[-1792:-1024].reshape(3, 256)
+    for i in range(3):
+        assert np.array_equal(BQR[i], (sd[f"Q.{i + 1}.0.bias"] * inv2pi).astype(np.float32))
+    Q0R = packed[-1024:].reshape(4, 256)
+    for jj in range(3):
+        assert np.array_equal(Q0R[jj], (q0[:, jj] * inv2pi).astype(np.float32))
+    assert np.array_equal(Q0R[3], (sd["Q.0.0.bias"] * inv2pi).astype(np.float32))
     # every channel appears exactly once per lane-half in the activation register order
     seen = sorted(_chan_of(kk, h) for kk in range(128) for h in range(2))
     assert seen == list(range(256))

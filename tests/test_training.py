@@ -74,18 +74,18 @@ def test_pack_gather_index_is_the_host_packer():
     ref = D.pack_state_dict(sd).numpy()
     off, size = C.c_size_t(), C.c_size_t()
     keep = np.ones(ref.size, bool)
-    for section in (7, 9):                         # bf16 sections: rounded values, left zero by the gather
+    for section in (7, 9, 10, 11):                 # bf16-path sections: derived values, left zero by the gather
         assert lib.diinn_packed_section(section, C.byref(off), C.byref(size)) == 0
         keep[off.value:off.value + size.value] = False
     assert np.array_equal(got[keep], ref[keep]) and not got[~keep].any()
     total = 0
-    for s in range(10):
+    for s in range(12):
         o, z = C.c_size_t(), C.c_size_t()
         assert lib.diinn_packed_section(s, C.byref(o), C.byref(z)) == 0
         assert o.value == total                    # sections are contiguous
         total = o.value + z.value
     assert total == ref.size == lib.diinn_packed_weight_floats()
-    assert lib.diinn_packed_section(10, C.byref(off), C.byref(size)) != 0
+    assert lib.diinn_packed_section(12, C.byref(off), C.byref(size)) != 0
 
 
 def test_backward_formulas_on_cpu(gold):
