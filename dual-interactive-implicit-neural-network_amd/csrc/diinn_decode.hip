@@ -28,6 +28,31 @@
 
 template <int SIN_MODE, bool KPART = true, bool SAVE = false>
 __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
+    // The small tables of layer 0 and of the head go through LDS: a vector-memory instruction blocks its wave for
+    // ~60 cycles (stamps), and a wave reading them straight from the packed image issued 128 + 96
+    // of those per tile.  Rows: Q0h, Q0w, t = fma(Q0r, ratio, bQ0) (the pixel-independent part of the sine
+    // argument, the same first fma the per-pixel chain used to start with: results are bit-identical), L0, L1, L2.
+    __shared__ __attribute__((aligned(16))) float tab[6 * HID + 4];      // + the head bias bL
+    {
+        const int i = threadIdx.x & 63, part = threadIdx.x >> 6;
+        const float* __restrict__ Q0s = p.Wt + OFF_Q0 + 4 * i;
+        if (part == 0) {
+            *(f32x4*)(tab + 0 * HID + 4 * i) = *(const f32x4*)(Q0s + 0 * HID);
+            *(f32x4*)(tab + 1 * HID + 4 * i) = *(const f32x4*)(Q0s + 1 * HID);
+        } else if (part == 1) {
+            const f32x4 wr = *(const f32x4*)(Q0s + 2 * HID), bq = *(const f32x4*)(Q0s + 3 * HID);
+            f32x4 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = __builtin_fmaf(wr[e], p.ratio, bq[e]);
+            *(f32x4*)(tab + 2 * HID + 4 * i) = t;
+        } else if (part == 2) {
+            *(f32x4*)(tab + 3 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 0 * HID + 4 * i);
+            *(f32x4*)(tab + 4 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 1 * HID + 4 * i);
+        } else {
+            *(f32x4*)(tab + 5 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 2 * HID + 4 * i);
+            if (i == 0) *(f32x4*)(tab + 6 * HID) = *(const f32x4*)(p.Wt + OFF_BL);
+        }
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform (scalar offsets)
     const int h = lane >> 5, j = lane & 31;
@@ -48,7 +73,8 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
         b = blockIdx.z;
     }
     const bool valid = (x < p.Wu) && (y < p.y1);
-    // whole wave outside the band/image: nothing to do (wave-uniform, no barriers in this kernel)
+    __syncthreads();                                             // the tables are in LDS
+    // whole wave outside the band/image: nothing to do (wave-uniform; no barrier follows)
     if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
     const int xc = x < p.Wu ? x : p.Wu - 1;
     const int yc = y < p.y1 ? y : p.y1 - 1;
@@ -83,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     // ---- layer 0: q0 = relu(P_0[cell]) * sin(Q0 . (rel_h, rel_w, ratio) + bQ0)   (diinn.py:133-134)
     float q[128];
     {
-        const float* __restrict__ Q0 = Wt + OFF_Q0 + 4 * h;
+        const float* __restrict__ Q0 = tab + 4 * h;
         const __amdgpu_buffer_rsrc_t ar0 = act_rsrc(0);
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
@@ -93,11 +119,10 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
                 const f32x4 pv = *(const f32x4*)(Pc + c0);
                 const f32x4 wh = *(const f32x4*)(Q0 + 0 * HID + c0);
                 const f32x4 ww = *(const f32x4*)(Q0 + 1 * HID + c0);
-                const f32x4 wr = *(const f32x4*)(Q0 + 2 * HID + c0);
-                const f32x4 bq = *(const f32x4*)(Q0 + 3 * HID + c0);
+                const f32x4 tq = *(const f32x4*)(Q0 + 2 * HID + c0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float a = __builtin_fmaf(wr[e], p.ratio, bq[e]);
+                    float a = tq[e];
                     a = __builtin_fmaf(ww[e], relw, a);
                     a = __builtin_fmaf(wh[e], relh, a);
                     const float kv = relu0(pv[e]);
@@ -218,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     // ---- head: out = L . q3 + bL   (diinn.py:138)
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
     {
-        const float* __restrict__ L = Wt + OFF_L + 4 * h;
+        const float* __restrict__ L = tab + 3 * HID + 4 * h;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
 #pragma unroll
@@ -243,9 +268,9 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     if (valid && h == 0) {
         const size_t plane = (size_t)p.Orows * p.Wu;
         float* o = p.out + (size_t)b * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
-        o[0] = o0 + Wt[OFF_BL + 0];
-        o[plane] = o1 + Wt[OFF_BL + 1];
-        o[2 * plane] = o2 + Wt[OFF_BL + 2];
+        o[0] = o0 + tab[6 * HID + 0];
+        o[plane] = o1 + tab[6 * HID + 1];
+        o[2 * plane] = o2 + tab[6 * HID + 2];
     }
     STAMP(5);
 }

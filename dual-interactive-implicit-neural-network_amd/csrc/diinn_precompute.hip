@@ -38,6 +38,30 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
     const int x0 = blockIdx.x * PT_COLS;
     const int y0 = p.r0 + blockIdx.y * PT_ROWS;
 
+#ifndef P_NO_WARMUP
+    // L2 warm-up.  Inside a decode step this kernel starts right after decode_kernel has streamed hundreds of MB of
+    // P through every L2, so the 2.25 MiB weight image is gone; all waves of an XCD then walk it in lock-step and
+    // the whole first round of workgroups advances at HBM-latency pace (67 % MFMA utilisation at c2 against 80 % warm).
+    // Every workgroup touches a slice of the image first so the fills run while the feature tile is staged.  The
+    // loaded values are dead; their registers stay reserved until the staging loop's waits have drained them.
+    float warm[4];
+    {
+        const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const unsigned per_xcd = (nwg + 7) / 8, slot = wg >> 3;      // workgroups are dealt to the 8 XCDs round-robin
+        constexpr unsigned LINES = (unsigned)(SZ_WP * sizeof(float) / 128);   // 128-byte lines of the WP image
+        const unsigned share = (LINES + per_xcd - 1) / per_xcd;       // lines this workgroup touches (at most 1024)
+        const char* wpb = (const char*)(p.Wt + OFF_WP);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned k = threadIdx.x + 256 * i;
+            unsigned line = slot * share + k;
+            line = (k < share && line < LINES) ? line : 0;            // surplus lanes re-touch line 0
+            asm volatile("global_load_dword %0, %1, off" : "=v"(warm[i]) : "v"(wpb + (size_t)line * 128) : "memory");
+        }
+    }
+#endif
+
     // stage feat[b, :, y0-1 .. y0+4, x0-1 .. x0+32] (zeros outside the map)
     const float* __restrict__ fb = p.feat + (size_t)b * C_IN * p.Frows * p.W;
     const int fy_hi = p.Frow0 + p.Frows - 1;              // rows of the map the feature window holds: [Frow0, fy_hi]
@@ -60,6 +84,9 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
         const float v = fb[((size_t)c * p.Frows + yc) * p.W + xc];
         tile[idx] = ok ? v : 0.0f;
     }
+#ifndef P_NO_WARMUP
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(warm[0]), "v"(warm[1]), "v"(warm[2]), "v"(warm[3]) : "memory");
+#endif
     __syncthreads();
 
     const int x = x0 + j, y = y0 + wave;
