@@ -1,6 +1,7 @@
 // diinn_precompute.hip -- the hoisted 3x3 convolution P = Wx . unfold3x3(feat) + bK (fp32 and bf16 operands)
 // (part of libdiinn_hip.so; shared definitions in diinn_device.h, layout in diinn_layout.h)
 #include "diinn_device.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------
 // P kernel: P[b,y,x, i*256+ch] = sum_{c,ky,kx} Wx_i[ch,c,ky,kx] * feat[b,c,y+ky-1,x+kx-1] + bK_i[ch]
@@ -272,6 +273,145 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_kernel(const PParams
     }
 }
 
+// ---------------------------------------------------------------------------------
+// precompute_P_bf16_wide_kernel (DIINN_COMPUTE_BF16_FULL, large maps): the same bf16 convolution with the weights
+// REUSED.  precompute_P_bf16_kernel streams one 1 KiB weight fragment per MFMA through the vector-memory path, and a
+// vector-memory instruction blocks its wave for ~60 cycles against the MFMA's 32 (21 % utilisation at c5).  Here a
+// workgroup covers 8 rows x 32 columns of LR cells and its four waves split the 32 M-tiles instead of the rows:
+// wave w owns M-tiles w, w+4, .., keeps the 36 fragments of the current one in registers and runs all 8 cell rows
+// past them, so a fragment is fetched once per 8 MFMAs; the B fragments come from the staged halo tile
+// (ds_read_b128 per MFMA, conflict-free as in the narrow kernel), the bias seeds from an LDS table, and the 4 KiB
+// rows of P are stored under the next tile's MFMAs.  The halo tile is staged with 16-byte loads.
+// ---------------------------------------------------------------------------------
+constexpr int PW_ROWS = 8;                                    // cell rows per workgroup
+constexpr int PW_LR = PW_ROWS + 2;                            // with the 3x3 halo: 10 x 34 pixels
+constexpr int PW_PIX = PW_LR * PT_LC;                         // 340 staged pixels
+constexpr int PW_LDS = PW_PIX * PB_PITCH;                     // bf16 elements: 48,960 B
+constexpr int PW_XQ = 10;                                     // 16-byte pieces per staged row: columns x0-4 .. x0+35
+constexpr int PW_TR_PITCH = 36;                               // floats per cell in the store transpose (32 + 4: rotates banks)
+
+__global__ __launch_bounds__(256, 2) void precompute_P_bf16_wide_kernel(const PParams p) {
+    __shared__ __attribute__((aligned(16))) __bf16 tile[PW_LDS];
+    __shared__ __attribute__((aligned(16))) float bk[PCH];       // bK, all 1024 channels
+    __shared__ __attribute__((aligned(16))) float tr[4][32 * PW_TR_PITCH];   // per wave: one result tile, for the transpose
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * PT_COLS;
+    const int y0 = p.r0 + blockIdx.y * PW_ROWS;
+
+    // ---- stage feat[b, :, y0-1 .. y0+8, x0-1 .. x0+32] as bf16, channel-innermost (zeros outside the map)
+    const float* __restrict__ fb = p.feat + (size_t)b * C_IN * p.Frows * p.W;
+    const int fy_hi = p.Frow0 + p.Frows - 1;
+    *(f32x4*)(bk + 4 * threadIdx.x) = *(const f32x4*)(p.Wt + OFF_BK + 4 * threadIdx.x);
+    // item = (channel c, staged row ly, piece q): 4 consecutive columns x0 - 4 + 4q .. +3 of one row (16-byte aligned:
+    // the launch requires W % 4 == 0); the tile keeps columns x0-1 .. x0+32, i.e. lx = 4q - 3 + e
+    constexpr int ITEMS = C_IN * PW_LR * PW_XQ;                  // 6,400 = 25 per thread
+    static_assert(ITEMS % 256 == 0, "staging loop has a fixed trip count");
+#pragma unroll 5
+    for (int it = 0; it < ITEMS / 256; ++it) {
+        const int idx = it * 256 + threadIdx.x;
+        const int q = idx % PW_XQ;
+        const int rest = idx / PW_XQ;
+        const int ly = rest % PW_LR, c = rest / PW_LR;
+        const int yy = y0 + ly - 1, xx = x0 - 4 + 4 * q;
+        const bool rowok = (yy >= 0) && (yy < p.H);
+        const int yc = (yy < p.Frow0 ? p.Frow0 : (yy > fy_hi ? fy_hi : yy)) - p.Frow0;
+        const int xc = xx < 0 ? 0 : (xx > p.W - 4 ? p.W - 4 : xx);
+        const f32x4 v = *(const f32x4*)(fb + ((size_t)c * p.Frows + yc) * p.W + xc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int lx = 4 * q - 3 + e;
+            if (lx >= 0 && lx < PT_LC) {
+                const bool ok = rowok && (xx + e >= 0) && (xx + e < p.W);
+                tile[(ly * PT_LC + lx) * PB_PITCH + c] = (__bf16)(ok ? v[e] : 0.0f);
+            }
+        }
+    }
+    __syncthreads();
+
+    // B fragment of (cell row t, k-step ks = 4*tap + cg): tile[((t + ky) * 34 + j + kx) * 72 + 16cg + 8h .. +7]
+    const __bf16* __restrict__ tb = tile + j * PB_PITCH + 8 * h;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);
+    const int lane_off = lane * 16;
+    // WPB piece of (M-tile mo, k-step ks): ((mo >> 1) * 36 + ks) * 2 + (mo & 1)
+    auto piece = [&](const int mo, const int ks) {
+        return (int)(OFF_WPB * sizeof(float)) + ((((mo >> 1) * WPB_KS + ks) * 2) + (mo & 1)) * PIECE_BYTES;
+    };
+    f32x4 A[WPB_KS];
+#pragma unroll
+    for (int ks = 0; ks < WPB_KS; ++ks) A[ks] = ld_piece(wrs, lane_off, piece(wave, ks));
+
+    // Results leave through a per-wave LDS transpose so that every store instruction writes whole 128-byte lines:
+    // the accumulator holds, per lane (h, cell j), four 16-byte groups of the cell's 32 channels (chunk q = 2g + h);
+    // store instruction i covers cells 8i .. 8i+7, lane L writing chunk L & 7 of cell 8i + (L >> 3).  (Storing the
+    // groups straight from the accumulator layout writes 32 bytes per line per instruction and leaves the merging to
+    // L2: 1.66 ms against 0.88 ms without stores at c5.)
+    float* const trw = tr[wave];
+    f32x16 pacc = {};                                            // the previous tile's result, stored under this tile's MFMAs
+    int pmo = 0, prow = 0;
+    bool prowok = false;
+    auto tr_write = [&]() {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = pacc[4 * g + e];
+            *(f32x4*)(trw + j * PW_TR_PITCH + 4 * (2 * g + h)) = v;
+        }
+    };
+    auto store_i = [&](const int i) {
+        const int cell = 8 * i + (lane >> 3), q = lane & 7;
+        const f32x4 v = *(const f32x4*)(trw + cell * PW_TR_PITCH + 4 * q);
+        if (prowok && x0 + cell < p.W) {
+            float* dst = p.P + (((size_t)b * p.Prows + prow) * p.W + x0 + cell) * PCH + 32 * pmo + 4 * q;
+#ifdef ABL_PW_NOSTORE
+            asm volatile("" :: "v"(v), "v"(dst));
+#else
+            // streaming store: P is hundreds of MB and is read back by the next launch only after all of it has been
+            // written, so the lines need not stay in L2 (1.43 -> 1.20 ms at c5; the packed weights stay resident)
+            __builtin_nontemporal_store(v, (f32x4*)dst);
+#endif
+        }
+    };
+#pragma unroll 1
+    for (int mi = 0; mi < 8; ++mi) {
+        const int mo = wave + 4 * mi;                            // this wave's M-tile: channels 32 mo .. 32 mo + 31
+        f32x4 sd[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sd[g] = *(const f32x4*)(bk + 32 * mo + 4 * h + 8 * g);
+#pragma unroll
+        for (int t = 0; t < PW_ROWS; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[4 * g + e] = sd[g][e];
+#pragma unroll
+            for (int ks = 0; ks < WPB_KS; ++ks) {
+                const int tap = ks >> 2, cg = ks & 3;
+                const bf16x8 bv = *(const bf16x8*)(tb + ((t + tap / 3) * PT_LC + (tap % 3)) * PB_PITCH + 16 * cg);
+                acc = MFMA_BF16(__builtin_bit_cast(bf16x8, A[ks]), bv, acc);
+#ifndef ABL_PW_NOREFILL
+                if (t == PW_ROWS - 1 && mi < 7) A[ks] = ld_piece(wrs, lane_off, piece(mo + 4, ks));
+#endif
+                if (ks == 2) tr_write();                         // the previous tile: transpose ..
+                if ((ks & 7) == 6) store_i(ks >> 3);             // .. and its four stores, spread out
+                if ((ks & 3) == 3) asm volatile("" ::: "memory");   // memory operations stay inside a 4-step window
+            }
+            pacc = acc;
+            pmo = mo;
+            prow = y0 + t - p.Prow0;
+            prowok = y0 + t < p.r1;
+        }
+    }
+    tr_write();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_i(i);
+}
+
 int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,
              int B, int H, int W, int r0, int r1, int mp_total, bool bf16, const RowWin* feat_win, const RowWin* p_win) {
     if (!feat_dev || !packed_dev || !P_dev) return DIINN_ERR_INVALID_ARG;
@@ -293,7 +433,15 @@ int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float
     if ((long long)B * msplit > 65535) return DIINN_ERR_TOO_LARGE;
     PParams p{feat_dev, packed_dev, P_dev, B, H, W, r0, r1, fw.row0, fw.rows, pw.row0, pw.rows, msplit, mp_total};
     const dim3 grid((W + PT_COLS - 1) / PT_COLS, (r1 - r0 + PT_ROWS - 1) / PT_ROWS, B * msplit);
-    if (bf16)
+    // diagnostic override (tests / A-B timing): DIINN_PBF16_KERNEL = 1 narrow, 2 wide
+    const char* fenv = getenv("DIINN_PBF16_KERNEL");
+    const int force = fenv ? atoi(fenv) : 0;
+    const dim3 gridw((W + PT_COLS - 1) / PT_COLS, (r1 - r0 + PW_ROWS - 1) / PW_ROWS, B);
+    const bool wide_ok = bf16 && mp_total == 16 && W % 4 == 0 && ((uintptr_t)feat_dev % 16) == 0 && B <= 65535;
+    const bool wide = wide_ok && (force ? force == 2 : (long long)gridw.x * gridw.y * gridw.z >= 256);
+    if (wide)
+        hipLaunchKernelGGL(precompute_P_bf16_wide_kernel, gridw, dim3(256), 0, (hipStream_t)stream, p);
+    else if (bf16)
         hipLaunchKernelGGL(precompute_P_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(precompute_P_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
