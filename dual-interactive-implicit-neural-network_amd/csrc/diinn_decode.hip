@@ -25,6 +25,10 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (explicit fmaf where wanted)
 #include "diinn_device.h"
+#include <stdlib.h>
+
+struct TagCoopF { static constexpr bool value = false; };
+struct TagCoopT { static constexpr bool value = true; };
 
 template <int SIN_MODE, bool KPART = true, bool SAVE = false>
 __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
@@ -278,6 +282,191 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
 
 
 // ---------------------------------------------------------------------------------
+// decode_coop_kernel: the fp32 decode for SMALL launches (latency variant).  decode_kernel gives one wave a
+// 32-pixel tile and 6,144 dependent MFMAs (0.165 ms at any size); an image with fewer than ~200 workgroups of
+// 16 x 8 pixels (BASELINE config 1: 96 x 96 -> 72) leaves most of the chip idle for that long.  Here the four
+// waves of a workgroup share ONE 32-pixel tile and split the output channels: wave w owns M-tiles 2w and 2w+1 of
+// the modulation rows and of the synthesis rows (4 independent accumulators, 512 MFMAs per layer), the layer
+// input sits in LDS as B operands in the k-order of the packed weights ([k-group 32][lane 64] x 16 B: one
+// ds_read_b128 feeds 16 MFMAs), and the waves exchange their 64 output channels through the second LDS image
+// once per layer.  Four times the workgroups, a quarter of the dependent chain.  Per output channel the
+// arithmetic is decode_kernel's (same seed, same k-ordered fmaf chain, same epilogue): results are bit-identical.
+// ---------------------------------------------------------------------------------
+template <int SIN_MODE>
+__global__ __launch_bounds__(256, 2) void decode_coop_kernel(const DecodeParams p) {
+    __shared__ __attribute__((aligned(16))) f32x4 qs[2][WL_KG][64];        // 2 x 32 KiB: activation as B operands
+    __shared__ __attribute__((aligned(16))) float tab[6 * HID + 4];        // Q0h, Q0w, fma(Q0r, ratio, bQ0), L0..L2, bL
+    {
+        const int i = threadIdx.x & 63, part = threadIdx.x >> 6;
+        const float* __restrict__ Q0s = p.Wt + OFF_Q0 + 4 * i;
+        if (part == 0) {
+            *(f32x4*)(tab + 0 * HID + 4 * i) = *(const f32x4*)(Q0s + 0 * HID);
+            *(f32x4*)(tab + 1 * HID + 4 * i) = *(const f32x4*)(Q0s + 1 * HID);
+        } else if (part == 1) {
+            const f32x4 wr = *(const f32x4*)(Q0s + 2 * HID), bq = *(const f32x4*)(Q0s + 3 * HID);
+            f32x4 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = __builtin_fmaf(wr[e], p.ratio, bq[e]);
+            *(f32x4*)(tab + 2 * HID + 4 * i) = t;
+        } else if (part == 2) {
+            *(f32x4*)(tab + 3 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 0 * HID + 4 * i);
+            *(f32x4*)(tab + 4 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 1 * HID + 4 * i);
+        } else {
+            *(f32x4*)(tab + 5 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 2 * HID + 4 * i);
+            if (i == 0) *(f32x4*)(tab + 6 * HID) = *(const f32x4*)(p.Wt + OFF_BL);
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    // one 8 x 4 pixel tile per workgroup
+    const int x = blockIdx.x * TILE_W + (j & (TILE_W - 1));
+    const int y = p.y0 + blockIdx.y * TILE_H + (j / TILE_W);
+    const int b = blockIdx.z;
+    const bool valid = (x < p.Wu) && (y < p.y1);
+    const int xc = x < p.Wu ? x : p.Wu - 1;
+    const int yc = y < p.y1 ? y : p.y1 - 1;
+    int iy, ix;
+    float relh, relw;
+    axis_eval(p.ah, yc, iy, relh);
+    axis_eval(p.aw, xc, ix, relw);
+    const float* __restrict__ Wt = p.Wt;
+    const float* __restrict__ Pc = p.P + (((size_t)b * p.Prows + (iy - p.Prow0)) * p.W + ix) * PCH + 4 * h;
+    __syncthreads();
+
+    // ---- layer 0: this wave's 64 channels (M-tiles 2w, 2w+1), written as B operands: k-group 4m + g of lane (h, j)
+    // holds registers 4g .. 4g+3 of M-tile m, i.e. channels 32m + 8g + 4h .. +3 = chan_of(4 (4m+g) + e, h)
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm) {
+        const int m = 2 * wave + mm;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = 32 * m + 8 * g;
+            const f32x4 pv = *(const f32x4*)(Pc + c0);
+            const f32x4 wh = *(const f32x4*)(tab + 0 * HID + 4 * h + c0);
+            const f32x4 ww = *(const f32x4*)(tab + 1 * HID + 4 * h + c0);
+            const f32x4 tq = *(const f32x4*)(tab + 2 * HID + 4 * h + c0);
+            f32x4 q0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = tq[e];
+                a = __builtin_fmaf(ww[e], relw, a);
+                a = __builtin_fmaf(wh[e], relh, a);
+                q0[e] = relu0(pv[e]) * dsin<SIN_MODE>(a);
+            }
+            qs[0][4 * m + g][lane] = q0;
+        }
+    }
+
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);
+    const int lane_off = lane * 16;
+    // piece of (M-tile 2w + mm, k-group kg, part): ((m * 32 + kg) * 2 + part) KiB into the layer
+    int wp = (int)(OFF_WL * sizeof(float)) + (2 * wave) * (WL_KG * 2 * PIECE_BYTES);
+    auto ld_w = [&](const int mm, const int kg, const int part) {
+        return ld_piece(wrs, lane_off, wp + ((mm * WL_KG + kg) * 2 + part) * PIECE_BYTES);
+    };
+    __syncthreads();
+
+    auto layer_body = [&](auto cur_tag, const int layer) {
+        constexpr int CUR = decltype(cur_tag)::value ? 1 : 0;
+        f32x16 acc[2][2];                                        // [M-tile mm][part]: modulation, synthesis
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * (2 * wave + mm) + 8 * g;
+                const f32x4 sk = *(const f32x4*)(Pc + (layer + 1) * HID + c0);
+                const f32x4 sq = *(const f32x4*)(Wt + OFF_BQ + layer * HID + 4 * h + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[mm][0][4 * g + e] = sk[e];
+                    acc[mm][1][4 * g + e] = sq[e];
+                }
+            }
+        // weight ring: 3 slots of one k-group (4 pieces: [M-tile][part]); while group kg is consumed the slot of group
+        // kg-1 is refilled with group kg+2, one piece after each quad of MFMAs (a vector-memory instruction blocks the
+        // wave for ~60 cycles: behind an MFMA of 64 it is free, four in a row are not)
+        f32x4 rw[3][2][2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int part = 0; part < 2; ++part) rw[d][mm][part] = ld_w(mm, d, part);
+        f32x4 bq = qs[CUR][0][lane];
+#pragma unroll
+        for (int kg = 0; kg < WL_KG; ++kg) {
+            const f32x4 bv = bq;
+            if (kg + 1 < WL_KG) bq = qs[CUR][kg + 1][lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int part = 0; part < 2; ++part)
+                        acc[mm][part] = MFMA32(rw[kg % 3][mm][part][e], bv[e], acc[mm][part]);
+                if (kg + 2 < WL_KG) rw[(kg + 2) % 3][e >> 1][e & 1] = ld_w(e >> 1, kg + 2, e & 1);
+                asm volatile("" ::: "memory");                   // keeps each load behind its quad of MFMAs' issue slot
+            }
+        }
+        // epilogue: q = relu(k) * sin(s) for this wave's 64 channels -> the other LDS image (or the head)
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+            const int m = 2 * wave + mm;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 qn;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qn[e] = relu0(acc[mm][0][4 * g + e]) * dsin<SIN_MODE>(acc[mm][1][4 * g + e]);
+                qs[1 - CUR][4 * m + g][lane] = qn;
+            }
+        }
+        __syncthreads();
+    };
+    layer_body(TagCoopF{}, 0);                                   // image 0 -> 1
+    wp += (int)(WL_LAYER * sizeof(float));
+    layer_body(TagCoopT{}, 1);                                   // 1 -> 0
+    wp += (int)(WL_LAYER * sizeof(float));
+    layer_body(TagCoopF{}, 2);                                   // 0 -> 1
+
+    // ---- head (diinn.py:138): the last activation is in LDS in decode_kernel's register order, so one wave runs
+    // decode_kernel's head on it verbatim (same fmaf chain per lane half, same cross-half sum): the two kernels agree
+    // bit for bit, and a row band decoded by one stitches exactly into an image decoded by the other
+    if (wave == 0) {
+        float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+        const float* __restrict__ L = tab + 3 * HID + 4 * h;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * m + 8 * g;
+                const f32x4 v = qs[1][4 * m + g][lane];          // layer 3 wrote image 1
+                const f32x4 l0 = *(const f32x4*)(L + 0 * HID + c0);
+                const f32x4 l1 = *(const f32x4*)(L + 1 * HID + c0);
+                const f32x4 l2 = *(const f32x4*)(L + 2 * HID + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0 = __builtin_fmaf(l0[e], v[e], o0);
+                    o1 = __builtin_fmaf(l1[e], v[e], o1);
+                    o2 = __builtin_fmaf(l2[e], v[e], o2);
+                }
+            }
+        }
+        o0 += __shfl_xor(o0, 32);
+        o1 += __shfl_xor(o1, 32);
+        o2 += __shfl_xor(o2, 32);
+        if (valid && h == 0) {
+            const size_t plane = (size_t)p.Orows * p.Wu;
+            float* op = p.out + (size_t)b * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
+            op[0] = o0 + tab[6 * HID + 0];
+            op[plane] = o1 + tab[6 * HID + 1];
+            op[2 * plane] = o2 + tab[6 * HID + 2];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // cell_chain_kernel (decoder modes 1 and 2, diinn.py:116-131): the modulation chain depends on the
 // LR cell only: k_0 = relu(P_0), k_i = relu(K_i^k k_{i-1} + P_i), i = 1..3.  Same register-resident
 // scheme as decode_kernel with LR cells in place of HR pixels and the modulation half of the
@@ -421,6 +610,20 @@ static int decode_band_impl(void* stream, const float* P_dev, const float* packe
             hipLaunchKernelGGL((decode_kernel<DIINN_SIN_HW_REDUCED, false>), grid, dim3(blk), 0, (hipStream_t)stream, p);
         else
             hipLaunchKernelGGL((decode_kernel<DIINN_SIN_ACCURATE, false>), grid, dim3(blk), 0, (hipStream_t)stream, p);
+        return hip_status(hipGetLastError());
+    }
+    // small launches: the latency variant (4 waves share a tile): fewer than ~3/4 of a round of 16 x 8 workgroups.
+    // DIINN_F32_KERNEL = 1 / 2 forces the throughput / latency kernel (tests, A-B timing).
+    const char* fenv = getenv("DIINN_F32_KERNEL");
+    const int force = fenv ? atoi(fenv) : 0;
+    const dim3 gridc((Wu + TILE_W - 1) / TILE_W, (y1 - y0 + TILE_H - 1) / TILE_H, B);
+    if (gridc.y <= 65535 && (force ? force == 2 : (long long)gx * gy * gz <= 192)) {
+        if (sin_mode == DIINN_SIN_HW)
+            hipLaunchKernelGGL(decode_coop_kernel<DIINN_SIN_HW>, gridc, dim3(256), 0, (hipStream_t)stream, p);
+        else if (sin_mode == DIINN_SIN_HW_REDUCED)
+            hipLaunchKernelGGL(decode_coop_kernel<DIINN_SIN_HW_REDUCED>, gridc, dim3(256), 0, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(decode_coop_kernel<DIINN_SIN_ACCURATE>, gridc, dim3(256), 0, (hipStream_t)stream, p);
         return hip_status(hipGetLastError());
     }
     if (sin_mode == DIINN_SIN_HW)

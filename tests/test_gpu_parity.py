@@ -339,3 +339,31 @@ def test_modes_1_and_2(golden, dev, mode):
         got2 = dec(torch.from_numpy(feat2).to(dev), (40, 100), 30000).cpu().numpy()
     ref2 = orc.decode_reference_form(sd, feat2, (40, 100), 30000, mode=mode).numpy()
     assert float(np.abs(got2 - ref2).max()) <= _tol(ref2)
+
+
+def test_latency_kernel_is_bit_identical_to_throughput_kernel(golden, dev, monkeypatch):
+    """Small launches take decode_coop_kernel (four waves share one 32-pixel tile).  Per output channel it performs
+    decode_kernel's arithmetic in decode_kernel's order, so the two must agree bit for bit on every fixture, on
+    row bands and on batches; the fixtures' reference outputs bound both."""
+    import diinn_amd.decoder as D
+    cases = list(golden_cases(golden))
+    for name, b, h, w, hu, wu, gain in cases:
+        sd = synth.decoder_state_dict(123, gain)
+        feat = synth.encoder_features(123, b, h, w)
+        outs = {}
+        for k in ("1", "2"):
+            monkeypatch.setenv("DIINN_F32_KERNEL", k)
+            outs[k] = _decode(sd, feat, (hu, wu), dev)
+        assert np.array_equal(outs["1"], outs["2"]), name
+        ref = golden[f"out/{name}"]
+        assert float(np.abs(outs["2"] - ref).max()) <= _tol(ref), name
+    monkeypatch.setenv("DIINN_F32_KERNEL", "2")
+    sd = synth.decoder_state_dict(5)
+    feat = torch.from_numpy(synth.encoder_features(5, 2, 19, 23)).to(dev)
+    packed = D.pack_state_dict(sd).to(dev)
+    full = D.decode_features(feat, packed, (61, 70))
+    out = torch.zeros_like(full)
+    for y0, y1 in [(0, 17), (17, 18), (18, 61)]:
+        D.decode_features(feat, packed, (61, 70), out=out, rows=(y0, y1))
+    torch.cuda.synchronize()
+    assert torch.equal(full, out)
