@@ -220,6 +220,8 @@ def main():
                          f"per GPU, and pass the same N as --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the DIINN decode path has no CPU implementation")
+    if os.environ.get("DIINN_BENCH_ONE_DEVICE") == "1":   # test hook: every rank on cuda:0 (exercises the N>1 code path
+        local_rank = 0                                    # on a one-GPU box when the collective library permits it)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ     # launched by torch.distributed.run: one rank per GPU
@@ -246,12 +248,12 @@ def main():
     mult = world if args.scaling == "weak" else 1
     H, W, HU, WU = h1 * mult, w1, hu1 * mult, wu1
     shape = (1, 64, H, W)
-    # every rank draws the same map (same seed, same device type): rank 0's copy is the encoder output that is
-    # handed off, the others keep theirs only to verify what they received
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(123)
-    feat_all = torch.randn(shape, device=dev, generator=gen)
-    feat = feat_all if rank == 0 else None
+    # rank 0 holds the encoder output (synthetic, seeded); every other rank only ever sees the rows handed to it
+    feat = None
+    if rank == 0:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(123)
+        feat = torch.randn(shape, device=dev, generator=gen)
 
     dec = S.BandDecoder(shape, (HU, WU), packed, src=0, mode=args.dist_mode, sin_mode=sin_mode, compute=args.compute)
     bd = dec.band
@@ -313,14 +315,27 @@ def main():
     # ---- the output that was timed, against the oracle (outside the timed region)
     checked = None
     if not args.no_check:
+        # transport check: rank 0 publishes (sum, sum of squares) of every rank's window in float64; each rank
+        # recomputes them on what it received (the same reduction on the same values on the same kind of device)
         handoff_ok = True
-        if rank != 0:
-            handoff_ok = bool(torch.equal(win, feat_all[:, :, row0:row0 + win.shape[2]]))
+        if use_dist and world > 1:
+            sums = torch.zeros((world, 2), device=dev, dtype=torch.float64)
+            if rank == 0:
+                for r, b2 in enumerate(dec.bands):
+                    if not b2.empty:
+                        w64 = feat[:, :, b2.a0:b2.a1].double()
+                        sums[r, 0], sums[r, 1] = w64.sum(), (w64 * w64).sum()
+            dist.broadcast(sums, src=0)
+            lo = bd.a0 - row0
+            mine = win[:, :, lo:lo + bd.a1 - bd.a0].double()
+            got = torch.stack([mine.sum(), (mine * mine).sum()])
+            handoff_ok = bool(torch.allclose(got, sums[rank], rtol=1e-12, atol=0.0))
         nrows = min(4, bd.y1 - bd.y0)
         mid = (bd.y0 + bd.y1) // 2
         starts = sorted({bd.y0, max(bd.y0, min(bd.y1 - nrows, mid)), bd.y1 - nrows})
         rows_list = [(s, s + nrows) for s in starts]
-        win_cpu = feat_all[:, :, bd.a0:bd.a1].cpu()
+        lo = bd.a0 - row0
+        win_cpu = win[:, :, lo:lo + bd.a1 - bd.a0].cpu()       # the rows this rank actually decoded from
         out_cpu = dec.out_band.cpu()
         torch.set_num_threads(effective_cores())
         err, ok = check_band_rows(sd, win_cpu, bd.a0, H, (HU, WU), out_cpu, bd.y0, rows_list, args.compute)
@@ -401,7 +416,7 @@ def main():
         if gather_ms is not None:
             res["gather_ms"] = round(gather_ms, 4)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sd, feat_all.cpu(), (HU, WU), args.workload)
+            res["cpu_baseline"] = cpu_baseline(sd, feat.cpu(), (HU, WU), args.workload)
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()
