@@ -420,7 +420,7 @@ struct CoopTagTrue { static constexpr bool value = true; };
 
 // the sine of the synthesis branch on revolutions, split so that its two halves can sit in different MFMA gaps
 template <int MODE> __device__ __forceinline__ float co_sin_prep(float x) { return x; }
-template <> __device__ __forceinline__ float co_sin_prep<DIINN_SIN_HW_REDUCED>(float x) { return __builtin_amdgcn_fractf(x); }
+template <> __device__ __forceinline__ float co_sin_prep<DIINN_SIN_HW_REDUCED>(float x) { return __builtin_amdgcn_fractf(x); }   // bf16: the fract's 6e-8 is noise
 template <int MODE> __device__ __forceinline__ float co_sin_fin(float y) { return __builtin_amdgcn_sinf(y); }
 template <> __device__ __forceinline__ float co_sin_fin<DIINN_SIN_ACCURATE>(float y) { return dsin_rev<DIINN_SIN_ACCURATE>(y); }
 

@@ -37,9 +37,21 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     // of those per tile.  Rows: Q0h, Q0w, t = fma(Q0r, ratio, bQ0) (the pixel-independent part of the sine
     // argument, the same first fma the per-pixel chain used to start with: results are bit-identical), L0, L1, L2.
     __shared__ __attribute__((aligned(16))) float tab[6 * HID + 4];      // + the head bias bL
+    // Inference (no SAVE) keeps the synthesis branch in REVOLUTIONS: weights, biases and the Q0 table come from the
+    // sections divided by 2 pi (WLR, BQR, Q0R), so every sine is v_fract + v_sin instead of a 5-op reduction (each VALU
+    // instruction costs ~3 cycles of fp32-MFMA issue).  The training forward saves sine arguments in radians and
+    // stays on the plain sections.
+    constexpr size_t S_WL = SAVE ? OFF_WL : OFF_WLR, S_BQ = SAVE ? OFF_BQ : OFF_BQR, S_Q0 = SAVE ? OFF_Q0 : OFF_Q0R;
+    auto sine = [](float v) {
+#ifdef ABL_NOSIN
+        return v;
+#else
+        if constexpr (SAVE) return dsin<SIN_MODE>(v); else return dsin_rev<SIN_MODE>(v);
+#endif
+    };
     {
         const int i = threadIdx.x & 63, part = threadIdx.x >> 6;
-        const float* __restrict__ Q0s = p.Wt + OFF_Q0 + 4 * i;
+        const float* __restrict__ Q0s = p.Wt + S_Q0 + 4 * i;
         if (part == 0) {
             *(f32x4*)(tab + 0 * HID + 4 * i) = *(const f32x4*)(Q0s + 0 * HID);
             *(f32x4*)(tab + 1 * HID + 4 * i) = *(const f32x4*)(Q0s + 1 * HID);
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
                     a = __builtin_fmaf(ww[e], relw, a);
                     a = __builtin_fmaf(wh[e], relh, a);
                     const float kv = relu0(pv[e]);
-                    q[16 * m + 4 * g + e] = kv * dsin<SIN_MODE>(a);
+                    q[16 * m + 4 * g + e] = kv * sine(a);
                     if constexpr (SAVE) {
                         st_act(ar0, act_voff, (unsigned)(c0 + e) * PLANE_ROW_BYTES, kv);
                         st_act(ar0, act_voff, (unsigned)(HID + c0 + e) * PLANE_ROW_BYTES, a);
@@ -152,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);   // reads past the end return 0
     const int lane_off = lane * 16;
-    int wp = (int)(OFF_WL * sizeof(float));                      // byte offset; advances one layer per iteration
+    int wp = (int)(S_WL * sizeof(float));                        // byte offset; advances one layer per iteration
     f32x4 rk[PF], rq[PF];
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
@@ -163,15 +175,15 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         sk[g] = *(const f32x4*)(Pc + HID + 8 * g);
-        sq[g] = *(const f32x4*)(Wt + OFF_BQ + 4 * h + 8 * g);
+        sq[g] = *(const f32x4*)(Wt + S_BQ + 4 * h + 8 * g);
     }
 #pragma unroll 1
     for (int layer = 0; layer < DECODE_RUN_LAYERS; ++layer) {
         const int nl = layer < 2 ? layer + 1 : 2;                // seeds of the next layer's tile 0 (clamped)
         const float* __restrict__ Pl = Pc + (layer + 1) * HID;
-        const float* __restrict__ Bq = Wt + OFF_BQ + layer * HID + 4 * h;
+        const float* __restrict__ Bq = Wt + S_BQ + layer * HID + 4 * h;
         const float* __restrict__ Pn = Pc + (nl + 1) * HID;
-        const float* __restrict__ Bn = Wt + OFF_BQ + nl * HID + 4 * h;
+        const float* __restrict__ Bn = Wt + S_BQ + nl * HID + 4 * h;
         float qn[128];
         f32x16 pk, ps;                                           // finished accumulators of the previous tile
         const __amdgpu_buffer_rsrc_t arl = act_rsrc(layer + 1);
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
                 if (m > 0 && (kg & 1) == 0) {                     // one epilogue element of tile m-1 every 16 MFMAs
                     const int r = kg >> 1;
                     const float kv = relu0(pk[r]);
-                    qn[16 * (m - 1) + r] = kv * ABL_SIN(ps[r]);
+                    qn[16 * (m - 1) + r] = kv * sine(ps[r]);
                     if constexpr (SAVE) {                        // register r of tile m-1 = channel 32(m-1) + (r&3) + 8(r>>2) + 4h
                         const unsigned so = (unsigned)(32 * (m - 1) + (r & 3) + 8 * (r >> 2)) * PLANE_ROW_BYTES;
                         st_act(arl, act_voff, so, kv);
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float kv = relu0(pk[r]);
-            qn[16 * 7 + r] = kv * dsin<SIN_MODE>(ps[r]);
+            qn[16 * 7 + r] = kv * sine(ps[r]);
             if constexpr (SAVE) {
                 const unsigned so = (unsigned)(32 * 7 + (r & 3) + 8 * (r >> 2)) * PLANE_ROW_BYTES;
                 st_act(arl, act_voff, so, kv);
@@ -298,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void decode_coop_kernel(const DecodeParams 
     __shared__ __attribute__((aligned(16))) float tab[6 * HID + 4];        // Q0h, Q0w, fma(Q0r, ratio, bQ0), L0..L2, bL
     {
         const int i = threadIdx.x & 63, part = threadIdx.x >> 6;
-        const float* __restrict__ Q0s = p.Wt + OFF_Q0 + 4 * i;
+        const float* __restrict__ Q0s = p.Wt + OFF_Q0R + 4 * i;    // revolutions, as decode_kernel (inference)
         if (part == 0) {
             *(f32x4*)(tab + 0 * HID + 4 * i) = *(const f32x4*)(Q0s + 0 * HID);
             *(f32x4*)(tab + 1 * HID + 4 * i) = *(const f32x4*)(Q0s + 1 * HID);
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void decode_coop_kernel(const DecodeParams 
                 float a = tq[e];
                 a = __builtin_fmaf(ww[e], relw, a);
                 a = __builtin_fmaf(wh[e], relh, a);
-                q0[e] = relu0(pv[e]) * dsin<SIN_MODE>(a);
+                q0[e] = relu0(pv[e]) * dsin_rev<SIN_MODE>(a);
             }
             qs[0][4 * m + g][lane] = q0;
         }
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void decode_coop_kernel(const DecodeParams 
         (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);
     const int lane_off = lane * 16;
     // piece of (M-tile 2w + mm, k-group kg, part): ((m * 32 + kg) * 2 + part) KiB into the layer
-    int wp = (int)(OFF_WL * sizeof(float)) + (2 * wave) * (WL_KG * 2 * PIECE_BYTES);
+    int wp = (int)(OFF_WLR * sizeof(float)) + (2 * wave) * (WL_KG * 2 * PIECE_BYTES);
     auto ld_w = [&](const int mm, const int kg, const int part) {
         return ld_piece(wrs, lane_off, wp + ((mm * WL_KG + kg) * 2 + part) * PIECE_BYTES);
     };
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void decode_coop_kernel(const DecodeParams 
             for (int g = 0; g < 4; ++g) {
                 const int c0 = 32 * (2 * wave + mm) + 8 * g;
                 const f32x4 sk = *(const f32x4*)(Pc + (layer + 1) * HID + c0);
-                const f32x4 sq = *(const f32x4*)(Wt + OFF_BQ + layer * HID + 4 * h + c0);
+                const f32x4 sq = *(const f32x4*)(Wt + OFF_BQR + layer * HID + 4 * h + c0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     acc[mm][0][4 * g + e] = sk[e];
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void decode_coop_kernel(const DecodeParams 
             for (int g = 0; g < 4; ++g) {
                 f32x4 qn;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qn[e] = relu0(acc[mm][0][4 * g + e]) * dsin<SIN_MODE>(acc[mm][1][4 * g + e]);
+                for (int e = 0; e < 4; ++e) qn[e] = relu0(acc[mm][0][4 * g + e]) * dsin_rev<SIN_MODE>(acc[mm][1][4 * g + e]);
                 qs[1 - CUR][4 * m + g][lane] = qn;
             }
         }

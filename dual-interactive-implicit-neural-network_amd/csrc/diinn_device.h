@@ -71,7 +71,7 @@ __device__ __forceinline__ float dsin<DIINN_SIN_HW_REDUCED>(float x) {
 
 // The same three modes for an argument already in REVOLUTIONS (the bf16 kernels: synthesis weights and biases
 // are stored pre-divided by 2 pi, packed sections 7 / 10): HW is the bare instruction (valid for |x| <= 256
-// revolutions), HW_REDUCED adds the fract that makes it valid for any magnitude, ACCURATE converts back to
+// revolutions), HW_REDUCED adds the exact reduction x - rint(x) that makes it valid for any magnitude, ACCURATE converts back to
 // radians and runs the polynomial.
 template <int MODE>
 __device__ __forceinline__ float dsin_rev(float x);
@@ -79,7 +79,13 @@ template <>
 __device__ __forceinline__ float dsin_rev<DIINN_SIN_HW>(float x) { return __builtin_amdgcn_sinf(x); }
 template <>
 __device__ __forceinline__ float dsin_rev<DIINN_SIN_HW_REDUCED>(float x) {
+#ifdef SIN_REV_FRACT
     return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x));
+#else
+    // x - rint(x) is exact and keeps the precision of small arguments (fract maps a small negative x to 1 - |x|,
+    // whose ulp is 6e-8: 7e-8 output error against 3e-8, measured on the fixtures)
+    return __builtin_amdgcn_sinf(x - __builtin_rintf(x));
+#endif
 }
 template <>
 __device__ __forceinline__ float dsin_rev<DIINN_SIN_ACCURATE>(float x) {

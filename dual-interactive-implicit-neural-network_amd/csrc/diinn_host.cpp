@@ -85,11 +85,11 @@ size_t diinn_metasr_workspace_bytes(int B, int H, int W) {
 }
 
 int diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats) {
-    static const size_t off[12] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT, OFF_WPB, OFF_BQR,
-                                   OFF_Q0R};
-    static const size_t sz[12]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT, SZ_WPB, 3 * HID,
-                                   4 * HID};
-    if (section < 0 || section > 11 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
+    static const size_t off[13] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT, OFF_WPB, OFF_BQR,
+                                   OFF_Q0R, OFF_WLR};
+    static const size_t sz[13]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT, SZ_WPB, 3 * HID,
+                                   4 * HID, SZ_WL};
+    if (section < 0 || section > 12 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
     *offset_floats = off[section];
     *size_floats = sz[section];
     return DIINN_OK;
@@ -128,6 +128,13 @@ int diinn_pack_weights(const float* K0w, const float* K0b,
                         }
                     }
                 }
+    }
+    // WLR: WL with the synthesis pieces in revolutions
+    for (size_t pc = 0; pc < SZ_WL / WL_PIECE; ++pc) {
+        const float* src = packed + OFF_WL + pc * WL_PIECE;
+        float* dst = packed + OFF_WLR + pc * WL_PIECE;
+        const bool synth = (pc & 1) != 0;                       // [..][part 2][lane][e]: odd pieces are part 1
+        for (size_t i = 0; i < WL_PIECE; ++i) dst[i] = synth ? src[i] * INV_2PI : src[i];
     }
     // WLT: WL with the two channel indices swapped (backward pass)
     for (int i = 0; i < 3; ++i) {

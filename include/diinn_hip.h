@@ -89,9 +89,10 @@ size_t diinn_packed_weight_floats(void);
  * hoisted 3x3 conv, 2 bK, 3 Q0 (+bQ0), 4 bQ1..3, 5 L, 6 bL, 7 WLB (bf16 copy of WL), 8 WLT (WL transposed,
  * read by the backward pass), 9 WPB (bf16 copy of WP), 10 BQR (bQ1..3 / (2 pi): the bf16 kernels evaluate the
  * sine on revolutions, and the synthesis rows inside section 7 are pre-multiplied by 1/(2 pi) to match), 11 Q0R
- * (section 3 / (2 pi)).  Every section but 7 and 9..11 is a pure permutation (plus zero padding) of the reference
- * tensors, so a training loop can re-pack on the device with one gather; sections 7 and 9..11 hold derived values
- * and are only read by the bf16 compute modes. */
+ * (section 3 / (2 pi)), 12 WLR (section 0 with its synthesis pieces / (2 pi): the fp32 inference kernels evaluate the
+ * sine on revolutions as well).  Every section but 7 and 9..12 is a pure permutation (plus zero padding) of the
+ * reference tensors, so a training loop can re-pack on the device with one gather; sections 7 and 9..12 hold derived
+ * values, read by the inference kernels only (the training forward and LIIF read sections 0 and 4). */
 int    diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats);
 int    diinn_pack_weights(const float* K0w, const float* K0b,
                           const float* const Kw[3], const float* const Kb[3],

@@ -86,7 +86,7 @@ def test_packed_image_layout(lib):
     import diinn_amd.decoder as D
     sd = synth.decoder_state_dict(11)
     packed = D.pack_state_dict(sd).numpy()
-    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608 + 393_216 + 294_912 + 768 + 1024
+    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608 + 393_216 + 294_912 + 768 + 1024 + 393_216
     lane = np.arange(64)
     out_l, h_l = lane & 31, lane >> 5
     # WL section
@@ -153,13 +153,18 @@ def test_packed_image_layout(lib):
         o, cin = 32 * m + (l & 31), 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (jj >> 2) + 4 * hh + (jj & 3)
         w = sd[f"K.{i + 1}.0.weight"][o, cin, 0, 0] if part == 0 else np.float32(sd[f"Q.{i + 1}.0.weight"][o, cin, 0, 0] * inv2pi)
         assert int(WLB[i, m, ks, part, l, jj]) == bf16_bits(w)
-    BQR = packed[-1792:-1024].reshape(3, 256)
+    tail = packed[986_628 + 196_608 + 393_216 + 294_912:]
+    BQR = tail[:768].reshape(3, 256)
     for i in range(3):
         assert np.array_equal(BQR[i], (sd[f"Q.{i + 1}.0.bias"] * inv2pi).astype(np.float32))
-    Q0R = packed[-1024:].reshape(4, 256)
+    Q0R = tail[768:1792].reshape(4, 256)
     for jj in range(3):
         assert np.array_equal(Q0R[jj], (q0[:, jj] * inv2pi).astype(np.float32))
     assert np.array_equal(Q0R[3], (sd["Q.0.0.bias"] * inv2pi).astype(np.float32))
+    # WLR: WL with the synthesis pieces (part 1) in revolutions
+    WLR = tail[1792:].reshape(3, 8, 32, 2, 64, 4)
+    assert np.array_equal(WLR[:, :, :, 0], WL[:, :, :, 0])
+    assert np.array_equal(WLR[:, :, :, 1], (WL[:, :, :, 1] * inv2pi).astype(np.float32))
     # every channel appears exactly once per lane-half in the activation register order
     seen = sorted(_chan_of(kk, h) for kk in range(128) for h in range(2))
     assert seen == list(range(256))

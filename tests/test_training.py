@@ -74,18 +74,18 @@ def test_pack_gather_index_is_the_host_packer():
     ref = D.pack_state_dict(sd).numpy()
     off, size = C.c_size_t(), C.c_size_t()
     keep = np.ones(ref.size, bool)
-    for section in (7, 9, 10, 11):                 # bf16-path sections: derived values, left zero by the gather
+    for section in (7, 9, 10, 11, 12):             # inference-only sections: derived values, left zero by the gather
         assert lib.diinn_packed_section(section, C.byref(off), C.byref(size)) == 0
         keep[off.value:off.value + size.value] = False
     assert np.array_equal(got[keep], ref[keep]) and not got[~keep].any()
     total = 0
-    for s in range(12):
+    for s in range(13):
         o, z = C.c_size_t(), C.c_size_t()
         assert lib.diinn_packed_section(s, C.byref(o), C.byref(z)) == 0
         assert o.value == total                    # sections are contiguous
         total = o.value + z.value
     assert total == ref.size == lib.diinn_packed_weight_floats()
-    assert lib.diinn_packed_section(12, C.byref(off), C.byref(size)) != 0
+    assert lib.diinn_packed_section(13, C.byref(off), C.byref(size)) != 0
 
 
 def test_backward_formulas_on_cpu(gold):
@@ -139,7 +139,9 @@ def test_hip_training_forward_saves_the_oracle_planes(gold):
         n = b * hu * wu
         out, acts = _train_forward(lib, N, packed, f, b, h, w, hu, wu, dev)
         infer = D.decode_features(f, packed, (hu, wu))
-        assert torch.equal(out, infer)                     # same arithmetic, different pixel-to-lane mapping
+        # the inference kernel keeps the synthesis branch in revolutions (weights / (2 pi), sine = v_sin(x - rint(x))),
+        # the training forward in radians (it saves the sine arguments): same mathematics, fp32 rounding apart
+        assert float((out - infer).abs().max()) <= 2e-6 * max(1.0, float(ref_out.abs().max()))
         tol = 1e-4 * max(1.0, float(ref_out.abs().max()))
         assert float((out.cpu() - ref_out).abs().max()) <= tol
         flat = acts.permute(0, 2, 1, 3).reshape(4, 512, -1)
