@@ -21,6 +21,7 @@ struct PParams {
     int Frow0, Frows, Prow0, Prows;
     int msplit;          // the M-tile pairs are divided over `msplit` workgroups (blockIdx.z = b*msplit + part)
     int mp_total;        // M-tile pairs (64 channels each) to compute: 16 = all 1024 channels; LIIF needs the first 4
+    int stream_stores;   // P is far larger than the caches: write it with streaming (nt) stores
 };
 
 constexpr int PT_ROWS = 4, PT_COLS = 32;                 // cells per workgroup: 4 x 32
@@ -28,8 +29,11 @@ constexpr int PT_LR = PT_ROWS + 2, PT_LC = PT_COLS + 2;  // with the 3x3 halo: 6
 constexpr int PT_CH = PT_LR * PT_LC;                     // 204 floats per channel
 constexpr int PT_LDS_FLOATS = C_IN * PT_CH;              // 13,056 floats = 52,224 B
 
+constexpr int PT_TR_PITCH = 36;                           // floats per cell in the store transpose (32 + 4: rotates banks)
+
 __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
     __shared__ __attribute__((aligned(16))) float tile[PT_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float tr[4][32 * PT_TR_PITCH];   // per wave: one 32 x 32 result tile
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
@@ -107,7 +111,31 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
     const int lane_off = lane * 16;
     int wp = (int)(OFF_WP * sizeof(float)) + mp_begin * (WP_KG * 2 * PIECE_BYTES);   // advances one M-tile pair per iteration
     const float* __restrict__ Bk = p.Wt + OFF_BK + 4 * h;
-    float* __restrict__ Pout = p.P + (((size_t)b * p.Prows + ((y < p.r1 ? y : p.r1 - 1) - p.Prow0)) * p.W + (x < p.W ? x : p.W - 1)) * PCH + 4 * h;
+    // Results leave through a per-wave LDS transpose so that every store instruction writes whole 128-byte lines (the
+    // accumulator holds 16 bytes of 8 different lines per lane; storing those directly leaves the merging to L2 -- on
+    // the bf16 kernel that cost 15 % of the run), and the stores of M-tile pair mp-1 are spread over the MFMAs of pair
+    // mp.  Store instruction i covers cells 8i .. 8i+7: lane L writes chunk L & 7 (4 channels) of cell 8i + (L >> 3).
+    float* const trw = tr[wave];
+    float* const Prow = p.P + (((size_t)b * p.Prows + (y - p.Prow0)) * p.W + x0) * PCH;   // y < r1 for every storing wave
+    f32x16 pa0 = {}, pa1 = {};                                   // the previous pair's results
+    auto tr_write = [&](const f32x16& a) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = a[4 * g + e];
+            *(f32x4*)(trw + j * PT_TR_PITCH + 4 * (2 * g + h)) = v;
+        }
+    };
+    auto store_i = [&](const int i, const int ch0) {
+        const int cell = 8 * i + (lane >> 3), q = lane & 7;
+        const f32x4 v = *(const f32x4*)(trw + cell * PT_TR_PITCH + 4 * q);
+        if (y < p.r1 && x0 + cell < p.W) {
+            float* dst = Prow + (size_t)cell * PCH + ch0 + 4 * q;
+            if (p.stream_stores) __builtin_nontemporal_store(v, (f32x4*)dst);
+            else *(f32x4*)dst = v;
+        }
+    };
     f32x4 r0v[PF], r1v[PF];
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
@@ -121,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
         int off = tb_off;
         asm volatile("" : "+v"(off));
         const float* tbm = tile + off;          // still an LDS (ds_read) address
+        const bool prev = mp > mp_begin;
         f32x16 a0, a1;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -145,21 +174,25 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
             }
             r0v[kg % PF] = ld_piece(wrs, lane_off, wp + (2 * (kg + PF) + 0) * PIECE_BYTES);
             r1v[kg % PF] = ld_piece(wrs, lane_off, wp + (2 * (kg + PF) + 1) * PIECE_BYTES);
-        }
-        if (store) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 v0, v1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v0[e] = a0[4 * g + e];
-                    v1[e] = a1[4 * g + e];
-                }
-                *(f32x4*)(Pout + 64 * mp + 8 * g) = v0;
-                *(f32x4*)(Pout + 64 * mp + 32 + 8 * g) = v1;
+            if (prev) {                                          // the previous pair: transpose and store, spread out
+                if (kg == 4) tr_write(pa0);
+                if (kg >= 8 && kg < 40 && (kg & 7) == 0) store_i((kg - 8) >> 3, 64 * (mp - 1));
+                if (kg == 36) tr_write(pa1);
+                if (kg >= 40 && kg < 72 && (kg & 7) == 0) store_i((kg - 40) >> 3, 64 * (mp - 1) + 32);
             }
         }
+        pa0 = a0;
+        pa1 = a1;
         wp += WP_KG * 2 * PIECE_BYTES;
+    }
+    {
+        const int mpl = mp_begin + mp_count - 1;
+        tr_write(pa0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_i(i, 64 * mpl);
+        tr_write(pa1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_i(i, 64 * mpl + 32);
     }
 }
 
@@ -431,7 +464,9 @@ int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float
     int msplit = 1;
     while (msplit < mp_total && blocks * msplit < 1024) msplit *= 2;
     if ((long long)B * msplit > 65535) return DIINN_ERR_TOO_LARGE;
-    PParams p{feat_dev, packed_dev, P_dev, B, H, W, r0, r1, fw.row0, fw.rows, pw.row0, pw.rows, msplit, mp_total};
+    // streaming stores once P no longer fits beside anything in the 256 MiB last-level cache
+    const int stream_stores = (double)B * (r1 - r0) * W * PCH * 4.0 >= 128.0 * 1024 * 1024;
+    PParams p{feat_dev, packed_dev, P_dev, B, H, W, r0, r1, fw.row0, fw.rows, pw.row0, pw.rows, msplit, mp_total, stream_stores};
     const dim3 grid((W + PT_COLS - 1) / PT_COLS, (r1 - r0 + PT_ROWS - 1) / PT_ROWS, B * msplit);
     // diagnostic override (tests / A-B timing): DIINN_PBF16_KERNEL = 1 narrow, 2 wide
     const char* fenv = getenv("DIINN_PBF16_KERNEL");
