@@ -451,6 +451,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_coop_kernel(const DecodePa
     const int b = blockIdx.z;
     const float* __restrict__ Wt = p.Wt;
     const int ncx = p.seed_cols;                                  // cells per slab row (host: max over the launch)
+    const int ncx_inv = 65536 / ncx + 1;
 #ifdef DIINN_STAMPS
     const size_t co_stamp_base = ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 16;
 #endif
@@ -459,41 +460,33 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_coop_kernel(const DecodePa
     // pixel of this lane in tile t: x = bx*16 + (t&1)*8 + (j&7), y = y0 + by*8 + (t>>1)*4 + (j>>3)
     const int x0 = blockIdx.x * (2 * TILE_W) + (j & (TILE_W - 1));
     const int yb = p.y0 + blockIdx.y * (2 * TILE_H) + (j / TILE_W);
-    // first LR cell of the block (wave-uniform)
-    int ix0, iy0;
-    {
-        float rel;
-        const int xf = blockIdx.x * (2 * TILE_W), yf = p.y0 + blockIdx.y * (2 * TILE_H);
-        axis_eval(p.aw, xf < p.Wu ? xf : p.Wu - 1, ix0, rel);
-        axis_eval(p.ah, yf < p.y1 ? yf : p.y1 - 1, iy0, rel);
-        ix0 = __builtin_amdgcn_readfirstlane(ix0);
-        iy0 = __builtin_amdgcn_readfirstlane(iy0);
+    // LR index and relative coordinate of this lane's column / row in the two tile columns / rows of the block; lane 0
+    // holds the block's first pixel, so its indices are the block's first LR cell (wave-uniform)
+    int ixs[2], iys[2];
+    float relws[2], relhs[2];
+#pragma unroll
+    for (int tx = 0; tx < 2; ++tx) {
+        const int x = x0 + tx * TILE_W;
+        axis_eval(p.aw, x < p.Wu ? x : p.Wu - 1, ixs[tx], relws[tx]);
     }
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty) {
+        const int y = yb + ty * TILE_H;
+        axis_eval(p.ah, y < p.y1 ? y : p.y1 - 1, iys[ty], relhs[ty]);
+    }
+    const int ix0 = __builtin_amdgcn_readfirstlane(ixs[0]), iy0 = __builtin_amdgcn_readfirstlane(iys[0]);
     // slab row of every tile's pixel: byte offset of its cell's staged P row (+ this lane-half's 16 bytes)
     int srow[TILES];
-    {
-        int ixs[2], iys[2];
-        float rel;
 #pragma unroll
-        for (int tx = 0; tx < 2; ++tx) {
-            const int x = x0 + tx * TILE_W;
-            axis_eval(p.aw, x < p.Wu ? x : p.Wu - 1, ixs[tx], rel);
-        }
-#pragma unroll
-        for (int ty = 0; ty < 2; ++ty) {
-            const int y = yb + ty * TILE_H;
-            axis_eval(p.ah, y < p.y1 ? y : p.y1 - 1, iys[ty], rel);
-        }
-#pragma unroll
-        for (int t = 0; t < TILES; ++t)
-            srow[t] = (((iys[t >> 1] - iy0) * ncx + (ixs[t & 1] - ix0)) * CO_SEED_PITCH + 4 * h) * (int)sizeof(float);
-    }
+    for (int t = 0; t < TILES; ++t)
+        srow[t] = (((iys[t >> 1] - iy0) * ncx + (ixs[t & 1] - ix0)) * CO_SEED_PITCH + 4 * h) * (int)sizeof(float);
     // the cells this wave stages (slab rows wave, wave + 4, ...): element offset of their P rows, clamped into the window
     size_t scell[CO_SEED_CELLS / 4];
 #pragma unroll
     for (int i = 0; i < CO_SEED_CELLS / 4; ++i) {
         const int c = wave + 4 * i;
-        int cy = iy0 + c / ncx, cx = ix0 + c % ncx;
+        const int cq = (c * ncx_inv) >> 16;                      // c / ncx (exact for c < 24 <= 65536 / ncx)
+        int cy = iy0 + cq, cx = ix0 + (c - cq * ncx);
         const int ylast = p.Prow0 + p.Prows - 1;
         cy = cy < ylast ? cy : ylast;
         cx = cx < p.W - 1 ? cx : p.W - 1;
@@ -527,10 +520,11 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_coop_kernel(const DecodePa
         Ak[ks] = ld_w(wp, 2 * ks + 0);
         As[ks] = ld_w(wp, 2 * ks + 1);
     }
+    CO_STAMP(13);
     // ---- prologue: everything layer 0 reads is staged in LDS first (a vector-memory instruction blocks its wave
     // for ~60 cycles; the 160 scattered loads a wave would need become 14 row loads).  The Q0 table and the P_0
     // slice live in the second activation buffer, which is free until layer 1's epilogue starts writing it.
-    float* const q0tab = reinterpret_cast<float*>(&qa[1][0][0][0]);          // [4][256]: Q0h, Q0w, Q0r, bQ0 (revolutions)
+    float* const q0tab = reinterpret_cast<float*>(&qa[1][0][0][0]);          // [4][256]: Q0h, Q0w, fma(Q0r, ratio, bQ0), - (revolutions)
     float* const seed0 = q0tab + 4 * HID;                                      // P_0 rows of the block's cells
     static_assert((4 * HID + CO_SEED_CELLS * CO_SEED_PITCH) * sizeof(float) <= sizeof(qa) / 2, "prologue tables fit in qa[1]");
     {
@@ -538,7 +532,12 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_coop_kernel(const DecodePa
 #pragma unroll
         for (int i = 0; i < CO_SEED_CELLS / 4; ++i) s0[i] = *(const f32x4*)(p.P + scell[i]);
         stage_load(1);
-        const f32x4 tq = *(const f32x4*)(Wt + OFF_Q0R + 4 * threadIdx.x);
+        f32x4 tq = *(const f32x4*)(Wt + OFF_Q0R + 4 * threadIdx.x);       // rows Q0h, Q0w, Q0r, bQ0 (64 threads each)
+        if (wave == 2) {                                                   // row 2 becomes t = fma(Q0r, ratio, bQ0)
+            const f32x4 bq0 = *(const f32x4*)(Wt + OFF_Q0R + HID + 4 * threadIdx.x);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tq[e] = __builtin_fmaf(tq[e], p.ratio, bq0[e]);
+        }
         f32x4 tb = {0.0f, 0.0f, 0.0f, 0.0f};
         if (threadIdx.x < 3 * HID / 4) tb = *(const f32x4*)(Wt + OFF_BQR + 4 * threadIdx.x);
 #pragma unroll
@@ -549,42 +548,49 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_coop_kernel(const DecodePa
         if (threadIdx.x < 3 * HID / 4) *(f32x4*)(bias + 4 * threadIdx.x) = tb;
     }
     const float bl0 = Wt[OFF_BL + 0], bl1 = Wt[OFF_BL + 1], bl2 = Wt[OFF_BL + 2];   // head bias, needed at the very end
+    CO_STAMP(14);
     __syncthreads();
+    CO_STAMP(15);
 
     // ---- layer 0 (fp32): wave w evaluates tile w for all 256 channels and writes its B fragments
     {
         const float* __restrict__ Q0 = q0tab + 4 * h;
-        const int t = wave;
-        const int x = x0 + (t & 1) * TILE_W, y = yb + (t >> 1) * TILE_H;
-        int ix, iy;
-        float relw, relh;
-        axis_eval(p.aw, x < p.Wu ? x : p.Wu - 1, ix, relw);
-        axis_eval(p.ah, y < p.y1 ? y : p.y1 - 1, iy, relh);
+        const int t = wave;                                       // wave-uniform: select this tile's column / row
+        const int ix = (t & 1) ? ixs[1] : ixs[0], iy = (t >> 1) ? iys[1] : iys[0];
+        const float relw = (t & 1) ? relws[1] : relws[0], relh = (t >> 1) ? relhs[1] : relhs[0];
         const float* __restrict__ Pc = seed0 + ((iy - iy0) * ncx + (ix - ix0)) * CO_SEED_PITCH + 4 * h;
+        // groups of 4 channels (c0 = 32m + 8g + 4h ..): the four table reads of group i+1 are issued before group i is
+        // evaluated, so the LDS latency is paid once, not 32 times
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        f32x4 cpv, cwh, cww, ctq, npv, nwh, nww, ntq;
+        auto fetch = [&](const int i, f32x4& pv, f32x4& wh, f32x4& ww, f32x4& tq) {
+            const int c0 = 8 * i;                                 // = 32 (i >> 2) + 8 (i & 3)
+            pv = *(const f32x4*)(Pc + c0);
+            wh = *(const f32x4*)(Q0 + 0 * HID + c0);
+            ww = *(const f32x4*)(Q0 + 1 * HID + c0);
+            tq = *(const f32x4*)(Q0 + 2 * HID + c0);
+        };
+        fetch(0, cpv, cwh, cww, ctq);
+        u32x4 fragw;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            bf16x8 f[2];
+        for (int i = 0; i < 32; ++i) {
+            if (i + 1 < 32) fetch(i + 1, npv, nwh, nww, ntq);
+            f32x4 v;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = 32 * m + 8 * g;
-                const f32x4 pv = *(const f32x4*)(Pc + c0);
-                const f32x4 wh = *(const f32x4*)(Q0 + 0 * HID + c0);
-                const f32x4 ww = *(const f32x4*)(Q0 + 1 * HID + c0);
-                const f32x4 wr = *(const f32x4*)(Q0 + 2 * HID + c0);
-                const f32x4 bq = *(const f32x4*)(Q0 + 3 * HID + c0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float a = __builtin_fmaf(wr[e], p.ratio, bq[e]);
-                    a = __builtin_fmaf(ww[e], relw, a);
-                    a = __builtin_fmaf(wh[e], relh, a);
-                    f[g >> 1][4 * (g & 1) + e] = (__bf16)(relu0(pv[e]) * dsin_rev<SIN_MODE>(a));
-                }
+            for (int e = 0; e < 4; ++e) {
+                float a = __builtin_fmaf(cww[e], relw, ctq[e]);
+                a = __builtin_fmaf(cwh[e], relh, a);
+                v[e] = relu0(cpv[e]) * dsin_rev<SIN_MODE>(a);
             }
-            qa[0][t][2 * m][lane] = f[0];
-            qa[0][t][2 * m + 1][lane] = f[1];
+            const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+            fragw[2 * (i & 1) + 0] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+            fragw[2 * (i & 1) + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+            if (i & 1) qa[0][t][i >> 1][lane] = __builtin_bit_cast(bf16x8, fragw);   // k-step 2m + (g >> 1) = i >> 1
+            cpv = npv; cwh = nwh; cww = nww; ctq = ntq;
+            asm volatile("" ::: "memory");                        // keep each group's reads where they are written
         }
     }
-
     float o[TILES][3];                                            // partial RGB of this wave's channels (last layer)
     CO_STAMP(1);
     __syncthreads();

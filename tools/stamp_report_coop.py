@@ -25,6 +25,10 @@ names = ["prologue (layer 0, staging, A loads)", "barrier", "layer 1 units", "ba
          "layer 2 units", "barrier", "seed store + barrier", "layer 3 units", "barrier", "-", "head reduce + store"]
 idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12]
 tot = t[:, 12] - t[:, 0]
+if t[:, 13].max() > 0:
+    for a, b, n in ((0, 13, "  prologue: setup (axis, addresses)"), (13, 14, "  prologue: A loads + staging loads/stores"), (14, 15, "  prologue: barrier"), (15, 1, "  prologue: layer 0 compute + qa writes")):
+        d = t[:, b] - t[:, a]
+        print(f"{n:40s} median {np.median(d):8.0f}  p90 {np.percentile(d, 90):8.0f}")
 print(f"{wl}: waves {len(t)}  median wave lifetime {np.median(tot):.0f} cycles (MFMA floor 768*32 = 24576)")
 for i, n in enumerate(names):
     a, b = idx[i], idx[i + 1]
