@@ -411,6 +411,17 @@ def main():
                                                        else PEAK_F32_MFMA_TFLOPS), 4)},
             },
         }
+        if bf:
+            # second roof for the bf16 path: at one wave per SIMD a wave has ~8 issue slots of 4
+            # cycles per 32-cycle bf16 MFMA, and a vector-memory instruction holds ~15 of them.  Instruction mix per
+            # MFMA of decode_bf16_coop_kernel from the committed PMC pass (profiles/r02_pmc_summary.txt).
+            mix = {"mfma": 1.0, "valu": 5.3, "lds": 0.98, "vmem": 0.31, "salu": 0.39}
+            slots = 2.0 * mix["mfma"] + mix["valu"] + 2.0 * mix["lds"] + 15.0 * mix["vmem"] + mix["salu"]
+            issue_peak = PEAK_BF16_MFMA_TFLOPS * min(1.0, 8.0 / slots)
+            res["roofline_issue"] = {"bound": "instruction issue, one wave per SIMD", "instructions_per_mfma": mix,
+                                     "issue_slots_per_mfma": round(slots, 2), "peak": round(issue_peak, 1),
+                                     "unit": "TFLOP/s", "achieved": round(achieved, 3),
+                                     "frac": round(achieved / issue_peak, 4)}
         if checked is not None:
             res["checked"] = checked
         if gather_ms is not None:
