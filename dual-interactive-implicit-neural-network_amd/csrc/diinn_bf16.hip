@@ -756,6 +756,299 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_coop_kernel(const DecodePa
     CO_STAMP(12);
 }
 
+// ---------------------------------------------------------------------------------
+// decode_bf16_coop8_kernel: the cooperative kernel with EIGHT waves per workgroup, two per SIMD.
+// decode_bf16_coop_kernel needs ~390 registers per wave, so each SIMD hosts one wave, and whenever that wave is
+// blocked in a vector-memory instruction (~60 cycles each), evaluates its epilogue or runs the fp32 layer-0 prologue,
+// the matrix pipe idles: a layer takes 13.1 k cycles against the 8.2 k of its MFMAs, the prologue 15 k.  Here wave w
+// owns ONE M-tile (channels 32w .. 32w+31 of both branches) for the same 16 x 8 pixel block: 32 weight fragments
+// (128 registers) stay put for the whole layer, a single accumulator pair serves the four pixel tiles one after the
+// other, the epilogue of a tile runs right after its MFMAs -- and the other wave of the SIMD (w +- 4, which walks the
+// tiles in the order 2,3,0,1 so that the two are never in the same phase) has the matrix pipe meanwhile.  Everything
+// else -- B fragments in LDS, double-buffered images, staged seeds / biases / tables, revolutions -- is the coop
+// kernel's.  ~230 registers, 512 threads.
+// ---------------------------------------------------------------------------------
+template <int SIN_MODE>
+__global__ __launch_bounds__(512, 2) void decode_bf16_coop8_kernel(const DecodeParams p) {
+    constexpr int TILES = CO_TILES;
+    __shared__ __attribute__((aligned(16))) bf16x8 qa[2][TILES][16][64];       // 128 KiB: B fragments, double-buffered
+    __shared__ __attribute__((aligned(16))) float seed[CO_SEED_CELLS * CO_SEED_PITCH];   // P slice of the block's cells
+    __shared__ __attribute__((aligned(16))) float bias[3 * HID];               // bQ1..3 in revolutions
+    __shared__ __attribute__((aligned(16))) float ltab[3 * HID];               // head rows L0..L2
+    float (*red)[TILES * 32][3] = reinterpret_cast<float (*)[TILES * 32][3]>(seed);   // partial RGB per (wave, lane half)
+    static_assert(sizeof(seed) >= 16 * TILES * 32 * 3 * sizeof(float), "red aliases the seed slab");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..7 = this wave's M-tile
+    const int grp = wave >> 2;                                    // waves w and w + 4 share a SIMD
+    const int h = lane >> 5, j = lane & 31;
+    const int b = blockIdx.z;
+    const float* __restrict__ Wt = p.Wt;
+    const int ncx = p.seed_cols;
+    const int ncx_inv = 65536 / ncx + 1;
+#ifdef DIINN_STAMPS
+    const size_t co_stamp_base = ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 16;
+#endif
+    CO_STAMP(0);
+
+    const int x0 = blockIdx.x * (2 * TILE_W) + (j & (TILE_W - 1));
+    const int yb = p.y0 + blockIdx.y * (2 * TILE_H) + (j / TILE_W);
+    int ixs[2], iys[2];
+    float relws[2], relhs[2];
+#pragma unroll
+    for (int tx = 0; tx < 2; ++tx) {
+        const int x = x0 + tx * TILE_W;
+        axis_eval(p.aw, x < p.Wu ? x : p.Wu - 1, ixs[tx], relws[tx]);
+    }
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty) {
+        const int y = yb + ty * TILE_H;
+        axis_eval(p.ah, y < p.y1 ? y : p.y1 - 1, iys[ty], relhs[ty]);
+    }
+    const int ix0 = __builtin_amdgcn_readfirstlane(ixs[0]), iy0 = __builtin_amdgcn_readfirstlane(iys[0]);
+    // this wave visits the tiles in the order tile(ti) = ti ^ (2 grp); per visit: byte offset of the pixel's staged P
+    // row (+ this lane-half's 16 bytes) and of the tile's B fragments
+    int srow[TILES], qoff[TILES];
+#pragma unroll
+    for (int ti = 0; ti < TILES; ++ti) {
+        const int ta = ti, tb2 = ti ^ 2;                          // static candidates, selected by the wave's group
+        const int sa = (((iys[ta >> 1] - iy0) * ncx + (ixs[ta & 1] - ix0)) * CO_SEED_PITCH + 4 * h) * (int)sizeof(float);
+        const int sb = (((iys[tb2 >> 1] - iy0) * ncx + (ixs[tb2 & 1] - ix0)) * CO_SEED_PITCH + 4 * h) * (int)sizeof(float);
+        srow[ti] = grp ? sb : sa;
+        qoff[ti] = (grp ? tb2 : ta) * 16 * 64;                    // in bf16x8 elements
+    }
+    // cells this wave stages (slab rows wave, wave + 8, wave + 16)
+    size_t scell[CO_SEED_CELLS / 8];
+#pragma unroll
+    for (int i = 0; i < CO_SEED_CELLS / 8; ++i) {
+        const int c = wave + 8 * i;
+        const int cq = (c * ncx_inv) >> 16;
+        int cy = iy0 + cq, cx = ix0 + (c - cq * ncx);
+        const int ylast = p.Prow0 + p.Prows - 1;
+        cy = cy < ylast ? cy : ylast;
+        cx = cx < p.W - 1 ? cx : p.W - 1;
+        scell[i] = ((size_t)(b * p.Prows + (cy - p.Prow0)) * p.W + cx) * PCH + 4 * lane;
+    }
+    f32x4 st[CO_SEED_CELLS / 8];
+    auto stage_load = [&](const int slice) {
+#pragma unroll
+        for (int i = 0; i < CO_SEED_CELLS / 8; ++i) st[i] = *(const f32x4*)(p.P + scell[i] + slice * HID);
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < CO_SEED_CELLS / 8; ++i)
+            *(f32x4*)(seed + (wave + 8 * i) * CO_SEED_PITCH + 4 * lane) = st[i];
+    };
+
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);
+    const int lane_off = lane * 16;
+    auto ld_w = [&](const int mt, const int pc) {
+        return ld_piece(wrs, lane_off + (pc & 3) * PIECE_BYTES, mt + (pc >> 2) * 4 * PIECE_BYTES);
+    };
+    // this wave's M-tile of the current layer: [k-step] x {modulation, synthesis}, refilled with the next layer's
+    // fragment as soon as the last pixel tile has consumed it
+    f32x4 Ak[16], As[16];
+    int wp = (int)(OFF_WLB * sizeof(float)) + wave * CO_MT_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        Ak[ks] = ld_w(wp, 2 * ks + 0);
+        As[ks] = ld_w(wp, 2 * ks + 1);
+    }
+
+    // ---- prologue: tables and the P_0 / P_1 slices into LDS (the tables of layer 0 live in the second image)
+    float* const q0tab = reinterpret_cast<float*>(&qa[1][0][0][0]);          // [3][256]: Q0h, Q0w, fma(Q0r, ratio, bQ0)
+    float* const seed0 = q0tab + 4 * HID;
+    {
+        f32x4 s0[CO_SEED_CELLS / 8];
+#pragma unroll
+        for (int i = 0; i < CO_SEED_CELLS / 8; ++i) s0[i] = *(const f32x4*)(p.P + scell[i]);
+        stage_load(1);
+        const int ti = threadIdx.x;
+        if (ti < 192) {                                                      // rows Q0h, Q0w, Q0r -> t (64 threads each)
+            f32x4 tq = *(const f32x4*)(Wt + OFF_Q0R + 4 * ti);
+            if (ti >= 128) {
+                const f32x4 bq0 = *(const f32x4*)(Wt + OFF_Q0R + HID + 4 * ti);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tq[e] = __builtin_fmaf(tq[e], p.ratio, bq0[e]);
+            }
+            *(f32x4*)(q0tab + 4 * ti) = tq;
+        } else if (ti < 384) {
+            *(f32x4*)(bias + 4 * (ti - 192)) = *(const f32x4*)(Wt + OFF_BQR + 4 * (ti - 192));
+        } else if (ti < 384 + 128) {
+            const int k = ti - 384;                                          // 128 threads: 192 pieces of L, two rounds
+            *(f32x4*)(ltab + 4 * k) = *(const f32x4*)(Wt + OFF_L + 4 * k);
+            if (k < 64) *(f32x4*)(ltab + 4 * (k + 128)) = *(const f32x4*)(Wt + OFF_L + 4 * (k + 128));
+        }
+#pragma unroll
+        for (int i = 0; i < CO_SEED_CELLS / 8; ++i)
+            *(f32x4*)(seed0 + (wave + 8 * i) * CO_SEED_PITCH + 4 * lane) = s0[i];
+        stage_store();
+    }
+    const float bl0 = Wt[OFF_BL + 0], bl1 = Wt[OFF_BL + 1], bl2 = Wt[OFF_BL + 2];
+    CO_STAMP(14);
+    __syncthreads();
+    CO_STAMP(15);
+
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    // ---- layer 0 (fp32): wave w evaluates tile w & 3, channels 128 grp .. 128 grp + 127 (k-steps 8 grp .. 8 grp + 7)
+    {
+        const float* __restrict__ Q0 = q0tab + 4 * h;
+        const int t = wave & 3;
+        const int ix = (t & 1) ? ixs[1] : ixs[0], iy = (t >> 1) ? iys[1] : iys[0];
+        const float relw = (t & 1) ? relws[1] : relws[0], relh = (t >> 1) ? relhs[1] : relhs[0];
+        const float* __restrict__ Pc = seed0 + ((iy - iy0) * ncx + (ix - ix0)) * CO_SEED_PITCH + 4 * h;
+        const int g0 = 16 * grp;                                 // first group of 4 channels (c0 = 8 (g0 + i))
+        f32x4 cpv, cwh, cww, ctq, npv, nwh, nww, ntq;
+        auto fetch = [&](const int i, f32x4& pv, f32x4& wh, f32x4& ww, f32x4& tq) {
+            const int c0 = 8 * (g0 + i);
+            pv = *(const f32x4*)(Pc + c0);
+            wh = *(const f32x4*)(Q0 + 0 * HID + c0);
+            ww = *(const f32x4*)(Q0 + 1 * HID + c0);
+            tq = *(const f32x4*)(Q0 + 2 * HID + c0);
+        };
+        fetch(0, cpv, cwh, cww, ctq);
+        u32x4 fragw;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i + 1 < 16) fetch(i + 1, npv, nwh, nww, ntq);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = __builtin_fmaf(cww[e], relw, ctq[e]);
+                a = __builtin_fmaf(cwh[e], relh, a);
+                v[e] = relu0(cpv[e]) * dsin_rev<SIN_MODE>(a);
+            }
+            const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+            fragw[2 * (i & 1) + 0] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+            fragw[2 * (i & 1) + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+            if (i & 1) qa[0][t][8 * grp + (i >> 1)][lane] = __builtin_bit_cast(bf16x8, fragw);
+            cpv = npv; cwh = nwh; cww = nww; ctq = ntq;
+            asm volatile("" ::: "memory");
+        }
+    }
+    float o[TILES][3];
+    CO_STAMP(1);
+    __syncthreads();
+    CO_STAMP(2);
+
+    auto layer_body = [&](auto last_tag, auto cur_tag, const int layer) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        constexpr int CUR = decltype(cur_tag)::value ? 1 : 0;
+        constexpr int NXT = 1 - CUR;
+        const bf16x8* __restrict__ qin = &qa[CUR][0][0][lane];
+        const float* __restrict__ bl = bias + layer * HID + 32 * wave + 4 * h;
+        const float* __restrict__ hl = ltab + 32 * wave + 4 * h;
+        if (LAST) {
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) o[t][0] = o[t][1] = o[t][2] = 0.0f;
+        }
+        bf16x8 bq[CO_BRING];
+#pragma unroll
+        for (int i = 0; i < CO_BRING; ++i) bq[i] = qin[qoff[0] + i * 64];
+#pragma unroll
+        for (int ti = 0; ti < TILES; ++ti) {
+            f32x16 ak, as;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const f32x4 sk = *(const f32x4*)((const char*)seed + srow[ti] + (32 * wave + 8 * gg) * (int)sizeof(float));
+                const f32x4 sq = *(const f32x4*)(bl + 8 * gg);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ak[4 * gg + e] = sk[e];
+                    as[4 * gg + e] = sq[e];
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const bf16x8 bv = bq[ks % CO_BRING];
+                ak = MFMA_BF16(__builtin_bit_cast(bf16x8, Ak[ks]), bv, ak);
+                as = MFMA_BF16(__builtin_bit_cast(bf16x8, As[ks]), bv, as);
+#ifndef ABL_CO8_NOLDS
+                if (ks + CO_BRING < 16) bq[ks % CO_BRING] = qin[qoff[ti] + (ks + CO_BRING) * 64];
+                else if (ti + 1 < TILES) bq[ks % CO_BRING] = qin[qoff[ti + 1] + (ks + CO_BRING - 16) * 64];
+#endif
+                if (ti == TILES - 1 && !LAST) {                   // last use of this fragment: fetch the next layer's
+                    const int nwp = wp + (int)(WLB_LAYER * sizeof(float));
+                    Ak[ks] = ld_w(nwp, 2 * ks + 0);
+                    As[ks] = ld_w(nwp, 2 * ks + 1);
+                }
+                if (!LAST && ti == 1 && ks == 8) stage_load(layer + 2);   // next layer's P slice, into registers
+                if ((ks & 3) == 3) asm volatile("" ::: "memory");
+            }
+            // epilogue of this tile (the other wave of the SIMD has the matrix pipe): q = relu(k) * sin(s)
+            u32x4 fragw;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 v;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#ifdef ABL_CO8_NOEPI
+                    v[i] = ak[r + i] + as[r + i];
+#else
+                    v[i] = relu0(ak[r + i]) * co_sin_fin<SIN_MODE>(co_sin_prep<SIN_MODE>(as[r + i]));
+#endif
+                if (LAST) {                                       // head rows of this element's channel, from the LDS table
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int c = 8 * ((r + i) >> 2) + ((r + i) & 3);
+                        o[ti][0] = __builtin_fmaf(hl[0 * HID + c], v[i], o[ti][0]);
+                        o[ti][1] = __builtin_fmaf(hl[1 * HID + c], v[i], o[ti][1]);
+                        o[ti][2] = __builtin_fmaf(hl[2 * HID + c], v[i], o[ti][2]);
+                    }
+                } else {
+                    fragw[(r >> 1) & 3] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+                    if ((r & 7) == 6)
+                        *(bf16x8*)(&qa[NXT][0][0][lane] + qoff[ti] + (2 * wave + (r >> 3)) * 64) = __builtin_bit_cast(bf16x8, fragw);
+                }
+            }
+            if (LAST) asm volatile("" : "+v"(o[ti][0]), "+v"(o[ti][1]), "+v"(o[ti][2]));
+        }
+        CO_STAMP(3 + 3 * (LAST ? 2 : CUR));
+        __syncthreads();                                          // layer output complete; input and seed slab are free
+        CO_STAMP(4 + 3 * (LAST ? 2 : CUR));
+        if (!LAST) {
+            stage_store();
+            __syncthreads();
+        }
+        CO_STAMP(5 + 3 * (LAST ? 2 : CUR));
+    };
+
+    layer_body(CoopTagFalse{}, CoopTagFalse{}, 0);
+    wp += (int)(WLB_LAYER * sizeof(float));
+    layer_body(CoopTagFalse{}, CoopTagTrue{}, 1);
+    wp += (int)(WLB_LAYER * sizeof(float));
+    layer_body(CoopTagTrue{}, CoopTagFalse{}, 2);
+
+    // ---- head: the 16 partial sums of a pixel (8 waves x 2 lane halves) meet in LDS (diinn.py:138).
+    // o[ti] belongs to tile ti ^ (2 grp)
+#pragma unroll
+    for (int ti = 0; ti < TILES; ++ti) {
+        const int t = ti ^ (2 * grp);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) red[2 * wave + h][t * 32 + j][k] = o[ti][k];
+    }
+    __syncthreads();
+    if (threadIdx.x < TILES * 32) {
+        const int t = threadIdx.x >> 5, jj = threadIdx.x & 31;
+        const int x = blockIdx.x * (2 * TILE_W) + (t & 1) * TILE_W + (jj & (TILE_W - 1));
+        const int y = p.y0 + blockIdx.y * (2 * TILE_H) + (t >> 1) * TILE_H + (jj / TILE_W);
+        float acc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int w16 = 0; w16 < 16; ++w16)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[k] += red[w16][threadIdx.x][k];
+        if (x < p.Wu && y < p.y1) {
+            const size_t plane = (size_t)p.Orows * p.Wu;
+            float* op = p.out + (size_t)b * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
+            op[0] = acc[0] + bl0;
+            op[plane] = acc[1] + bl1;
+            op[2 * plane] = acc[2] + bl2;
+        }
+    }
+    CO_STAMP(12);
+}
+
 // cells of the LR footprint of the widest 16 x 8 block of the launch: (columns, rows)
 static void coop_footprint(const DecodeParams& p, int& ncx, int& ncy) {
     ncx = ncy = 1;
@@ -784,7 +1077,7 @@ int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int 
         const dim3 grid2(gx, (y1 - y0 + 2 * TILE_H * WG_TILES_Y - 1) / (2 * TILE_H * WG_TILES_Y), gz);   // 16 x 16 pixels per workgroup
         const bool two_tiles = (long long)grid2.x * grid2.y * grid2.z >= 512;
         // diagnostic override (tests / A-B timing): DIINN_BF16_KERNEL = 1 one tile per wave, 2 two tiles per wave,
-        // 4 cooperative; unset = pick by launch size and scale
+        // 4 / 8 cooperative with 4 / 8 waves; unset = pick by launch size and scale
         const char* fenv = getenv("DIINN_BF16_KERNEL");
         const int force = fenv ? atoi(fenv) : 0;
         // the cooperative kernel stages the P rows of a block's LR footprint in LDS: needs the footprint to fit
@@ -794,8 +1087,15 @@ int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int 
         coop_footprint(p, ncx, ncy);
         pc.seed_cols = ncx;
         const bool coop_ok = ncx * ncy <= CO_SEED_CELLS;
-        const bool coop = coop_ok && (force ? force == 4 : (long long)gx * gy * gz >= 1024);
-        if (coop) {                                               // 16 x 8 pixel blocks: the grid of the one-tile kernel
+        const bool coop = coop_ok && (force ? (force == 4 || force == 8) : (long long)gx * gy * gz >= 1024);
+        if (coop && force != 4) {                                 // 16 x 8 pixel blocks, 8 waves: the grid of the one-tile kernel
+            if (sin_mode == DIINN_SIN_HW)
+                hipLaunchKernelGGL(decode_bf16_coop8_kernel<DIINN_SIN_HW>, grid, dim3(512), 0, (hipStream_t)stream, pc);
+            else if (sin_mode == DIINN_SIN_HW_REDUCED)
+                hipLaunchKernelGGL(decode_bf16_coop8_kernel<DIINN_SIN_HW_REDUCED>, grid, dim3(512), 0, (hipStream_t)stream, pc);
+            else
+                hipLaunchKernelGGL(decode_bf16_coop8_kernel<DIINN_SIN_ACCURATE>, grid, dim3(512), 0, (hipStream_t)stream, pc);
+        } else if (coop) {                                        // the 4-wave form (DIINN_BF16_KERNEL=4)
             if (sin_mode == DIINN_SIN_HW)
                 hipLaunchKernelGGL(decode_bf16_coop_kernel<DIINN_SIN_HW>, grid, dim3(blk), 0, (hipStream_t)stream, pc);
             else if (sin_mode == DIINN_SIN_HW_REDUCED)

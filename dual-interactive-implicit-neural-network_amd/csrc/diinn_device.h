@@ -153,12 +153,12 @@ constexpr int TILE_W = 8, TILE_H = 4;           // one wave: 8x4 HR pixels
 #define DECODE_PREFETCH 4                       // weight ring depth, in steps of 8 MFMAs
 #endif
 
-// relu without the canonicalising v_max that fmaxf(x, 0) emits for an MFMA result
-__device__ __forceinline__ float relu0(float x) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));     // one VALU op (fmaxf adds a canonicalising v_max)
-    return r;
-}
+// relu as ONE v_max_f32.  The translation units are built with -fno-honor-nans, under which fmaxf(x, 0) needs no
+// canonicalising v_max in front.  (Round 1 used an inline-asm v_max here.  hipcc inserts no MFMA -> VALU wait states
+// in front of an asm statement, so an asm that reads an accumulator register straight after the MFMA that writes it
+// reads it too early: harmless while the accumulators sat in AGPRs and were read back long after, wrong results as
+// soon as a kernel with VGPR accumulators evaluated its epilogue right behind the MFMAs.)
+__device__ __forceinline__ float relu0(float x) { return __builtin_fmaxf(x, 0.0f); }
 
 // Weight-stream loads go through a buffer descriptor: address = SGPR descriptor base + SGPR byte
 // offset (scalar unit) + one constant per-lane VGPR offset, so the stream costs no VALU address

@@ -367,3 +367,27 @@ def test_latency_kernel_is_bit_identical_to_throughput_kernel(golden, dev, monke
         D.decode_features(feat, packed, (61, 70), out=out, rows=(y0, y1))
     torch.cuda.synchronize()
     assert torch.equal(full, out)
+
+
+def test_bf16_kernel_variants_agree(golden, dev, monkeypatch):
+    """The four bf16 decode kernels (one tile per wave, two tiles per wave, cooperative with 4 and with 8 waves) are
+    the same arithmetic (same products, same k-order; only the head's summation order differs) laid out differently:
+    their outputs agree to a small fraction of the bf16 error (the cooperative kernels evaluate layer 0's sine on
+    revolutions as well, and a 1e-7 difference in an activation can flip a bf16 rounding), and each meets the restated
+    tolerance.  DIINN_BF16_KERNEL selects the kernel;
+    the cooperative ones need a block's LR footprint to fit their seed slab (scales from about x3), otherwise the
+    launch falls back by itself."""
+    for name, b, h, w, hu, wu, gain in golden_cases(golden):
+        if gain != 1.0:
+            continue
+        sd = synth.decoder_state_dict(123, gain)
+        feat = synth.encoder_features(123, b, h, w)
+        ref = golden[f"out/{name}"]
+        scale = float(np.abs(ref).max())
+        outs = {}
+        for k in ("1", "2", "4", "8"):
+            monkeypatch.setenv("DIINN_BF16_KERNEL", k)
+            outs[k] = _decode(sd, feat, (hu, wu), dev, compute="bf16")
+            assert float(np.abs(outs[k] - ref).max()) <= 2e-3 * scale + 1e-6, (name, k)
+        for k in ("2", "4", "8"):
+            assert float(np.abs(outs[k] - outs["1"]).max()) <= 5e-4 * scale, (name, k)
