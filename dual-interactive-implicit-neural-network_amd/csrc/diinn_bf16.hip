@@ -849,11 +849,6 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8_kernel(const DecodeP
     // fragment as soon as the last pixel tile has consumed it
     f32x4 Ak[16], As[16];
     int wp = (int)(OFF_WLB * sizeof(float)) + wave * CO_MT_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-        Ak[ks] = ld_w(wp, 2 * ks + 0);
-        As[ks] = ld_w(wp, 2 * ks + 1);
-    }
 
     // ---- prologue: tables and the P_0 / P_1 slices into LDS (the tables of layer 0 live in the second image)
     float* const q0tab = reinterpret_cast<float*>(&qa[1][0][0][0]);          // [3][256]: Q0h, Q0w, fma(Q0r, ratio, bQ0)
@@ -864,10 +859,20 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8_kernel(const DecodeP
         for (int i = 0; i < CO_SEED_CELLS / 8; ++i) s0[i] = *(const f32x4*)(p.P + scell[i]);
         stage_load(1);
         const int ti = threadIdx.x;
-        if (ti < 192) {                                                      // rows Q0h, Q0w, Q0r -> t (64 threads each)
-            f32x4 tq = *(const f32x4*)(Wt + OFF_Q0R + 4 * ti);
-            if (ti >= 128) {
-                const f32x4 bq0 = *(const f32x4*)(Wt + OFF_Q0R + HID + 4 * ti);
+        f32x4 tq = {}, bq0 = {};
+        if (ti < 192) tq = *(const f32x4*)(Wt + OFF_Q0R + 4 * ti);          // rows Q0h, Q0w, Q0r (64 threads each)
+        if (ti >= 128 && ti < 192) bq0 = *(const f32x4*)(Wt + OFF_Q0R + HID + 4 * ti);
+        // the first M-tile's 32 weight fragments (256 KiB per workgroup: ~4 k cycles of L1 time) are requested AFTER
+        // the few rows layer 0 waits for, and arrive while layer 0 is computed
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            Ak[ks] = ld_w(wp, 2 * ks + 0);
+            As[ks] = ld_w(wp, 2 * ks + 1);
+        }
+        asm volatile("" ::: "memory");
+        if (ti < 192) {
+            if (ti >= 128) {                                                 // row 2 becomes t = fma(Q0r, ratio, bQ0)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) tq[e] = __builtin_fmaf(tq[e], p.ratio, bq0[e]);
             }
