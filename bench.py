@@ -412,16 +412,17 @@ def main():
             },
         }
         if bf:
-            # second roof for the bf16 path: at one wave per SIMD a wave has ~8 issue slots of 4
-            # cycles per 32-cycle bf16 MFMA, and a vector-memory instruction holds ~15 of them.  Instruction mix per
-            # MFMA of decode_bf16_coop_kernel from the committed PMC pass (profiles/r02_pmc_summary.txt).
-            mix = {"mfma": 1.0, "valu": 5.3, "lds": 0.98, "vmem": 0.31, "salu": 0.39}
-            slots = 2.0 * mix["mfma"] + mix["valu"] + 2.0 * mix["lds"] + 15.0 * mix["vmem"] + mix["salu"]
-            issue_peak = PEAK_BF16_MFMA_TFLOPS * min(1.0, 8.0 / slots)
-            res["roofline_issue"] = {"bound": "instruction issue, one wave per SIMD", "instructions_per_mfma": mix,
-                                     "issue_slots_per_mfma": round(slots, 2), "peak": round(issue_peak, 1),
-                                     "unit": "TFLOP/s", "achieved": round(achieved, 3),
-                                     "frac": round(achieved / issue_peak, 4)}
+            # second roof for the bf16 path: the vector L1 (64 B/clk/CU).  The cooperative kernel
+            # moves, per 128-pixel block, 768 KiB of weights (each wave its own slice, no reuse between waves), 4 slices
+            # of up to 24 staged P rows of 1 KiB, and ~8 KiB of tables through it; VALU / LDS / wait shares from the PMC
+            # passes are in profiles/r02_pmc_summary.txt.
+            l1_bytes_px = (768 * 1024 + 4 * 24 * 1024 + 8 * 1024) / 128.0
+            l1_peak = 64.0 * 256 * 2.4e9 / 1e12                      # TB/s at 2.4 GHz
+            l1_ach = l1_bytes_px * px_launch / (k_ms * 1e-3) / 1e12
+            res["roofline_l1"] = {"bound": "vector L1", "bytes_per_pixel": round(l1_bytes_px), "achieved": round(l1_ach, 2),
+                                  "peak": round(l1_peak, 1), "unit": "TB/s", "frac": round(l1_ach / l1_peak, 4),
+                                  "note": "weight refills arrive in bursts (one per layer, all 8 waves at once): the "
+                                          "bound is the burst, not the average"}
         if checked is not None:
             res["checked"] = checked
         if gather_ms is not None:

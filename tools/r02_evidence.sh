@@ -51,7 +51,7 @@ for cfg in c2 c5; do
 done
 # stamps of the cooperative bf16 kernel (variant library built beforehand)
 if [ -f variants/libdiinn_stamps.so ]; then
-  DIINN_HIP_LIB=variants/libdiinn_stamps.so python tools/stamp_report_coop.py c5 > $O/bf16_coop_stamps.txt 2>&1
+  DIINN_HIP_LIB=variants/libdiinn_stamps.so python tools/stamp_report_coop.py c5 > $O/bf16_coop8_stamps.txt 2>&1; DIINN_BF16_KERNEL=4 DIINN_HIP_LIB=variants/libdiinn_stamps.so python tools/stamp_report_coop.py c5 > $O/bf16_coop4_stamps.txt 2>&1
 fi
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 du -sh $O
