@@ -34,6 +34,9 @@ struct ConvKsplitParams {
     float* out1;             // optional destination 1
     long long in_bs, out0_bs, out1_bs, res_bs;
     int Cin, B, H, W, relu;
+#ifdef DIINN_STAMPS
+    unsigned long long* stamps;   // diagnostic build only (tools/stamp_report_enc.py)
+#endif
 };
 
 // NH = 1: a workgroup computes one 32-output half (blockIdx.y) -- twice the workgroups, for maps with few tiles.
@@ -49,7 +52,21 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvKsplitParams& p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
     const int tiles_x = (p.W + CS_TW - 1) / CS_TW, tiles_y = (p.H + CS_TH - 1) / CS_TH;
-    int t = blockIdx.x;
+    // workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2): give every XCD a contiguous
+    // run of tiles, so the workgroups that share 128-byte lines of the feature planes (a tile row is 32-40 bytes)
+    // and halo rows meet in ONE L2 instead of fetching the line into four (r02: 23.7 -> 22.1 ms per trunk at 256x256)
+    const int per_xcd = gridDim.x >> 3;
+    int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (t >= p.B * tiles_x * tiles_y) return;
+#ifdef DIINN_STAMPS
+    const size_t stamp_base = ((size_t)blockIdx.x * CS_WAVES + wave) * 8;
+    if (p.stamps && lane == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        p.stamps[stamp_base + 6] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
+    STAMP(0);
     const int b = t / (tiles_x * tiles_y);
     t -= b * tiles_x * tiles_y;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
@@ -140,6 +157,9 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvKsplitParams& p) {
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (mine_lane) ldst[u * PIX] = ok ? vpre[u] : 0.0f;
+#ifdef DIINN_STAMPS
+            if (chunk == 0) STAMP(1);
+#endif
 #pragma unroll
             for (int u = 0; u < 8; ++u) vpre[u] = ld_act(irs, lsrc_off, (unsigned)(8 * (chunk + 1) + u) * plane_b);
 #pragma unroll
@@ -220,6 +240,7 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvKsplitParams& p) {
         }
     }
 
+    STAMP(2);
     // ---- sum the 8 partial tiles through LDS (one output half per pass: 32 KiB), then the epilogue
     const int y = y0 + j / CS_TW, x = x0 + j % CS_TW;
     const bool inside = (y < p.H) && (x < p.W);
@@ -245,7 +266,11 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvKsplitParams& p) {
                 if (p.out1) p.out1[(size_t)b * p.out1_bs + o] = v;
             }
         }
+#ifdef DIINN_STAMPS
+        if (hh == 0) STAMP(3);
+#endif
     }
+    STAMP(4);
 }
 
 // 3x3 layers: 32 KiB of LDS and <= 80 VGPRs -> three workgroups (6 waves per SIMD) share a CU, which covers one
@@ -258,11 +283,15 @@ template <int NH>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
 void conv_ksplit_kernel_1x1(const ConvKsplitParams p) { conv_ksplit_body<1, NH>(p); }
 
-static int launch_conv_ksplit(void* stream, const ConvKsplitParams& p, int taps) {
-    const int tiles = ((p.W + CS_TW - 1) / CS_TW) * ((p.H + CS_TH - 1) / CS_TH) * p.B;
+static int launch_conv_ksplit(void* stream, const ConvKsplitParams& p_in, int taps) {
+    const int tiles = ((p_in.W + CS_TW - 1) / CS_TW) * ((p_in.H + CS_TH - 1) / CS_TH) * p_in.B;
     // both output halves per workgroup once the tiles alone give every CU two workgroups; otherwise one half each
     const bool both = tiles >= 512;
-    const dim3 grid(tiles, both ? 1 : 2);
+    const dim3 grid((tiles + 7) / 8 * 8, both ? 1 : 2);          // a multiple of 8: see the XCD mapping in the kernel
+    ConvKsplitParams p = p_in;
+#ifdef DIINN_STAMPS
+    p.stamps = g_stamps;
+#endif
     if (taps == 9) {
         if (both) hipLaunchKernelGGL(conv_ksplit_kernel_3x3<2>, grid, dim3(512), 0, (hipStream_t)stream, p);
         else      hipLaunchKernelGGL(conv_ksplit_kernel_3x3<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
@@ -285,7 +314,7 @@ int diinn_conv_ksplit(void* stream, const float* in_dev, long long in_batch_stri
     if (st) return st;
     if (taps != 9 && taps != 1) return DIINN_ERR_UNSUPPORTED;
     if (Cin <= 0 || Cin % 64) return DIINN_ERR_UNSUPPORTED;
-    if ((long long)((W + CS_TW - 1) / CS_TW) * ((H + CS_TH - 1) / CS_TH) * B > 2147483647LL) return DIINN_ERR_TOO_LARGE;
+    if ((long long)((W + CS_TW - 1) / CS_TW) * ((H + CS_TH - 1) / CS_TH) * B > 2147483000LL) return DIINN_ERR_TOO_LARGE;
     if ((long long)(Cin / CS_WAVES) * H * W * 4 > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;   // a wave's channel slice is addressed with 32-bit byte offsets
     ConvKsplitParams p;
     p.in = in_dev; p.w = packed_w_dev; p.bias = bias_dev; p.res = res_dev; p.out0 = out0_dev; p.out1 = out1_dev;

@@ -1,0 +1,68 @@
+"""Diagnostic: phases of conv_ksplit_kernel from in-kernel s_memtime stamps, and the timeline of the workgroups of one CU.
+Needs a -DDIINN_STAMPS build:  tools/build_variant.sh stamps -DDIINN_STAMPS
+   DIINN_HIP_LIB=variants/libdiinn_stamps.so python tools/stamp_report_enc.py [LR] [Cin] [taps]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import diinn_amd._native as N, diinn_amd.modules as M
+
+lr = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+cin = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+taps = int(sys.argv[3]) if len(sys.argv) > 3 else 9
+dev = torch.device("cuda:0")
+lib = N.load()
+raw = C.CDLL(N.LIB_PATH)
+hw = lr * lr
+buf = (torch.randn(1, 1024 + 64, lr, lr, device=dev) * 0.1).clamp_(min=0)
+bias = torch.zeros(64, device=dev)
+k = 3 if taps == 9 else 1
+w = M.pack_conv_ksplit(torch.randn(64, cin, k, k) * 0.01).to(dev)
+out = buf[:, 1024:]
+stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def run():
+    N.check(lib.diinn_conv_ksplit(stream, C.c_void_p(buf.data_ptr()), (1024 + 64) * hw, cin, taps, C.c_void_p(w.data_ptr()),
+                                  C.c_void_p(bias.data_ptr()), None, 0, C.c_void_p(out.data_ptr()), (1024 + 64) * hw, None, 0,
+                                  1, 1, lr, lr), "conv")
+
+
+nwg = (hw // 32 + 7) // 8 * 8
+stamps = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device=dev)
+for _ in range(5):
+    run()
+torch.cuda.synchronize()
+raw.diinn_debug_set_stamp_buffer(C.c_void_p(stamps.data_ptr()))
+for _ in range(3):
+    run()                                                     # the last launch's stamps stay (back-to-back launches, as in the trunk)
+torch.cuda.synchronize()
+t = stamps.cpu().numpy().reshape(nwg, 8, 8).astype(np.int64)
+t = t[t[:, 0, 0] != 0]
+t0 = t[:, :, 0].min()
+# s_memtime ticks: constant 100 MHz on gfx950
+tick_ns = 10.0
+names = ["prologue (first chunk staged)", "MFMA loop", "reduction + epilogue half 0", "half 1"]
+wg_start = t[:, :, 0].min(axis=1)
+wg_end = t[:, :, 4].max(axis=1)
+print(f"Cin {cin} taps {taps} {lr}x{lr}: {len(t)} workgroups; kernel span {(wg_end.max() - t0) * tick_ns / 1e3:.1f} us "
+      f"(first start .. last end); starts spread over {(wg_start.max() - t0) * tick_ns / 1e3:.1f} us")
+life = (wg_end - wg_start) * tick_ns / 1e3
+print(f"workgroup lifetime: median {np.median(life):.1f} us, p10 {np.percentile(life, 10):.1f}, p90 {np.percentile(life, 90):.1f}")
+d = np.diff(t[:, :, :5], axis=2) * tick_ns / 1e3              # per wave phases
+for i, n in enumerate(names):
+    print(f"  {n:32s} median {np.median(d[:, :, i]):7.2f} us   p90 {np.percentile(d[:, :, i], 90):7.2f}")
+# timeline of one CU: group by (xcc, se, cu) from HW_ID (gfx9: cu_id bits 11:8, sh 12, se 15:13)
+hwid = t[:, 0, 6]
+xcc = (hwid >> 32) & 0xF
+cu = (hwid >> 8) & 0xF
+se = (hwid >> 13) & 0x7
+key = xcc * 1000 + se * 16 + cu
+ks, counts = np.unique(key, return_counts=True)
+print(f"distinct (xcc, se, cu): {len(ks)}; workgroups per CU min {counts.min()} max {counts.max()}")
+k0 = ks[len(ks) // 2]
+sel = np.where(key == k0)[0]
+sel = sel[np.argsort(wg_start[sel])]
+print(f"timeline of CU key {k0} (us from kernel start): start | MFMA loop begins | MFMA loop ends | end")
+for i in sel:
+    print(f"   wg {i:5d}: {(wg_start[i] - t0) * tick_ns / 1e3:7.1f} | {(t[i, :, 1].max() - t0) * tick_ns / 1e3:7.1f} | "
+          f"{(t[i, :, 2].max() - t0) * tick_ns / 1e3:7.1f} | {(wg_end[i] - t0) * tick_ns / 1e3:7.1f}")
