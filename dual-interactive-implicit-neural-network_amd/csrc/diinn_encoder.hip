@@ -336,21 +336,34 @@ size_t diinn_rdn_workspace_floats(int B, int H, int W) {
     return (size_t)B * H * W * (2 * 576 + 1024 + 64);
 }
 
-int diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packed_dev, const float* biases_dev,
-                      float* workspace_dev, float* out_dev, int B, int H, int W) {
+size_t diinn_rdn_wino_packed_floats(void) {
+    // the 3x3 layers only, 16 floats per (output, input) pair: SFENet2, 16 x 8 dense convs, GFF.1
+    size_t n = (size_t)2 * 64 * 64 * 16;
+    for (int c = 0; c < 8; ++c) n += (size_t)16 * 64 * (64 + 64 * c) * 16;
+    return n;
+}
+
+static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
+                            const float* biases_dev, float* workspace_dev, float* out_dev, int B, int H, int W) {
     if (!sfe1_dev || !packed_dev || !biases_dev || !workspace_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
     if (st) return st;
     const long long hw = (long long)H * W;
+    // Winograd blocks are 16 x 8 pixels, one workgroup per CU: worth it once they fill the chip
+    const bool wino = packed_wino_dev && (long long)B * hw >= 32768;
     float* buf[2] = {workspace_dev, workspace_dev + (size_t)B * 576 * hw};     // dense buffers [B,576,H,W]
     float* gff_in = workspace_dev + (size_t)2 * B * 576 * hw;                    // [B,1024,H,W]
     float* tmp = gff_in + (size_t)B * 1024 * hw;                                 // [B,64,H,W]
     const float* w = packed_dev;
+    const float* wu = packed_wino_dev;
     const float* bias = biases_dev;
     auto conv = [&](const float* in, long long in_bs, int cin, int taps, const float* res, long long res_bs,
                     float* o0, long long o0_bs, float* o1, long long o1_bs, int relu) {
-        const int s = diinn_conv_ksplit(stream, in, in_bs, cin, taps, w, bias, res, res_bs, o0, o0_bs, o1, o1_bs, relu, B, H, W);
+        const int s = (wino && taps == 9 && !o1)
+            ? diinn_conv_wino(stream, in, in_bs, cin, wu, bias, res, res_bs, o0, o0_bs, relu, B, H, W)
+            : diinn_conv_ksplit(stream, in, in_bs, cin, taps, w, bias, res, res_bs, o0, o0_bs, o1, o1_bs, relu, B, H, W);
         w += (size_t)64 * cin * taps;
+        if (taps == 9 && wu) wu += (size_t)64 * cin * 16;
         bias += 64;
         return s;
     };
@@ -372,6 +385,17 @@ int diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packed_d
     st = conv(gff_in, 1024 * hw, 1024, 1, nullptr, 0, tmp, 64 * hw, nullptr, 0, 0);
     if (st) return st;
     return conv(tmp, 64 * hw, 64, 9, sfe1_dev, 64 * hw, out_dev, 64 * hw, nullptr, 0, 0);
+}
+
+int diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packed_dev, const float* biases_dev,
+                      float* workspace_dev, float* out_dev, int B, int H, int W) {
+    return rdn_forward_impl(stream, sfe1_dev, packed_dev, nullptr, biases_dev, workspace_dev, out_dev, B, H, W);
+}
+
+int diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
+                           const float* biases_dev, float* workspace_dev, float* out_dev, int B, int H, int W) {
+    if (!packed_wino_dev) return DIINN_ERR_INVALID_ARG;
+    return rdn_forward_impl(stream, sfe1_dev, packed_dev, packed_wino_dev, biases_dev, workspace_dev, out_dev, B, H, W);
 }
 
 }  // extern "C"

@@ -1,0 +1,277 @@
+// diinn_winograd.hip -- the 3x3 convolutions of the RDN trunk as Winograd F(2x2, 3x3) on the fp32 MFMA (gfx950).
+// (part of libdiinn_hip.so; shared definitions in diinn_device.h)
+//
+// Reference: src/models/components/rdn.py:9-35,90-105 -- 130 of the trunk's 147 convolutions are 3x3, stride 1,
+// zero padding 1, 64 outputs, 64..512 inputs: 93 % of the encoder's arithmetic.  F(2x2, 3x3) computes a 2x2 output
+// block from a 4x4 input patch with 16 multiplies per (input, output) channel pair instead of 36:
+//     Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A
+// so the 64 x Cin reduction becomes 16 independent GEMMs (one per position of the transformed 4x4 tile) of 2.25x
+// fewer MFMAs in total; only additions are added (B^T, A^T hold 0 / +-1), and G's halves are folded into the packed
+// weight on the host.  fp32 throughout; the result differs from the direct sum by reassociation only (~1e-6
+// relative; the library convolutions PyTorch calls use the same algorithm for fp32 3x3 layers).
+//
+// Work split: a workgroup owns a block of 8 x 4 Winograd tiles (16 x 8 output pixels) = one 32-wide MFMA N-tile;
+// wave i (of 4, one per SIMD, the whole register file each) owns ROW i of the transformed tile: positions (i, 0..3),
+// both 32-output halves -> 8 accumulators.  Per pair of input channels a wave loads two rows of every tile's 4x4
+// patch straight from the feature planes (one 16-byte load per row; L1 serves the overlap between tiles and
+// between waves), combines them (row i of B^T d: one fma per element), applies the column transform (4 adds) and
+// feeds the 4 values as B operands to 8 MFMAs.  No LDS, no barrier, no cross-wave reduction until the end, where
+// the four rows meet once through LDS for A^T (.) A, bias, ReLU, residual and the store.
+// Operand streams: weights (8 KiB per wave and 8 channels) and patch rows are requested TWO chunks of 8 channels
+// ahead into a three-stage register ring, one request after every second MFMA (a 1 KiB vector-memory instruction
+// holds its wave's issue for ~60 cycles -- an MFMA's own length -- so they are spread, not batched), and the
+// transform of k-step e+1 is issued between the MFMAs of k-step e.
+#include "diinn_device.h"
+
+constexpr int WN_TX = 8, WN_TY = 4;                  // Winograd tiles per block (x, y): 32 = one MFMA N-tile
+constexpr int WN_PIECE_BYTES = 1024;                 // one A piece: 64 lanes x 4 k-steps
+constexpr int WN_CHUNK_BYTES = 8 * WN_PIECE_BYTES;   // per wave and chunk of 8 channels: 4 positions x 2 halves
+constexpr int WN_ZS_FLOATS = 4 * 2 * 2 * 16 * 64;    // epilogue exchange: [row i][half][q][acc reg][lane]
+
+struct ConvWinoParams {
+    const float* in;         // input channel planes: in + b*in_bs + c*H*W
+    const float* wu;         // packed transformed weight: [row i 4][chunk Cin/8][col j 4][half 2][lane 64][4]
+    const float* bias;       // [64]
+    const float* res;        // optional residual [B,64,H,W] (batch stride res_bs), added after bias (no ReLU with it)
+    float* out;              // out + b*out_bs + co*H*W
+    long long in_bs, out_bs, res_bs;
+    int Cin, B, H, W, relu;
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x4 ld_row(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
+}
+
+#define WN_SB() __builtin_amdgcn_sched_barrier(0)
+
+template <int N> struct IC { static constexpr int value = N; };
+
+template <bool EDGE>
+__device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* __restrict__ zs, int b, int tx0, int ty0) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = row i of the transformed tile
+    const int h = lane >> 5, m = lane & 31;
+    const int tx = tx0 + (m & (WN_TX - 1)), ty = ty0 + m / WN_TX;
+    const size_t plane = (size_t)p.H * p.W;
+    const unsigned plane_b = (unsigned)(plane * sizeof(float));
+    const float* __restrict__ in_b = p.in + (size_t)b * p.in_bs;
+    const int n = p.Cin / 8;                                     // chunks of 8 input channels
+    const int lane_off = lane * 16;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.wu + (size_t)wave * n * (WN_CHUNK_BYTES / 4)), 0, n * WN_CHUNK_BYTES, 0x00020000);
+    // rows of B^T:  i = 0: d0 - d2,  1: d1 + d2,  2: d2 - d1,  3: d1 - d3   ->   t = d[ra] + sgn d[rb]
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 2 ? 1 : (wave == 1 ? 2 : 3));
+    const float sgn = wave == 1 ? 1.0f : -1.0f;
+    // patch of tile (tx, ty): rows 2 ty - 1 .. 2 ty + 2, columns 2 tx - 1 .. 2 tx + 2.  Rows outside the map (and
+    // tiles outside it) get an offset the descriptor's range check answers with zeros; column -1 is handled by
+    // loading from column 0 and shifting, columns >= W by selects (EDGE blocks only).
+    const bool tile_in = 2 * tx < p.W && 2 * ty < p.H;
+    const bool left = EDGE && tx == 0;
+    const bool ok2 = 2 * tx + 1 < p.W, ok3 = 2 * tx + 2 < p.W;
+    const int xc = left ? 0 : 2 * tx - 1;
+    const int ya = 2 * ty - 1 + ra, yb = 2 * ty - 1 + rb;
+    constexpr unsigned OUTSIDE = 0x80000000u;
+    const unsigned offa = (tile_in && ya >= 0 && ya < p.H) ? (unsigned)h * plane_b + (unsigned)(ya * p.W + xc) * 4u : OUTSIDE;
+    const unsigned offb = (tile_in && yb >= 0 && yb < p.H) ? (unsigned)h * plane_b + (unsigned)(yb * p.W + xc) * 4u : OUTSIDE;
+
+    f32x4 A[3][8];           // weight pieces of three chunks: [stage][col j * 2 + half], components = k-steps
+    f32x4 R[3][8];           // patch rows of three chunks: [stage][2 e + {row a, row b}], components = patch columns
+    f32x16 acc[4][2];        // [col j][half]
+    f32x4 V;                 // the B operands of the upcoming k-step (transformed patch row, 4 columns)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][hh][r] = 0.0f;
+
+    // the descriptor of a chunk's 8 planes, rebased per chunk: offsets inside stay small whatever Cin * H * W is
+    auto chunk_rsrc = [&](int c) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(in_b + (size_t)8 * c * plane), 0, (int)(8u * plane_b), 0x00020000);
+    };
+    // request #IDX (0..15) of chunk c into stage S: 8 weight pieces, then 8 patch rows
+    auto request = [&](auto S_, auto IDX_, int c, __amdgpu_buffer_rsrc_t irs) {
+        constexpr int S = decltype(S_)::value, IDX = decltype(IDX_)::value;
+        if constexpr (IDX < 8) A[S][IDX] = ld_piece(wrs, lane_off, c * WN_CHUNK_BYTES + IDX * WN_PIECE_BYTES);
+        else R[S][IDX - 8] = ld_row(irs, ((IDX - 8) & 1) ? offb : offa, (unsigned)(2 * ((IDX - 8) >> 1)) * plane_b);
+    };
+    // row i of B^T d for one channel: t = d[ra] + sgn d[rb]; border columns: the patch's column -1 is padding (the
+    // row was loaded from column 0 and is shifted here), columns >= W are padding
+    auto combine = [&](const f32x4& a, const f32x4& bb) {
+        f32x4 t;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) t[x] = __builtin_fmaf(sgn, bb[x], a[x]);
+        if constexpr (EDGE) {
+            f32x4 d;
+            d[0] = left ? 0.0f : t[0];
+            d[1] = left ? t[0] : t[1];
+            d[2] = left ? t[1] : t[2];
+            d[3] = left ? t[2] : t[3];
+            d[2] = ok2 ? d[2] : 0.0f;
+            d[3] = ok3 ? d[3] : 0.0f;
+            t = d;
+        }
+        return t;
+    };
+    // (B^T d) B: columns of the transformed row
+    auto columns = [&](const f32x4& t) {
+        f32x4 v;
+        v[0] = t[0] - t[2];
+        v[1] = t[1] + t[2];
+        v[2] = t[2] - t[1];
+        v[3] = t[1] - t[3];
+        return v;
+    };
+    // One k-step (a pair of input channels) of the chunk in stage S: 8 MFMAs; between them the B operands of the next
+    // k-step are prepared (the chunk's last k-step prepares the next chunk's first, from stage S+1) and four of the
+    // sixteen requests of chunk cload go out into stage S+2.
+    auto kstep = [&](auto S_, auto E_, int cload, __amdgpu_buffer_rsrc_t irs) {
+        constexpr int S = decltype(S_)::value, E = decltype(E_)::value;
+        constexpr int SL = (S + 2) % 3, SN = (S + 1) % 3;
+        const f32x4 vc = V;
+        const f32x4& ra4 = E < 3 ? R[S][2 * ((E + 1) & 3)] : R[SN][0];
+        const f32x4& rb4 = E < 3 ? R[S][2 * ((E + 1) & 3) + 1] : R[SN][1];
+        acc[0][0] = MFMA32(A[S][0][E], vc[0], acc[0][0]);
+        const f32x4 t = combine(ra4, rb4);
+        WN_SB();
+        acc[0][1] = MFMA32(A[S][1][E], vc[0], acc[0][1]);
+        request(IC<SL>{}, IC<4 * E + 0>{}, cload, irs);
+        WN_SB();
+        acc[1][0] = MFMA32(A[S][2][E], vc[1], acc[1][0]);
+        V = columns(t);
+        WN_SB();
+        acc[1][1] = MFMA32(A[S][3][E], vc[1], acc[1][1]);
+        request(IC<SL>{}, IC<4 * E + 1>{}, cload, irs);
+        WN_SB();
+        acc[2][0] = MFMA32(A[S][4][E], vc[2], acc[2][0]);
+        WN_SB();
+        acc[2][1] = MFMA32(A[S][5][E], vc[2], acc[2][1]);
+        request(IC<SL>{}, IC<4 * E + 2>{}, cload, irs);
+        WN_SB();
+        acc[3][0] = MFMA32(A[S][6][E], vc[3], acc[3][0]);
+        WN_SB();
+        acc[3][1] = MFMA32(A[S][7][E], vc[3], acc[3][1]);
+        request(IC<SL>{}, IC<4 * E + 3>{}, cload, irs);
+        WN_SB();
+    };
+    auto chunk = [&](auto S_, int cload) {
+        const __amdgpu_buffer_rsrc_t irs = chunk_rsrc(cload);
+        kstep(S_, IC<0>{}, cload, irs);
+        kstep(S_, IC<1>{}, cload, irs);
+        kstep(S_, IC<2>{}, cload, irs);
+        kstep(S_, IC<3>{}, cload, irs);
+    };
+    auto request_all = [&](auto S_, int c) {
+        const __amdgpu_buffer_rsrc_t irs = chunk_rsrc(c);
+        request(S_, IC<0>{}, c, irs);  request(S_, IC<1>{}, c, irs);  request(S_, IC<2>{}, c, irs);  request(S_, IC<3>{}, c, irs);
+        request(S_, IC<4>{}, c, irs);  request(S_, IC<5>{}, c, irs);  request(S_, IC<6>{}, c, irs);  request(S_, IC<7>{}, c, irs);
+        request(S_, IC<8>{}, c, irs);  request(S_, IC<9>{}, c, irs);  request(S_, IC<10>{}, c, irs); request(S_, IC<11>{}, c, irs);
+        request(S_, IC<12>{}, c, irs); request(S_, IC<13>{}, c, irs); request(S_, IC<14>{}, c, irs); request(S_, IC<15>{}, c, irs);
+    };
+
+    request_all(IC<0>{}, 0);
+    request_all(IC<1>{}, n > 1 ? 1 : 0);
+    WN_SB();
+    V = columns(combine(R[0][0], R[0][1]));
+    WN_SB();
+    // chunk c sits in stage c % 3; while it is computed chunk c + 2 is requested (past the end: the last chunk again,
+    // never used)
+    int c = 0;
+    for (; c + 3 <= n; c += 3) {
+        chunk(IC<0>{}, c + 2 < n ? c + 2 : n - 1);
+        chunk(IC<1>{}, c + 3 < n ? c + 3 : n - 1);
+        chunk(IC<2>{}, c + 4 < n ? c + 4 : n - 1);
+    }
+    if (c < n) chunk(IC<0>{}, n - 1);
+    if (c + 1 < n) chunk(IC<1>{}, n - 1);
+
+    // ---- A^T (.) A: the column half in registers, the row half through LDS (the only barrier of the kernel)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m0 = acc[0][hh][r], m1 = acc[1][hh][r], m2 = acc[2][hh][r], m3 = acc[3][hh][r];
+            zs[(((wave * 2 + hh) * 2 + 0) * 16 + r) * 64 + lane] = (m0 + m1) + m2;
+            zs[(((wave * 2 + hh) * 2 + 1) * 16 + r) * 64 + lane] = (m1 - m2) - m3;
+        }
+    __syncthreads();
+    // wave: output row pr of the 2x2 block and output half hh; a lane: both columns of its tile, 16 channels
+    const int pr = wave & 1, hh = wave >> 1;
+    const float s2 = pr == 0 ? 1.0f : -1.0f;                    // row 0: Z0 + Z1 + Z2, row 1: Z1 - Z2 - Z3
+    const int oy = 2 * ty + pr, ox = 2 * tx;
+    const bool in0 = oy < p.H && ox < p.W, in1 = oy < p.H && ox + 1 < p.W;
+    const bool pair = (p.W & 1) == 0 && (p.out_bs & 1) == 0 && (((size_t)p.out) & 7) == 0;   // 8-byte stores stay aligned
+    float* __restrict__ outb = p.out + (size_t)b * p.out_bs;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float y[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float z0 = zs[((((pr + 0) * 2 + hh) * 2 + q) * 16 + r) * 64 + lane];
+            const float z1 = zs[((((pr + 1) * 2 + hh) * 2 + q) * 16 + r) * 64 + lane];
+            const float z2 = zs[((((pr + 2) * 2 + hh) * 2 + q) * 16 + r) * 64 + lane];
+            y[q] = __builtin_fmaf(s2, z2, __builtin_fmaf(s2, z1, z0));
+        }
+        const int co = 32 * hh + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float bias = p.bias[co];
+        const size_t o = (size_t)co * plane + (size_t)oy * p.W + ox;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            y[q] += bias;
+            if (p.relu) y[q] = relu0(y[q]);
+            if (p.res && (q == 0 ? in0 : in1)) y[q] += p.res[(size_t)b * p.res_bs + o + q];
+        }
+        if (pair) {
+            if (in0) *reinterpret_cast<f32x2*>(outb + o) = f32x2{y[0], y[1]};
+        } else {
+            if (in0) outb[o] = y[0];
+            if (in1) outb[o + 1] = y[1];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvWinoParams p) {
+    __shared__ __attribute__((aligned(16))) float zs[WN_ZS_FLOATS];
+    const int tiles_x = (p.W + 1) / 2, tiles_y = (p.H + 1) / 2;
+    const int bx_n = (tiles_x + WN_TX - 1) / WN_TX, by_n = (tiles_y + WN_TY - 1) / WN_TY;
+    // every XCD takes a contiguous run of blocks (blocks b and b + 8 share an L2): neighbours share patch rows
+    const int per_xcd = gridDim.x >> 3;
+    int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (t >= p.B * bx_n * by_n) return;
+    // (integer division runs on the vector unit: pin the results back into scalar registers, or every descriptor
+    // derived from them is treated as divergent and each load becomes a waterfall loop)
+    const int b = __builtin_amdgcn_readfirstlane(t / (bx_n * by_n));
+    t -= b * bx_n * by_n;
+    const int by = __builtin_amdgcn_readfirstlane(t / bx_n), bx = t - by * bx_n;
+    const int tx0 = bx * WN_TX, ty0 = by * WN_TY;
+    const bool edge = tx0 == 0 || 2 * (tx0 + WN_TX - 1) + 2 >= p.W;
+    if (edge) conv_wino_body<true>(p, zs, b, tx0, ty0);
+    else      conv_wino_body<false>(p, zs, b, tx0, ty0);
+}
+
+extern "C" {
+
+int diinn_conv_wino(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
+                    const float* packed_u_dev, const float* bias_dev, const float* res_dev, long long res_batch_stride,
+                    float* out_dev, long long out_batch_stride, int relu, int B, int H, int W) {
+    if (!in_dev || !packed_u_dev || !bias_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (Cin <= 0 || Cin % 8) return DIINN_ERR_UNSUPPORTED;
+    if ((((size_t)in_dev) & 3) || (((size_t)packed_u_dev) & 15)) return DIINN_ERR_INVALID_ARG;
+    const long long blocks = (long long)(((W + 1) / 2 + WN_TX - 1) / WN_TX) * (((H + 1) / 2 + WN_TY - 1) / WN_TY) * B;
+    if (blocks > 2147483000LL) return DIINN_ERR_TOO_LARGE;
+    if ((long long)H * W * 4 * 8 > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;      // a chunk of 8 planes is addressed with 32-bit byte offsets
+    if ((long long)Cin * WN_CHUNK_BYTES / 8 * 4 > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;
+    ConvWinoParams p;
+    p.in = in_dev; p.wu = packed_u_dev; p.bias = bias_dev; p.res = res_dev; p.out = out_dev;
+    p.in_bs = in_batch_stride; p.out_bs = out_batch_stride; p.res_bs = res_batch_stride;
+    p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0;
+    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+}  // extern "C"

@@ -82,6 +82,20 @@ def pack_conv_ksplit(weight: torch.Tensor) -> torch.Tensor:
     return w.permute(0, 2, 6, 3, 5, 1, 4).reshape(-1)                               # [half, wave, tap, g, h, i, e]
 
 
+def pack_conv_wino(weight: torch.Tensor) -> torch.Tensor:
+    """3x3 conv weight [64, Cin, 3, 3] (Cin % 8 == 0) -> the Winograd F(2x2, 3x3) image ``diinn_conv_wino`` reads
+    (include/diinn_hip.h): U = G W G^T per (output, input) pair, computed in float64 and rounded once, laid out
+    [row i 4][chunk Cin/8][col j 4][half 2][lane 64][4] with cout = 32 half + (lane & 31) and input channel =
+    8 chunk + 2 e + (lane >> 5)."""
+    co, cin, kh, kw = weight.shape
+    if co != 64 or cin % 8 or (kh, kw) != (3, 3):
+        raise ValueError(f"unsupported convolution shape {tuple(weight.shape)}")
+    g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    u = torch.einsum("ia,ocab,jb->ocij", g, weight.detach().to(torch.float64).cpu(), g).to(torch.float32)
+    u = u.reshape(2, 32, cin // 8, 4, 2, 4, 4)                  # [half, m, chunk, e, h, i, j]
+    return u.permute(5, 2, 6, 0, 4, 1, 3).reshape(-1)           # [i, chunk, j, half, h, m, e]
+
+
 class RDN(nn.Module):
     _CONFIGS = {"A": (20, 6, 32), "B": (16, 8, 64)}
     # Inference (no autograd, fp32, config 'B') runs the trunk -- everything after SFENet1 -- on conv_ksplit_kernel
@@ -91,6 +105,9 @@ class RDN(nn.Module):
     # 192x192, 23.9 vs 28.1 at 256x256, 53.5 vs 60.2 at 384x384, 96.9 vs 108.4 at 512x512.  The attribute caps the
     # batch*H*W that takes this path (workspace: 2,240 floats per pixel); None disables it (MIOpen everywhere).
     hip_trunk_max_pixels: Optional[int] = 1024 * 1024          # byte offsets of a wave's channel slice stay far below 2^31
+    # 3x3 layers as Winograd F(2x2, 3x3) (csrc/diinn_winograd.hip) on maps of >= 32768 pixels: 2.25x fewer MFMAs, fp32,
+    # equal to the direct sum up to reassociation (~1e-6 relative).  False keeps every layer on the direct kernel.
+    hip_winograd: bool = True
 
     def __init__(self, G0: int = 64, RDNkSize: int = 3, RDNconfig: str = "B", n_colors: int = 3):
         super().__init__()
@@ -120,7 +137,8 @@ class RDN(nn.Module):
         if self._hip_pack is None or self._hip_key != key:
             w = torch.cat([pack_conv_ksplit(l.weight) for l in layers]).to(device)
             b = torch.cat([l.bias.detach().to(torch.float32) for l in layers]).to(device)
-            self._hip_pack, self._hip_key = (w, b), key
+            wu = torch.cat([pack_conv_wino(l.weight) for l in layers if l.kernel_size == (3, 3)]).to(device)
+            self._hip_pack, self._hip_key = (w, b, wu), key
         return self._hip_pack
 
     def _forward_hip_trunk(self, shallow):
@@ -129,14 +147,20 @@ class RDN(nn.Module):
         lib = _native.load()
         b, _, h, w = shallow.shape
         shallow = shallow.contiguous()
-        packed, biases = self._hip_packed(shallow.device)
+        packed, biases, packed_wino = self._hip_packed(shallow.device)
         ws = torch.empty(lib.diinn_rdn_workspace_floats(b, h, w), dtype=torch.float32, device=shallow.device)
         out = torch.empty_like(shallow)
         with torch.cuda.device(shallow.device):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            _native.check(lib.diinn_rdn_forward(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                                C.c_void_p(biases.data_ptr()), C.c_void_p(ws.data_ptr()),
-                                                C.c_void_p(out.data_ptr()), b, h, w), "diinn_rdn_forward")
+            if self.hip_winograd:
+                _native.check(lib.diinn_rdn_forward_wino(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                                         C.c_void_p(packed_wino.data_ptr()), C.c_void_p(biases.data_ptr()),
+                                                         C.c_void_p(ws.data_ptr()), C.c_void_p(out.data_ptr()), b, h, w),
+                              "diinn_rdn_forward_wino")
+            else:
+                _native.check(lib.diinn_rdn_forward(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                                    C.c_void_p(biases.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                                    C.c_void_p(out.data_ptr()), b, h, w), "diinn_rdn_forward")
         return out
 
     def forward(self, x):

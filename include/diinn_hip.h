@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIINN_ABI_VERSION 3   /* 2: training, LIIF/MetaSR, encoder-trunk entry points; packed image sections 8-9
+#define DIINN_ABI_VERSION 4   /* 2: training, LIIF/MetaSR, encoder-trunk entry points; packed image sections 8-9
                                  3: row-window entry points (band-sized buffers for the multi-GPU row-band split) */
 
 /* status codes */
@@ -292,6 +292,25 @@ size_t diinn_rdn_packed_floats(void);
 size_t diinn_rdn_workspace_floats(int B, int H, int W);
 int    diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packed_dev, const float* biases_dev,
                          float* workspace_dev, float* out_dev, int B, int H, int W);
+
+/* Winograd F(2x2, 3x3) for the trunk's 3x3 convolutions (csrc/diinn_winograd.hip): 2.25x fewer MFMAs than the direct
+ * sum, fp32, results equal up to reassociation (~1e-6 relative).
+ * diinn_conv_wino: one 3x3 zero-padded 64-output convolution over Cin % 8 == 0 input planes (addressing, epilogue
+ *   and error behaviour as diinn_conv_ksplit with one destination).  packed_u_dev holds U = G W G^T (G of F(2x2,3x3))
+ *   as [row i 4][chunk Cin/8][col j 4][half 2][lane 64][4]:
+ *   value = U[32 half + (lane&31)][8 chunk + 2 e + (lane>>5)][i][j]            (16 * 64 * Cin floats).
+ * diinn_rdn_wino_packed_floats: floats of the 130 transformed 3x3 weights of the trunk, in execution order.
+ * diinn_rdn_forward_wino: diinn_rdn_forward with the 3x3 layers on diinn_conv_wino where the map is big enough to
+ *   fill the chip with its 16 x 8-pixel blocks (B*H*W >= 32768) and on the split-K kernel otherwise; packed_dev and
+ *   biases_dev as for diinn_rdn_forward (the 1x1 layers and small maps read them), packed_wino_dev = the transformed
+ *   3x3 weights. */
+int    diinn_conv_wino(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
+                      const float* packed_u_dev, const float* bias_dev,
+                      const float* res_dev, long long res_batch_stride,
+                      float* out_dev, long long out_batch_stride, int relu, int B, int H, int W);
+size_t diinn_rdn_wino_packed_floats(void);
+int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
+                              const float* biases_dev, float* workspace_dev, float* out_dev, int B, int H, int W);
 
 /* Dominant-kernel launch geometry, for benchmarks/roofline accounting. */
 int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,

@@ -25,6 +25,62 @@ def test_pack_conv_ksplit_layout():
         M.pack_conv_ksplit(torch.zeros(64, 3, 3, 3))
 
 
+def test_pack_conv_wino_layout():
+    """The packed Winograd image holds U = G W G^T (float64 reference) at the documented positions."""
+    import diinn_amd.modules as M
+    rng = np.random.default_rng(1)
+    g = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
+    for cin in (8, 64, 192):
+        w = rng.standard_normal((64, cin, 3, 3)).astype(np.float32)
+        packed = M.pack_conv_wino(torch.from_numpy(w)).numpy()
+        assert packed.size == 16 * 64 * cin
+        pk = packed.reshape(4, cin // 8, 4, 2, 64, 4)
+        u = np.einsum("ia,ocab,jb->ocij", g, w.astype(np.float64), g).astype(np.float32)
+        for _ in range(300):
+            i, chunk, j, half, lane, e = (int(rng.integers(n)) for n in (4, cin // 8, 4, 2, 64, 4))
+            assert pk[i, chunk, j, half, lane, e] == u[32 * half + (lane & 31), 8 * chunk + 2 * e + (lane >> 5), i, j]
+    with pytest.raises(ValueError):
+        M.pack_conv_wino(torch.zeros(64, 64, 1, 1))
+
+
+@pytest.mark.gpu
+def test_conv_wino_kernel_matches_fp64_conv():
+    """diinn_conv_wino (Winograd F(2x2,3x3)): ReLU, residual, strided channel-plane views, odd / ragged maps (partial
+    tiles, partial blocks, one-pixel maps), left / right border blocks and interior blocks, batch > 1."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    gen = torch.Generator(device=dev).manual_seed(5)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
+    for (b, cin, h, w, relu, use_res) in [(1, 64, 48, 48, 1, 0), (2, 320, 13, 21, 1, 0), (1, 512, 5, 3, 0, 1),
+                                          (1, 8, 1, 1, 0, 0), (1, 72, 1, 37, 1, 0), (1, 64, 33, 1, 0, 1),
+                                          (1, 192, 128, 136, 1, 0), (2, 128, 70, 61, 0, 1), (1, 64, 64, 80, 1, 1),
+                                          (1, 576, 31, 50, 1, 0)]:
+        total = cin + 64
+        buf = torch.randn((b, total, h, w), device=dev, generator=gen)          # input = first cin planes of a larger buffer
+        wt = torch.randn((64, cin, 3, 3), device=dev, generator=gen) / (cin * 9) ** 0.5
+        bias = torch.randn(64, device=dev, generator=gen)
+        res = torch.randn((b, 64, h, w), device=dev, generator=gen) if use_res else None
+        out = torch.full((b, 96, h, w), float("nan"), device=dev)
+        packed = M.pack_conv_wino(wt).to(dev)
+        st = lib.diinn_conv_wino(stream, ptr(buf), total * h * w, cin, ptr(packed), ptr(bias),
+                                 ptr(res) if use_res else None, 64 * h * w, ptr(out[:, 32:]), 96 * h * w, relu, b, h, w)
+        assert st == 0
+        torch.cuda.synchronize()
+        ref = F.conv2d(buf[:, :cin].double(), wt.double(), bias.double(), padding=1)
+        if relu:
+            ref = torch.relu(ref)
+        if use_res:
+            ref = ref + res.double()
+        err = float((out[:, 32:].double() - ref).abs().max())
+        assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (cin, h, w, err)
+        assert torch.isnan(out[:, :32]).all()
+    assert lib.diinn_conv_wino(stream, ptr(buf), 1, 12, ptr(packed), ptr(bias), None, 0, ptr(out), 1, 0, 1, 4, 4) == N.ERR_UNSUPPORTED
+
+
 @pytest.mark.gpu
 def test_conv_ksplit_kernel_matches_torch():
     """diinn_conv_ksplit: 3x3 / 1x1, ReLU, residual, two destinations, strided channel-plane views, ragged maps."""
@@ -75,7 +131,8 @@ def test_rdn_hip_trunk_matches_miopen():
     shapes = {k: list(v.shape) for k, v in enc.state_dict().items()}
     enc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_for(shapes, 123, "enc.").items()})
     enc = enc.to(dev).eval()
-    for (b, h, w) in [(1, 48, 48), (2, 20, 33), (1, 160, 112)]:          # the last one has >= 512 tiles (both-halves kernels)
+    # (1,160,112): >= 512 tiles (both-halves kernels); (1,200,180), (2,128,130): >= 32768 pixels (Winograd 3x3 layers)
+    for (b, h, w) in [(1, 48, 48), (2, 20, 33), (1, 160, 112), (1, 200, 180), (2, 128, 130)]:
         x = torch.from_numpy(synth.uniform(7, f"img:{b}x{h}x{w}", (b, 3, h, w), 0.5) + np.float32(0.5)).to(dev)
         with torch.no_grad():
             got = enc(x)

@@ -18,6 +18,7 @@ PEAK = 157.3e12
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     lr = int(args[0]) if args else 256
+    wino = "--wino" in sys.argv                                # 3x3 layers on diinn_conv_wino (% of peak = direct-conv flops / time)
     dev = torch.device("cuda:0")
     lib = _native.load()
     hw = lr * lr
@@ -30,10 +31,16 @@ def main():
     shapes = [(64 * k, 9, 16 if k > 1 else 18) for k in range(1, 9)] + [(576, 1, 16), (1024, 1, 1)]
     for cin, taps, count in shapes:
         k = 3 if taps == 9 else 1
-        w = M.pack_conv_ksplit(torch.randn(64, cin, k, k) * 0.01).to(dev)
+        wt = torch.randn(64, cin, k, k) * 0.01
+        w = (M.pack_conv_wino(wt) if wino and taps == 9 else M.pack_conv_ksplit(wt)).to(dev)
         out = buf[:, 1024:]
 
         def run():
+            if wino and taps == 9:
+                _native.check(lib.diinn_conv_wino(stream, C.c_void_p(buf.data_ptr()), (1024 + 64) * hw, cin,
+                                                  C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), None, 0,
+                                                  C.c_void_p(out.data_ptr()), (1024 + 64) * hw, 1, 1, lr, lr), "conv")
+                return
             _native.check(lib.diinn_conv_ksplit(stream, C.c_void_p(buf.data_ptr()), (1024 + 64) * hw, cin, taps,
                                                 C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), None, 0,
                                                 C.c_void_p(out.data_ptr()), (1024 + 64) * hw, None, 0, 1, 1, lr, lr), "conv")
