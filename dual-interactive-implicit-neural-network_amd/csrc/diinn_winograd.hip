@@ -26,19 +26,24 @@
 constexpr int WN_TX = 8, WN_TY = 4;                  // Winograd tiles per block (x, y): 32 = one MFMA N-tile
 constexpr int WN_PIECE_BYTES = 1024;                 // one A piece: 64 lanes x 4 k-steps
 constexpr int WN_CHUNK_BYTES = 8 * WN_PIECE_BYTES;   // per wave and chunk of 8 channels: 4 positions x 2 halves
-constexpr int WN_ZS_FLOATS = 4 * 2 * 2 * 16 * 64;    // epilogue exchange: [row i][half][q][acc reg][lane]
+constexpr int WN_ZS_PITCH = 20;                      // a lane's 16 values + 4 floats of padding: 16-byte LDS accesses without bank conflicts
+constexpr int WN_ZS_FLOATS = 4 * 2 * 2 * 64 * WN_ZS_PITCH;   // epilogue exchange: [row i][half][q][lane][acc reg]
 
 struct ConvWinoParams {
     const float* in;         // input channel planes: in + b*in_bs + c*H*W
-    const float* wu;         // packed transformed weight: [row i 4][chunk Cin/8][col j 4][half 2][lane 64][4]
+    const float* wu;         // packed transformed weight: [row i 4][chunk Cin/8][col j 4][half 2][lane 64][4], column 2 negated
     const float* bias;       // [64]
     const float* res;        // optional residual [B,64,H,W] (batch stride res_bs), added after bias (no ReLU with it)
     float* out;              // out + b*out_bs + co*H*W
     long long in_bs, out_bs, res_bs;
     int Cin, B, H, W, relu;
+#ifdef DIINN_STAMPS
+    unsigned long long* stamps;   // diagnostic build only (tools/stamp_report_enc.py)
+#endif
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x4 ld_row(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
@@ -71,16 +76,24 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
     const bool tile_in = 2 * tx < p.W && 2 * ty < p.H;
     const bool left = EDGE && tx == 0;
     const bool ok2 = 2 * tx + 1 < p.W, ok3 = 2 * tx + 2 < p.W;
+#ifdef WN_ABL_ALIGNED
+    const int xc = 2 * tx;                                       // timing experiment: 8-byte aligned rows (wrong results)
+#else
     const int xc = left ? 0 : 2 * tx - 1;
+#endif
     const int ya = 2 * ty - 1 + ra, yb = 2 * ty - 1 + rb;
     constexpr unsigned OUTSIDE = 0x80000000u;
+#ifdef WN_ABL_OUTSIDE
+    const unsigned offa = OUTSIDE, offb = OUTSIDE;               // timing experiment: every row answered by the range check
+#else
     const unsigned offa = (tile_in && ya >= 0 && ya < p.H) ? (unsigned)h * plane_b + (unsigned)(ya * p.W + xc) * 4u : OUTSIDE;
     const unsigned offb = (tile_in && yb >= 0 && yb < p.H) ? (unsigned)h * plane_b + (unsigned)(yb * p.W + xc) * 4u : OUTSIDE;
+#endif
 
     f32x4 A[3][8];           // weight pieces of three chunks: [stage][col j * 2 + half], components = k-steps
     f32x4 R[3][8];           // patch rows of three chunks: [stage][2 e + {row a, row b}], components = patch columns
     f32x16 acc[4][2];        // [col j][half]
-    f32x4 V;                 // the B operands of the upcoming k-step (transformed patch row, 4 columns)
+    f32x2 V01, V23;          // the B operands of the upcoming k-step: the transformed patch row, columns 0 1 | -2 3
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -95,35 +108,41 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
     // request #IDX (0..15) of chunk c into stage S: 8 weight pieces, then 8 patch rows
     auto request = [&](auto S_, auto IDX_, int c, __amdgpu_buffer_rsrc_t irs) {
         constexpr int S = decltype(S_)::value, IDX = decltype(IDX_)::value;
-        if constexpr (IDX < 8) A[S][IDX] = ld_piece(wrs, lane_off, c * WN_CHUNK_BYTES + IDX * WN_PIECE_BYTES);
-        else R[S][IDX - 8] = ld_row(irs, ((IDX - 8) & 1) ? offb : offa, (unsigned)(2 * ((IDX - 8) >> 1)) * plane_b);
-    };
-    // row i of B^T d for one channel: t = d[ra] + sgn d[rb]; border columns: the patch's column -1 is padding (the
-    // row was loaded from column 0 and is shifted here), columns >= W are padding
-    auto combine = [&](const f32x4& a, const f32x4& bb) {
-        f32x4 t;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) t[x] = __builtin_fmaf(sgn, bb[x], a[x]);
-        if constexpr (EDGE) {
-            f32x4 d;
-            d[0] = left ? 0.0f : t[0];
-            d[1] = left ? t[0] : t[1];
-            d[2] = left ? t[1] : t[2];
-            d[3] = left ? t[2] : t[3];
-            d[2] = ok2 ? d[2] : 0.0f;
-            d[3] = ok3 ? d[3] : 0.0f;
-            t = d;
+        if constexpr (IDX < 8) {
+#ifndef WN_ABL_NOW
+            A[S][IDX] = ld_piece(wrs, lane_off, c * WN_CHUNK_BYTES + IDX * WN_PIECE_BYTES);
+#endif
+        } else {
+#ifndef WN_ABL_NOROWS
+            R[S][IDX - 8] = ld_row(irs, ((IDX - 8) & 1) ? offb : offa, (unsigned)(2 * ((IDX - 8) >> 1)) * plane_b);
+#endif
         }
-        return t;
     };
-    // (B^T d) B: columns of the transformed row
-    auto columns = [&](const f32x4& t) {
-        f32x4 v;
-        v[0] = t[0] - t[2];
-        v[1] = t[1] + t[2];
-        v[2] = t[2] - t[1];
-        v[3] = t[1] - t[3];
-        return v;
+    // The transform of one channel's two patch rows, 4 packed-fp32 instructions (each VALU instruction between two
+    // fp32 MFMAs costs ~3 cycles of MFMA issue):
+    //   row i of B^T d:  t = d[ra] + sgn d[rb]                                        (2 v_pk_fma)
+    //   (B^T d) B:       v0 = t0 - t2, v1 = t1 + t2 | -v2 = t1 - t2, v3 = t1 - t3      (v_pk_fma with (-1, 1), v_pk_add;
+    //                    the sign of column 2 lives in the packed weight)
+    // Border columns (EDGE blocks): the patch's column -1 is padding (the row was loaded from column 0 and is shifted
+    // here), columns >= W are padding.
+    f32x2 pm = {-1.0f, 1.0f};
+    asm volatile("" : "+v"(pm));                                 // a register pair: (-1, 1) is no inline constant
+    const f32x2 sgn2 = {sgn, sgn};
+    auto transform = [&](const f32x4& a, const f32x4& bb, f32x2& v01, f32x2& v23) {
+        f32x2 t01 = __builtin_elementwise_fma(sgn2, f32x2{bb[0], bb[1]}, f32x2{a[0], a[1]});
+        f32x2 t23 = __builtin_elementwise_fma(sgn2, f32x2{bb[2], bb[3]}, f32x2{a[2], a[3]});
+        if constexpr (EDGE) {
+            const float d0 = left ? 0.0f : t01[0];
+            const float d1 = left ? t01[0] : t01[1];
+            float d2 = left ? t01[1] : t23[0];
+            float d3 = left ? t23[0] : t23[1];
+            d2 = ok2 ? d2 : 0.0f;
+            d3 = ok3 ? d3 : 0.0f;
+            t01 = f32x2{d0, d1};
+            t23 = f32x2{d2, d3};
+        }
+        v01 = __builtin_elementwise_fma(f32x2{t23[0], t23[0]}, pm, t01);
+        v23 = f32x2{t01[1], t01[1]} - t23;
     };
     // One k-step (a pair of input channels) of the chunk in stage S: 8 MFMAs; between them the B operands of the next
     // k-step are prepared (the chunk's last k-step prepares the next chunk's first, from stage S+1) and four of the
@@ -131,29 +150,32 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
     auto kstep = [&](auto S_, auto E_, int cload, __amdgpu_buffer_rsrc_t irs) {
         constexpr int S = decltype(S_)::value, E = decltype(E_)::value;
         constexpr int SL = (S + 2) % 3, SN = (S + 1) % 3;
-        const f32x4 vc = V;
+        const f32x2 c01 = V01, c23 = V23;
         const f32x4& ra4 = E < 3 ? R[S][2 * ((E + 1) & 3)] : R[SN][0];
         const f32x4& rb4 = E < 3 ? R[S][2 * ((E + 1) & 3) + 1] : R[SN][1];
-        acc[0][0] = MFMA32(A[S][0][E], vc[0], acc[0][0]);
-        const f32x4 t = combine(ra4, rb4);
+        acc[0][0] = MFMA32(A[S][0][E], c01[0], acc[0][0]);
+#ifndef WN_ABL_NOVALU
+        transform(ra4, rb4, V01, V23);
+#else
+        V01 = f32x2{ra4[0], ra4[1]}, V23 = f32x2{rb4[2], rb4[3]};
+#endif
         WN_SB();
-        acc[0][1] = MFMA32(A[S][1][E], vc[0], acc[0][1]);
+        acc[0][1] = MFMA32(A[S][1][E], c01[0], acc[0][1]);
         request(IC<SL>{}, IC<4 * E + 0>{}, cload, irs);
         WN_SB();
-        acc[1][0] = MFMA32(A[S][2][E], vc[1], acc[1][0]);
-        V = columns(t);
+        acc[1][0] = MFMA32(A[S][2][E], c01[1], acc[1][0]);
         WN_SB();
-        acc[1][1] = MFMA32(A[S][3][E], vc[1], acc[1][1]);
+        acc[1][1] = MFMA32(A[S][3][E], c01[1], acc[1][1]);
         request(IC<SL>{}, IC<4 * E + 1>{}, cload, irs);
         WN_SB();
-        acc[2][0] = MFMA32(A[S][4][E], vc[2], acc[2][0]);
+        acc[2][0] = MFMA32(A[S][4][E], c23[0], acc[2][0]);
         WN_SB();
-        acc[2][1] = MFMA32(A[S][5][E], vc[2], acc[2][1]);
+        acc[2][1] = MFMA32(A[S][5][E], c23[0], acc[2][1]);
         request(IC<SL>{}, IC<4 * E + 2>{}, cload, irs);
         WN_SB();
-        acc[3][0] = MFMA32(A[S][6][E], vc[3], acc[3][0]);
+        acc[3][0] = MFMA32(A[S][6][E], c23[1], acc[3][0]);
         WN_SB();
-        acc[3][1] = MFMA32(A[S][7][E], vc[3], acc[3][1]);
+        acc[3][1] = MFMA32(A[S][7][E], c23[1], acc[3][1]);
         request(IC<SL>{}, IC<4 * E + 3>{}, cload, irs);
         WN_SB();
     };
@@ -172,11 +194,16 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
         request(S_, IC<12>{}, c, irs); request(S_, IC<13>{}, c, irs); request(S_, IC<14>{}, c, irs); request(S_, IC<15>{}, c, irs);
     };
 
+#ifdef DIINN_STAMPS
+    const size_t stamp_base = ((size_t)blockIdx.x * 4 + wave) * 8;
+#endif
+    STAMP(0);
     request_all(IC<0>{}, 0);
     request_all(IC<1>{}, n > 1 ? 1 : 0);
     WN_SB();
-    V = columns(combine(R[0][0], R[0][1]));
+    transform(R[0][0], R[0][1], V01, V23);
     WN_SB();
+    STAMP(1);
     // chunk c sits in stage c % 3; while it is computed chunk c + 2 is requested (past the end: the last chunk again,
     // never used)
     int c = 0;
@@ -188,49 +215,70 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
     if (c < n) chunk(IC<0>{}, n - 1);
     if (c + 1 < n) chunk(IC<1>{}, n - 1);
 
-    // ---- A^T (.) A: the column half in registers, the row half through LDS (the only barrier of the kernel)
+    STAMP(2);
+    // ---- A^T (.) A: the column half in registers, the row half through LDS (the only barrier of the kernel).
+    // A lane's 16 values of one (row, half, q) are contiguous (pitch 20 floats): 16-byte LDS accesses, no conflicts.
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float m0 = acc[0][hh][r], m1 = acc[1][hh][r], m2 = acc[2][hh][r], m3 = acc[3][hh][r];
-            zs[(((wave * 2 + hh) * 2 + 0) * 16 + r) * 64 + lane] = (m0 + m1) + m2;
-            zs[(((wave * 2 + hh) * 2 + 1) * 16 + r) * 64 + lane] = (m1 - m2) - m3;
+        for (int g = 0; g < 4; ++g) {
+            f32x4 z0, z1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                const float m0 = acc[0][hh][r], m1 = acc[1][hh][r], m2 = acc[2][hh][r], m3 = acc[3][hh][r];
+                z0[e] = (m0 + m1) + m2;
+                z1[e] = (m1 - m2) - m3;
+            }
+            *reinterpret_cast<f32x4*>(zs + ((((wave * 2 + hh) * 2 + 0) * 64 + lane) * WN_ZS_PITCH + 4 * g)) = z0;
+            *reinterpret_cast<f32x4*>(zs + ((((wave * 2 + hh) * 2 + 1) * 64 + lane) * WN_ZS_PITCH + 4 * g)) = z1;
         }
     __syncthreads();
+    STAMP(3);
     // wave: output row pr of the 2x2 block and output half hh; a lane: both columns of its tile, 16 channels
+    // (co = 32 hh + 8 g + e + 4 h for accumulator register 4 g + e)
     const int pr = wave & 1, hh = wave >> 1;
     const float s2 = pr == 0 ? 1.0f : -1.0f;                    // row 0: Z0 + Z1 + Z2, row 1: Z1 - Z2 - Z3
     const int oy = 2 * ty + pr, ox = 2 * tx;
     const bool in0 = oy < p.H && ox < p.W, in1 = oy < p.H && ox + 1 < p.W;
     const bool pair = (p.W & 1) == 0 && (p.out_bs & 1) == 0 && (((size_t)p.out) & 7) == 0;   // 8-byte stores stay aligned
-    float* __restrict__ outb = p.out + (size_t)b * p.out_bs;
+    // stores through a descriptor over this batch element's 64 planes: lane offset = plane 4 h + pixel, scalar offset =
+    // plane 32 hh + 8 g + e; pixels outside the map get an offset the range check drops
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)b * p.out_bs), 0,
+                                                                         (int)(64u * plane_b), 0x00020000);
+    const unsigned pix_b = (unsigned)(4 * h) * plane_b + (unsigned)(oy * p.W + ox) * 4u;
+    const unsigned st0 = in0 ? pix_b : OUTSIDE, st1 = in1 ? pix_b + 4u : OUTSIDE;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float y[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float z0 = zs[((((pr + 0) * 2 + hh) * 2 + q) * 16 + r) * 64 + lane];
-            const float z1 = zs[((((pr + 1) * 2 + hh) * 2 + q) * 16 + r) * 64 + lane];
-            const float z2 = zs[((((pr + 2) * 2 + hh) * 2 + q) * 16 + r) * 64 + lane];
-            y[q] = __builtin_fmaf(s2, z2, __builtin_fmaf(s2, z1, z0));
-        }
-        const int co = 32 * hh + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float bias = p.bias[co];
-        const size_t o = (size_t)co * plane + (size_t)oy * p.W + ox;
+    for (int g = 0; g < 4; ++g) {
+        f32x4 y[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            y[q] += bias;
-            if (p.relu) y[q] = relu0(y[q]);
-            if (p.res && (q == 0 ? in0 : in1)) y[q] += p.res[(size_t)b * p.res_bs + o + q];
+            const f32x4 z0 = *reinterpret_cast<const f32x4*>(zs + (((((pr + 0) * 2 + hh) * 2 + q) * 64 + lane) * WN_ZS_PITCH + 4 * g));
+            const f32x4 z1 = *reinterpret_cast<const f32x4*>(zs + (((((pr + 1) * 2 + hh) * 2 + q) * 64 + lane) * WN_ZS_PITCH + 4 * g));
+            const f32x4 z2 = *reinterpret_cast<const f32x4*>(zs + (((((pr + 2) * 2 + hh) * 2 + q) * 64 + lane) * WN_ZS_PITCH + 4 * g));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[q][e] = __builtin_fmaf(s2, z2[e], __builtin_fmaf(s2, z1[e], z0[e]));
         }
-        if (pair) {
-            if (in0) *reinterpret_cast<f32x2*>(outb + o) = f32x2{y[0], y[1]};
-        } else {
-            if (in0) outb[o] = y[0];
-            if (in1) outb[o + 1] = y[1];
+        const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + 32 * hh + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float y0 = y[0][e] + bias4[e], y1 = y[1][e] + bias4[e];
+            if (p.relu) y0 = relu0(y0), y1 = relu0(y1);
+            const int cs = 32 * hh + 8 * g + e;                  // the scalar part of the output channel
+            if (p.res) {
+                const float* __restrict__ rp = p.res + (size_t)b * p.res_bs + (size_t)(cs + 4 * h) * plane + (size_t)oy * p.W + ox;
+                if (in0) y0 += rp[0];
+                if (in1) y1 += rp[1];
+            }
+            if (pair) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{y0, y1}), ors, (int)st0, (int)((unsigned)cs * plane_b), 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y0), ors, (int)st0, (int)((unsigned)cs * plane_b), 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y1), ors, (int)st1, (int)((unsigned)cs * plane_b), 0);
+            }
         }
     }
+    STAMP(4);
 }
 
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvWinoParams p) {
@@ -261,15 +309,18 @@ int diinn_conv_wino(void* stream, const float* in_dev, long long in_batch_stride
     int st = check_dims(B, H, W);
     if (st) return st;
     if (Cin <= 0 || Cin % 8) return DIINN_ERR_UNSUPPORTED;
-    if ((((size_t)in_dev) & 3) || (((size_t)packed_u_dev) & 15)) return DIINN_ERR_INVALID_ARG;
+    if ((((size_t)in_dev) & 3) || (((size_t)packed_u_dev) & 15) || (((size_t)bias_dev) & 15)) return DIINN_ERR_INVALID_ARG;
     const long long blocks = (long long)(((W + 1) / 2 + WN_TX - 1) / WN_TX) * (((H + 1) / 2 + WN_TY - 1) / WN_TY) * B;
     if (blocks > 2147483000LL) return DIINN_ERR_TOO_LARGE;
-    if ((long long)H * W * 4 * 8 > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;      // a chunk of 8 planes is addressed with 32-bit byte offsets
+    if ((long long)H * W * 4 * 64 > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;     // the 64 output planes (and a chunk of 8 input planes) are addressed with 32-bit byte offsets
     if ((long long)Cin * WN_CHUNK_BYTES / 8 * 4 > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;
     ConvWinoParams p;
     p.in = in_dev; p.wu = packed_u_dev; p.bias = bias_dev; p.res = res_dev; p.out = out_dev;
     p.in_bs = in_batch_stride; p.out_bs = out_batch_stride; p.res_bs = res_batch_stride;
     p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0;
+#ifdef DIINN_STAMPS
+    p.stamps = g_stamps;
+#endif
     hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }

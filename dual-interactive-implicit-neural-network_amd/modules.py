@@ -86,12 +86,13 @@ def pack_conv_wino(weight: torch.Tensor) -> torch.Tensor:
     """3x3 conv weight [64, Cin, 3, 3] (Cin % 8 == 0) -> the Winograd F(2x2, 3x3) image ``diinn_conv_wino`` reads
     (include/diinn_hip.h): U = G W G^T per (output, input) pair, computed in float64 and rounded once, laid out
     [row i 4][chunk Cin/8][col j 4][half 2][lane 64][4] with cout = 32 half + (lane & 31) and input channel =
-    8 chunk + 2 e + (lane >> 5)."""
+    8 chunk + 2 e + (lane >> 5); column j = 2 is stored negated."""
     co, cin, kh, kw = weight.shape
     if co != 64 or cin % 8 or (kh, kw) != (3, 3):
         raise ValueError(f"unsupported convolution shape {tuple(weight.shape)}")
     g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
     u = torch.einsum("ia,ocab,jb->ocij", g, weight.detach().to(torch.float64).cpu(), g).to(torch.float32)
+    u[..., 2] = -u[..., 2]                                      # the kernel's input transform produces column 2 negated
     u = u.reshape(2, 32, cin // 8, 4, 2, 4, 4)                  # [half, m, chunk, e, h, i, j]
     return u.permute(5, 2, 6, 0, 4, 1, 3).reshape(-1)           # [i, chunk, j, half, h, m, e]
 

@@ -298,7 +298,8 @@ int    diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packe
  * diinn_conv_wino: one 3x3 zero-padded 64-output convolution over Cin % 8 == 0 input planes (addressing, epilogue
  *   and error behaviour as diinn_conv_ksplit with one destination).  packed_u_dev holds U = G W G^T (G of F(2x2,3x3))
  *   as [row i 4][chunk Cin/8][col j 4][half 2][lane 64][4]:
- *   value = U[32 half + (lane&31)][8 chunk + 2 e + (lane>>5)][i][j]            (16 * 64 * Cin floats).
+ *   value = s_j U[32 half + (lane&31)][8 chunk + 2 e + (lane>>5)][i][j], s_2 = -1, else 1   (16 * 64 * Cin floats;
+ *   bias_dev 16-byte aligned).
  * diinn_rdn_wino_packed_floats: floats of the 130 transformed 3x3 weights of the trunk, in execution order.
  * diinn_rdn_forward_wino: diinn_rdn_forward with the 3x3 layers on diinn_conv_wino where the map is big enough to
  *   fill the chip with its 16 x 8-pixel blocks (B*H*W >= 32768) and on the split-K kernel otherwise; packed_dev and

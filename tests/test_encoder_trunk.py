@@ -38,7 +38,7 @@ def test_pack_conv_wino_layout():
         u = np.einsum("ia,ocab,jb->ocij", g, w.astype(np.float64), g).astype(np.float32)
         for _ in range(300):
             i, chunk, j, half, lane, e = (int(rng.integers(n)) for n in (4, cin // 8, 4, 2, 64, 4))
-            assert pk[i, chunk, j, half, lane, e] == u[32 * half + (lane & 31), 8 * chunk + 2 * e + (lane >> 5), i, j]
+            assert pk[i, chunk, j, half, lane, e] == (-1 if j == 2 else 1) * u[32 * half + (lane & 31), 8 * chunk + 2 * e + (lane >> 5), i, j]
     with pytest.raises(ValueError):
         M.pack_conv_wino(torch.zeros(64, 64, 1, 1))
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-layer durations of the RDN trunk from a rocprofv3 --kernel-trace CSV of tools/enc_trunk_time.py --only-hip:
-the trunk is 147 conv_ksplit launches in a fixed order, so launch index mod 147 names the layer.
+the trunk is 147 conv_ksplit / conv_wino launches in a fixed order, so launch index mod 147 names the layer.
 usage: enc_trace_layers.py kernel_trace.csv [H W]"""
 import csv
 import sys
@@ -12,7 +12,7 @@ PEAK = 157.3e12
 def main():
     path = sys.argv[1]
     h, w = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (256, 256)
-    rows = [r for r in csv.DictReader(open(path)) if "conv_ksplit" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "conv_ksplit" in r["Kernel_Name"] or "conv_wino" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     n = len(rows) // 147 * 147
     rows = rows[len(rows) - n:]                                  # whole forwards only, the last ones (warm)

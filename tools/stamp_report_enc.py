@@ -9,6 +9,7 @@ import diinn_amd._native as N, diinn_amd.modules as M
 lr = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 cin = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 taps = int(sys.argv[3]) if len(sys.argv) > 3 else 9
+wino = len(sys.argv) > 4 and sys.argv[4] == "wino"
 dev = torch.device("cuda:0")
 lib = N.load()
 raw = C.CDLL(N.LIB_PATH)
@@ -16,19 +17,26 @@ hw = lr * lr
 buf = (torch.randn(1, 1024 + 64, lr, lr, device=dev) * 0.1).clamp_(min=0)
 bias = torch.zeros(64, device=dev)
 k = 3 if taps == 9 else 1
-w = M.pack_conv_ksplit(torch.randn(64, cin, k, k) * 0.01).to(dev)
+wt = torch.randn(64, cin, k, k) * 0.01
+w = (M.pack_conv_wino(wt) if wino else M.pack_conv_ksplit(wt)).to(dev)
 out = buf[:, 1024:]
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def run():
+    if wino:
+        N.check(lib.diinn_conv_wino(stream, C.c_void_p(buf.data_ptr()), (1024 + 64) * hw, cin, C.c_void_p(w.data_ptr()),
+                                    C.c_void_p(bias.data_ptr()), None, 0, C.c_void_p(out.data_ptr()), (1024 + 64) * hw,
+                                    1, 1, lr, lr), "conv")
+        return
     N.check(lib.diinn_conv_ksplit(stream, C.c_void_p(buf.data_ptr()), (1024 + 64) * hw, cin, taps, C.c_void_p(w.data_ptr()),
                                   C.c_void_p(bias.data_ptr()), None, 0, C.c_void_p(out.data_ptr()), (1024 + 64) * hw, None, 0,
                                   1, 1, lr, lr), "conv")
 
 
-nwg = (hw // 32 + 7) // 8 * 8
-stamps = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device=dev)
+nwaves = 4 if wino else 8
+nwg = ((hw // 128 if wino else hw // 32) + 7) // 8 * 8
+stamps = torch.zeros(nwg * nwaves * 8, dtype=torch.int64, device=dev)
 for _ in range(5):
     run()
 torch.cuda.synchronize()
@@ -36,12 +44,11 @@ raw.diinn_debug_set_stamp_buffer(C.c_void_p(stamps.data_ptr()))
 for _ in range(3):
     run()                                                     # the last launch's stamps stay (back-to-back launches, as in the trunk)
 torch.cuda.synchronize()
-t = stamps.cpu().numpy().reshape(nwg, 8, 8).astype(np.int64)
+t = stamps.cpu().numpy().reshape(nwg, nwaves, 8).astype(np.int64)
 t = t[t[:, 0, 0] != 0]
 t0 = t[:, :, 0].min()
-# s_memtime ticks: constant 100 MHz on gfx950
-tick_ns = 10.0
-names = ["prologue (first chunk staged)", "MFMA loop", "reduction + epilogue half 0", "half 1"]
+tick_ns = 1.0 / 2.4          # s_memtime counts shader clocks (~2.4 GHz under this load)
+names = ["prologue (first operands ready)", "MFMA loop", "exchange + barrier", "output transform + stores"] if wino else ["prologue (first chunk staged)", "MFMA loop", "reduction + epilogue half 0", "half 1"]
 wg_start = t[:, :, 0].min(axis=1)
 wg_end = t[:, :, 4].max(axis=1)
 print(f"Cin {cin} taps {taps} {lr}x{lr}: {len(t)} workgroups; kernel span {(wg_end.max() - t0) * tick_ns / 1e3:.1f} us "
@@ -52,6 +59,8 @@ d = np.diff(t[:, :, :5], axis=2) * tick_ns / 1e3              # per wave phases
 for i, n in enumerate(names):
     print(f"  {n:32s} median {np.median(d[:, :, i]):7.2f} us   p90 {np.percentile(d[:, :, i], 90):7.2f}")
 # timeline of one CU: group by (xcc, se, cu) from HW_ID (gfx9: cu_id bits 11:8, sh 12, se 15:13)
+if wino:
+    sys.exit(0)
 hwid = t[:, 0, 6]
 xcc = (hwid >> 32) & 0xF
 cu = (hwid >> 8) & 0xF
