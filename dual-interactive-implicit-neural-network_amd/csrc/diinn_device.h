@@ -20,6 +20,9 @@ using namespace diinn;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int N> struct IC { static constexpr int value = N; };   // compile-time index for generic lambdas
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -191,6 +194,15 @@ constexpr int ACT_ROWS = 2 * HID;                               // rows 0..255: 
 constexpr unsigned PLANE_ROW_BYTES = PLANE_TILE * sizeof(float);   // 128
 __device__ __forceinline__ void st_act(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, (int)soff, 0);
+}
+// 128-bit buffer store with a scalar offset register.  Measured on gfx950 (tools/: the LFF layer's second destination
+// came out wrong in 16 lanes, first dword, some launches): a VALU instruction that writes one of the store's data
+// registers in the slot right behind the store overwrites what the store's first quarter-wave still has to read.
+// hipcc inserts a wait state for this hazard only when the store has NO offset register (the documented condition),
+// so the data registers are pinned across an s_nop here.
+__device__ __forceinline__ void st_b128(f32x4 v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)voff, (int)soff, 0);
+    asm volatile("s_nop 1" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
 }
 __device__ __forceinline__ float ld_act(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));

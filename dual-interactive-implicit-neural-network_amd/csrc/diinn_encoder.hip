@@ -283,6 +283,160 @@ template <int NH>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
 void conv_ksplit_kernel_1x1(const ConvKsplitParams p) { conv_ksplit_body<1, NH>(p); }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 layers on big maps (LFF 576 -> 64, GFF.0 1024 -> 64): conv1x1_stream_kernel.  A 1x1 convolution is a plain GEMM
+// over the flattened plane, so nothing needs staging: a workgroup owns 128 consecutive pixels, lane j holds pixels
+// 4j..4j+3 (one 16-byte load per channel; pixel 4j+q belongs to MFMA N-tile q), and each of the 4 waves (one per
+// SIMD) reduces a quarter of the input channels into 4 N-tiles x 2 output halves = 8 accumulators with operands
+// streamed through a three-stage register ring: 6 vector-memory instructions and no VALU per 32 MFMAs.  The four
+// partial sums meet once in LDS; wave w then finishes channels 8w..8w+3 (+4h, +32 half) of all 128 pixels, so every
+// store is 16 bytes per lane, 512 bytes contiguous.  (conv_ksplit_kernel_1x1 ran these layers at 44 % of the MFMA
+// peak: its 32-pixel tiles stage 64 channels per wave through LDS and wait for every chunk.)
+constexpr int S1_PIX = 128;                           // pixels per workgroup
+constexpr int S1_PITCH = 20;                          // LDS floats per (wave, q, lane): 16 + 4 padding
+constexpr int S1_LDS_FLOATS = 4 * 4 * 64 * S1_PITCH;  // one output half of the four partial sums: 80 KiB
+
+__global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const ConvKsplitParams p) {
+    __shared__ __attribute__((aligned(16))) float red[S1_LDS_FLOATS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const size_t plane = (size_t)p.H * p.W;
+    const unsigned plane_b = (unsigned)(plane * sizeof(float));
+    const int blocks_per = (int)((plane + S1_PIX - 1) / S1_PIX);
+    const int per_xcd = gridDim.x >> 3;                          // every XCD a contiguous run of blocks
+    int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (t >= p.B * blocks_per) return;
+    const int b = __builtin_amdgcn_readfirstlane(t / blocks_per);
+    const int blk = t - b * blocks_per;
+    const int g8 = p.Cin / 64;                                   // pieces per part of the packed weight
+    const int n = 2 * g8;                                        // chunks of 8 channels this wave reduces (two parts)
+    const int lane_off = lane * 16;
+    // packed weight [half 2][part 8][group g8][lane 64][4]: this wave walks parts 2w and 2w + 1, which are contiguous
+    const int half_bytes = CS_WAVES * g8 * PIECE_BYTES;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.w + (size_t)(2 * wave) * g8 * WL_PIECE), 0, half_bytes + n * PIECE_BYTES, 0x00020000);
+    const float* __restrict__ in_w = p.in + (size_t)b * p.in_bs + (size_t)(wave * (p.Cin / 4)) * plane;
+    constexpr unsigned OUTSIDE = 0x80000000u;
+    const size_t pix0 = (size_t)blk * S1_PIX + 4 * j;           // this lane's first pixel
+    const bool pix_in = pix0 < plane;                            // plane % 4 == 0: a lane's 4 pixels are in or out together
+    const unsigned roff = pix_in ? (unsigned)h * plane_b + (unsigned)pix0 * 4u : OUTSIDE;
+
+    f32x4 A[3][2], R[3][4];
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][hh][r] = 0.0f;
+#define S1_SB() __builtin_amdgcn_sched_barrier(0)
+    auto chunk_rsrc = [&](int c) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(in_w + (size_t)8 * c * plane), 0, (int)(8u * plane_b), 0x00020000);
+    };
+    // request #IDX (0..5) of chunk c into stage S: 2 weight pieces, 4 pixel rows (channels 8c + 2e + h)
+    auto request = [&](auto S_, auto IDX_, int c, __amdgpu_buffer_rsrc_t irs) {
+        constexpr int S = decltype(S_)::value, IDX = decltype(IDX_)::value;
+        if constexpr (IDX < 2) A[S][IDX] = ld_piece(wrs, lane_off, IDX * half_bytes + c * PIECE_BYTES);
+        else R[S][IDX - 2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, (int)roff, (int)((unsigned)(2 * (IDX - 2)) * plane_b), 0));
+    };
+    auto chunk = [&](auto S_, int cload) {
+        constexpr int S = decltype(S_)::value;
+        constexpr int SL = (S + 2) % 3;
+        const __amdgpu_buffer_rsrc_t irs = chunk_rsrc(cload);
+        auto estep = [&](auto E_) {
+            constexpr int E = decltype(E_)::value;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[q][0] = MFMA32(A[S][0][E], R[S][E][q], acc[q][0]);
+                S1_SB();
+                acc[q][1] = MFMA32(A[S][1][E], R[S][E][q], acc[q][1]);
+                if (q == 0) {                                    // 6 requests over the chunk's 16 MFMA pairs
+                    if constexpr (E == 0) request(IC<SL>{}, IC<0>{}, cload, irs);
+                    if constexpr (E == 1) request(IC<SL>{}, IC<2>{}, cload, irs);
+                    if constexpr (E == 2) request(IC<SL>{}, IC<4>{}, cload, irs);
+                }
+                if (q == 2) {
+                    if constexpr (E == 0) request(IC<SL>{}, IC<1>{}, cload, irs);
+                    if constexpr (E == 1) request(IC<SL>{}, IC<3>{}, cload, irs);
+                    if constexpr (E == 2) request(IC<SL>{}, IC<5>{}, cload, irs);
+                }
+                S1_SB();
+            }
+        };
+        estep(IC<0>{}); estep(IC<1>{}); estep(IC<2>{}); estep(IC<3>{});
+    };
+    auto request_all = [&](auto S_, int c) {
+        const __amdgpu_buffer_rsrc_t irs = chunk_rsrc(c);
+        request(S_, IC<0>{}, c, irs); request(S_, IC<1>{}, c, irs); request(S_, IC<2>{}, c, irs);
+        request(S_, IC<3>{}, c, irs); request(S_, IC<4>{}, c, irs); request(S_, IC<5>{}, c, irs);
+    };
+    request_all(IC<0>{}, 0);
+    request_all(IC<1>{}, 1);
+    S1_SB();
+    auto ahead = [&](int cc) { return cc + 2 < n ? cc + 2 : n - 1; };
+    int c = 0;
+    for (; c + 3 <= n; c += 3) {
+        chunk(IC<0>{}, ahead(c));
+        chunk(IC<1>{}, ahead(c + 1));
+        chunk(IC<2>{}, ahead(c + 2));
+    }
+    if (c < n) chunk(IC<0>{}, n - 1);
+    if (c + 1 < n) chunk(IC<1>{}, n - 1);
+#undef S1_SB
+
+    // ---- the four partial sums meet in LDS, one output half per pass; wave w finishes accumulator registers 4w..4w+3
+    // (channels 32 half + 8 w + e + 4 h) of all four N-tiles = the lane's 4 consecutive pixels
+    const __amdgpu_buffer_rsrc_t o0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out0 + (size_t)b * p.out0_bs), 0, (int)(64u * plane_b), 0x00020000);
+    const __amdgpu_buffer_rsrc_t o1 = __builtin_amdgcn_make_buffer_rsrc((void*)((p.out1 ? p.out1 : p.out0) + (size_t)b * (p.out1 ? p.out1_bs : p.out0_bs)), 0, (int)(64u * plane_b), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)((p.res ? p.res : p.in) + (size_t)b * (p.res ? p.res_bs : p.in_bs)), 0, (int)(64u * plane_b), 0x00020000);
+    const unsigned ooff = pix_in ? (unsigned)(4 * h) * plane_b + (unsigned)pix0 * 4u : OUTSIDE;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        if (hh) __syncthreads();                                 // the previous pass has been read
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[q][hh][4 * g + e];
+                *reinterpret_cast<f32x4*>(red + (((wave * 4 + q) * 64 + lane) * S1_PITCH + 4 * g)) = v;
+            }
+        __syncthreads();
+        f32x4 y[4];                                              // [q] x components e
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 s = *reinterpret_cast<const f32x4*>(red + (((0 * 4 + q) * 64 + lane) * S1_PITCH + 4 * wave));
+#pragma unroll
+            for (int w4 = 1; w4 < 4; ++w4) s += *reinterpret_cast<const f32x4*>(red + (((w4 * 4 + q) * 64 + lane) * S1_PITCH + 4 * wave));
+            y[q] = s;
+        }
+        const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + 32 * hh + 8 * wave + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned soff = (unsigned)(32 * hh + 8 * wave + e) * plane_b;
+            f32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o[q] = y[q][e] + bias4[e];
+                if (p.relu) o[q] = relu0(o[q]);
+            }
+            if (p.res) o += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)ooff, (int)soff, 0));
+            st_b128(o, o0, ooff, soff);
+            if (p.out1) st_b128(o, o1, ooff, soff);
+        }
+    }
+}
+
+static bool conv1x1_stream_ok(const ConvKsplitParams& p) {
+    const long long plane = (long long)p.H * p.W;
+    auto a16 = [](const void* q) { return (((size_t)q) & 15) == 0; };
+    return plane % 4 == 0 && p.Cin % 64 == 0 && (long long)p.B * ((plane + S1_PIX - 1) / S1_PIX) >= 256 &&
+           plane * 4 * 64 <= 0x7FFFFFFFLL && a16(p.in) && a16(p.w) && a16(p.bias) && a16(p.out0) && a16(p.out1) && a16(p.res) &&
+           p.in_bs % 4 == 0 && p.out0_bs % 4 == 0 && p.out1_bs % 4 == 0 && p.res_bs % 4 == 0;
+}
+
 static int launch_conv_ksplit(void* stream, const ConvKsplitParams& p_in, int taps) {
     const int tiles = ((p_in.W + CS_TW - 1) / CS_TW) * ((p_in.H + CS_TH - 1) / CS_TH) * p_in.B;
     // both output halves per workgroup once the tiles alone give every CU two workgroups; otherwise one half each
@@ -292,7 +446,11 @@ static int launch_conv_ksplit(void* stream, const ConvKsplitParams& p_in, int ta
 #ifdef DIINN_STAMPS
     p.stamps = g_stamps;
 #endif
-    if (taps == 9) {
+    static const bool no_stream = getenv("DIINN_ENC_NO_STREAM1X1") != nullptr;   // A/B switch for tools/
+    if (taps == 1 && !no_stream && conv1x1_stream_ok(p)) {
+        const long long blocks = (long long)p.B * (((long long)p.H * p.W + S1_PIX - 1) / S1_PIX);
+        hipLaunchKernelGGL(conv1x1_stream_kernel, dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (taps == 9) {
         if (both) hipLaunchKernelGGL(conv_ksplit_kernel_3x3<2>, grid, dim3(512), 0, (hipStream_t)stream, p);
         else      hipLaunchKernelGGL(conv_ksplit_kernel_3x3<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
     } else {

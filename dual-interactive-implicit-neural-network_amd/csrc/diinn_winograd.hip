@@ -26,6 +26,10 @@
 constexpr int WN_TX = 8, WN_TY = 4;                  // Winograd tiles per block (x, y): 32 = one MFMA N-tile
 constexpr int WN_PIECE_BYTES = 1024;                 // one A piece: 64 lanes x 4 k-steps
 constexpr int WN_CHUNK_BYTES = 8 * WN_PIECE_BYTES;   // per wave and chunk of 8 channels: 4 positions x 2 halves
+#ifndef WN_STAGES
+#define WN_STAGES 3
+#endif
+constexpr int WN_NS = WN_STAGES;                     // register ring: chunks in flight + the one being computed
 constexpr int WN_ZS_PITCH = 20;                      // a lane's 16 values + 4 floats of padding: 16-byte LDS accesses without bank conflicts
 constexpr int WN_ZS_FLOATS = 4 * 2 * 2 * 64 * WN_ZS_PITCH;   // epilogue exchange: [row i][half][q][lane][acc reg]
 
@@ -42,16 +46,12 @@ struct ConvWinoParams {
 #endif
 };
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x4 ld_row(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
 }
 
 #define WN_SB() __builtin_amdgcn_sched_barrier(0)
-
-template <int N> struct IC { static constexpr int value = N; };
 
 template <bool EDGE>
 __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* __restrict__ zs, int b, int tx0, int ty0) {
@@ -90,8 +90,8 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
     const unsigned offb = (tile_in && yb >= 0 && yb < p.H) ? (unsigned)h * plane_b + (unsigned)(yb * p.W + xc) * 4u : OUTSIDE;
 #endif
 
-    f32x4 A[3][8];           // weight pieces of three chunks: [stage][col j * 2 + half], components = k-steps
-    f32x4 R[3][8];           // patch rows of three chunks: [stage][2 e + {row a, row b}], components = patch columns
+    f32x4 A[WN_NS][8];       // weight pieces of the ring's chunks: [stage][col j * 2 + half], components = k-steps
+    f32x4 R[WN_NS][8];       // patch rows of the ring's chunks: [stage][2 e + {row a, row b}], components = patch columns
     f32x16 acc[4][2];        // [col j][half]
     f32x2 V01, V23;          // the B operands of the upcoming k-step: the transformed patch row, columns 0 1 | -2 3
 #pragma unroll
@@ -149,7 +149,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
     // sixteen requests of chunk cload go out into stage S+2.
     auto kstep = [&](auto S_, auto E_, int cload, __amdgpu_buffer_rsrc_t irs) {
         constexpr int S = decltype(S_)::value, E = decltype(E_)::value;
-        constexpr int SL = (S + 2) % 3, SN = (S + 1) % 3;
+        constexpr int SL = (S + WN_NS - 1) % WN_NS, SN = (S + 1) % WN_NS;
         const f32x2 c01 = V01, c23 = V23;
         const f32x4& ra4 = E < 3 ? R[S][2 * ((E + 1) & 3)] : R[SN][0];
         const f32x4& rb4 = E < 3 ? R[S][2 * ((E + 1) & 3) + 1] : R[SN][1];
@@ -200,20 +200,26 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
     STAMP(0);
     request_all(IC<0>{}, 0);
     request_all(IC<1>{}, n > 1 ? 1 : 0);
+    if constexpr (WN_NS > 3) request_all(IC<2>{}, n > 2 ? 2 : n - 1);
     WN_SB();
     transform(R[0][0], R[0][1], V01, V23);
     WN_SB();
     STAMP(1);
-    // chunk c sits in stage c % 3; while it is computed chunk c + 2 is requested (past the end: the last chunk again,
-    // never used)
+    // chunk c sits in stage c % NS; while it is computed chunk c + NS - 1 is requested (past the end: the last chunk
+    // again, never used)
+    auto ahead = [&](int cc) { return cc + WN_NS - 1 < n ? cc + WN_NS - 1 : n - 1; };
     int c = 0;
-    for (; c + 3 <= n; c += 3) {
-        chunk(IC<0>{}, c + 2 < n ? c + 2 : n - 1);
-        chunk(IC<1>{}, c + 3 < n ? c + 3 : n - 1);
-        chunk(IC<2>{}, c + 4 < n ? c + 4 : n - 1);
+    for (; c + WN_NS <= n; c += WN_NS) {
+        chunk(IC<0>{}, ahead(c));
+        chunk(IC<1>{}, ahead(c + 1));
+        chunk(IC<2>{}, ahead(c + 2));
+        if constexpr (WN_NS > 3) chunk(IC<3>{}, ahead(c + 3));
     }
     if (c < n) chunk(IC<0>{}, n - 1);
     if (c + 1 < n) chunk(IC<1>{}, n - 1);
+    if constexpr (WN_NS > 3) {
+        if (c + 2 < n) chunk(IC<2>{}, n - 1);
+    }
 
     STAMP(2);
     // ---- A^T (.) A: the column half in registers, the row half through LDS (the only barrier of the kernel).

@@ -96,7 +96,10 @@ def test_conv_ksplit_kernel_matches_torch():
                                                   (1, 576, 1, 48, 48, 0, 1, 1), (1, 1024, 1, 9, 7, 0, 0, 0),
                                                   (1, 512, 3, 5, 3, 0, 1, 0),
                                                   # >= 512 tiles: the both-output-halves variant of the kernel
-                                                  (1, 192, 3, 128, 136, 1, 0, 1), (2, 576, 1, 70, 61, 0, 1, 0)]:
+                                                  (1, 192, 3, 128, 136, 1, 0, 1), (2, 576, 1, 70, 61, 0, 1, 0),
+                                                  # >= 256 blocks of 128 pixels: conv1x1_stream_kernel (ragged last block)
+                                                  (1, 576, 1, 256, 128, 0, 1, 1), (2, 1024, 1, 129, 132, 1, 0, 0),
+                                                  (1, 64, 1, 200, 164, 0, 0, 1)]:
         total = max(cin, 64) + 64
         buf = torch.randn((b, total, h, w), device=dev, generator=gen)          # input = first cin planes of a larger buffer
         wt = torch.randn((64, cin, k, k), device=dev, generator=gen) / (cin * k * k) ** 0.5
@@ -119,6 +122,12 @@ def test_conv_ksplit_kernel_matches_torch():
         assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (cin, k, h, w, err)
         if two:
             assert torch.equal(out1[:, 32:96], out0) and torch.isnan(out1[:, :32]).all()
+            for _ in range(40):                                  # the two destinations agree on every launch (st_b128 hazard)
+                out1[:, 32:].fill_(float("nan"))
+                lib.diinn_conv_ksplit(stream, ptr(buf), total * h * w, cin, k * k, ptr(packed), ptr(bias),
+                                      ptr(res) if use_res else None, 64 * h * w, ptr(out0), 64 * h * w,
+                                      ptr(out1[:, 32:]), 96 * h * w, relu, b, h, w)
+                assert torch.equal(out1[:, 32:96], out0)
     assert lib.diinn_conv_ksplit(stream, ptr(buf), 1, 96, 9, ptr(packed), ptr(bias), None, 0, ptr(out0), 1, None, 0, 0, 1, 4, 4) == N.ERR_UNSUPPORTED
 
 

@@ -12,7 +12,7 @@ PEAK = 157.3e12
 def main():
     path = sys.argv[1]
     h, w = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (256, 256)
-    rows = [r for r in csv.DictReader(open(path)) if "conv_ksplit" in r["Kernel_Name"] or "conv_wino" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if any(k in r["Kernel_Name"] for k in ("conv_ksplit", "conv_wino", "conv1x1_stream"))]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     n = len(rows) // 147 * 147
     rows = rows[len(rows) - n:]                                  # whole forwards only, the last ones (warm)
