@@ -311,6 +311,9 @@ def main():
     achieved = FLOP_DECODE_PER_PX * px_launch / (k_ms * 1e-3) / 1e12
     p_mean = sum(p_ms) / max(len(p_ms), 1)
     p_tflops = FLOP_P_PER_CELL * (bd.r1 - bd.r0) * W / (p_mean * 1e-3) / 1e12
+    # the library runs the fp32 hoisted conv in Winograd F(2x2,3x3) form on maps of >= 32,768 cells (csrc/diinn_precompute.hip:
+    # launch_P): 2.25x fewer MFMAs than the direct-convolution FLOPs counted in `tflops`
+    p_wino = args.compute != "bf16_full" and H * W >= 32768      # batch 1
 
     # ---- the output that was timed, against the oracle (outside the timed region)
     checked = None
@@ -408,7 +411,11 @@ def main():
                 "traffic": load_traffic() if (not bf and args.workload == "c2" and world == 1) else None,
                 "p_kernel": {"ms": round(p_mean, 4), "ms_min": round(min(p_ms), 4), "tflops": round(p_tflops, 2),
                              "frac": round(p_tflops / (PEAK_BF16_MFMA_TFLOPS if args.compute == "bf16_full"
-                                                       else PEAK_F32_MFMA_TFLOPS), 4)},
+                                                       else PEAK_F32_MFMA_TFLOPS), 4),
+                             "algorithm": "winograd F(2x2,3x3)" if p_wino else "direct",
+                             "mfma_frac": round(p_tflops / (2.25 if p_wino else 1.0) /
+                                                (PEAK_BF16_MFMA_TFLOPS if args.compute == "bf16_full" else PEAK_F32_MFMA_TFLOPS), 4),
+                             "note": "tflops / frac count direct-convolution FLOPs; mfma_frac = MFMA work actually issued / peak"},
             },
         }
         if bf:

@@ -660,7 +660,7 @@ static int decode_impl(void* stream, const float* feat_dev, const float* packed_
         compute != DIINN_COMPUTE_BF16_FULL)
         return DIINN_ERR_UNSUPPORTED;
     st = launch_P(stream, feat_dev, packed_dev, workspace_dev, B, H, W, r0, r1, 16, compute == DIINN_COMPUTE_BF16_FULL,
-                  &fw, &pw);
+                  &fw, &pw, true);
     if (st) return st;
     if (compute == DIINN_COMPUTE_F32_QONLY) {                   // modes 1 and 2: per-cell modulation chain
         st = cell_chain_impl(stream, workspace_dev, packed_dev, B, H, W, r0, r1, pw);

@@ -85,11 +85,11 @@ size_t diinn_metasr_workspace_bytes(int B, int H, int W) {
 }
 
 int diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats) {
-    static const size_t off[13] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT, OFF_WPB, OFF_BQR,
-                                   OFF_Q0R, OFF_WLR};
-    static const size_t sz[13]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT, SZ_WPB, 3 * HID,
-                                   4 * HID, SZ_WL};
-    if (section < 0 || section > 12 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
+    static const size_t off[14] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT, OFF_WPB, OFF_BQR,
+                                   OFF_Q0R, OFF_WLR, OFF_WPU};
+    static const size_t sz[14]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT, SZ_WPB, 3 * HID,
+                                   4 * HID, SZ_WL, SZ_WPU};
+    if (section < 0 || section > 13 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
     *offset_floats = off[section];
     *size_floats = sz[section];
     return DIINN_OK;
@@ -174,6 +174,33 @@ int diinn_pack_weights(const float* K0w, const float* K0b,
                     dst[lane * 4 + e] = w[(size_t)ch * ld + col0 + (size_t)c * 9 + t];
                 }
             }
+        }
+    }
+    // WPU: U = G Wx G^T per (output, input) pair in float64, rounded once; column 2 negated (diinn_layout.h)
+    {
+        static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+        for (int mt = 0; mt < 32; ++mt) {
+            const int il = mt >> 3;
+            const float* w = (il == 0) ? K0w : Kw[il - 1];
+            const size_t ld = (il == 0) ? (size_t)UNF : (size_t)(HID + UNF);
+            const size_t col0 = (il == 0) ? 0 : (size_t)HID;
+            for (int sg = 0; sg < 8; ++sg)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int ch = 32 * (mt & 7) + (lane & 31);
+                        const int c = 8 * sg + 2 * e + (lane >> 5);
+                        const float* g = w + (size_t)ch * ld + col0 + (size_t)c * 9;       // g[ky*3 + kx]
+                        double t[4][3];                                                     // G g
+                        for (int i = 0; i < 4; ++i)
+                            for (int b = 0; b < 3; ++b)
+                                t[i][b] = G[i][0] * g[b] + G[i][1] * g[3 + b] + G[i][2] * g[6 + b];
+                        for (int i = 0; i < 4; ++i)
+                            for (int j = 0; j < 4; ++j) {
+                                const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+                                float* dst = packed + OFF_WPU + ((((size_t)mt * 4 + i) * 8 + sg) * 4 + j) * WL_PIECE;
+                                dst[lane * 4 + e] = (float)(j == 2 ? -u : u);
+                            }
+                    }
         }
     }
     // small tables

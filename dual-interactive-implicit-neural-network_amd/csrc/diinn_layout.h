@@ -79,7 +79,14 @@ constexpr size_t OFF_Q0R    = OFF_BQR + 3 * HID;
 //     permutation of the reference tensors: the training forward saves sine arguments in radians, LIIF reads the
 //     synthesis slots as plain MLP weights, and the device re-pack of a training step is a gather.
 constexpr size_t OFF_WLR    = OFF_Q0R + 4 * HID;
-constexpr size_t PACKED_FLOATS = OFF_WLR + SZ_WL;          // 2,266,372
+// WPU: the hoisted 3x3 conv in Winograd F(2x2, 3x3) form, U = G Wx G^T (4 x 4 per output / input channel pair; G folds
+//     the halves), for precompute_P_wino_kernel.  [mt 32][row i 4][sg 8][col j 4][lane 64][e 4]; M-tile mt = outputs
+//     32 mt .. 32 mt + 31, k-step 4 sg + e = input channels 8 sg + 2 e + (lane>>5);
+//     value = s_j U[ o = 32 mt + (lane&31) ][ c ][ i ][ j ],  s_2 = -1 (the kernel's input transform yields column 2
+//     negated), else 1.  Derived (float64, rounded once): an inference-only section like WLR.
+constexpr size_t OFF_WPU    = OFF_WLR + SZ_WL;
+constexpr size_t SZ_WPU     = (size_t)32 * 4 * 8 * 4 * WL_PIECE;   // 1,048,576 floats = 4 MiB
+constexpr size_t PACKED_FLOATS = OFF_WPU + SZ_WPU;         // 3,314,948
 
 // channel held by activation register (m, r) of lane-half h
 DIINN_HD int chan_of(int kk /* = 16*m + r */, int h) {

@@ -446,7 +446,8 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_wide_kernel(const PP
 }
 
 int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,
-             int B, int H, int W, int r0, int r1, int mp_total, bool bf16, const RowWin* feat_win, const RowWin* p_win) {
+             int B, int H, int W, int r0, int r1, int mp_total, bool bf16, const RowWin* feat_win, const RowWin* p_win,
+             bool derived_ok) {
     if (!feat_dev || !packed_dev || !P_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
     if (st) return st;
@@ -458,6 +459,15 @@ int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float
     if (st) return st;
     st = check_window(pw.row0, pw.rows, H, r0, r1);
     if (st) return st;
+    // fp32, all 1024 channels, a map big enough to fill the chip with 16 x 8-cell blocks: the Winograd form
+    // (diinn_precompute_wino.hip; 2.25x fewer MFMAs).  The choice depends on the MAP, never on the band, so that a
+    // band stays bit-identical to the same rows of a full launch.  derived_ok: the caller's packed image holds the
+    // derived sections (the gather-packed image of a training step does not).  DIINN_P_KERNEL = 1 direct, 2 Winograd.
+    {
+        static const int forcep = [] { const char* e = getenv("DIINN_P_KERNEL"); return e ? atoi(e) : 0; }();
+        const bool wino = derived_ok && !bf16 && mp_total == 16 && forcep != 1 && (forcep == 2 || (long long)B * H * W >= 32768);
+        if (wino) return launch_P_wino(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, fw, pw);
+    }
     // Small maps: split the 1024 output channels over up to 16 workgroups per cell block so the
     // launch still fills the chip (2 workgroups/CU resident -> aim for >= 2 rounds of 512).
     const long long blocks = (long long)((W + PT_COLS - 1) / PT_COLS) * ((r1 - r0 + PT_ROWS - 1) / PT_ROWS) * B;
@@ -495,7 +505,7 @@ int diinn_precompute_P_ex(void* stream, const float* feat_dev, const float* pack
     if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY &&
         compute != DIINN_COMPUTE_BF16_FULL)
         return DIINN_ERR_UNSUPPORTED;
-    return launch_P(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, 16, compute == DIINN_COMPUTE_BF16_FULL);
+    return launch_P(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, 16, compute == DIINN_COMPUTE_BF16_FULL, nullptr, nullptr, true);
 }
 
 int diinn_precompute_P_win(void* stream, const float* feat_win_dev, int feat_row0, int feat_rows,
@@ -506,7 +516,7 @@ int diinn_precompute_P_win(void* stream, const float* feat_win_dev, int feat_row
         return DIINN_ERR_UNSUPPORTED;
     const RowWin fw{feat_row0, feat_rows}, pw{p_row0, p_rows};
     return launch_P(stream, feat_win_dev, packed_dev, P_win_dev, B, H, W, r0, r1, 16, compute == DIINN_COMPUTE_BF16_FULL,
-                    &fw, &pw);
+                    &fw, &pw, true);
 }
 
 }  // extern "C"

@@ -90,9 +90,11 @@ size_t diinn_packed_weight_floats(void);
  * read by the backward pass), 9 WPB (bf16 copy of WP), 10 BQR (bQ1..3 / (2 pi): the bf16 kernels evaluate the
  * sine on revolutions, and the synthesis rows inside section 7 are pre-multiplied by 1/(2 pi) to match), 11 Q0R
  * (section 3 / (2 pi)), 12 WLR (section 0 with its synthesis pieces / (2 pi): the fp32 inference kernels evaluate the
- * sine on revolutions as well).  Every section but 7 and 9..12 is a pure permutation (plus zero padding) of the
- * reference tensors, so a training loop can re-pack on the device with one gather; sections 7 and 9..12 hold derived
- * values, read by the inference kernels only (the training forward and LIIF read sections 0 and 4). */
+ * sine on revolutions as well), 13 WPU (section 1 in Winograd F(2x2,3x3) form, U = G Wx G^T: what the fp32 inference
+ * entry points -- everything but diinn_precompute_P -- read on maps of >= 32,768 cells).  Every section but 7 and
+ * 9..13 is a pure permutation (plus zero padding) of the reference tensors, so a training loop can re-pack on the
+ * device with one gather; sections 7 and 9..13 hold derived values, read by the inference kernels only (the
+ * training forward and LIIF read sections 0, 1 and 4; diinn_precompute_P reads section 1 whatever the map size). */
 int    diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats);
 int    diinn_pack_weights(const float* K0w, const float* K0b,
                           const float* const Kw[3], const float* const Kb[3],

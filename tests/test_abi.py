@@ -86,7 +86,7 @@ def test_packed_image_layout(lib):
     import diinn_amd.decoder as D
     sd = synth.decoder_state_dict(11)
     packed = D.pack_state_dict(sd).numpy()
-    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608 + 393_216 + 294_912 + 768 + 1024 + 393_216
+    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608 + 393_216 + 294_912 + 768 + 1024 + 393_216 + 1_048_576
     lane = np.arange(64)
     out_l, h_l = lane & 31, lane >> 5
     # WL section
@@ -162,9 +162,21 @@ def test_packed_image_layout(lib):
         assert np.array_equal(Q0R[jj], (q0[:, jj] * inv2pi).astype(np.float32))
     assert np.array_equal(Q0R[3], (sd["Q.0.0.bias"] * inv2pi).astype(np.float32))
     # WLR: WL with the synthesis pieces (part 1) in revolutions
-    WLR = tail[1792:].reshape(3, 8, 32, 2, 64, 4)
+    WLR = tail[1792:1792 + 393_216].reshape(3, 8, 32, 2, 64, 4)
     assert np.array_equal(WLR[:, :, :, 0], WL[:, :, :, 0])
     assert np.array_equal(WLR[:, :, :, 1], (WL[:, :, :, 1] * inv2pi).astype(np.float32))
+    # WPU: the 3x3 conv in Winograd F(2x2,3x3) form, U = G Wx G^T (float64, rounded once), column 2 negated:
+    # [mt][row i][sg][col j][lane][e], output 32 mt + (lane & 31), input channel 8 sg + 2 e + (lane >> 5)
+    WPU = tail[1792 + 393_216:].reshape(32, 4, 8, 4, 64, 4)
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
+    for _ in range(300):
+        mt, i, sg, jj, l, e = (int(rng.integers(n)) for n in (32, 4, 8, 4, 64, 4))
+        layer, ch = mt >> 3, 32 * (mt & 7) + (l & 31)
+        c = 8 * sg + 2 * e + (l >> 5)
+        col0 = 0 if layer == 0 else 256
+        g = sd[f"K.{layer}.0.weight"][ch, col0 + 9 * c: col0 + 9 * c + 9, 0, 0].astype(np.float64).reshape(3, 3)
+        u = (G @ g @ G.T)[i, jj]
+        assert WPU[mt, i, sg, jj, l, e] == np.float32(-u if jj == 2 else u)
     # every channel appears exactly once per lane-half in the activation register order
     seen = sorted(_chan_of(kk, h) for kk in range(128) for h in range(2))
     assert seen == list(range(256))

@@ -278,6 +278,44 @@ def test_bf16_full_path(golden, dev):
         assert err2 <= rel * scale + 1e-6, f"{name}: bf16_full kernel vs emulation {err2:.3e}"
         print(f"bf16_full {name}: vs fp32 reference {err/scale:.1e} rel  vs emulation {err2/scale:.1e} rel")
 
+def test_p_winograd_form(dev):
+    """The hoisted 3x3 conv in Winograd F(2x2,3x3) form (precompute_P_wino_kernel: what the fp32 inference entry points
+    run on maps of >= 32,768 cells) against (1) a float64 convolution and (2) the direct kernel (diinn_precompute_P),
+    on odd maps, border / interior blocks and batch > 1; row bands through windows (odd first / last rows, so the
+    first and last Winograd tile rows stick out of the band) are bit-identical to the same rows of the full launch."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.decoder as D
+    import diinn_oracle as orc
+    import torch.nn.functional as F
+    lib = N.load()
+    sd = synth.decoder_state_dict(123)
+    packed = D.pack_state_dict(sd).to(dev)
+    sw = orc.split_weights(sd)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
+    for (b, h, w) in [(1, 192, 176), (2, 129, 131), (1, 181, 183), (1, 256, 130)]:
+        assert b * h * w >= 32768
+        feat = torch.from_numpy(synth.encoder_features(5, b, h, w)).to(dev)
+        pw = torch.full((b, h, w, 1024), float("nan"), device=dev)
+        pd = torch.full((b, h, w, 1024), float("nan"), device=dev)
+        N.check(lib.diinn_precompute_P_ex(stream, ptr(feat), ptr(packed), ptr(pw), b, h, w, 0, h, N.COMPUTE_F32), "P wino")
+        N.check(lib.diinn_precompute_P(stream, ptr(feat), ptr(packed), ptr(pd), b, h, w, 0, h), "P direct")
+        ref = F.conv2d(feat.double(), sw["Wx"].view(1024, 64, 3, 3).double().to(dev), sw["bK"].reshape(-1).double().to(dev), padding=1).permute(0, 2, 3, 1)
+        scale = max(1.0, float(ref.abs().max()))
+        ew, ed = float((pw.double() - ref).abs().max()), float((pd.double() - ref).abs().max())
+        assert torch.isfinite(pw).all() and ew <= 1e-5 * scale and ed <= 1e-5 * scale, (b, h, w, ew, ed)
+        print(f"P {b}x{h}x{w}: Winograd vs float64 {ew:.2e}, direct vs float64 {ed:.2e} (max|P| {scale:.2f})")
+        # bands through row windows
+        for (r0, r1) in [(0, 7), (3, 10), (5, h), (h - 9, h - 2), (64, 65)]:
+            f0, f1 = max(r0 - 1, 0), min(r1 + 1, h)
+            fwin = feat[:, :, f0:f1].contiguous()
+            pwin = torch.full((b, r1 - r0, w, 1024), float("nan"), device=dev)
+            N.check(lib.diinn_precompute_P_win(stream, ptr(fwin), f0, f1 - f0, ptr(packed), ptr(pwin), r0, r1 - r0,
+                                               b, h, w, r0, r1, N.COMPUTE_F32), "P win")
+            assert torch.equal(pwin, pw[:, r0:r1]), (b, h, w, r0, r1)
+
+
 def test_random_shapes_vs_oracle(dev):
     """Fuzz: random LR/HR shapes, batch sizes and scales (up- and down-scaling, tile edges that do
     not divide the 16x8 workgroup block or the 4x32 cell block) against the oracle."""
