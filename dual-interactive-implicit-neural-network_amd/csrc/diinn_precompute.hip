@@ -459,13 +459,14 @@ int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float
     if (st) return st;
     st = check_window(pw.row0, pw.rows, H, r0, r1);
     if (st) return st;
-    // fp32, all 1024 channels, a map big enough to fill the chip with 16 x 8-cell blocks: the Winograd form
-    // (diinn_precompute_wino.hip; 2.25x fewer MFMAs).  The choice depends on the MAP, never on the band, so that a
-    // band stays bit-identical to the same rows of a full launch.  derived_ok: the caller's packed image holds the
+    // fp32, all 1024 channels: the Winograd form (diinn_precompute_wino.hip; 2.25x fewer MFMAs, faster from 16x16 cells
+    // up: tools/p_time.py).  The choice never depends on the band, so a band stays bit-identical to the same rows of a
+    // full launch.  derived_ok: the caller's packed image holds the
     // derived sections (the gather-packed image of a training step does not).  DIINN_P_KERNEL = 1 direct, 2 Winograd.
     {
         static const int forcep = [] { const char* e = getenv("DIINN_P_KERNEL"); return e ? atoi(e) : 0; }();
-        const bool wino = derived_ok && !bf16 && mp_total == 16 && forcep != 1 && (forcep == 2 || (long long)B * H * W >= 32768);
+        static const long long wino_min = [] { const char* e = getenv("DIINN_P_WINO_MIN"); return e ? atoll(e) : 0LL; }();
+        const bool wino = derived_ok && !bf16 && mp_total == 16 && forcep != 1 && (forcep == 2 || (long long)B * H * W >= wino_min);
         if (wino) return launch_P_wino(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, fw, pw);
     }
     // Small maps: split the 1024 output channels over up to 16 workgroups per cell block so the

@@ -30,6 +30,7 @@ struct PWinoParams {
     int Frow0, Frows, Prow0, Prows;
     int ty_first;        // first Winograd tile row of the band: r0 >> 1
     int bx_n, by_n;      // blocks of 8 x 4 tiles
+    int msplit;          // the 32 M-tiles are divided over `msplit` workgroups per block (small maps: fills the chip)
     int stream_stores;
 };
 
@@ -42,7 +43,7 @@ constexpr int PWN_MT_BYTES = 4 * 8 * 4 * PIECE_BYTES;            // bytes of WPU
 #define PWN_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <bool EDGE>
-__device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, float* __restrict__ zs, int b, int tx0, int ty0) {
+__device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, float* __restrict__ zs, int b, int tx0, int ty0, int mt0, int mtn) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = row i of the transformed tile
     const int h = lane >> 5, m = lane & 31;
@@ -127,10 +128,10 @@ __device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, flo
         constexpr int SLOT = decltype(SLOT_)::value, J = decltype(J_)::value;
         A[SLOT][J] = ld_piece(wrs, lane_off, mt * PWN_MT_BYTES + (sg * 4 + J) * PIECE_BYTES);
     };
-    static_assert(PWN_RING == 4, "the prologue requests k-groups 0..2 of M-tile 0");
-    request(IC<0>{}, IC<0>{}, 0, 0); request(IC<0>{}, IC<1>{}, 0, 0); request(IC<0>{}, IC<2>{}, 0, 0); request(IC<0>{}, IC<3>{}, 0, 0);
-    request(IC<1>{}, IC<0>{}, 0, 1); request(IC<1>{}, IC<1>{}, 0, 1); request(IC<1>{}, IC<2>{}, 0, 1); request(IC<1>{}, IC<3>{}, 0, 1);
-    request(IC<2>{}, IC<0>{}, 0, 2); request(IC<2>{}, IC<1>{}, 0, 2); request(IC<2>{}, IC<2>{}, 0, 2); request(IC<2>{}, IC<3>{}, 0, 2);
+    static_assert(PWN_RING == 4, "the prologue requests k-groups 0..2 of the first M-tile");
+    request(IC<0>{}, IC<0>{}, mt0, 0); request(IC<0>{}, IC<1>{}, mt0, 0); request(IC<0>{}, IC<2>{}, mt0, 0); request(IC<0>{}, IC<3>{}, mt0, 0);
+    request(IC<1>{}, IC<0>{}, mt0, 1); request(IC<1>{}, IC<1>{}, mt0, 1); request(IC<1>{}, IC<2>{}, mt0, 1); request(IC<1>{}, IC<3>{}, mt0, 1);
+    request(IC<2>{}, IC<0>{}, mt0, 2); request(IC<2>{}, IC<1>{}, mt0, 2); request(IC<2>{}, IC<2>{}, mt0, 2); request(IC<2>{}, IC<3>{}, mt0, 2);
     PWN_SB();
 
     f32x4 zc[2][4];                                              // column-transformed previous M-tile: [q][group g of 4 registers]
@@ -221,18 +222,20 @@ __device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, flo
         kgroup(IC<6>{});
         kgroup(IC<7>{});
     };
+    // this workgroup's M-tiles [mt0, mt0 + mtn): mt0 and mtn are even, so an M-tile's parity is its accumulator set
 #pragma unroll 1
-    for (int mt = 0; mt < 32; mt += 2) {
-        mtile(IC<0>{}, mt, mt > 0);
+    for (int mt = mt0; mt < mt0 + mtn; mt += 2) {
+        mtile(IC<0>{}, mt, mt > mt0);
         mtile(IC<1>{}, mt + 1, true);
     }
+    const int mtl = mt0 + mtn - 1;
     // the last M-tile (parity 1)
     col_transform(IC<1>{}, IC<0>{}); col_transform(IC<1>{}, IC<1>{}); col_transform(IC<1>{}, IC<2>{}); col_transform(IC<1>{}, IC<3>{});
-    exchange_write(31 & 1);
-    bias4 = *reinterpret_cast<const f32x4*>(bk + 32 * 31);
+    exchange_write(mtl & 1);
+    bias4 = *reinterpret_cast<const f32x4*>(bk + 32 * mtl);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) store_group(k, 31 & 1, 31);
+    for (int k = 0; k < 4; ++k) store_group(k, mtl & 1, mtl);
 }
 
 __global__ __launch_bounds__(256, 1) void precompute_P_wino_kernel(const PWinoParams p) {
@@ -240,14 +243,17 @@ __global__ __launch_bounds__(256, 1) void precompute_P_wino_kernel(const PWinoPa
     const int per_xcd = gridDim.x >> 3;                          // every XCD a contiguous run of blocks
     int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     const int per_b = p.bx_n * p.by_n;
-    if (t >= p.B * per_b) return;
+    if (t >= p.B * per_b * p.msplit) return;
+    const int part = __builtin_amdgcn_readfirstlane(t % p.msplit);   // the parts of a block are neighbours: they share its patch rows
+    t /= p.msplit;
+    const int mtn = 32 / p.msplit, mt0 = part * mtn;
     const int b = __builtin_amdgcn_readfirstlane(t / per_b);
     t -= b * per_b;
     const int by = __builtin_amdgcn_readfirstlane(t / p.bx_n), bx = t - by * p.bx_n;
     const int tx0 = bx * PWN_TX, ty0 = p.ty_first + by * PWN_TY;
     const bool edge = tx0 == 0 || 2 * (tx0 + PWN_TX - 1) + 2 >= p.W;
-    if (edge) precompute_P_wino_body<true>(p, zs, b, tx0, ty0);
-    else      precompute_P_wino_body<false>(p, zs, b, tx0, ty0);
+    if (edge) precompute_P_wino_body<true>(p, zs, b, tx0, ty0, mt0, mtn);
+    else      precompute_P_wino_body<false>(p, zs, b, tx0, ty0, mt0, mtn);
 }
 
 // Winograd form of launch_P for the fp32 hoisted convolution of all 1024 channels (diinn_precompute.hip decides when)
@@ -261,7 +267,21 @@ int launch_P_wino(void* stream, const float* feat_dev, const float* packed_dev, 
     const int ty_n = ((r1 - 1) >> 1) - p.ty_first + 1, tx_n = (W + 1) / 2;
     p.bx_n = (tx_n + PWN_TX - 1) / PWN_TX;
     p.by_n = (ty_n + PWN_TY - 1) / PWN_TY;
-    const long long blocks = (long long)p.bx_n * p.by_n * B;
+    long long blocks = (long long)p.bx_n * p.by_n * B;
+    // The 32 M-tiles of a block may be divided over up to 16 workgroups (one per CU at a time): pick the split with the
+    // fewest rounds x (prologue + M-tiles per workgroup).  It fills the chip on small maps and evens out the last round
+    // on odd ones; results do not depend on it.
+    {
+        const double prologue_us = 4.0, mtile_us = 3.4;          // measured: V + pipeline fill; 128 MFMAs
+        double best = 1e30;
+        p.msplit = 1;
+        for (int ms = 1; ms <= 16; ms *= 2) {
+            const double rounds = (double)((blocks * ms + 255) / 256);
+            const double cost = rounds * (prologue_us + (32 / ms) * mtile_us);
+            if (cost < best * 0.97) { best = cost; p.msplit = ms; }   // prefer the coarser split unless clearly worse
+        }
+    }
+    blocks *= p.msplit;
     if (blocks > 2147483000LL) return DIINN_ERR_TOO_LARGE;
     if ((long long)C_IN * fw.rows * W * 4 > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;   // the feature window is addressed with 32-bit byte offsets
     p.stream_stores = (double)B * (r1 - r0) * W * PCH * 4.0 >= 128.0 * 1024 * 1024;

@@ -139,9 +139,10 @@ def test_hip_training_forward_saves_the_oracle_planes(gold):
         n = b * hu * wu
         out, acts = _train_forward(lib, N, packed, f, b, h, w, hu, wu, dev)
         infer = D.decode_features(f, packed, (hu, wu))
-        # the inference kernel keeps the synthesis branch in revolutions (weights / (2 pi), sine = v_sin(x - rint(x))),
-        # the training forward in radians (it saves the sine arguments): same mathematics, fp32 rounding apart
-        assert float((out - infer).abs().max()) <= 2e-6 * max(1.0, float(ref_out.abs().max()))
+        # the inference kernel keeps the synthesis branch in revolutions (weights / (2 pi), sine = v_sin(x - rint(x))) and
+        # takes P from the Winograd form of the hoisted conv; the training forward works in radians (it saves the sine
+        # arguments) on the direct conv: same mathematics, fp32 rounding apart (the x3 stress weights amplify it)
+        assert float((out - infer).abs().max()) <= 2e-5 * gain * max(1.0, float(ref_out.abs().max()))
         tol = 1e-4 * max(1.0, float(ref_out.abs().max()))
         assert float((out.cpu() - ref_out).abs().max()) <= tol
         flat = acts.permute(0, 2, 1, 3).reshape(4, 512, -1)
