@@ -210,7 +210,7 @@ class _GraphReplay:
         return (tuple(x.shape), x.dtype, x.device, int(size[0]), int(size[1]),
                 tuple((p.data_ptr(), p._version) for p in self.parameters()),
                 getattr(dec, "sin_mode", None), getattr(dec, "compute", None), getattr(dec, "mode", None),
-                getattr(enc, "hip_trunk_max_pixels", None))
+                getattr(enc, "hip_trunk_max_pixels", None), getattr(enc, "hip_winograd", None))
 
     def _forward_graphed(self, x, size, bsize):
         key = self._graph_key(x, size)
