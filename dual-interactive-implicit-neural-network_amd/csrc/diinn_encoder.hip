@@ -432,7 +432,8 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const ConvKsplit
 static bool conv1x1_stream_ok(const ConvKsplitParams& p) {
     const long long plane = (long long)p.H * p.W;
     auto a16 = [](const void* q) { return (((size_t)q) & 15) == 0; };
-    return plane % 4 == 0 && p.Cin % 64 == 0 && (long long)p.B * ((plane + S1_PIX - 1) / S1_PIX) >= 256 &&
+    static const long long min_blocks = [] { const char* e = getenv("DIINN_ENC_S1_MIN_BLOCKS"); return e ? atoll(e) : 128LL; }();
+    return plane % 4 == 0 && p.Cin % 64 == 0 && (long long)p.B * ((plane + S1_PIX - 1) / S1_PIX) >= min_blocks &&
            plane * 4 * 64 <= 0x7FFFFFFFLL && a16(p.in) && a16(p.w) && a16(p.bias) && a16(p.out0) && a16(p.out1) && a16(p.res) &&
            p.in_bs % 4 == 0 && p.out0_bs % 4 == 0 && p.out1_bs % 4 == 0 && p.res_bs % 4 == 0;
 }
@@ -507,8 +508,10 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     int st = check_dims(B, H, W);
     if (st) return st;
     const long long hw = (long long)H * W;
-    // Winograd blocks are 16 x 8 pixels, one workgroup per CU: worth it once they fill the chip
-    const bool wino = packed_wino_dev && (long long)B * hw >= 32768;
+    // Winograd blocks are 16 x 8 pixels and a workgroup walks all input channels: faster than the split-K kernel from
+    // about 90 x 90 pixels up (tools/r02_ab_env.sh: 96x96 3.6 vs 4.5 ms, 64x64 3.4 vs 2.1 ms per trunk)
+    static const long long wino_min = [] { const char* e = getenv("DIINN_ENC_WINO_MIN"); return e ? atoll(e) : 8192LL; }();
+    const bool wino = packed_wino_dev && (long long)B * hw >= wino_min;
     float* buf[2] = {workspace_dev, workspace_dev + (size_t)B * 576 * hw};     // dense buffers [B,576,H,W]
     float* gff_in = workspace_dev + (size_t)2 * B * 576 * hw;                    // [B,1024,H,W]
     float* tmp = gff_in + (size_t)B * 1024 * hw;                                 // [B,64,H,W]

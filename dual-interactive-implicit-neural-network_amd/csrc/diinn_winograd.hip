@@ -53,8 +53,15 @@ __device__ __forceinline__ f32x4 ld_row(__amdgpu_buffer_rsrc_t rsrc, unsigned vo
 
 #define WN_SB() __builtin_amdgcn_sched_barrier(0)
 
-template <bool EDGE>
-__device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* __restrict__ zs, int b, int tx0, int ty0) {
+// NH = 2: both 32-output halves per workgroup (8 accumulators per wave, one workgroup per CU): big maps.
+// NH = 1: one half (hh0) per workgroup: twice the workgroups at half the registers (two per CU, which cover each
+//         other's prologue and epilogue) at the price of loading and transforming every patch row twice: maps whose
+//         blocks alone do not fill the chip.
+template <bool EDGE, int NH>
+__device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* __restrict__ zs, int b, int tx0, int ty0, int hh0) {
+    constexpr int NW = 4 * NH;                                   // weight pieces per chunk and wave
+    constexpr int NREQ = NW + 8;                                 // + 8 patch rows
+    constexpr int RPK = NH + 2;                                  // requests per k-step (4 k-steps per chunk)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = row i of the transformed tile
     const int h = lane >> 5, m = lane & 31;
@@ -90,14 +97,14 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
     const unsigned offb = (tile_in && yb >= 0 && yb < p.H) ? (unsigned)h * plane_b + (unsigned)(yb * p.W + xc) * 4u : OUTSIDE;
 #endif
 
-    f32x4 A[WN_NS][8];       // weight pieces of the ring's chunks: [stage][col j * 2 + half], components = k-steps
+    f32x4 A[WN_NS][NW];      // weight pieces of the ring's chunks: [stage][col j * NH + half], components = k-steps
     f32x4 R[WN_NS][8];       // patch rows of the ring's chunks: [stage][2 e + {row a, row b}], components = patch columns
-    f32x16 acc[4][2];        // [col j][half]
+    f32x16 acc[4][NH];       // [col j][half]
     f32x2 V01, V23;          // the B operands of the upcoming k-step: the transformed patch row, columns 0 1 | -2 3
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
+        for (int hh = 0; hh < NH; ++hh)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][hh][r] = 0.0f;
 
@@ -105,16 +112,16 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
     auto chunk_rsrc = [&](int c) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(in_b + (size_t)8 * c * plane), 0, (int)(8u * plane_b), 0x00020000);
     };
-    // request #IDX (0..15) of chunk c into stage S: 8 weight pieces, then 8 patch rows
+    // request #IDX (0..NREQ-1) of chunk c into stage S: the weight pieces (col j, half), then 8 patch rows
     auto request = [&](auto S_, auto IDX_, int c, __amdgpu_buffer_rsrc_t irs) {
         constexpr int S = decltype(S_)::value, IDX = decltype(IDX_)::value;
-        if constexpr (IDX < 8) {
+        if constexpr (IDX < NW) {
 #ifndef WN_ABL_NOW
-            A[S][IDX] = ld_piece(wrs, lane_off, c * WN_CHUNK_BYTES + IDX * WN_PIECE_BYTES);
+            A[S][IDX] = ld_piece(wrs, lane_off, c * WN_CHUNK_BYTES + (NH == 2 ? IDX : 2 * IDX + hh0) * WN_PIECE_BYTES);
 #endif
-        } else {
+        } else if constexpr (IDX < NREQ) {
 #ifndef WN_ABL_NOROWS
-            R[S][IDX - 8] = ld_row(irs, ((IDX - 8) & 1) ? offb : offa, (unsigned)(2 * ((IDX - 8) >> 1)) * plane_b);
+            R[S][IDX - NW] = ld_row(irs, ((IDX - NW) & 1) ? offb : offa, (unsigned)(2 * ((IDX - NW) >> 1)) * plane_b);
 #endif
         }
     };
@@ -153,31 +160,30 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
         const f32x2 c01 = V01, c23 = V23;
         const f32x4& ra4 = E < 3 ? R[S][2 * ((E + 1) & 3)] : R[SN][0];
         const f32x4& rb4 = E < 3 ? R[S][2 * ((E + 1) & 3) + 1] : R[SN][1];
-        acc[0][0] = MFMA32(A[S][0][E], c01[0], acc[0][0]);
+        const float cj[4] = {c01[0], c01[1], c23[0], c23[1]};
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {                           // MFMA q: col q / NH, half q % NH
+            acc[q / NH][q % NH] = MFMA32(A[S][q][E], cj[q / NH], acc[q / NH][q % NH]);
+            if (q == 0) {
 #ifndef WN_ABL_NOVALU
-        transform(ra4, rb4, V01, V23);
+                transform(ra4, rb4, V01, V23);
 #else
-        V01 = f32x2{ra4[0], ra4[1]}, V23 = f32x2{rb4[2], rb4[3]};
+                V01 = f32x2{ra4[0], ra4[1]}, V23 = f32x2{rb4[2], rb4[3]};
 #endif
-        WN_SB();
-        acc[0][1] = MFMA32(A[S][1][E], c01[0], acc[0][1]);
-        request(IC<SL>{}, IC<4 * E + 0>{}, cload, irs);
-        WN_SB();
-        acc[1][0] = MFMA32(A[S][2][E], c01[1], acc[1][0]);
-        WN_SB();
-        acc[1][1] = MFMA32(A[S][3][E], c01[1], acc[1][1]);
-        request(IC<SL>{}, IC<4 * E + 1>{}, cload, irs);
-        WN_SB();
-        acc[2][0] = MFMA32(A[S][4][E], c23[0], acc[2][0]);
-        WN_SB();
-        acc[2][1] = MFMA32(A[S][5][E], c23[0], acc[2][1]);
-        request(IC<SL>{}, IC<4 * E + 2>{}, cload, irs);
-        WN_SB();
-        acc[3][0] = MFMA32(A[S][6][E], c23[1], acc[3][0]);
-        WN_SB();
-        acc[3][1] = MFMA32(A[S][7][E], c23[1], acc[3][1]);
-        request(IC<SL>{}, IC<4 * E + 3>{}, cload, irs);
-        WN_SB();
+            }
+            // RPK requests per k-step: after every second MFMA of 8, or after each of the first three of 4
+            if constexpr (NH == 2) {
+                if (q == 1) request(IC<SL>{}, IC<RPK * E + 0>{}, cload, irs);
+                if (q == 3) request(IC<SL>{}, IC<RPK * E + 1>{}, cload, irs);
+                if (q == 5) request(IC<SL>{}, IC<RPK * E + 2>{}, cload, irs);
+                if (q == 7) request(IC<SL>{}, IC<RPK * E + 3>{}, cload, irs);
+            } else {
+                if (q == 0) request(IC<SL>{}, IC<RPK * E + 0>{}, cload, irs);
+                if (q == 1) request(IC<SL>{}, IC<RPK * E + 1>{}, cload, irs);
+                if (q == 2) request(IC<SL>{}, IC<RPK * E + 2>{}, cload, irs);
+            }
+            WN_SB();
+        }
     };
     auto chunk = [&](auto S_, int cload) {
         const __amdgpu_buffer_rsrc_t irs = chunk_rsrc(cload);
@@ -225,7 +231,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
     // ---- A^T (.) A: the column half in registers, the row half through LDS (the only barrier of the kernel).
     // A lane's 16 values of one (row, half, q) are contiguous (pitch 20 floats): 16-byte LDS accesses, no conflicts.
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
+    for (int hh = 0; hh < NH; ++hh)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 z0, z1;
@@ -236,14 +242,18 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
                 z0[e] = (m0 + m1) + m2;
                 z1[e] = (m1 - m2) - m3;
             }
-            *reinterpret_cast<f32x4*>(zs + ((((wave * 2 + hh) * 2 + 0) * 64 + lane) * WN_ZS_PITCH + 4 * g)) = z0;
-            *reinterpret_cast<f32x4*>(zs + ((((wave * 2 + hh) * 2 + 1) * 64 + lane) * WN_ZS_PITCH + 4 * g)) = z1;
+            *reinterpret_cast<f32x4*>(zs + ((((wave * NH + hh) * 2 + 0) * 64 + lane) * WN_ZS_PITCH + 4 * g)) = z0;
+            *reinterpret_cast<f32x4*>(zs + ((((wave * NH + hh) * 2 + 1) * 64 + lane) * WN_ZS_PITCH + 4 * g)) = z1;
         }
     __syncthreads();
     STAMP(3);
-    // wave: output row pr of the 2x2 block and output half hh; a lane: both columns of its tile, 16 channels
+    // wave: output row pr of the 2x2 block and (NH = 2) output half wave >> 1, all 16 accumulator registers, or (NH = 1)
+    // registers 8 (wave >> 1) .. + 7 of the workgroup's half; a lane: both columns of its tile
     // (co = 32 hh + 8 g + e + 4 h for accumulator register 4 g + e)
-    const int pr = wave & 1, hh = wave >> 1;
+    const int pr = wave & 1;
+    const int hl = NH == 2 ? wave >> 1 : 0;                      // the half's index in the exchange buffer
+    const int hh = NH == 2 ? wave >> 1 : hh0;                    // .. and among the output channels
+    const int g0 = NH == 2 ? 0 : 2 * (wave >> 1);
     const float s2 = pr == 0 ? 1.0f : -1.0f;                    // row 0: Z0 + Z1 + Z2, row 1: Z1 - Z2 - Z3
     const int oy = 2 * ty + pr, ox = 2 * tx;
     const bool in0 = oy < p.H && ox < p.W, in1 = oy < p.H && ox + 1 < p.W;
@@ -255,13 +265,14 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
     const unsigned pix_b = (unsigned)(4 * h) * plane_b + (unsigned)(oy * p.W + ox) * 4u;
     const unsigned st0 = in0 ? pix_b : OUTSIDE, st1 = in1 ? pix_b + 4u : OUTSIDE;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int gi = 0; gi < 2 * NH; ++gi) {
+        const int g = g0 + gi;
         f32x4 y[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const f32x4 z0 = *reinterpret_cast<const f32x4*>(zs + (((((pr + 0) * 2 + hh) * 2 + q) * 64 + lane) * WN_ZS_PITCH + 4 * g));
-            const f32x4 z1 = *reinterpret_cast<const f32x4*>(zs + (((((pr + 1) * 2 + hh) * 2 + q) * 64 + lane) * WN_ZS_PITCH + 4 * g));
-            const f32x4 z2 = *reinterpret_cast<const f32x4*>(zs + (((((pr + 2) * 2 + hh) * 2 + q) * 64 + lane) * WN_ZS_PITCH + 4 * g));
+            const f32x4 z0 = *reinterpret_cast<const f32x4*>(zs + (((((pr + 0) * NH + hl) * 2 + q) * 64 + lane) * WN_ZS_PITCH + 4 * g));
+            const f32x4 z1 = *reinterpret_cast<const f32x4*>(zs + (((((pr + 1) * NH + hl) * 2 + q) * 64 + lane) * WN_ZS_PITCH + 4 * g));
+            const f32x4 z2 = *reinterpret_cast<const f32x4*>(zs + (((((pr + 2) * NH + hl) * 2 + q) * 64 + lane) * WN_ZS_PITCH + 4 * g));
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[q][e] = __builtin_fmaf(s2, z2[e], __builtin_fmaf(s2, z1[e], z0[e]));
         }
@@ -287,14 +298,19 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
     STAMP(4);
 }
 
-__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvWinoParams p) {
-    __shared__ __attribute__((aligned(16))) float zs[WN_ZS_FLOATS];
+template <int NH>
+__device__ __forceinline__ void conv_wino_entry(const ConvWinoParams& p, float* zs) {
     const int tiles_x = (p.W + 1) / 2, tiles_y = (p.H + 1) / 2;
     const int bx_n = (tiles_x + WN_TX - 1) / WN_TX, by_n = (tiles_y + WN_TY - 1) / WN_TY;
     // every XCD takes a contiguous run of blocks (blocks b and b + 8 share an L2): neighbours share patch rows
     const int per_xcd = gridDim.x >> 3;
     int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (t >= p.B * bx_n * by_n) return;
+    if (t >= p.B * bx_n * by_n * (3 - NH)) return;
+    int hh0 = 0;
+    if constexpr (NH == 1) {                                     // the two halves of a block are neighbours: they share its patch rows
+        hh0 = t & 1;
+        t >>= 1;
+    }
     // (integer division runs on the vector unit: pin the results back into scalar registers, or every descriptor
     // derived from them is treated as divergent and each load becomes a waterfall loop)
     const int b = __builtin_amdgcn_readfirstlane(t / (bx_n * by_n));
@@ -302,8 +318,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvWinoParams 
     const int by = __builtin_amdgcn_readfirstlane(t / bx_n), bx = t - by * bx_n;
     const int tx0 = bx * WN_TX, ty0 = by * WN_TY;
     const bool edge = tx0 == 0 || 2 * (tx0 + WN_TX - 1) + 2 >= p.W;
-    if (edge) conv_wino_body<true>(p, zs, b, tx0, ty0);
-    else      conv_wino_body<false>(p, zs, b, tx0, ty0);
+    if (edge) conv_wino_body<true, NH>(p, zs, b, tx0, ty0, hh0);
+    else      conv_wino_body<false, NH>(p, zs, b, tx0, ty0, hh0);
+}
+
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvWinoParams p) {
+    __shared__ __attribute__((aligned(16))) float zs[WN_ZS_FLOATS];
+    conv_wino_entry<2>(p, zs);
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wino_half_kernel(const ConvWinoParams p) {
+    __shared__ __attribute__((aligned(16))) float zs[WN_ZS_FLOATS / 2];
+    conv_wino_entry<1>(p, zs);
 }
 
 extern "C" {
@@ -327,7 +353,12 @@ int diinn_conv_wino(void* stream, const float* in_dev, long long in_batch_stride
 #ifdef DIINN_STAMPS
     p.stamps = g_stamps;
 #endif
-    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, p);
+    // one half per workgroup (two workgroups per CU) while the blocks alone leave CUs idle or give a thin second round
+    static const long long half_max = [] { const char* e = getenv("DIINN_ENC_WINO_HALF_MAX"); return e ? atoll(e) : 448LL; }();
+    if (blocks < half_max)
+        hipLaunchKernelGGL(conv_wino_half_kernel, dim3((unsigned)((2 * blocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
 

@@ -106,7 +106,7 @@ class RDN(nn.Module):
     # 192x192, 23.9 vs 28.1 at 256x256, 53.5 vs 60.2 at 384x384, 96.9 vs 108.4 at 512x512.  The attribute caps the
     # batch*H*W that takes this path (workspace: 2,240 floats per pixel); None disables it (MIOpen everywhere).
     hip_trunk_max_pixels: Optional[int] = 1024 * 1024          # byte offsets of a wave's channel slice stay far below 2^31
-    # 3x3 layers as Winograd F(2x2, 3x3) (csrc/diinn_winograd.hip) on maps of >= 32768 pixels: 2.25x fewer MFMAs, fp32,
+    # 3x3 layers as Winograd F(2x2, 3x3) (csrc/diinn_winograd.hip) on maps of >= 8192 pixels: 2.25x fewer MFMAs, fp32,
     # equal to the direct sum up to reassociation (~1e-6 relative).  False keeps every layer on the direct kernel.
     hip_winograd: bool = True
 

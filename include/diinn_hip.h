@@ -303,8 +303,8 @@ int    diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packe
  *   value = s_j U[32 half + (lane&31)][8 chunk + 2 e + (lane>>5)][i][j], s_2 = -1, else 1   (16 * 64 * Cin floats;
  *   bias_dev 16-byte aligned).
  * diinn_rdn_wino_packed_floats: floats of the 130 transformed 3x3 weights of the trunk, in execution order.
- * diinn_rdn_forward_wino: diinn_rdn_forward with the 3x3 layers on diinn_conv_wino where the map is big enough to
- *   fill the chip with its 16 x 8-pixel blocks (B*H*W >= 32768) and on the split-K kernel otherwise; packed_dev and
+ * diinn_rdn_forward_wino: diinn_rdn_forward with the 3x3 layers on diinn_conv_wino where that is the faster kernel
+ *   (B*H*W >= 8192) and on the split-K kernel otherwise; packed_dev and
  *   biases_dev as for diinn_rdn_forward (the 1x1 layers and small maps read them), packed_wino_dev = the transformed
  *   3x3 weights. */
 int    diinn_conv_wino(void* stream, const float* in_dev, long long in_batch_stride, int Cin,

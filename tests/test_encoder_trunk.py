@@ -58,7 +58,9 @@ def test_conv_wino_kernel_matches_fp64_conv():
     for (b, cin, h, w, relu, use_res) in [(1, 64, 48, 48, 1, 0), (2, 320, 13, 21, 1, 0), (1, 512, 5, 3, 0, 1),
                                           (1, 8, 1, 1, 0, 0), (1, 72, 1, 37, 1, 0), (1, 64, 33, 1, 0, 1),
                                           (1, 192, 128, 136, 1, 0), (2, 128, 70, 61, 0, 1), (1, 64, 64, 80, 1, 1),
-                                          (1, 576, 31, 50, 1, 0)]:
+                                          (1, 576, 31, 50, 1, 0),
+                                          # >= 448 blocks: both halves per workgroup (smaller maps: one half each)
+                                          (1, 64, 256, 240, 1, 1), (1, 128, 250, 255, 0, 0)]:
         total = cin + 64
         buf = torch.randn((b, total, h, w), device=dev, generator=gen)          # input = first cin planes of a larger buffer
         wt = torch.randn((64, cin, 3, 3), device=dev, generator=gen) / (cin * 9) ** 0.5
@@ -97,7 +99,7 @@ def test_conv_ksplit_kernel_matches_torch():
                                                   (1, 512, 3, 5, 3, 0, 1, 0),
                                                   # >= 512 tiles: the both-output-halves variant of the kernel
                                                   (1, 192, 3, 128, 136, 1, 0, 1), (2, 576, 1, 70, 61, 0, 1, 0),
-                                                  # >= 256 blocks of 128 pixels: conv1x1_stream_kernel (ragged last block)
+                                                  # >= 128 blocks of 128 pixels: conv1x1_stream_kernel (ragged last block)
                                                   (1, 576, 1, 256, 128, 0, 1, 1), (2, 1024, 1, 129, 132, 1, 0, 0),
                                                   (1, 64, 1, 200, 164, 0, 0, 1)]:
         total = max(cin, 64) + 64
@@ -140,8 +142,9 @@ def test_rdn_hip_trunk_matches_miopen():
     shapes = {k: list(v.shape) for k, v in enc.state_dict().items()}
     enc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_for(shapes, 123, "enc.").items()})
     enc = enc.to(dev).eval()
-    # (1,160,112): >= 512 tiles (both-halves kernels); (1,200,180), (2,128,130): >= 32768 pixels (Winograd 3x3 layers)
-    for (b, h, w) in [(1, 48, 48), (2, 20, 33), (1, 160, 112), (1, 200, 180), (2, 128, 130)]:
+    # up to 8192 pixels the split-K kernel ((1,70,112)); from there on Winograd 3x3 layers, one
+    # output half per workgroup below 448 blocks ((1,160,112), (2,128,130)), both from there on ((1,250,260))
+    for (b, h, w) in [(1, 48, 48), (2, 20, 33), (1, 70, 112), (1, 160, 112), (1, 200, 180), (2, 128, 130), (1, 250, 260)]:
         x = torch.from_numpy(synth.uniform(7, f"img:{b}x{h}x{w}", (b, 3, h, w), 0.5) + np.float32(0.5)).to(dev)
         with torch.no_grad():
             got = enc(x)
