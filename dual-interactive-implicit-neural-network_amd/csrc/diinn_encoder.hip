@@ -42,8 +42,12 @@ struct ConvKsplitParams {
 // NH = 1: a workgroup computes one 32-output half (blockIdx.y) -- twice the workgroups, for maps with few tiles.
 // NH = 2: both halves from the same staged features (half the staging and half the LDS reads per MFMA), for maps
 //         with enough tiles to fill the chip anyway.
-template <int TAPS, int NH>
+// LAT (3x3, NH = 1: small maps, about one wave per SIMD, so nobody covers a wave's waits): the weight ring holds a
+// whole chunk (9 taps) and every request goes out a chunk ahead, B values are read one tap ahead, and the issue order
+// is pinned with scheduling barriers -- left alone the compiler sinks each weight request to one MFMA before its use.
+template <int TAPS, int NH, bool LAT = false>
 __device__ __forceinline__ void conv_ksplit_body(const ConvKsplitParams& p) {
+    static_assert(!LAT || (TAPS == 9 && NH == 1), "the latency variant is the small-map 3x3 kernel");
     // staging slices of the 8 waves, then (one output half at a time) their partial sums: 3x3 layers stage 8 channels
     // at a time (32 KiB per workgroup: three workgroups per CU), 1x1 layers 32 or 64 (64 KiB)
     constexpr int SLICE = TAPS == 9 ? 1024 : CS_STAGE_FLOATS;
@@ -136,6 +140,48 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvKsplitParams& p) {
     for (int hh = 0; hh < NH; ++hh)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[hh][r] = 0.0f;
+    if constexpr (LAT) {
+        f32x4 ring[9];                                           // tap t of the chunk in flight sits in slot t
+        float vpre[8];
+#define CS_SB() __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) ring[tap] = ld_piece(wrs, lane_off, (tap * groups + 0) * PIECE_BYTES);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vpre[u] = ld_act(irs, lsrc_off, (unsigned)u * plane_b);
+        CS_SB();
+        for (int chunk = 0; chunk < groups; ++chunk) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (mine_lane) ldst[u * PIX] = ok ? vpre[u] : 0.0f;
+#ifdef DIINN_STAMPS
+            if (chunk == 0) STAMP(1);
+#endif
+            CS_SB();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vpre[u] = ld_act(irs, lsrc_off, (unsigned)(8 * (chunk + 1) + u) * plane_b);
+            const float* __restrict__ bbase = mine + h * PIX + pix_off;
+            float bv[2][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[0][e] = bbase[(2 * e) * PIX];
+            CS_SB();
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 1 < 9) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)                  // channel 8 chunk + 2e + h under tap + 1
+                        bv[(tap + 1) & 1][e] = bbase[(2 * e) * PIX + ((tap + 1) / 3) * LW + ((tap + 1) % 3)];
+                }
+                f32x4 a4 = ring[tap];
+                CS_SB();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[0] = MFMA32(a4[e], bv[tap & 1][e], acc[0]);
+                // the same tap of the next chunk (past the wave's slice: other slices' data or zeros, never used)
+                ring[tap] = ld_piece(wrs, lane_off, (tap * groups + chunk + 1) * PIECE_BYTES);
+                CS_SB();
+            }
+        }
+#undef CS_SB
+    } else
     if constexpr (PIPE) {
         // 3x3 layers, everything prefetched.  A chunk is 8 channels = one weight piece per (tap, half):
         //  * weight pieces live in a ring of 3 taps and are requested two taps (16 NH MFMAs) before use; 9 taps per
@@ -278,6 +324,9 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvKsplitParams& p) {
 template <int NH>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6)))
 void conv_ksplit_kernel_3x3(const ConvKsplitParams p) { conv_ksplit_body<9, NH>(p); }
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
+void conv_ksplit_kernel_3x3_lat(const ConvKsplitParams p) { conv_ksplit_body<9, 1, true>(p); }
 
 template <int NH>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
@@ -447,12 +496,15 @@ static int launch_conv_ksplit(void* stream, const ConvKsplitParams& p_in, int ta
 #ifdef DIINN_STAMPS
     p.stamps = g_stamps;
 #endif
-    static const bool no_stream = getenv("DIINN_ENC_NO_STREAM1X1") != nullptr;   // A/B switch for tools/
+    static const bool no_stream = getenv("DIINN_ENC_NO_STREAM1X1") != nullptr;   // A/B switches for tools/
+    static const int lat_max = [] { const char* e = getenv("DIINN_ENC_LAT_MAX_TILES"); return e ? atoi(e) : 256; }();
+    const bool lat = tiles <= lat_max;                           // <= 2 workgroups per CU: about one wave per SIMD
     if (taps == 1 && !no_stream && conv1x1_stream_ok(p)) {
         const long long blocks = (long long)p.B * (((long long)p.H * p.W + S1_PIX - 1) / S1_PIX);
         hipLaunchKernelGGL(conv1x1_stream_kernel, dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, p);
     } else if (taps == 9) {
         if (both) hipLaunchKernelGGL(conv_ksplit_kernel_3x3<2>, grid, dim3(512), 0, (hipStream_t)stream, p);
+        else if (lat) hipLaunchKernelGGL(conv_ksplit_kernel_3x3_lat, grid, dim3(512), 0, (hipStream_t)stream, p);
         else      hipLaunchKernelGGL(conv_ksplit_kernel_3x3<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
     } else {
         if (both) hipLaunchKernelGGL(conv_ksplit_kernel_1x1<2>, grid, dim3(512), 0, (hipStream_t)stream, p);
