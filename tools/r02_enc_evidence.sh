@@ -9,4 +9,4 @@ if [ -f variants/libdiinn_stamps.so ]; then
   for c in 64 512; do DIINN_HIP_LIB=variants/libdiinn_stamps.so python tools/stamp_report_enc.py 256 $c 9 wino; done > $O/wino_stamps.txt 2>&1
 fi
 timeout 600 python -m pytest tests/test_encoder_trunk.py tests/test_modules.py tests/test_scripts.py -q -m gpu 2>&1 | tail -3 > $O/tests.txt
-tail -3 $O/enc_trunk_times.txt $O/e2e_times.txt $O/tests.txt
+for f in enc_trunk_times e2e_times tests; do tail -n 3 $O/$f.txt; done
