@@ -84,6 +84,40 @@ def test_conv_wino_kernel_matches_fp64_conv():
 
 
 @pytest.mark.gpu
+def test_conv_wino_kernel_fuzz():
+    """Seeded random shapes (batch 1..3, 8..136 input channels, maps from 1x1 to 70x90, ReLU / residual at random)
+    through diinn_conv_wino against a float64 convolution: every border / partial-tile / partial-block combination."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    rng = np.random.default_rng(11)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
+    for _ in range(40):
+        b, cin = int(rng.integers(1, 4)), 8 * int(rng.integers(1, 18))
+        h, w = int(rng.integers(1, 71)), int(rng.integers(1, 91))
+        relu, use_res = int(rng.integers(2)), int(rng.integers(2))
+        x = torch.randn((b, cin, h, w), device=dev, generator=gen)
+        wt = torch.randn((64, cin, 3, 3), device=dev, generator=gen) / (cin * 9) ** 0.5
+        bias = torch.randn(64, device=dev, generator=gen)
+        res = torch.randn((b, 64, h, w), device=dev, generator=gen) if use_res else None
+        out = torch.full((b, 64, h, w), float("nan"), device=dev)
+        packed = M.pack_conv_wino(wt).to(dev)
+        assert lib.diinn_conv_wino(stream, ptr(x), cin * h * w, cin, ptr(packed), ptr(bias), ptr(res) if use_res else None,
+                                   64 * h * w, ptr(out), 64 * h * w, relu, b, h, w) == 0
+        ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+        if relu:
+            ref = torch.relu(ref)
+        if use_res:
+            ref = ref + res.double()
+        err = float((out.double() - ref).abs().max())
+        assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (b, cin, h, w, relu, use_res, err)
+
+
+@pytest.mark.gpu
 def test_conv_ksplit_kernel_matches_torch():
     """diinn_conv_ksplit: 3x3 / 1x1, ReLU, residual, two destinations, strided channel-plane views, ragged maps."""
     import ctypes as C

@@ -316,6 +316,36 @@ def test_p_winograd_form(dev):
             assert torch.equal(pwin, pw[:, r0:r1]), (b, h, w, r0, r1)
 
 
+def test_p_winograd_fuzz(dev):
+    """Seeded random maps (1x1 .. 90x70, batch 1..3) and random row bands through the Winograd P kernel (every M-tile
+    split the cost model picks on small maps) against the direct kernel and, band against full launch, bit for bit."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.decoder as D
+    lib = N.load()
+    packed = D.pack_state_dict(synth.decoder_state_dict(5)).to(dev)
+    rng = np.random.default_rng(3)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
+    for _ in range(25):
+        b, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 91)), int(rng.integers(1, 71))
+        feat = torch.from_numpy(synth.encoder_features(int(rng.integers(100)), b, h, w)).to(dev)
+        pw = torch.full((b, h, w, 1024), float("nan"), device=dev)
+        pd = torch.full((b, h, w, 1024), float("nan"), device=dev)
+        N.check(lib.diinn_precompute_P_ex(stream, ptr(feat), ptr(packed), ptr(pw), b, h, w, 0, h, N.COMPUTE_F32), "P wino")
+        N.check(lib.diinn_precompute_P(stream, ptr(feat), ptr(packed), ptr(pd), b, h, w, 0, h), "P direct")
+        scale = max(1.0, float(pd.abs().max()))
+        assert torch.isfinite(pw).all() and float((pw - pd).abs().max()) <= 1e-5 * scale, (b, h, w)
+        r0 = int(rng.integers(0, h))
+        r1 = int(rng.integers(r0 + 1, h + 1))
+        f0, f1 = max(r0 - 1, 0), min(r1 + 1, h)
+        fwin = feat[:, :, f0:f1].contiguous()
+        pwin = torch.full((b, r1 - r0, w, 1024), float("nan"), device=dev)
+        N.check(lib.diinn_precompute_P_win(stream, ptr(fwin), f0, f1 - f0, ptr(packed), ptr(pwin), r0, r1 - r0,
+                                           b, h, w, r0, r1, N.COMPUTE_F32), "P win")
+        assert torch.equal(pwin, pw[:, r0:r1]), (b, h, w, r0, r1)
+
+
 def test_random_shapes_vs_oracle(dev):
     """Fuzz: random LR/HR shapes, batch sizes and scales (up- and down-scaling, tile edges that do
     not divide the 16x8 workgroup block or the 4x32 cell block) against the oracle."""
