@@ -12,9 +12,12 @@
 //   * small maps (48x48: the reference's runtime_test.py and training patches, 72 tiles): a workgroup per
 //     (tile, 32-output half) -- a library convolution is launch/latency-bound there (~35 us per layer);
 //   * maps with >= 512 tiles: both output halves per workgroup (half the staging and LDS reads per MFMA).
-// Measured against MIOpen (PyTorch-ROCm), whole encoder: 2.1 vs 6.8 ms at 48x48, 23.9 vs 28.1 ms at 256x256
-// (120 TFLOP/s), 96.9 vs 108.4 ms at 512x512 (tools/enc_trunk_time.py).
-// diinn_rdn_forward runs the whole trunk (everything after SFENet1) as 147 launches from C++.
+// This file: that split-K kernel (round 2: every layer of maps up to 8,192 pixels, and the fallback), the streaming
+// kernel for the 1x1 layers of bigger maps (conv1x1_stream_kernel, below), and the trunk drivers.  From 8,192 pixels
+// on the 3x3 layers run as Winograd F(2x2,3x3) in csrc/diinn_winograd.hip.
+// Measured against MIOpen (PyTorch-ROCm), whole encoder: 2.0 vs 7.4 ms at 48x48, 3.8 vs 7.9 at 128x128, 11.7 vs 28.1
+// at 256x256, 46.0 vs 108.1 at 512x512 (tools/enc_trunk_time.py; round 1, this kernel alone: 2.1 / 6.5 / 23.9 / 96.9).
+// diinn_rdn_forward[_wino] runs the whole trunk (everything after SFENet1) as 147 launches from C++.
 #include "diinn_device.h"
 
 constexpr int CS_WAVES = 8;                       // K-split: waves per workgroup, each 1/8 of the input channels
