@@ -209,3 +209,31 @@ def test_rdn_hip_trunk_odd_shapes():
         assert got.shape == ref.shape == (b, 64, h, w)
         err = float((got - ref).abs().max())
         assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (b, h, w, err)
+
+
+@pytest.mark.gpu
+def test_rdn_hip_trunk_matches_the_reference_on_big_maps():
+    """RDN.forward on maps that take the Winograd 3x3 kernels (one half / both halves per workgroup) and the streaming
+    1x1 kernel, against the REAL reference's encoder run on the CPU: 16,384 sampled outputs and per-channel sums from
+    tests/golden/rdn_big_golden.npz (tests/golden/make_golden_rdn_big.py imports /root/reference's make_rdn)."""
+    import json
+    import os
+    import diinn_amd.modules as M
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rdn_big_golden.npz"))
+    dev = torch.device("cuda:0")
+    enc = M.make_rdn()
+    shapes = json.loads(str(gold["rdn/shapes_json"]))
+    assert shapes == {k: list(v.shape) for k, v in enc.state_dict().items()}
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_for(shapes, 123, "enc.").items()})
+    enc = enc.to(dev).eval()
+    for (b, h, w) in [(1, 96, 100), (1, 240, 256), (2, 50, 90)]:
+        key = f"{b}x{h}x{w}"
+        x = torch.from_numpy(synth.uniform(7, f"img:{b}x{h}x{w}", (b, 3, h, w), 0.5) + np.float32(0.5)).to(dev)
+        with torch.no_grad():
+            y = enc(x).cpu().numpy()
+        idx = np.random.default_rng(1000 * h + w).choice(y.size, size=min(16384, y.size), replace=False)
+        scale = max(1.0, float(gold[f"rdn/{key}/absmax"]))
+        err = float(np.abs(y.reshape(-1)[idx] - gold[f"rdn/{key}/values"]).max())
+        assert err <= 2e-5 * scale, (key, err)
+        sums = y.astype(np.float64).sum(axis=(0, 2, 3))
+        assert float(np.abs(sums - gold[f"rdn/{key}/channel_sums"]).max()) <= 1e-6 * b * h * w * scale, key
