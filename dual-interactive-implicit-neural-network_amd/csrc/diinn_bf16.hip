@@ -781,7 +781,12 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8_kernel(const DecodeP
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..7 = this wave's M-tile
     const int grp = wave >> 2;                                    // waves w and w + 4 share a SIMD
     const int h = lane >> 5, j = lane & 31;
-    const int b = blockIdx.z;
+#ifdef CO8_NO_XCD_RUNS
+    const BlockXYZ blk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+#else
+    const BlockXYZ blk = xcd_run_block();
+#endif
+    const int b = blk.z;
     const float* __restrict__ Wt = p.Wt;
     const int ncx = p.seed_cols;
     const int ncx_inv = 65536 / ncx + 1;
@@ -790,8 +795,8 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8_kernel(const DecodeP
 #endif
     CO_STAMP(0);
 
-    const int x0 = blockIdx.x * (2 * TILE_W) + (j & (TILE_W - 1));
-    const int yb = p.y0 + blockIdx.y * (2 * TILE_H) + (j / TILE_W);
+    const int x0 = blk.x * (2 * TILE_W) + (j & (TILE_W - 1));
+    const int yb = p.y0 + blk.y * (2 * TILE_H) + (j / TILE_W);
     int ixs[2], iys[2];
     float relws[2], relhs[2];
 #pragma unroll
@@ -1036,8 +1041,8 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8_kernel(const DecodeP
     __syncthreads();
     if (threadIdx.x < TILES * 32) {
         const int t = threadIdx.x >> 5, jj = threadIdx.x & 31;
-        const int x = blockIdx.x * (2 * TILE_W) + (t & 1) * TILE_W + (jj & (TILE_W - 1));
-        const int y = p.y0 + blockIdx.y * (2 * TILE_H) + (t >> 1) * TILE_H + (jj / TILE_W);
+        const int x = blk.x * (2 * TILE_W) + (t & 1) * TILE_W + (jj & (TILE_W - 1));
+        const int y = p.y0 + blk.y * (2 * TILE_H) + (t >> 1) * TILE_H + (jj / TILE_W);
         float acc[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int w16 = 0; w16 < 16; ++w16)

@@ -195,6 +195,20 @@ constexpr unsigned PLANE_ROW_BYTES = PLANE_TILE * sizeof(float);   // 128
 __device__ __forceinline__ void st_act(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, (int)soff, 0);
 }
+// Workgroups are dealt round-robin over the 8 XCDs in launch order (x fastest): blocks b and b + 8 share an L2.  This
+// gives every XCD a contiguous run of the launch's blocks instead, so that neighbouring blocks -- which at non-integer
+// scales read the same P rows -- meet in ONE L2.  A bijection of the 3-D grid onto itself (the last < 8 blocks keep
+// their place).
+struct BlockXYZ { int x, y, z; };
+__device__ __forceinline__ BlockXYZ xcd_run_block() {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned total = gx * gy * gridDim.z, full = total & ~7u;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned t = lin < full ? (lin & 7u) * (full >> 3) + (lin >> 3) : lin;
+    const unsigned z = t / (gx * gy), r = t - z * gx * gy, y = r / gx;
+    return BlockXYZ{__builtin_amdgcn_readfirstlane((int)(r - y * gx)), __builtin_amdgcn_readfirstlane((int)y), __builtin_amdgcn_readfirstlane((int)z)};
+}
+
 // 128-bit buffer store with a scalar offset register.  Measured on gfx950 (tools/: the LFF layer's second destination
 // came out wrong in 16 lanes, first dword, some launches): a VALU instruction that writes one of the store's data
 // registers in the slot right behind the store overwrites what the store's first quarter-wave still has to read.
