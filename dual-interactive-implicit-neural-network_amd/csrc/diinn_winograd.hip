@@ -302,24 +302,32 @@ template <int NH>
 __device__ __forceinline__ void conv_wino_entry(const ConvWinoParams& p, float* zs) {
     const int tiles_x = (p.W + 1) / 2, tiles_y = (p.H + 1) / 2;
     const int bx_n = (tiles_x + WN_TX - 1) / WN_TX, by_n = (tiles_y + WN_TY - 1) / WN_TY;
-    // every XCD takes a contiguous run of blocks (blocks b and b + 8 share an L2): neighbours share patch rows
-    const int per_xcd = gridDim.x >> 3;
-    int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (t >= p.B * bx_n * by_n * (3 - NH)) return;
-    int hh0 = 0;
-    if constexpr (NH == 1) {                                     // the two halves of a block are neighbours: they share its patch rows
-        hh0 = t & 1;
-        t >>= 1;
+    const int total = p.B * bx_n * by_n * (3 - NH);
+    // Every XCD takes a contiguous run of work items (blocks b and b + 8 share an L2: neighbours share patch rows).  The
+    // grid may be smaller than the work (persistent workgroups: conv_wino_kernel on big maps): round k of an XCD's
+    // workgroups covers the next gridDim.x / 8 items of its run.
+    const int wg_per_xcd = gridDim.x >> 3;
+    const int per_xcd = (total + 7) >> 3;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    for (int k = idx; k < per_xcd; k += wg_per_xcd) {
+        int t = xcd * per_xcd + k;
+        if (t >= total) break;
+        int hh0 = 0;
+        if constexpr (NH == 1) {                                 // the two halves of a block are neighbours: they share its patch rows
+            hh0 = t & 1;
+            t >>= 1;
+        }
+        // (integer division runs on the vector unit: pin the results back into scalar registers, or every descriptor
+        // derived from them is treated as divergent and each load becomes a waterfall loop)
+        const int b = __builtin_amdgcn_readfirstlane(t / (bx_n * by_n));
+        t -= b * bx_n * by_n;
+        const int by = __builtin_amdgcn_readfirstlane(t / bx_n), bx = t - by * bx_n;
+        const int tx0 = bx * WN_TX, ty0 = by * WN_TY;
+        const bool edge = tx0 == 0 || 2 * (tx0 + WN_TX - 1) + 2 >= p.W;
+        if (edge) conv_wino_body<true, NH>(p, zs, b, tx0, ty0, hh0);
+        else      conv_wino_body<false, NH>(p, zs, b, tx0, ty0, hh0);
+        __syncthreads();                                         // the exchange buffer is free again
     }
-    // (integer division runs on the vector unit: pin the results back into scalar registers, or every descriptor
-    // derived from them is treated as divergent and each load becomes a waterfall loop)
-    const int b = __builtin_amdgcn_readfirstlane(t / (bx_n * by_n));
-    t -= b * bx_n * by_n;
-    const int by = __builtin_amdgcn_readfirstlane(t / bx_n), bx = t - by * bx_n;
-    const int tx0 = bx * WN_TX, ty0 = by * WN_TY;
-    const bool edge = tx0 == 0 || 2 * (tx0 + WN_TX - 1) + 2 >= p.W;
-    if (edge) conv_wino_body<true, NH>(p, zs, b, tx0, ty0, hh0);
-    else      conv_wino_body<false, NH>(p, zs, b, tx0, ty0, hh0);
 }
 
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvWinoParams p) {
@@ -357,8 +365,12 @@ int diinn_conv_wino(void* stream, const float* in_dev, long long in_batch_stride
     static const long long half_max = [] { const char* e = getenv("DIINN_ENC_WINO_HALF_MAX"); return e ? atoll(e) : 448LL; }();
     if (blocks < half_max)
         hipLaunchKernelGGL(conv_wino_half_kernel, dim3((unsigned)((2 * blocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, p);
+    else {
+        // persistent workgroups, one per CU: the second and later blocks of a workgroup start without a dispatch
+        static const long long persist = [] { const char* e = getenv("DIINN_ENC_WINO_PERSIST"); return e ? atoll(e) : 256LL; }();
+        const long long grid = persist > 0 && blocks > persist ? persist : (blocks + 7) / 8 * 8;
+        hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+    }
     return hip_status(hipGetLastError());
 }
 
