@@ -178,7 +178,9 @@ def test_rdn_hip_trunk_matches_miopen():
     enc = enc.to(dev).eval()
     # up to 8192 pixels the split-K kernel ((1,70,112)); from there on Winograd 3x3 layers, one
     # output half per workgroup below 448 blocks ((1,160,112), (2,128,130)), both from there on ((1,250,260))
-    for (b, h, w) in [(1, 48, 48), (2, 20, 33), (1, 70, 112), (1, 160, 112), (1, 200, 180), (2, 128, 130), (1, 250, 260)]:
+    # (2,200,180): 600 blocks over two images on 256 persistent workgroups
+    for (b, h, w) in [(1, 48, 48), (2, 20, 33), (1, 70, 112), (1, 160, 112), (1, 200, 180), (2, 128, 130), (1, 250, 260),
+                      (2, 200, 180)]:
         x = torch.from_numpy(synth.uniform(7, f"img:{b}x{h}x{w}", (b, 3, h, w), 0.5) + np.float32(0.5)).to(dev)
         with torch.no_grad():
             got = enc(x)
