@@ -490,6 +490,52 @@ static bool conv1x1_stream_ok(const ConvKsplitParams& p) {
            p.in_bs % 4 == 0 && p.out0_bs % 4 == 0 && p.out1_bs % 4 == 0 && p.res_bs % 4 == 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// SFENet1 (rdn.py:96): 3x3, n_colors (<= 4) -> 64, zero padding.  0.2 % of the encoder's arithmetic and no use for the
+// matrix cores (K = 27): a workgroup owns 64 pixels, wave q of 4 the outputs 16q .. 16q+15; a thread keeps its pixel's
+// 9 * Cin inputs in registers and walks its 16 outputs with the weights as scalar operands (wave-uniform addresses:
+// fetched through the scalar cache); stores are 256 contiguous bytes per wave and output channel.  It exists so that
+// the whole encoder runs through this library (no library convolution, no find pass on the first call).
+struct Sfe1Params {
+    const float* in;     // [B,Cin,H,W]
+    const float* w;      // [64,Cin,3,3], the reference's own layout
+    const float* bias;   // [64]
+    float* out;          // [B,64,H,W]
+    int B, H, W;
+};
+
+template <int CIN>
+__global__ __launch_bounds__(256) void sfe1_conv_kernel(const Sfe1Params p) {
+    const long long plane = (long long)p.H * p.W;
+    const long long pix = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int og = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // this wave's 16 outputs
+    const int b = blockIdx.y;
+    if (pix >= plane) return;
+    const int y = (int)(pix / p.W), x = (int)(pix - (long long)y * p.W);
+    float v[CIN * 9];
+    const float* __restrict__ ib = p.in + (size_t)b * CIN * plane;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            const bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            const int yc = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy), xc = xx < 0 ? 0 : (xx >= p.W ? p.W - 1 : xx);
+            const float u = ib[(size_t)c * plane + (size_t)yc * p.W + xc];   // clamped address, then select: no branch per element
+            v[c * 9 + t] = ok ? u : 0.0f;
+        }
+    float* __restrict__ ob = p.out + (size_t)b * 64 * plane + pix;
+#pragma unroll 4
+    for (int oo = 0; oo < 16; ++oo) {
+        const int o = 16 * og + oo;
+        const float* __restrict__ wo = p.w + o * CIN * 9;        // wave-uniform: scalar loads
+        float acc = p.bias[o];
+#pragma unroll
+        for (int k = 0; k < CIN * 9; ++k) acc = __builtin_fmaf(wo[k], v[k], acc);
+        ob[(size_t)o * plane] = acc;
+    }
+}
+
 static int launch_conv_ksplit(void* stream, const ConvKsplitParams& p_in, int taps) {
     const int tiles = ((p_in.W + CS_TW - 1) / CS_TW) * ((p_in.H + CS_TH - 1) / CS_TH) * p_in.B;
     // both output halves per workgroup once the tiles alone give every CU two workgroups; otherwise one half each
@@ -535,6 +581,24 @@ int diinn_conv_ksplit(void* stream, const float* in_dev, long long in_batch_stri
     p.in_bs = in_batch_stride; p.out0_bs = out0_batch_stride; p.out1_bs = out1_batch_stride; p.res_bs = res_batch_stride;
     p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0;
     return launch_conv_ksplit(stream, p, taps);
+}
+
+int diinn_sfe1_forward(void* stream, const float* x_dev, int Cin, const float* w_dev, const float* bias_dev, float* out_dev,
+                       int B, int H, int W) {
+    if (!x_dev || !w_dev || !bias_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (Cin < 1 || Cin > 4) return DIINN_ERR_UNSUPPORTED;
+    Sfe1Params p{x_dev, w_dev, bias_dev, out_dev, B, H, W};
+    const long long plane = (long long)H * W;
+    const dim3 grid((unsigned)((plane + 63) / 64), (unsigned)B);
+    switch (Cin) {
+        case 1: hipLaunchKernelGGL(sfe1_conv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+        case 2: hipLaunchKernelGGL(sfe1_conv_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+        case 3: hipLaunchKernelGGL(sfe1_conv_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+        default: hipLaunchKernelGGL(sfe1_conv_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+    }
+    return hip_status(hipGetLastError());
 }
 
 size_t diinn_rdn_packed_floats(void) {

@@ -164,11 +164,30 @@ class RDN(nn.Module):
                                                     C.c_void_p(out.data_ptr()), b, h, w), "diinn_rdn_forward")
         return out
 
+    def _sfe1_hip(self, x):
+        """SFENet1 on the library's own kernel (diinn_sfe1_forward): the whole inference encoder then runs without a
+        library convolution."""
+        import ctypes as C
+        from . import _native
+        lib = _native.load()
+        x = x.contiguous()
+        b, c, h, w = x.shape
+        wt, bias = self.SFENet1.weight.detach().contiguous(), self.SFENet1.bias.detach().contiguous()
+        out = torch.empty((b, 64, h, w), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _native.check(lib.diinn_sfe1_forward(stream, C.c_void_p(x.data_ptr()), c, C.c_void_p(wt.data_ptr()),
+                                                 C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()), b, h, w),
+                          "diinn_sfe1_forward")
+        return out
+
     def forward(self, x):
-        shallow = self.SFENet1(x)
         if (self._hip_ok and self.hip_trunk_max_pixels is not None and x.is_cuda and not torch.is_grad_enabled()
                 and x.dtype == torch.float32 and x.shape[0] * x.shape[-2] * x.shape[-1] <= self.hip_trunk_max_pixels):
-            return self._forward_hip_trunk(shallow)
+            if x.shape[1] <= 4 and self.SFENet1.weight.dtype == torch.float32:
+                return self._forward_hip_trunk(self._sfe1_hip(x))
+            return self._forward_hip_trunk(self.SFENet1(x))
+        shallow = self.SFENet1(x)
         x = self.SFENet2(shallow)
         blocks = []
         for rdb in self.RDBs:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIINN_ABI_VERSION 4   /* 2: training, LIIF/MetaSR, encoder-trunk entry points; packed image sections 8-9
+#define DIINN_ABI_VERSION 5   /* 2: training, LIIF/MetaSR, encoder-trunk entry points; packed image sections 8-9
                                  3: row-window entry points (band-sized buffers for the multi-GPU row-band split) */
 
 /* status codes */
@@ -307,6 +307,11 @@ int    diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packe
  *   (B*H*W >= 8192) and on the split-K kernel otherwise; packed_dev and
  *   biases_dev as for diinn_rdn_forward (the 1x1 layers and small maps read them), packed_wino_dev = the transformed
  *   3x3 weights. */
+/* diinn_sfe1_forward: SFENet1 (rdn.py:96): 3x3 zero-padded convolution n_colors = Cin (1..4) -> 64 on the image itself,
+ *   x_dev [B,Cin,H,W], w_dev [64,Cin,3,3] and bias_dev [64] in the reference's own layout, out_dev [B,64,H,W] = the
+ *   sfe1_dev argument of diinn_rdn_forward[_wino]: with it the whole encoder runs through this library. */
+int    diinn_sfe1_forward(void* stream, const float* x_dev, int Cin, const float* w_dev, const float* bias_dev,
+                          float* out_dev, int B, int H, int W);
 int    diinn_conv_wino(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
                       const float* packed_u_dev, const float* bias_dev,
                       const float* res_dev, long long res_batch_stride,

@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.diinn_abi_version() == 4
+    assert lib.diinn_abi_version() == 5
     assert lib.diinn_status_string(0) == b"ok"
     assert b"invalid" in lib.diinn_status_string(1)
 

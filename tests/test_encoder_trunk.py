@@ -84,6 +84,28 @@ def test_conv_wino_kernel_matches_fp64_conv():
 
 
 @pytest.mark.gpu
+def test_sfe1_kernel_matches_fp64_conv():
+    """diinn_sfe1_forward (SFENet1: 3x3, 1..4 -> 64 channels, zero padding) against a float64 convolution."""
+    import ctypes as C
+    import diinn_amd._native as N
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    gen = torch.Generator(device=dev).manual_seed(2)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
+    for (b, cin, h, w) in [(1, 3, 48, 48), (2, 3, 17, 301), (1, 1, 1, 1), (1, 4, 5, 3), (1, 3, 256, 256), (3, 2, 33, 1)]:
+        x = torch.randn((b, cin, h, w), device=dev, generator=gen)
+        wt = torch.randn((64, cin, 3, 3), device=dev, generator=gen) / (cin * 9) ** 0.5
+        bias = torch.randn(64, device=dev, generator=gen)
+        out = torch.full((b, 64, h, w), float("nan"), device=dev)
+        assert lib.diinn_sfe1_forward(stream, ptr(x), cin, ptr(wt), ptr(bias), ptr(out), b, h, w) == 0
+        ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+        err = float((out.double() - ref).abs().max())
+        assert err <= 5e-6 * max(1.0, float(ref.abs().max())), (b, cin, h, w, err)
+    assert lib.diinn_sfe1_forward(stream, ptr(x), 5, ptr(wt), ptr(bias), ptr(out), 1, 4, 4) == N.ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
 def test_conv_wino_kernel_fuzz():
     """Seeded random shapes (batch 1..3, 8..136 input channels, maps from 1x1 to 70x90, ReLU / residual at random)
     through diinn_conv_wino against a float64 convolution: every border / partial-tile / partial-block combination."""
