@@ -361,9 +361,14 @@ int diinn_conv_wino(void* stream, const float* in_dev, long long in_batch_stride
 #ifdef DIINN_STAMPS
     p.stamps = g_stamps;
 #endif
-    // one half per workgroup (two workgroups per CU) while the blocks alone leave CUs idle or give a thin second round
-    static const long long half_max = [] { const char* e = getenv("DIINN_ENC_WINO_HALF_MAX"); return e ? atoll(e) : 448LL; }();
-    if (blocks < half_max)
+    // Both halves per workgroup (one per CU at a time) or one half (two per CU, 0.57x the work each, every patch row
+    // loaded and transformed twice)?  Whichever gives the busiest CU less to do: a CU ends up with ceil(b / 256) whole
+    // blocks or ceil(2 b / 256) halves (measured on 176 .. 320-pixel maps, tools/r02_ab_env.sh).
+    // DIINN_ENC_WINO_HALF_MAX = n forces halves below n blocks and whole blocks from there on.
+    static const long long half_max = [] { const char* e = getenv("DIINN_ENC_WINO_HALF_MAX"); return e ? atoll(e) : -1LL; }();
+    const double cost_whole = (double)((blocks + 255) / 256), cost_half = 0.57 * (double)((2 * blocks + 255) / 256);
+    const bool halves = half_max >= 0 ? blocks < half_max : cost_half < cost_whole;
+    if (halves)
         hipLaunchKernelGGL(conv_wino_half_kernel, dim3((unsigned)((2 * blocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, p);
     else {
         // persistent workgroups, one per CU: the second and later blocks of a workgroup start without a dispatch
