@@ -99,12 +99,12 @@ def pack_conv_wino(weight: torch.Tensor) -> torch.Tensor:
 
 class RDN(nn.Module):
     _CONFIGS = {"A": (20, 6, 32), "B": (16, 8, 64)}
-    # Inference (no autograd, fp32, config 'B') runs the trunk -- everything after SFENet1 -- on conv_ksplit_kernel
-    # (C ABI diinn_rdn_forward, csrc/diinn_encoder.hip): workgroups split the reduction over their 8 waves, which
-    # suits convolutions with 64 outputs and up to 1024 inputs at every map size.  Measured (tools/enc_trunk_time.py,
-    # HIP vs MIOpen eager): 2.1 vs 6.8 ms at 48x48, 5.0 vs 7.6 at 96x96, 6.5 vs 7.9 at 128x128, 14.7 vs 20.2 at
-    # 192x192, 23.9 vs 28.1 at 256x256, 53.5 vs 60.2 at 384x384, 96.9 vs 108.4 at 512x512.  The attribute caps the
-    # batch*H*W that takes this path (workspace: 2,240 floats per pixel); None disables it (MIOpen everywhere).
+    # Inference (no autograd, fp32, config 'B') runs the whole encoder on the library's kernels:
+    # SFENet1 on diinn_sfe1_forward, the 147 convolutions after it through diinn_rdn_forward[_wino] -- the split-K
+    # kernel on small maps, Winograd 3x3 + streaming 1x1 kernels from 8192 pixels on.  Measured (tools/enc_trunk_time.py,
+    # HIP vs MIOpen eager): 1.95 vs 7.6 ms at 48x48, 3.6 vs 7.6 at 96x96, 3.9 vs 8.1 at 128x128, 9.3 vs 20.2 at 192x192,
+    # 11.8 vs 28.6 at 256x256, 28.3 vs 61.6 at 384x384, 47.0 vs 109.5 at 512x512.  The attribute caps the batch*H*W
+    # that takes this path (workspace: 2,240 floats per pixel); None disables it (MIOpen everywhere).
     hip_trunk_max_pixels: Optional[int] = 1024 * 1024          # byte offsets of a wave's channel slice stay far below 2^31
     # 3x3 layers as Winograd F(2x2, 3x3) (csrc/diinn_winograd.hip) on maps of >= 8192 pixels: 2.25x fewer MFMAs, fp32,
     # equal to the direct sum up to reassociation (~1e-6 relative).  False keeps every layer on the direct kernel.
