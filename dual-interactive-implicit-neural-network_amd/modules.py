@@ -90,8 +90,9 @@ def pack_conv_wino(weight: torch.Tensor) -> torch.Tensor:
     co, cin, kh, kw = weight.shape
     if co != 64 or cin % 8 or (kh, kw) != (3, 3):
         raise ValueError(f"unsupported convolution shape {tuple(weight.shape)}")
-    g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
-    u = torch.einsum("ia,ocab,jb->ocij", g, weight.detach().to(torch.float64).cpu(), g).to(torch.float32)
+    g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64,
+                     device=weight.device)                       # on the weight's device: 1.4 s for the trunk on the CPU, ms on the GPU
+    u = torch.einsum("ia,ocab,jb->ocij", g, weight.detach().to(torch.float64), g).to(torch.float32)
     u[..., 2] = -u[..., 2]                                      # the kernel's input transform produces column 2 negated
     u = u.reshape(2, 32, cin // 8, 4, 2, 4, 4)                  # [half, m, chunk, e, h, i, j]
     return u.permute(5, 2, 6, 0, 4, 1, 3).reshape(-1)           # [i, chunk, j, half, h, m, e]
