@@ -26,6 +26,8 @@
 constexpr int WN_TX = 8, WN_TY = 4;                  // Winograd tiles per block (x, y): 32 = one MFMA N-tile
 constexpr int WN_PIECE_BYTES = 1024;                 // one A piece: 64 lanes x 4 k-steps
 constexpr int WN_CHUNK_BYTES = 8 * WN_PIECE_BYTES;   // per wave and chunk of 8 channels: 4 positions x 2 halves
+// WN_ABL_* are timing-ablation hooks for tools/r02_wino_ablation.sh (wrong results when defined; never in the shipped
+// build); WN_STAGES = 4 deepens the register ring (measured: no gain).
 #ifndef WN_STAGES
 #define WN_STAGES 3
 #endif
