@@ -605,7 +605,7 @@ static int decode_band_impl(void* stream, const float* P_dev, const float* packe
     p.B = B; p.H = H; p.W = W; p.Hu = Hu; p.Wu = Wu; p.y0 = y0; p.y1 = y1;
     p.ratio = (float)(((double)H * (double)W) / ((double)Hu * (double)Wu));
     p.Prow0 = pw.row0; p.Prows = pw.rows; p.Orow0 = ow.row0; p.Orows = ow.rows;
-    p.acts = nullptr; p.npix = 0; p.seed_cols = 0;
+    p.acts = nullptr; p.npix = 0; p.seed_cols = 0; p.xcd_runs = 0;
 #ifdef DIINN_STAMPS
     p.stamps = g_stamps;
 #endif
@@ -724,7 +724,7 @@ int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed
     p.B = B; p.H = H; p.W = W; p.Hu = Hu; p.Wu = Wu; p.y0 = 0; p.y1 = Hu;
     p.ratio = (float)(((double)H * (double)W) / ((double)Hu * (double)Wu));
     p.Prow0 = 0; p.Prows = H; p.Orow0 = 0; p.Orows = Hu;
-    p.acts = acts_dev; p.npix = npix; p.seed_cols = 0;
+    p.acts = acts_dev; p.npix = npix; p.seed_cols = 0; p.xcd_runs = 0;
 #ifdef DIINN_STAMPS
     p.stamps = nullptr;
 #endif
