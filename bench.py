@@ -50,6 +50,9 @@ WORKLOADS = {
     "c4": ((1024, 1024), (8192, 8192), "c4: 1024x1024 LR, x8 decode -> 8192x8192 HR"),
     "c5": ((720, 1280), (2376, 4224), "c5: 720x1280 LR, x3.3 decode -> 2376x4224 HR"),
 }
+_M = "decoded Mpixels/sec (DIINN implicit decoder, %s)"
+METRIC = {"c1": _M % "x2 on 48^2 LR", "c2": _M % "x4 on 256^2 LR", "c3": _M % "x4 on 512^2 LR",
+          "tgt": _M % "x4 on 1024^2 LR", "c4": _M % "x8 on 1024^2 LR", "c5": _M % "x3.3 on 720x1280 LR"}
 FLOP_DECODE_PER_PX = 789_504.0        # 3 stacked 512x256 layers + Q0 + head, 2*MAC
 FLOP_P_PER_CELL = 1_179_648.0         # hoisted 3x3 conv 64 -> 1024, 2*MAC
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -74,6 +77,16 @@ def parse():
     ap.add_argument("--dist-mode", choices=["halo", "bcast"], default="halo")
     ap.add_argument("--gather", action="store_true", help="also time assembling the image on rank 0 (reported "
                                                            "as gather_ms, never part of value)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL over xGMI (one rank per GPU).  gloo: messages staged through pinned host memory; "
+                         "with DIINN_BENCH_ONE_DEVICE=1 all ranks share cuda:0, which is how every N>1 branch is "
+                         "exercised on a one-GPU box (RCCL refuses two ranks on one device) -- a test transport, "
+                         "its timings mean nothing")
+    ap.add_argument("--no-strong", action="store_true", help="N>1: skip the strong-scaling legs")
+    ap.add_argument("--strong-legs", default=None, help="N>1: comma-separated workloads of the strong-scaling legs "
+                                                          "(default by N: tgt+c3 at 2/4, tgt+c4 at 8)")
+    ap.add_argument("--strong-steps", type=int, default=3)
+    ap.add_argument("--no-target", action="store_true", help="N=1: skip the two extra steps at the target shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args()
@@ -210,125 +223,165 @@ def pct(xs, q):
     return xs[i]
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run, one rank "
-                         f"per GPU, and pass the same N as --gpus")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU: the DIINN decode path has no CPU implementation")
-    if os.environ.get("DIINN_BENCH_ONE_DEVICE") == "1":   # test hook: every rank on cuda:0 (exercises the N>1 code path
-        local_rank = 0                                    # on a one-GPU box when the collective library permits it)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or "RANK" in os.environ     # launched by torch.distributed.run: one rank per GPU
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        dist.barrier()           # first RCCL call is a plain collective on every rank
+class Job:
+    """Process-wide state of one bench.py run: ranks, device, collective backend, library handles."""
 
-    import diinn_amd._native as N
-    import diinn_amd.decoder as D
-    import diinn_amd.sharded as S
-    import diinn_amd.synth as synth
+    def __init__(self, args):
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch N>1 with torch.distributed.run, "
+                             f"one rank per GPU, and pass the same N as --gpus")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU: the DIINN decode path has no CPU implementation")
+        if os.environ.get("DIINN_BENCH_ONE_DEVICE") == "1":   # test hook: every rank on cuda:0 (with --backend gloo this
+            local_rank = 0                                    # runs every N>1 branch on a one-GPU box)
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.use_dist = self.world > 1 or "RANK" in os.environ     # launched by torch.distributed.run
+        self.gloo = args.backend == "gloo"
+        if self.use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            if self.gloo:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            dist.barrier()           # first RCCL call is a plain collective on every rank
 
-    lib = N.load()
-    sin_mode = {"accurate": N.SIN_ACCURATE, "hw": N.SIN_HW, "hw_reduced": N.SIN_HW_REDUCED,
-                "default": N.SIN_DEFAULT}[args.sin]
-    sin_name = {N.SIN_ACCURATE: "accurate", N.SIN_HW: "hw", N.SIN_HW_REDUCED: "hw_reduced"}[sin_mode]
-    comp = N.COMPUTE[args.compute]
-    sd = synth.decoder_state_dict(123)
-    packed = D.pack_state_dict(sd).to(dev)
+        import diinn_amd._native as N
+        import diinn_amd.decoder as D
+        import diinn_amd.sharded as S
+        import diinn_amd.synth as synth
+        self.N, self.D, self.S, self.synth = N, D, S, synth
+        self.lib = N.load()
+        self.sin_mode = {"accurate": N.SIN_ACCURATE, "hw": N.SIN_HW, "hw_reduced": N.SIN_HW_REDUCED,
+                         "default": N.SIN_DEFAULT}[args.sin]
+        self.sin_name = {N.SIN_ACCURATE: "accurate", N.SIN_HW: "hw", N.SIN_HW_REDUCED: "hw_reduced"}[self.sin_mode]
+        self.comp = N.COMPUTE[args.compute]
+        self.sd = synth.decoder_state_dict(123)
+        self.packed = D.pack_state_dict(self.sd).to(self.dev)
 
-    (h1, w1), (hu1, wu1), wl_label = WORKLOADS[args.workload]
-    mult = world if args.scaling == "weak" else 1
+    # collectives of the harness itself (timing / verdict exchange): host tensors on gloo, device tensors on RCCL
+    def _t(self, vals):
+        return torch.tensor(vals, dtype=torch.float64, device="cpu" if self.gloo else self.dev)
+
+    def reduce_max(self, vals):
+        if not self.use_dist:
+            return [float(v) for v in vals]
+        t = self._t(vals)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.cpu()]
+
+    def bcast_from0(self, t64):
+        """float64 device tensor, published by rank 0."""
+        if not self.use_dist:
+            return t64
+        if self.gloo:
+            h = t64.cpu()
+            dist.broadcast(h, src=0)
+            return h.to(t64.device)
+        dist.broadcast(t64, src=0)
+        return t64
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+
+def run_workload(job, name, scaling, steps, warmup, solo=False, check=True, gather=False):
+    """Time ``steps`` steps of one workload.  ``solo``: rank 0 decodes the whole image alone (the same-run one-GPU
+    reference of a strong-scaling leg) while the other ranks wait at the barriers.  Returns a dict on every rank
+    (timings are this rank's, ``elapsed`` the max over ranks)."""
+    args, N, S, lib, dev = job.args, job.N, job.S, job.lib, job.dev
+    world = 1 if solo else job.world
+    rank = job.rank
+    idle = solo and rank != 0
+    (h1, w1), (hu1, wu1), wl_label = WORKLOADS[name]
+    mult = world if scaling == "weak" else 1
     H, W, HU, WU = h1 * mult, w1, hu1 * mult, wu1
     shape = (1, 64, H, W)
+    res = {"H": H, "W": W, "HU": HU, "WU": WU, "label": wl_label, "world": world}
+    if idle:
+        job.barrier()
+        job.barrier()
+        res["elapsed"] = job.reduce_max([0.0])[0]
+        if check:
+            job.reduce_max([0.0, 0.0])
+        return res
+
     # rank 0 holds the encoder output (synthetic, seeded); every other rank only ever sees the rows handed to it
     feat = None
     if rank == 0:
         gen = torch.Generator(device=dev)
         gen.manual_seed(123)
         feat = torch.randn(shape, device=dev, generator=gen)
-
-    dec = S.BandDecoder(shape, (HU, WU), packed, src=0, mode=args.dist_mode, sin_mode=sin_mode, compute=args.compute)
+    dec = S.BandDecoder(shape, (HU, WU), job.packed, src=0, mode=args.dist_mode, sin_mode=job.sin_mode,
+                        compute=args.compute, solo=solo)
     bd = dec.band
     if bd.empty:
         raise SystemExit("more ranks than HR rows")
     stream = torch.cuda.current_stream().cuda_stream
     mk = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
-    ev = [(mk(), mk(), mk(), mk()) for _ in range(args.steps)]
+    ev = [(mk(), mk(), mk(), mk()) for _ in range(steps)]
+    packed = job.packed
 
     def step(i=None):
         if i is not None:
             ev[i][0].record()
-        win, row0 = dec.handoff(feat)
+        win, row0 = dec.handoff(feat)            # rank 0: sends started on the side stream, not awaited
         if i is not None:
             ev[i][1].record()
         N.check(lib.diinn_precompute_P_win(C.c_void_p(stream), C.c_void_p(win.data_ptr()), row0, win.shape[2],
                                            C.c_void_p(packed.data_ptr()), C.c_void_p(dec.p_win.data_ptr()),
-                                           bd.r0, bd.r1 - bd.r0, 1, H, W, bd.r0, bd.r1, comp), "diinn_precompute_P_win")
+                                           bd.r0, bd.r1 - bd.r0, 1, H, W, bd.r0, bd.r1, job.comp), "diinn_precompute_P_win")
         if i is not None:
             ev[i][2].record()
         N.check(lib.diinn_decode_band_win(C.c_void_p(stream), C.c_void_p(dec.p_win.data_ptr()), bd.r0, bd.r1 - bd.r0,
                                           C.c_void_p(packed.data_ptr()), C.c_void_p(dec.out_band.data_ptr()),
-                                          bd.y0, bd.y1 - bd.y0, 1, H, W, HU, WU, bd.y0, bd.y1, sin_mode, comp),
+                                          bd.y0, bd.y1 - bd.y0, 1, H, W, HU, WU, bd.y0, bd.y1, job.sin_mode, job.comp),
                 "diinn_decode_band_win")
         if i is not None:
             ev[i][3].record()
+        dec.complete()                           # order the stream behind the sends (after the kernels are queued)
         return win, row0
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+    for _ in range(warmup):
+        win, row0 = step()
+    job.barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         win, row0 = step(i)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+    job.barrier()
     elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # per-step HIP-event durations on the launch stream (this rank)
-    step_ms = [e[0].elapsed_time(e[3]) for e in ev]
-    hand_ms = [e[0].elapsed_time(e[1]) for e in ev]
-    p_ms = [e[1].elapsed_time(e[2]) for e in ev]
-    k_ms_all = [e[2].elapsed_time(e[3]) for e in ev]
-    k_ms = sum(k_ms_all) / max(len(k_ms_all), 1)
-    px_launch = (bd.y1 - bd.y0) * WU
-    achieved = FLOP_DECODE_PER_PX * px_launch / (k_ms * 1e-3) / 1e12
-    p_mean = sum(p_ms) / max(len(p_ms), 1)
-    p_tflops = FLOP_P_PER_CELL * (bd.r1 - bd.r0) * W / (p_mean * 1e-3) / 1e12
-    # the library runs the fp32 hoisted conv in Winograd F(2x2,3x3) form (csrc/diinn_precompute.hip:
-    # launch_P): 2.25x fewer MFMAs than the direct-convolution FLOPs counted in `tflops`
-    p_wino = args.compute != "bf16_full"
+    res["elapsed"] = job.reduce_max([elapsed])[0] if not solo else elapsed
+    if solo:
+        job.reduce_max([elapsed])                # pairs with the idle ranks' call
+    res.update(
+        bd=bd, dec=dec,
+        step_ms=[e[0].elapsed_time(e[3]) for e in ev],
+        hand_ms=[e[0].elapsed_time(e[1]) for e in ev],
+        p_ms=[e[1].elapsed_time(e[2]) for e in ev],
+        k_ms_all=[e[2].elapsed_time(e[3]) for e in ev],
+    )
 
     # ---- the output that was timed, against the oracle (outside the timed region)
-    checked = None
-    if not args.no_check:
+    if check:
         # transport check: rank 0 publishes (sum, sum of squares) of every rank's window in float64; each rank
         # recomputes them on what it received (the same reduction on the same values on the same kind of device)
         handoff_ok = True
-        if use_dist and world > 1:
+        if job.use_dist and world > 1:
             sums = torch.zeros((world, 2), device=dev, dtype=torch.float64)
             if rank == 0:
                 for r, b2 in enumerate(dec.bands):
                     if not b2.empty:
                         w64 = feat[:, :, b2.a0:b2.a1].double()
                         sums[r, 0], sums[r, 1] = w64.sum(), (w64 * w64).sum()
-            dist.broadcast(sums, src=0)
+            sums = job.bcast_from0(sums)
             lo = bd.a0 - row0
             mine = win[:, :, lo:lo + bd.a1 - bd.a0].double()
             got = torch.stack([mine.sum(), (mine * mine).sum()])
@@ -341,43 +394,130 @@ def main():
         win_cpu = win[:, :, lo:lo + bd.a1 - bd.a0].cpu()       # the rows this rank actually decoded from
         out_cpu = dec.out_band.cpu()
         torch.set_num_threads(effective_cores())
-        err, ok = check_band_rows(sd, win_cpu, bd.a0, H, (HU, WU), out_cpu, bd.y0, rows_list, args.compute)
+        err, ok = check_band_rows(job.sd, win_cpu, bd.a0, H, (HU, WU), out_cpu, bd.y0, rows_list, args.compute)
         ok = ok and handoff_ok
-        if use_dist:
-            t = torch.tensor([err, 0.0 if ok else 1.0], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            err, ok = float(t[0].item()), float(t[1].item()) == 0.0
-        checked = {"rows": [list(r) for r in rows_list], "rows_of": "rank 0's band; every rank checks its own",
-                   "max_err": err, "tol": f"{CHECK_TOL[args.compute][0]:g} x max(1,|ref|)" if CHECK_TOL[args.compute][1]
-                   else f"{CHECK_TOL[args.compute][0]:g} x max|ref|", "handoff_exact": handoff_ok, "ok": ok}
+        err, bad = job.reduce_max([err, 0.0 if ok else 1.0])
+        tol = CHECK_TOL[args.compute]
+        res["checked"] = {"rows": [list(r) for r in rows_list], "rows_of": "rank 0's band; every rank checks its own",
+                          "max_err": err, "tol": f"{tol[0]:g} x max(1,|ref|)" if tol[1] else f"{tol[0]:g} x max|ref|",
+                          "handoff_exact": handoff_ok, "ok": bad == 0.0}
 
-    gather_ms = None
-    if args.gather:
+    if gather:
         full = torch.empty((1, 3, HU, WU), device=dev) if rank == 0 else None
         for _ in range(2):
             dec.gather(dec.out_band, dst=0, out=full)
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
+        job.barrier()
         tg = time.perf_counter()
         for _ in range(5):
             dec.gather(dec.out_band, dst=0, out=full)
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        gather_ms = (time.perf_counter() - tg) / 5 * 1e3
+        job.barrier()
+        res["gather_ms"] = (time.perf_counter() - tg) / 5 * 1e3
+        if check and rank == 0:                  # the assembled image holds rank 0's own band and the last band intact
+            last = dec.bands[-1]
+            res["gather_ok"] = bool(torch.equal(full[:, :, bd.y0:bd.y1], dec.out_band)) and \
+                bool(torch.isfinite(full[:, :, last.y0:last.y1]).all())
+    res["feat"] = feat
+    return res
+
+
+STRONG_LEGS = {2: ["tgt", "c3"], 4: ["tgt", "c3"], 8: ["tgt", "c4"]}      # north_star target; BASELINE c3 (2, 4), c4 (8)
+
+
+def strong_legs(job):
+    """For N > 1: ONE image split into N row bands against the same image decoded by rank 0 alone in the same run
+    (the north_star's ">= 6x tile-parallel scaling at 8 GPUs" is a strong-scaling claim; the headline is weak)."""
+    args = job.args
+    names = args.strong_legs.split(",") if args.strong_legs else STRONG_LEGS.get(job.world, ["tgt"])
+    legs = []
+    for name in [n for n in names if n]:
+        steps = args.strong_steps
+        many = run_workload(job, name, "strong", steps, 1, check=not args.no_check, gather=args.gather)
+        hand = job.reduce_max([statistics.median(many["hand_ms"])])[0]       # the slowest receiver
+        kern = job.reduce_max([statistics.median(many["step_ms"])])[0]
+        checked = many.get("checked")
+        ms_n = many["elapsed"] / steps * 1e3
+        del many
+        torch.cuda.empty_cache()
+        one = run_workload(job, name, "strong", steps, 1, solo=True, check=False)
+        ms_1 = job.reduce_max([one["elapsed"] / steps * 1e3])[0]
+        del one
+        torch.cuda.empty_cache()
+        (h, w), (hu, wu), label = WORKLOADS[name]
+        leg = {"workload": name, "what": label, "n_gpus": job.world, "steps": steps,
+               "ms_1gpu": round(ms_1, 4), "ms_Ngpu": round(ms_n, 4),
+               "speedup": round(ms_1 / ms_n, 3), "efficiency": round(ms_1 / ms_n / job.world, 4),
+               "handoff_ms": round(hand, 4), "slowest_band_ms": round(kern, 4),
+               "mpix_s_Ngpu": round(hu * wu / ms_n / 1e3, 2),
+               "note": "ms = wall per step between barriers, max over ranks; handoff_ms = slowest rank's median "
+                       "HIP-event time in the hand-off (receivers wait for their rows; rank 0 overlaps its sends)"}
+        if checked is not None:
+            leg["checked_ok"] = checked["ok"]
+            leg["max_err"] = checked["max_err"]
+        legs.append(leg)
+    return legs
+
+
+def main():
+    args = parse()
+    job = Job(args)
+    world, rank = job.world, job.rank
+    N = job.N
+
+    r = run_workload(job, args.workload, args.scaling, args.steps, args.warmup, check=not args.no_check,
+                     gather=args.gather)
+    elapsed, bd = r["elapsed"], r["bd"]
+    H, W, HU, WU, wl_label = r["H"], r["W"], r["HU"], r["WU"], r["label"]
+    (h1, w1), (hu1, wu1), _ = WORKLOADS[args.workload]
+    step_ms, hand_ms, p_ms, k_ms_all = r["step_ms"], r["hand_ms"], r["p_ms"], r["k_ms_all"]
+    checked, gather_ms = r.get("checked"), r.get("gather_ms")
+    feat_cpu = r["feat"].cpu() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    hand_max = job.reduce_max([statistics.median(hand_ms)])[0]
+    # which form of the hoisted conv the library ran for this launch (diinn_p_launch_info: env overrides included)
+    p_algo = C.c_int(0)
+    N.check(job.lib.diinn_p_launch_info(1, H, W, bd.r0, bd.r1, job.comp, C.byref(p_algo)), "diinn_p_launch_info")
+    p_wino = p_algo.value == N.P_ALGO_WINOGRAD
+    del r
+    torch.cuda.empty_cache()
+
+    strong = None
+    if world > 1 and not args.no_strong:
+        strong = strong_legs(job)
+    target = None
+    if world == 1 and args.workload == "c2" and args.compute == "f32" and not args.no_target:
+        # the north_star's target shape (1024^2 -> 4096^2 on one GPU) timed by the same run: 1 warm-up + 2 steps
+        t = run_workload(job, "tgt", "strong", 2, 1, check=False)
+        t_k = sum(t["k_ms_all"]) / len(t["k_ms_all"])
+        t_ach = FLOP_DECODE_PER_PX * 4096 * 4096 / (t_k * 1e-3) / 1e12
+        target = {"workload": WORKLOADS["tgt"][2], "steps": 2, "ms": round(t["elapsed"] / 2 * 1e3, 3),
+                  "mpix_s": round(4096 * 4096 / (t["elapsed"] / 2) / 1e6, 2), "kernel_ms": round(t_k, 3),
+                  "achieved": round(t_ach, 2), "frac": round(t_ach / PEAK_F32_MFMA_TFLOPS, 4),
+                  "p_kernel_ms": round(sum(t["p_ms"]) / len(t["p_ms"]), 3),
+                  "note": "decode_kernel's share of the fp32 MFMA peak at the target shape; parity at this size: "
+                          "tests/test_gpu_configs.py::test_target_1024_x4"}
+        del t
+        torch.cuda.empty_cache()
+
+    k_ms = sum(k_ms_all) / max(len(k_ms_all), 1)
+    px_launch = (bd.y1 - bd.y0) * WU
+    achieved = FLOP_DECODE_PER_PX * px_launch / (k_ms * 1e-3) / 1e12
+    p_mean = sum(p_ms) / max(len(p_ms), 1)
+    p_tflops = FLOP_P_PER_CELL * (bd.r1 - bd.r0) * W / (p_mean * 1e-3) / 1e12
 
     if rank == 0:
         total_px = HU * WU
         ms_per_step = elapsed / args.steps * 1e3
         bf = args.compute != "f32"
         peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
+        p_peak = PEAK_BF16_MFMA_TFLOPS if args.compute == "bf16_full" else PEAK_F32_MFMA_TFLOPS
         if args.scaling == "weak":
             wl = (f"{wl_label} per GPU, {HU}x{WU} HR total ({world} row band(s) of {hu1}x{WU}), B=1, mode=3")
         else:
             wl = (f"{wl_label}, split into {world} HR row band(s) of ~{HU // world}x{WU}, B=1, mode=3")
+        traffic, traffic_source = (load_traffic(), "profiles/decode_kernel_traffic.json: separate rocprofv3 --pmc "
+                                   "passes of this command, committed; not measured in this run") \
+            if (not bf and args.workload == "c2" and world == 1) else (None, None)
         res = {
-            "metric": "decoded Mpixels/sec (DIINN implicit decoder, x4 on 256^2 LR)",
+            "metric": METRIC[args.workload],
             "value": round(total_px * args.steps / elapsed / 1e6, 3),
             "unit": "Mpixels/s",
             "n_gpus": world,
@@ -391,13 +531,16 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": wl, "name": args.workload,
-                "lr": [H, W], "hr": [HU, WU], "sin": sin_name,
-                "parallelism": f"hr-row-bands x{world}" + (f" ({args.dist_mode} feature hand-off)" if world > 1 else ""),
-                "step": "feature hand-off (N>1) + precompute_P + decode_kernel, band-sized buffers",
+                "lr": [H, W], "hr": [HU, WU], "sin": job.sin_name,
+                "parallelism": f"hr-row-bands x{world}" + (f" ({args.dist_mode} feature hand-off, {args.backend})"
+                                                           if world > 1 else ""),
+                "step": "feature hand-off (N>1; rank 0's sends overlap its own band) + precompute_P + decode_kernel, "
+                        "band-sized buffers",
             },
             "step_ms": {"min": round(min(step_ms), 4), "median": round(statistics.median(step_ms), 4),
                         "p90": round(pct(step_ms, 0.9), 4), "mean_wall": round(ms_per_step, 4),
-                        "handoff_median": round(statistics.median(hand_ms), 4), "of": "rank 0, HIP events"},
+                        "handoff_median": round(statistics.median(hand_ms), 4),
+                        "handoff_median_slowest_rank": round(hand_max, 4), "of": "rank 0, HIP events"},
             "roofline": {
                 "bound": "mfma",
                 "kernel": "decode_kernel" if not bf else "decode_bf16 kernel",
@@ -408,14 +551,16 @@ def main():
                 "kernel_ms": round(k_ms, 4),
                 "kernel_ms_min": round(min(k_ms_all), 4),
                 "flop_per_launch": FLOP_DECODE_PER_PX * px_launch,
-                "traffic": load_traffic() if (not bf and args.workload == "c2" and world == 1) else None,
-                "p_kernel": {"ms": round(p_mean, 4), "ms_min": round(min(p_ms), 4), "tflops": round(p_tflops, 2),
-                             "frac": round(p_tflops / (PEAK_BF16_MFMA_TFLOPS if args.compute == "bf16_full"
-                                                       else PEAK_F32_MFMA_TFLOPS), 4),
+                "traffic": traffic,
+                "traffic_source": traffic_source,
+                "p_kernel": {"ms": round(p_mean, 4), "ms_min": round(min(p_ms), 4),
                              "algorithm": "winograd F(2x2,3x3)" if p_wino else "direct",
-                             "mfma_frac": round(p_tflops / (2.25 if p_wino else 1.0) /
-                                                (PEAK_BF16_MFMA_TFLOPS if args.compute == "bf16_full" else PEAK_F32_MFMA_TFLOPS), 4),
-                             "note": "tflops / frac count direct-convolution FLOPs; mfma_frac = MFMA work actually issued / peak"},
+                             "frac": round(p_tflops / (2.25 if p_wino else 1.0) / p_peak, 4),
+                             "direct_equiv_tflops": round(p_tflops, 2),
+                             "direct_equiv_frac": round(p_tflops / p_peak, 4),
+                             "note": "frac = MFMA work actually issued / peak (the roofline fraction); direct_equiv_* "
+                                     "count the 1,179,648 direct-convolution FLOP per cell the Winograd form avoids "
+                                     "2.25x of -- a speed figure, not a utilisation"},
             },
         }
         if bf:
@@ -434,13 +579,20 @@ def main():
             res["checked"] = checked
         if gather_ms is not None:
             res["gather_ms"] = round(gather_ms, 4)
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sd, feat.cpu(), (HU, WU), args.workload)
+        if target is not None:
+            res["target_shape"] = target
+        if strong is not None:
+            res["strong"] = strong
+        if feat_cpu is not None:
+            res["cpu_baseline"] = cpu_baseline(job.sd, feat_cpu, (HU, WU), args.workload)
         print(json.dumps(res), flush=True)
-    if use_dist:
+    if job.use_dist:
+        dist.barrier()
         dist.destroy_process_group()
-    if checked is not None and not checked["ok"]:
-        raise SystemExit(f"bench.py: timed output failed the oracle check: {checked}")
+    failed = (checked is not None and not checked["ok"]) or \
+        any(not leg.get("checked_ok", True) for leg in (strong or []))
+    if failed:
+        raise SystemExit(f"bench.py: timed output failed the oracle check: {checked} {strong}")
 
 
 if __name__ == "__main__":

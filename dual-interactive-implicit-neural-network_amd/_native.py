@@ -22,7 +22,9 @@ SIN_HW_REDUCED = 2
 # default: 2-term reduction in revolutions + v_sin_f32 (max abs error 2.5e-7 for |x| <= 1e4, measured in
 # tests/test_gpu_parity.py::test_device_sine_accuracy); SIN_ACCURATE (1e-7) costs ~4 % more time
 SIN_DEFAULT = SIN_HW_REDUCED
-ABI_VERSION = 5
+ABI_VERSION = 6
+PACKED_MAGIC = 0x44493036
+P_ALGO_DIRECT, P_ALGO_WINOGRAD, P_ALGO_DIRECT_BF16 = 0, 1, 2
 COMPUTE_F32 = 0
 COMPUTE_BF16 = 1
 COMPUTE_F32_QONLY = 2
@@ -70,6 +72,9 @@ SIGNATURES = {
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_cell_chain": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_decode_launch_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip]),
+    "diinn_p_launch_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
+    "diinn_debug_set": (C.c_int, [C.c_char_p, C.c_longlong]),
+    "diinn_debug_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_longlong)]),
     "diinn_metasr_packed_floats": (C.c_size_t, []),
     "diinn_metasr_pack_weights": (C.c_int, [_f, _f, _f, _f, _f]),
     "diinn_metasr_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -148,6 +153,17 @@ def check(status: int, what: str) -> None:
         msg = lib.diinn_status_string(status).decode()
         extra = f" (hipError_t {lib.diinn_last_hip_error()})" if status == 3 else ""
         raise DiinnNativeError(f"{what} failed: {msg}{extra}")
+
+
+def debug_set(name: str, value: int) -> None:
+    """Force a kernel-variant choice in-process (tests, A/B timing): include/diinn_hip.h "diagnostic overrides"."""
+    check(load().diinn_debug_set(name.encode(), int(value)), f"diinn_debug_set({name})")
+
+
+def debug_get(name: str) -> int:
+    v = C.c_longlong()
+    check(load().diinn_debug_get(name.encode(), C.byref(v)), f"diinn_debug_get({name})")
+    return v.value
 
 
 def fptr(arr):

@@ -120,12 +120,18 @@ __global__ __launch_bounds__(256, 1) void liif_kernel(const LiifParams p) {
                     if (m > 0 && (kg & 1) == 0) {
                         const int r = kg >> 1;
                         qn[16 * (m - 1) + r] = relu0(ps[r]);
+                        // opaque use: keeps each rectification where it is written, between the MFMAs.  Left free, the
+                        // scheduler regroups the 128 of them and the layer needs 954 registers more than exist (r02).
+                        asm volatile("" : "+v"(qn[16 * (m - 1) + r]));
                     }
                 }
                 ps = as;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) qn[16 * 7 + r] = relu0(ps[r]);
+            for (int r = 0; r < 16; ++r) {
+                qn[16 * 7 + r] = relu0(ps[r]);
+                asm volatile("" : "+v"(qn[16 * 7 + r]));
+            }
 #pragma unroll
             for (int i = 0; i < 128; ++i) q[i] = qn[i];
             wp += (int)(WL_LAYER * sizeof(float));

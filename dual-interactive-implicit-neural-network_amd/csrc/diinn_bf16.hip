@@ -161,9 +161,10 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_kernel(const DecodeParams 
     if (valid && h == 0) {
         const size_t plane = (size_t)p.Orows * p.Wu;
         float* o = p.out + (size_t)b * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
-        o[0] = o0 + Wt[OFF_BL + 0];
-        o[plane] = o1 + Wt[OFF_BL + 1];
-        o[2 * plane] = o2 + Wt[OFF_BL + 2];
+        const unsigned nanm = derived_nan_mask(Wt);
+        o[0] = o0 + or_bits(Wt[OFF_BL + 0], nanm);
+        o[plane] = o1 + or_bits(Wt[OFF_BL + 1], nanm);
+        o[2 * plane] = o2 + or_bits(Wt[OFF_BL + 2], nanm);
     }
 }
 
@@ -320,7 +321,10 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x2_kernel(const DecodeParam
                 if (m > 0) {                                      // one epilogue element of tile m-1 per k-step, both pixel tiles
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        const float v = relu0(pk[t][ks]) * dsin_rev<SIN_MODE>(ps[t][ks]);
+                        float v = relu0(pk[t][ks]) * dsin_rev<SIN_MODE>(ps[t][ks]);
+                        // opaque use: the element stays behind its k-step.  Without it the scheduler gathers the
+                        // epilogue of a tile into one clump and spills ~360 registers (r02; tests/test_kernel_resources.py)
+                        asm volatile("" : "+v"(v));
                         if (LAST) {
                             o[t][0] = __builtin_fmaf(l0[ks >> 2][ks & 3], v, o[t][0]);
                             o[t][1] = __builtin_fmaf(l1[ks >> 2][ks & 3], v, o[t][1]);
@@ -379,9 +383,10 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x2_kernel(const DecodeParam
         if (valid[t] && h == 0) {
             const size_t plane = (size_t)p.Orows * p.Wu;
             float* op = p.out + (size_t)b * 3 * plane + (size_t)(y[t] - p.Orow0) * p.Wu + x;
-            op[0] = o0 + Wt[OFF_BL + 0];
-            op[plane] = o1 + Wt[OFF_BL + 1];
-            op[2 * plane] = o2 + Wt[OFF_BL + 2];
+            const unsigned nanm = derived_nan_mask(Wt);
+            op[0] = o0 + or_bits(Wt[OFF_BL + 0], nanm);
+            op[plane] = o1 + or_bits(Wt[OFF_BL + 1], nanm);
+            op[2 * plane] = o2 + or_bits(Wt[OFF_BL + 2], nanm);
         }
     }
 }
@@ -547,7 +552,8 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_coop_kernel(const DecodePa
         *(f32x4*)(q0tab + 4 * threadIdx.x) = tq;
         if (threadIdx.x < 3 * HID / 4) *(f32x4*)(bias + 4 * threadIdx.x) = tb;
     }
-    const float bl0 = Wt[OFF_BL + 0], bl1 = Wt[OFF_BL + 1], bl2 = Wt[OFF_BL + 2];   // head bias, needed at the very end
+    const unsigned nanm = derived_nan_mask(Wt);
+    const float bl0 = or_bits(Wt[OFF_BL + 0], nanm), bl1 = or_bits(Wt[OFF_BL + 1], nanm), bl2 = or_bits(Wt[OFF_BL + 2], nanm);   // head bias, needed at the very end
     CO_STAMP(14);
     __syncthreads();
     CO_STAMP(15);
@@ -893,7 +899,8 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8_kernel(const DecodeP
             *(f32x4*)(seed0 + (wave + 8 * i) * CO_SEED_PITCH + 4 * lane) = s0[i];
         stage_store();
     }
-    const float bl0 = Wt[OFF_BL + 0], bl1 = Wt[OFF_BL + 1], bl2 = Wt[OFF_BL + 2];
+    const unsigned nanm = derived_nan_mask(Wt);
+    const float bl0 = or_bits(Wt[OFF_BL + 0], nanm), bl1 = or_bits(Wt[OFF_BL + 1], nanm), bl2 = or_bits(Wt[OFF_BL + 2], nanm);
     CO_STAMP(14);
     __syncthreads();
     CO_STAMP(15);
@@ -1058,7 +1065,9 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8_kernel(const DecodeP
     CO_STAMP(12);
 }
 
-// cells of the LR footprint of the widest 16 x 8 block of the launch: (columns, rows)
+// cells of the LR footprint of the widest 16 x 8 pixel block: (columns, rows).  Rows: the maximum over EVERY start
+// row of the full image, not over the blocks of the band at hand (they are anchored at y0), so that the kernel choice
+// below is the same for a band and for the whole image.
 static void coop_footprint(const DecodeParams& p, int& ncx, int& ncy) {
     ncx = ncy = 1;
     int a, b2;
@@ -1069,12 +1078,18 @@ static void coop_footprint(const DecodeParams& p, int& ncx, int& ncy) {
         axis_eval(p.aw, xl, b2, rel);
         ncx = b2 - a + 1 > ncx ? b2 - a + 1 : ncx;
     }
-    for (int y = p.y0; y < p.y1; y += 2 * TILE_H) {
-        const int yl = y + 2 * TILE_H - 1 < p.y1 ? y + 2 * TILE_H - 1 : p.y1 - 1;
-        axis_eval(p.ah, y, a, rel);
-        axis_eval(p.ah, yl, b2, rel);
-        ncy = b2 - a + 1 > ncy ? b2 - a + 1 : ncy;
+    static thread_local int key_h = -1, key_hu = -1, key_small = -1, cached = 1;
+    if (key_h != p.H || key_hu != p.Hu || key_small != p.ah.small_output) {
+        int m = 1;
+        for (int y = 0; y < p.Hu; ++y) {
+            const int yl = y + 2 * TILE_H - 1 < p.Hu ? y + 2 * TILE_H - 1 : p.Hu - 1;
+            axis_eval(p.ah, y, a, rel);
+            axis_eval(p.ah, yl, b2, rel);
+            m = b2 - a + 1 > m ? b2 - a + 1 : m;
+        }
+        key_h = p.H; key_hu = p.Hu; key_small = p.ah.small_output; cached = m;
     }
+    ncy = cached;
 }
 
 int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int gz, int sin_mode) {
@@ -1084,11 +1099,15 @@ int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int 
         // two pixel tiles per wave (half the weight bytes per MFMA) once the launch still fills the chip;
         // small images keep one tile per wave (twice the workgroups)
         const dim3 grid2(gx, (y1 - y0 + 2 * TILE_H * WG_TILES_Y - 1) / (2 * TILE_H * WG_TILES_Y), gz);   // 16 x 16 pixels per workgroup
-        const bool two_tiles = (long long)grid2.x * grid2.y * grid2.z >= 512;
+        // the choice between the variants is made from the FULL image (Hu rows), never from the band [y0,y1): the
+        // variants agree only to rounding (tests: 5e-4 x scale), and a row band of a multi-GPU split has to stitch
+        // bit-exactly into the same rows of an unsharded decode (sharded.py)
+        const long long full_gy = (p.Hu + TILE_H * WG_TILES_Y - 1) / (TILE_H * WG_TILES_Y);
+        const long long full_gy2 = (p.Hu + 2 * TILE_H * WG_TILES_Y - 1) / (2 * TILE_H * WG_TILES_Y);
+        const bool two_tiles = (long long)gx * full_gy2 * gz >= 512;
         // diagnostic override (tests / A-B timing): DIINN_BF16_KERNEL = 1 one tile per wave, 2 two tiles per wave,
         // 4 / 8 cooperative with 4 / 8 waves; unset = pick by launch size and scale
-        const char* fenv = getenv("DIINN_BF16_KERNEL");
-        const int force = fenv ? atoi(fenv) : 0;
+        const int force = (int)knob(diinn_knobs().bf16_kernel);
         // the cooperative kernel stages the P rows of a block's LR footprint in LDS: needs the footprint to fit
         // (scales from about x3 up), and >= 2 rounds of workgroups to be worth its prologue
         DecodeParams pc = p;
@@ -1098,7 +1117,7 @@ int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int 
         // a 16 x 8 block covers whole cells iff 16 / scale_x and 8 / scale_y are integers
         pc.xcd_runs = !((16LL * p.W) % p.Wu == 0 && (8LL * p.H) % p.Hu == 0);
         const bool coop_ok = ncx * ncy <= CO_SEED_CELLS;
-        const bool coop = coop_ok && (force ? (force == 4 || force == 8) : (long long)gx * gy * gz >= 1024);
+        const bool coop = coop_ok && (force ? (force == 4 || force == 8) : (long long)gx * full_gy * gz >= 1024);
         if (coop && force != 4) {                                 // 16 x 8 pixel blocks, 8 waves: the grid of the one-tile kernel
             if (sin_mode == DIINN_SIN_HW)
                 hipLaunchKernelGGL(decode_bf16_coop8_kernel<DIINN_SIN_HW>, grid, dim3(512), 0, (hipStream_t)stream, pc);

@@ -66,7 +66,11 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
             *(f32x4*)(tab + 4 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 1 * HID + 4 * i);
         } else {
             *(f32x4*)(tab + 5 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 2 * HID + 4 * i);
-            if (i == 0) *(f32x4*)(tab + 6 * HID) = *(const f32x4*)(p.Wt + OFF_BL);
+            if (i == 0) {                                        // bL + the image's validity word: inference reads derived
+                const f32x4 bl = *(const f32x4*)(p.Wt + OFF_BL); // sections, so an image without them decodes to NaN
+                const unsigned nanm = (SAVE || __builtin_bit_cast(unsigned, bl[3]) == DIINN_PACKED_MAGIC) ? 0u : 0x7fc00000u;
+                *(f32x4*)(tab + 6 * HID) = or_bits(bl, nanm);
+            }
         }
     }
     const int lane = threadIdx.x & 63;
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void decode_coop_kernel(const DecodeParams 
             *(f32x4*)(tab + 4 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 1 * HID + 4 * i);
         } else {
             *(f32x4*)(tab + 5 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 2 * HID + 4 * i);
-            if (i == 0) *(f32x4*)(tab + 6 * HID) = *(const f32x4*)(p.Wt + OFF_BL);
+            if (i == 0) *(f32x4*)(tab + 6 * HID) = or_bits(*(const f32x4*)(p.Wt + OFF_BL), derived_nan_mask(p.Wt));
         }
     }
     const int lane = threadIdx.x & 63;
@@ -626,8 +630,7 @@ static int decode_band_impl(void* stream, const float* P_dev, const float* packe
     }
     // small launches: the latency variant (4 waves share a tile): fewer than ~3/4 of a round of 16 x 8 workgroups.
     // DIINN_F32_KERNEL = 1 / 2 forces the throughput / latency kernel (tests, A-B timing).
-    const char* fenv = getenv("DIINN_F32_KERNEL");
-    const int force = fenv ? atoi(fenv) : 0;
+    const int force = (int)knob(diinn_knobs().f32_kernel);
     const dim3 gridc((Wu + TILE_W - 1) / TILE_W, (y1 - y0 + TILE_H - 1) / TILE_H, B);
     if (gridc.y <= 65535 && (force ? force == 2 : (long long)gx * gy * gz <= 192)) {
         if (sin_mode == DIINN_SIN_HW)

@@ -15,6 +15,7 @@
 
 #include "../../include/diinn_hip.h"
 #include "diinn_layout.h"
+#include "diinn_knobs.h"
 
 using namespace diinn;
 
@@ -157,12 +158,27 @@ constexpr int TILE_W = 8, TILE_H = 4;           // one wave: 8x4 HR pixels
 #define DECODE_PREFETCH 4                       // weight ring depth, in steps of 8 MFMAs
 #endif
 
-// relu as ONE v_max_f32.  The translation units are built with -fno-honor-nans, under which fmaxf(x, 0) needs no
-// canonicalising v_max in front.  (Round 1 used an inline-asm v_max here.  hipcc inserts no MFMA -> VALU wait states
-// in front of an asm statement, so an asm that reads an accumulator register straight after the MFMA that writes it
-// reads it too early: harmless while the accumulators sat in AGPRs and were read back long after, wrong results as
-// soon as a kernel with VGPR accumulators evaluated its epilogue right behind the MFMAs.)
-__device__ __forceinline__ float relu0(float x) { return __builtin_fmaxf(x, 0.0f); }
+// Validity word of the packed image (include/diinn_hip.h "VALIDITY WORD"): 0 when the derived sections are filled, the
+// quiet-NaN bit pattern otherwise.  OR-ing it into the bits of a float leaves the float alone or turns it into a NaN;
+// the inference kernels that read a derived section fold it into a bias they add to every output, outside their
+// inner loops.  Integer operations only: the translation units are built with -fno-honor-nans.
+__device__ __forceinline__ unsigned derived_nan_mask(const float* __restrict__ Wt) {
+    return __builtin_bit_cast(unsigned, Wt[OFF_BL + 3]) == DIINN_PACKED_MAGIC ? 0u : 0x7fc00000u;
+}
+__device__ __forceinline__ float or_bits(float v, unsigned m) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) | m);
+}
+__device__ __forceinline__ f32x4 or_bits(f32x4 v, unsigned m) {
+    return f32x4{or_bits(v[0], m), or_bits(v[1], m), or_bits(v[2], m), or_bits(v[3], m)};
+}
+
+// relu as ONE instruction that PROPAGATES NaN, like the reference's torch.relu (diinn.py:133-138: a NaN feature or
+// weight makes the output NaN there, and so it does here): llvm.maximum -> v_maximum3_f32 x, 0, 0, gfx950's
+// IEEE-754-2019 maximum.  (v_max_f32 returns the other operand for a NaN: relu would turn a NaN modulation value into
+// k = 0 and the pixel into a finite colour.  Rounds 1-2 used v_max_f32 -- first as inline asm, which gets no
+// MFMA -> VALU wait states from hipcc and read accumulators too early once a kernel evaluated its epilogue right behind
+// the MFMAs, then as fmaxf under -fno-honor-nans.)  The translation units are built WITHOUT -fno-honor-nans now.
+__device__ __forceinline__ float relu0(float x) { return __builtin_elementwise_maximum(x, 0.0f); }
 
 // Weight-stream loads go through a buffer descriptor: address = SGPR descriptor base + SGPR byte
 // offset (scalar unit) + one constant per-lane VGPR offset, so the stream costs no VALU address

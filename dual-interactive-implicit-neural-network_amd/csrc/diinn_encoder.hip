@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const ConvKsplit
 static bool conv1x1_stream_ok(const ConvKsplitParams& p) {
     const long long plane = (long long)p.H * p.W;
     auto a16 = [](const void* q) { return (((size_t)q) & 15) == 0; };
-    static const long long min_blocks = [] { const char* e = getenv("DIINN_ENC_S1_MIN_BLOCKS"); return e ? atoll(e) : 128LL; }();
+    const long long min_blocks = knob(diinn_knobs().enc_s1_min_blocks);
     return plane % 4 == 0 && p.Cin % 64 == 0 && (long long)p.B * ((plane + S1_PIX - 1) / S1_PIX) >= min_blocks &&
            plane * 4 * 64 <= 0x7FFFFFFFLL && a16(p.in) && a16(p.w) && a16(p.bias) && a16(p.out0) && a16(p.out1) && a16(p.res) &&
            p.in_bs % 4 == 0 && p.out0_bs % 4 == 0 && p.out1_bs % 4 == 0 && p.res_bs % 4 == 0;
@@ -545,8 +545,8 @@ static int launch_conv_ksplit(void* stream, const ConvKsplitParams& p_in, int ta
 #ifdef DIINN_STAMPS
     p.stamps = g_stamps;
 #endif
-    static const bool no_stream = getenv("DIINN_ENC_NO_STREAM1X1") != nullptr;   // A/B switches for tools/
-    static const int lat_max = [] { const char* e = getenv("DIINN_ENC_LAT_MAX_TILES"); return e ? atoi(e) : 256; }();
+    const bool no_stream = knob(diinn_knobs().enc_no_stream1x1) != 0;   // A/B switches for tools/
+    const int lat_max = (int)knob(diinn_knobs().enc_lat_max_tiles);
     const bool lat = tiles <= lat_max;                           // <= 2 workgroups per CU: about one wave per SIMD
     if (taps == 1 && !no_stream && conv1x1_stream_ok(p)) {
         const long long blocks = (long long)p.B * (((long long)p.H * p.W + S1_PIX - 1) / S1_PIX);
@@ -629,7 +629,7 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     const long long hw = (long long)H * W;
     // Winograd blocks are 16 x 8 pixels and a workgroup walks all input channels: faster than the split-K kernel from
     // about 90 x 90 pixels up (tools/r02_ab_env.sh: 96x96 3.6 vs 4.5 ms, 64x64 3.4 vs 2.1 ms per trunk)
-    static const long long wino_min = [] { const char* e = getenv("DIINN_ENC_WINO_MIN"); return e ? atoll(e) : 8192LL; }();
+    const long long wino_min = knob(diinn_knobs().enc_wino_min);
     const bool wino = packed_wino_dev && (long long)B * hw >= wino_min;
     float* buf[2] = {workspace_dev, workspace_dev + (size_t)B * 576 * hw};     // dense buffers [B,576,H,W]
     float* gff_in = workspace_dev + (size_t)2 * B * 576 * hw;                    // [B,1024,H,W]

@@ -5,10 +5,45 @@
 #include <cstring>
 #include <cstdint>
 
+#include <cstdlib>
+
 #include "../../include/diinn_hip.h"
 #include "diinn_layout.h"
+#include "diinn_knobs.h"
 
 using namespace diinn;
+
+// ---- diagnostic overrides (diinn_knobs.h): one table, read from the environment once ----------------------------
+namespace {
+struct KnobDef { const char* name; std::atomic<long long> DiinnKnobs::*field; long long dflt; bool presence; };
+const KnobDef KNOBS[] = {
+    {"DIINN_F32_KERNEL", &DiinnKnobs::f32_kernel, 0, false},
+    {"DIINN_BF16_KERNEL", &DiinnKnobs::bf16_kernel, 0, false},
+    {"DIINN_PBF16_KERNEL", &DiinnKnobs::pbf16_kernel, 0, false},
+    {"DIINN_P_KERNEL", &DiinnKnobs::p_kernel, 0, false},
+    {"DIINN_P_WINO_MIN", &DiinnKnobs::p_wino_min, 0, false},
+    {"DIINN_FUSE_MAX_BLOCKS", &DiinnKnobs::fuse_max_blocks, -1, false},
+    {"DIINN_ENC_S1_MIN_BLOCKS", &DiinnKnobs::enc_s1_min_blocks, 128, false},
+    {"DIINN_ENC_NO_STREAM1X1", &DiinnKnobs::enc_no_stream1x1, 0, true},
+    {"DIINN_ENC_LAT_MAX_TILES", &DiinnKnobs::enc_lat_max_tiles, 256, false},
+    {"DIINN_ENC_WINO_MIN", &DiinnKnobs::enc_wino_min, 8192, false},
+    {"DIINN_ENC_WINO_HALF_MAX", &DiinnKnobs::enc_wino_half_max, -1, false},
+    {"DIINN_ENC_WINO_PERSIST", &DiinnKnobs::enc_wino_persist, 256, false},
+};
+}  // namespace
+
+DiinnKnobs& diinn_knobs() {
+    static DiinnKnobs k;
+    static const bool once = [] {
+        for (const KnobDef& d : KNOBS) {
+            const char* e = std::getenv(d.name);
+            (k.*(d.field)).store(e ? (d.presence ? 1LL : std::atoll(e)) : d.dflt, std::memory_order_relaxed);
+        }
+        return true;
+    }();
+    (void)once;
+    return k;
+}
 
 static const float INV_2PI = 0.15915494309189533577f;      // fp32(1 / (2 pi))
 
@@ -36,6 +71,22 @@ const char* diinn_status_string(int status) {
 }
 
 size_t diinn_packed_weight_floats(void) { return PACKED_FLOATS; }
+
+int diinn_debug_set(const char* name, long long value) {
+    if (!name) return DIINN_ERR_INVALID_ARG;
+    DiinnKnobs& k = diinn_knobs();
+    for (const KnobDef& d : KNOBS)
+        if (!std::strcmp(name, d.name)) { (k.*(d.field)).store(value, std::memory_order_relaxed); return DIINN_OK; }
+    return DIINN_ERR_INVALID_ARG;
+}
+
+int diinn_debug_get(const char* name, long long* value) {
+    if (!name || !value) return DIINN_ERR_INVALID_ARG;
+    DiinnKnobs& k = diinn_knobs();
+    for (const KnobDef& d : KNOBS)
+        if (!std::strcmp(name, d.name)) { *value = (k.*(d.field)).load(std::memory_order_relaxed); return DIINN_OK; }
+    return DIINN_ERR_INVALID_ARG;
+}
 
 int diinn_liif_make_axis_tables(int n_in, int n_out, int v, int32_t* idx, float* rel, float* rel_cell) {
     if (n_in <= 0 || n_out <= 0 || (v != -1 && v != 1) || !idx || !rel) return DIINN_ERR_INVALID_ARG;
@@ -220,7 +271,9 @@ int diinn_pack_weights(const float* K0w, const float* K0b,
     for (int i = 0; i < 4 * HID; ++i) packed[OFF_Q0R + i] = q0[i] * INV_2PI;
     std::memcpy(packed + OFF_L, Lw, 3 * HID * sizeof(float));
     float* bl = packed + OFF_BL;
-    bl[0] = Lb[0]; bl[1] = Lb[1]; bl[2] = Lb[2]; bl[3] = 0.0f;
+    bl[0] = Lb[0]; bl[1] = Lb[1]; bl[2] = Lb[2];
+    const uint32_t magic = DIINN_PACKED_MAGIC;                  // validity word: this image holds its derived sections
+    std::memcpy(bl + 3, &magic, 4);
     // WLB: [layer][m][ks][part][lane][j] bf16
     uint16_t* wlb = reinterpret_cast<uint16_t*>(packed + OFF_WLB);
     for (int i = 0; i < 3; ++i)

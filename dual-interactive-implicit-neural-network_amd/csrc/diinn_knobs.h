@@ -1,0 +1,26 @@
+// diinn_knobs.h -- the diagnostic overrides of the launch functions, in ONE place.
+//
+// Every knob is read from the environment once, the first time any launch function asks (a thread-safe static
+// initialisation: no getenv on the launch path afterwards), and can be changed in-process through the test-only
+// C ABI pair diinn_debug_set / diinn_debug_get (include/diinn_hip.h).  0 / -1 = "not forced" as listed; none of
+// them changes results beyond the documented equivalences of the kernel variants (tests/test_gpu_parity.py).
+#pragma once
+#include <atomic>
+
+struct DiinnKnobs {
+    std::atomic<long long> f32_kernel;          // DIINN_F32_KERNEL: 1 throughput, 2 latency decode kernel (0: by launch size)
+    std::atomic<long long> bf16_kernel;         // DIINN_BF16_KERNEL: 1 / 2 tiles per wave, 4 / 8 cooperative waves (0: auto)
+    std::atomic<long long> pbf16_kernel;        // DIINN_PBF16_KERNEL: 1 narrow, 2 wide bf16 P kernel (0: auto)
+    std::atomic<long long> p_kernel;            // DIINN_P_KERNEL: 1 direct, 2 Winograd fp32 P kernel (0: auto)
+    std::atomic<long long> p_wino_min;          // DIINN_P_WINO_MIN: cells from which the Winograd P kernel runs (default 0)
+    std::atomic<long long> fuse_max_blocks;     // DIINN_FUSE_MAX_BLOCKS: largest launch (16x8 blocks) for the one-launch P+decode
+    std::atomic<long long> enc_s1_min_blocks;   // DIINN_ENC_S1_MIN_BLOCKS (default 128)
+    std::atomic<long long> enc_no_stream1x1;    // DIINN_ENC_NO_STREAM1X1 (default 0)
+    std::atomic<long long> enc_lat_max_tiles;   // DIINN_ENC_LAT_MAX_TILES (default 256)
+    std::atomic<long long> enc_wino_min;        // DIINN_ENC_WINO_MIN (default 8192 pixels)
+    std::atomic<long long> enc_wino_half_max;   // DIINN_ENC_WINO_HALF_MAX (default -1: by the busiest CU's load)
+    std::atomic<long long> enc_wino_persist;    // DIINN_ENC_WINO_PERSIST (default 256 blocks)
+};
+
+DiinnKnobs& diinn_knobs();                      // diinn_host.cpp
+inline long long knob(const std::atomic<long long>& k) { return k.load(std::memory_order_relaxed); }

@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_kernel(const PParams
     const int lane_off = lane * 16;
     int wp = (int)(OFF_WPB * sizeof(float)) + mp_begin * (WPB_KS * 2 * PIECE_BYTES);
     const float* __restrict__ Bk = p.Wt + OFF_BK + 4 * h;
+    const unsigned nanm = derived_nan_mask(p.Wt);              // section WPB missing -> NaN into every P value
     float* __restrict__ Pout = p.P + (((size_t)b * p.Prows + ((y < p.r1 ? y : p.r1 - 1) - p.Prow0)) * p.W + (x < p.W ? x : p.W - 1)) * PCH + 4 * h;
     f32x4 r0v[PF], r1v[PF];
 #pragma unroll
@@ -272,8 +273,8 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_kernel(const PParams
         f32x16 a0, a1;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 s0 = *(const f32x4*)(Bk + 64 * mp + 8 * g);
-            const f32x4 s1 = *(const f32x4*)(Bk + 64 * mp + 32 + 8 * g);
+            const f32x4 s0 = or_bits(*(const f32x4*)(Bk + 64 * mp + 8 * g), nanm);
+            const f32x4 s1 = or_bits(*(const f32x4*)(Bk + 64 * mp + 32 + 8 * g), nanm);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 a0[4 * g + e] = s0[e];
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_wide_kernel(const PP
     // ---- stage feat[b, :, y0-1 .. y0+8, x0-1 .. x0+32] as bf16, channel-innermost (zeros outside the map)
     const float* __restrict__ fb = p.feat + (size_t)b * C_IN * p.Frows * p.W;
     const int fy_hi = p.Frow0 + p.Frows - 1;
-    *(f32x4*)(bk + 4 * threadIdx.x) = *(const f32x4*)(p.Wt + OFF_BK + 4 * threadIdx.x);
+    *(f32x4*)(bk + 4 * threadIdx.x) = or_bits(*(const f32x4*)(p.Wt + OFF_BK + 4 * threadIdx.x), derived_nan_mask(p.Wt));   // section WPB missing -> NaN
     // item = (channel c, staged row ly, piece q): 4 consecutive columns x0 - 4 + 4q .. +3 of one row (16-byte aligned:
     // the launch requires W % 4 == 0); the tile keeps columns x0-1 .. x0+32, i.e. lx = 4q - 3 + e
     constexpr int ITEMS = C_IN * PW_LR * PW_XQ;                  // 6,400 = 25 per thread
@@ -445,6 +446,14 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_wide_kernel(const PP
     for (int i = 0; i < 4; ++i) store_i(i);
 }
 
+// fp32, all 1024 channels, derived sections present: the Winograd form.  One definition for the launch and for
+// diinn_p_launch_info (what bench.py reports).
+static bool p_uses_winograd(int B, int H, int W, int mp_total, bool bf16, bool derived_ok) {
+    const int forcep = (int)knob(diinn_knobs().p_kernel);
+    const long long wino_min = knob(diinn_knobs().p_wino_min);
+    return derived_ok && !bf16 && mp_total == 16 && forcep != 1 && (forcep == 2 || (long long)B * H * W >= wino_min);
+}
+
 int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,
              int B, int H, int W, int r0, int r1, int mp_total, bool bf16, const RowWin* feat_win, const RowWin* p_win,
              bool derived_ok) {
@@ -464,10 +473,7 @@ int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float
     // full launch.  derived_ok: the caller's packed image holds the
     // derived sections (the gather-packed image of a training step does not).  DIINN_P_KERNEL = 1 direct, 2 Winograd.
     {
-        static const int forcep = [] { const char* e = getenv("DIINN_P_KERNEL"); return e ? atoi(e) : 0; }();
-        static const long long wino_min = [] { const char* e = getenv("DIINN_P_WINO_MIN"); return e ? atoll(e) : 0LL; }();
-        const bool wino = derived_ok && !bf16 && mp_total == 16 && forcep != 1 && (forcep == 2 || (long long)B * H * W >= wino_min);
-        if (wino) return launch_P_wino(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, fw, pw);
+        if (p_uses_winograd(B, H, W, mp_total, bf16, derived_ok)) return launch_P_wino(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, fw, pw);
     }
     // Small maps: split the 1024 output channels over up to 16 workgroups per cell block so the
     // launch still fills the chip (2 workgroups/CU resident -> aim for >= 2 rounds of 512).
@@ -480,8 +486,7 @@ int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float
     PParams p{feat_dev, packed_dev, P_dev, B, H, W, r0, r1, fw.row0, fw.rows, pw.row0, pw.rows, msplit, mp_total, stream_stores};
     const dim3 grid((W + PT_COLS - 1) / PT_COLS, (r1 - r0 + PT_ROWS - 1) / PT_ROWS, B * msplit);
     // diagnostic override (tests / A-B timing): DIINN_PBF16_KERNEL = 1 narrow, 2 wide
-    const char* fenv = getenv("DIINN_PBF16_KERNEL");
-    const int force = fenv ? atoi(fenv) : 0;
+    const int force = (int)knob(diinn_knobs().pbf16_kernel);
     const dim3 gridw((W + PT_COLS - 1) / PT_COLS, (r1 - r0 + PW_ROWS - 1) / PW_ROWS, B);
     const bool wide_ok = bf16 && mp_total == 16 && W % 4 == 0 && ((uintptr_t)feat_dev % 16) == 0 && B <= 65535;
     const bool wide = wide_ok && (force ? force == 2 : (long long)gridw.x * gridw.y * gridw.z >= 256);
@@ -495,6 +500,19 @@ int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float
 }
 
 extern "C" {
+
+int diinn_p_launch_info(int B, int H, int W, int r0, int r1, int compute, int* algorithm) {
+    if (!algorithm || r0 < 0 || r1 > H || r0 >= r1) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY &&
+        compute != DIINN_COMPUTE_BF16_FULL)
+        return DIINN_ERR_UNSUPPORTED;
+    const bool bf16 = compute == DIINN_COMPUTE_BF16_FULL;
+    *algorithm = p_uses_winograd(B, H, W, 16, bf16, true) ? DIINN_P_ALGO_WINOGRAD
+                 : bf16 ? DIINN_P_ALGO_DIRECT_BF16 : DIINN_P_ALGO_DIRECT;
+    return DIINN_OK;
+}
 
 int diinn_precompute_P(void* stream, const float* feat_dev, const float* packed_dev,
                        float* P_dev, int B, int H, int W, int r0, int r1) {

@@ -116,6 +116,7 @@ __device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, flo
         pdst[k] = in ? p.P + (((size_t)b * p.Prows + (oy - p.Prow0)) * p.W + ox) * PCH + 4 * chunk : nullptr;
     }
     const float* __restrict__ bk = p.Wt + OFF_BK + 4 * chunk;
+    const unsigned nanm = derived_nan_mask(p.Wt);              // section WPU missing -> NaN into every P value
 
     // ---- main loop
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -203,7 +204,7 @@ __device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, flo
         kgroup(IC<1>{});
         if (prev) {
             exchange_write((mt - 1) & 1);
-            bias4 = *reinterpret_cast<const f32x4*>(bk + 32 * (mt - 1));
+            bias4 = or_bits(*reinterpret_cast<const f32x4*>(bk + 32 * (mt - 1)), nanm);
             __syncthreads();
         }
         PWN_SB();
@@ -232,7 +233,7 @@ __device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, flo
     // the last M-tile (parity 1)
     col_transform(IC<1>{}, IC<0>{}); col_transform(IC<1>{}, IC<1>{}); col_transform(IC<1>{}, IC<2>{}); col_transform(IC<1>{}, IC<3>{});
     exchange_write(mtl & 1);
-    bias4 = *reinterpret_cast<const f32x4*>(bk + 32 * mtl);
+    bias4 = or_bits(*reinterpret_cast<const f32x4*>(bk + 32 * mtl), nanm);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) store_group(k, mtl & 1, mtl);

@@ -367,14 +367,14 @@ int diinn_conv_wino(void* stream, const float* in_dev, long long in_batch_stride
     // loaded and transformed twice)?  Whichever gives the busiest CU less to do: a CU ends up with ceil(b / 256) whole
     // blocks or ceil(2 b / 256) halves (measured on 176 .. 320-pixel maps, tools/r02_ab_env.sh).
     // DIINN_ENC_WINO_HALF_MAX = n forces halves below n blocks and whole blocks from there on.
-    static const long long half_max = [] { const char* e = getenv("DIINN_ENC_WINO_HALF_MAX"); return e ? atoll(e) : -1LL; }();
+    const long long half_max = knob(diinn_knobs().enc_wino_half_max);
     const double cost_whole = (double)((blocks + 255) / 256), cost_half = 0.57 * (double)((2 * blocks + 255) / 256);
     const bool halves = half_max >= 0 ? blocks < half_max : cost_half < cost_whole;
     if (halves)
         hipLaunchKernelGGL(conv_wino_half_kernel, dim3((unsigned)((2 * blocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, p);
     else {
         // persistent workgroups, one per CU: the second and later blocks of a workgroup start without a dispatch
-        static const long long persist = [] { const char* e = getenv("DIINN_ENC_WINO_PERSIST"); return e ? atoll(e) : 256LL; }();
+        const long long persist = knob(diinn_knobs().enc_wino_persist);
         const long long grid = persist > 0 && blocks > persist ? persist : (blocks + 7) / 8 * 8;
         hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
     }

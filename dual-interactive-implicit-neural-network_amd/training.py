@@ -82,6 +82,10 @@ def pack_gather_index() -> torch.Tensor:
     for section in (7, 9, 10, 11, 12, 13):              # inference-only sections: derived values, not a permutation
         _native.check(lib.diinn_packed_section(section, C.byref(off), C.byref(size)), "diinn_packed_section")
         idx[off.value:off.value + size.value] = -1
+    # the validity word behind bL (DIINN_PACKED_MAGIC) reads as zero in a gathered image: the inference entry points,
+    # which read the derived sections, then answer NaN instead of decoding with empty weights
+    _native.check(lib.diinn_packed_section(6, C.byref(off), C.byref(size)), "diinn_packed_section")
+    idx[off.value + 3] = -1
     if idx.max() >= total or idx.min() < -1:
         raise RuntimeError("packed image is not a permutation of the reference tensors")
     used = np.zeros(total, bool)

@@ -31,8 +31,18 @@
 extern "C" {
 #endif
 
-#define DIINN_ABI_VERSION 5   /* 2: training, LIIF/MetaSR, encoder-trunk entry points; packed image sections 8-9
-                                 3: row-window entry points (band-sized buffers for the multi-GPU row-band split) */
+#define DIINN_ABI_VERSION 6
+/* History of the ABI number:
+ *   1  diinn_pack_weights, axis tables, diinn_precompute_P / diinn_decode_band / diinn_decode (+ _ex: compute modes)
+ *   2  training (diinn_decode_train_fwd, diinn_backward_*, diinn_plane_*), LIIF / MetaSR, the encoder trunk
+ *      (diinn_conv_ksplit, diinn_rdn_forward); packed image sections 8 (WLT) and 9 (WPB)
+ *   3  row-window entry points (diinn_window_rows, *_win): band-sized buffers for the multi-GPU row-band split
+ *   4  Winograd encoder (diinn_conv_wino, diinn_rdn_forward_wino); packed sections 10-12 (BQR, Q0R, WLR: the
+ *      synthesis branch in revolutions)
+ *   5  diinn_sfe1_forward; packed section 13 (WPU: the hoisted 3x3 conv in Winograd form)
+ *   6  the packed image carries a validity word for its derived sections (DIINN_PACKED_MAGIC, below);
+ *      diinn_p_launch_info; diinn_debug_set / diinn_debug_get; the one-launch form of diinn_decode* for small maps;
+ *      bf16 kernel choice taken from the full image, not the band */
 
 /* status codes */
 #define DIINN_OK                 0
@@ -49,10 +59,18 @@ extern "C" {
 #define DIINN_OUT         3
 #define DIINN_P_CHANNELS  (DIINN_LAYERS * DIINN_HIDDEN)   /* 1024 floats per LR cell */
 
-/* sine evaluation used by the synthesis branch (reference: torch.sin, diinn.py:25-26) */
-#define DIINN_SIN_ACCURATE 0   /* Cody-Waite reduction + polynomial, <= ~3 ulp        */
-#define DIINN_SIN_HW       1   /* v_sin_f32 after fract(x/2pi): abs error ~ |x|*6e-8, 3 VALU ops */
-#define DIINN_SIN_HW_REDUCED 2 /* two-term reduction in revolutions + v_sin_f32: 5 ops, 2.5e-7 for |x| <= 1e4 */
+/* sine evaluation used by the synthesis branch (reference: torch.sin, diinn.py:25-26).  The inference kernels keep
+ * the synthesis branch in REVOLUTIONS (weights, biases and the Q0 table of sections 10-12 are pre-multiplied by
+ * fp32(1/(2 pi))), so the accumulator already holds the argument v_sin_f32 takes; the training forward
+ * (diinn_decode_train_fwd) saves sine arguments in radians and uses the radian forms. */
+#define DIINN_SIN_ACCURATE 0   /* Cody-Waite reduction + polynomial, <= ~3 ulp (inference: after multiplying back
+                                  to radians) */
+#define DIINN_SIN_HW       1   /* inference: the bare v_sin_f32, 1 VALU op, valid for |arg| <= 512 pi; training
+                                  forward: v_sin_f32(fract(x / 2 pi)), abs error ~ |x| * 6e-8 */
+#define DIINN_SIN_HW_REDUCED 2 /* the default.  inference: v_sin_f32(r - rint(r)) on r in revolutions, an exact
+                                  reduction valid for any magnitude, 3 VALU ops, measured max error 3e-8 on the fixtures;
+                                  training forward: two-term Cody-Waite reduction in revolutions + v_sin_f32, 5 ops,
+                                  <= 4e-7 for |x| <= 1e4 */
 
 /* arithmetic of the per-pixel layers 1..3 (everything else is always fp32) */
 #define DIINN_COMPUTE_F32  0   /* v_mfma_f32_32x32x2_f32: the reference's precision, parity <= 1e-4           */
@@ -91,10 +109,20 @@ size_t diinn_packed_weight_floats(void);
  * sine on revolutions, and the synthesis rows inside section 7 are pre-multiplied by 1/(2 pi) to match), 11 Q0R
  * (section 3 / (2 pi)), 12 WLR (section 0 with its synthesis pieces / (2 pi): the fp32 inference kernels evaluate the
  * sine on revolutions as well), 13 WPU (section 1 in Winograd F(2x2,3x3) form, U = G Wx G^T: what the fp32 inference
- * entry points -- everything but diinn_precompute_P -- read on maps of >= 32,768 cells).  Every section but 7 and
+ * entry points -- everything but diinn_precompute_P -- read, at every map size).  Every section but 7 and
  * 9..13 is a pure permutation (plus zero padding) of the reference tensors, so a training loop can re-pack on the
  * device with one gather; sections 7 and 9..13 hold derived values, read by the inference kernels only (the
- * training forward and LIIF read sections 0, 1 and 4; diinn_precompute_P reads section 1 whatever the map size). */
+ * training forward and LIIF read sections 0, 1 and 4; diinn_precompute_P reads section 1 whatever the map size).
+ *
+ * VALIDITY WORD.  The pad word behind bL (float index 3 of section 6) holds the bit pattern DIINN_PACKED_MAGIC in an
+ * image written by diinn_pack_weights, i.e. one whose derived sections are filled.  An image assembled some other
+ * way (the device gather of a training step leaves the word and the derived sections zero) is only good for the entry
+ * points that read the permutation sections (diinn_precompute_P, diinn_decode_train_fwd, diinn_backward_data,
+ * diinn_liif_decode).  The launch functions cannot look into device memory without synchronising, so the check is
+ * made by the kernels: every inference entry point that reads a derived section (diinn_precompute_P_ex / _win,
+ * diinn_decode*, in every compute mode) writes NaN into ALL of its outputs when the word is missing -- a loud
+ * wrong answer instead of a silent one (tests/test_gpu_parity.py::test_image_without_derived_sections_is_refused). */
+#define DIINN_PACKED_MAGIC 0x44493036u   /* "DI06" */
 int    diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats);
 int    diinn_pack_weights(const float* K0w, const float* K0b,
                           const float* const Kw[3], const float* const Kb[3],
@@ -323,6 +351,24 @@ int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* 
 /* Dominant-kernel launch geometry, for benchmarks/roofline accounting. */
 int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,
                              int* grid_x, int* grid_y, int* grid_z, int* block);
+/* Which form of the hoisted 3x3 convolution diinn_precompute_P_ex / _win / diinn_decode* run for LR rows [r0,r1) of a
+ * [B,64,H,W] map in `compute` (the diagnostic overrides below included): what a benchmark should label its P time with. */
+#define DIINN_P_ALGO_DIRECT      0   /* implicit-im2col GEMM, fp32 (1,179,648 FLOP per cell)                 */
+#define DIINN_P_ALGO_WINOGRAD    1   /* Winograd F(2x2,3x3), fp32: 2.25x fewer MFMAs                          */
+#define DIINN_P_ALGO_DIRECT_BF16 2   /* implicit-im2col GEMM on bf16 operands (DIINN_COMPUTE_BF16_FULL)       */
+int diinn_p_launch_info(int B, int H, int W, int r0, int r1, int compute, int* algorithm);
+
+/* ---- diagnostic overrides (tests, A/B timing; never needed in production) -------------------------------------
+ * The launch functions pick kernel variants by launch size; each choice can be forced.  The knobs are named like the
+ * environment variables that seed them -- DIINN_F32_KERNEL, DIINN_BF16_KERNEL, DIINN_PBF16_KERNEL, DIINN_P_KERNEL,
+ * DIINN_P_WINO_MIN, DIINN_FUSE_MAX_BLOCKS, DIINN_ENC_S1_MIN_BLOCKS, DIINN_ENC_NO_STREAM1X1, DIINN_ENC_LAT_MAX_TILES,
+ * DIINN_ENC_WINO_MIN, DIINN_ENC_WINO_HALF_MAX, DIINN_ENC_WINO_PERSIST (csrc/diinn_knobs.h lists values and
+ * defaults).  The environment is read ONCE, at the first launch or the first call of either function; afterwards
+ * only diinn_debug_set changes a knob (process-wide, atomic stores: safe against concurrent launches, which see
+ * either the old or the new value).  Unknown name -> DIINN_ERR_INVALID_ARG.  This is the library's only mutable
+ * global state. */
+int diinn_debug_set(const char* name, long long value);
+int diinn_debug_get(const char* name, long long* value);
 
 #ifdef __cplusplus
 }

@@ -40,3 +40,20 @@ def golden_cases(g):
             b, h, w, hu, wu, gain, bs = g[k]
             out.append((name, int(b), int(h), int(w), int(hu), int(wu), float(gain)))
     return out
+
+
+@pytest.fixture
+def knobs():
+    """Force kernel-variant choices in-process through the C ABI's test hook (diinn_debug_set) and restore them:
+    ``knobs("DIINN_F32_KERNEL", 2)``.  (The environment is read once per process, so setenv would do nothing.)"""
+    import diinn_amd._native as N
+    saved = {}
+
+    def set_(name, value):
+        if name not in saved:
+            saved[name] = N.debug_get(name)
+        N.debug_set(name, value)
+
+    yield set_
+    for name, value in saved.items():
+        N.debug_set(name, value)

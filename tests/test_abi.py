@@ -39,9 +39,38 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.diinn_abi_version() == 5
+    assert lib.diinn_abi_version() == 6
     assert lib.diinn_status_string(0) == b"ok"
     assert b"invalid" in lib.diinn_status_string(1)
+
+
+def test_debug_knobs_roundtrip(lib):
+    """The diagnostic overrides live in one table behind diinn_debug_set / diinn_debug_get (no getenv per launch)."""
+    import diinn_amd._native as N
+    for name, dflt in [("DIINN_F32_KERNEL", 0), ("DIINN_BF16_KERNEL", 0), ("DIINN_PBF16_KERNEL", 0), ("DIINN_P_KERNEL", 0),
+                       ("DIINN_P_WINO_MIN", 0), ("DIINN_ENC_S1_MIN_BLOCKS", 128), ("DIINN_ENC_NO_STREAM1X1", 0),
+                       ("DIINN_ENC_LAT_MAX_TILES", 256), ("DIINN_ENC_WINO_MIN", 8192), ("DIINN_ENC_WINO_HALF_MAX", -1),
+                       ("DIINN_ENC_WINO_PERSIST", 256)]:
+        if name not in os.environ:
+            assert N.debug_get(name) == dflt, name
+        old = N.debug_get(name)
+        N.debug_set(name, 7)
+        assert N.debug_get(name) == 7
+        N.debug_set(name, old)
+    assert lib.diinn_debug_set(b"DIINN_NO_SUCH_KNOB", 1) == 1
+    v = C.c_longlong()
+    assert lib.diinn_debug_get(b"DIINN_NO_SUCH_KNOB", C.byref(v)) == 1 and lib.diinn_debug_get(None, C.byref(v)) == 1
+    # the P algorithm query follows the knob
+    a = C.c_int(-1)
+    assert lib.diinn_p_launch_info(1, 64, 64, 0, 64, N.COMPUTE_F32, C.byref(a)) == 0 and a.value == N.P_ALGO_WINOGRAD
+    assert lib.diinn_p_launch_info(1, 64, 64, 0, 64, N.COMPUTE_BF16_FULL, C.byref(a)) == 0 and a.value == N.P_ALGO_DIRECT_BF16
+    N.debug_set("DIINN_P_KERNEL", 1)
+    try:
+        assert lib.diinn_p_launch_info(1, 64, 64, 0, 64, N.COMPUTE_F32, C.byref(a)) == 0 and a.value == N.P_ALGO_DIRECT
+    finally:
+        N.debug_set("DIINN_P_KERNEL", 0)
+    assert lib.diinn_p_launch_info(1, 64, 64, 5, 5, N.COMPUTE_F32, C.byref(a)) == 1
+    assert lib.diinn_p_launch_info(1, 64, 64, 0, 64, 9, C.byref(a)) == 2
 
 
 def test_host_axis_tables_bit_exact_vs_reference(lib, golden):

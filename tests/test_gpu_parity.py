@@ -409,7 +409,7 @@ def test_modes_1_and_2(golden, dev, mode):
     assert float(np.abs(got2 - ref2).max()) <= _tol(ref2)
 
 
-def test_latency_kernel_is_bit_identical_to_throughput_kernel(golden, dev, monkeypatch):
+def test_latency_kernel_is_bit_identical_to_throughput_kernel(golden, dev, knobs):
     """Small launches take decode_coop_kernel (four waves share one 32-pixel tile).  Per output channel it performs
     decode_kernel's arithmetic in decode_kernel's order, so the two must agree bit for bit on every fixture, on
     row bands and on batches; the fixtures' reference outputs bound both."""
@@ -420,12 +420,13 @@ def test_latency_kernel_is_bit_identical_to_throughput_kernel(golden, dev, monke
         feat = synth.encoder_features(123, b, h, w)
         outs = {}
         for k in ("1", "2"):
-            monkeypatch.setenv("DIINN_F32_KERNEL", k)
+            knobs("DIINN_F32_KERNEL", int(k))
+            knobs("DIINN_FUSE_MAX_BLOCKS", 0)                      # two launches: the kernels under test
             outs[k] = _decode(sd, feat, (hu, wu), dev)
         assert np.array_equal(outs["1"], outs["2"]), name
         ref = golden[f"out/{name}"]
         assert float(np.abs(outs["2"] - ref).max()) <= _tol(ref), name
-    monkeypatch.setenv("DIINN_F32_KERNEL", "2")
+    knobs("DIINN_F32_KERNEL", 2)
     sd = synth.decoder_state_dict(5)
     feat = torch.from_numpy(synth.encoder_features(5, 2, 19, 23)).to(dev)
     packed = D.pack_state_dict(sd).to(dev)
@@ -437,7 +438,7 @@ def test_latency_kernel_is_bit_identical_to_throughput_kernel(golden, dev, monke
     assert torch.equal(full, out)
 
 
-def test_bf16_kernel_variants_agree(golden, dev, monkeypatch):
+def test_bf16_kernel_variants_agree(golden, dev, knobs):
     """The four bf16 decode kernels (one tile per wave, two tiles per wave, cooperative with 4 and with 8 waves) are
     the same arithmetic (same products, same k-order; only the head's summation order differs) laid out differently:
     their outputs agree to a small fraction of the bf16 error (the cooperative kernels evaluate layer 0's sine on
@@ -454,8 +455,114 @@ def test_bf16_kernel_variants_agree(golden, dev, monkeypatch):
         scale = float(np.abs(ref).max())
         outs = {}
         for k in ("1", "2", "4", "8"):
-            monkeypatch.setenv("DIINN_BF16_KERNEL", k)
+            knobs("DIINN_BF16_KERNEL", int(k))
             outs[k] = _decode(sd, feat, (hu, wu), dev, compute="bf16")
             assert float(np.abs(outs[k] - ref).max()) <= 2e-3 * scale + 1e-6, (name, k)
         for k in ("2", "4", "8"):
             assert float(np.abs(outs[k] - outs["1"]).max()) <= 5e-4 * scale, (name, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# non-finite inputs: the reference's relu / conv / sin propagate NaN (diinn.py:133-138), and so
+# does the HIP path: relu0 is the NaN-propagating v_maximum3_f32 (csrc/diinn_device.h)
+# ---------------------------------------------------------------------------------------------------------------------
+def _same_nonfinite(got, ref, what):
+    gn, rn = ~np.isfinite(got), ~np.isfinite(ref)
+    assert np.array_equal(gn, rn), f"{what}: non-finite pixels differ ({gn.sum()} vs {rn.sum()} in the reference)"
+    assert rn.any() and not rn.all(), what
+    fin = ~rn
+    assert float(np.abs(got[fin] - ref[fin]).max()) <= _tol(ref[fin]), what
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), float("-inf")])
+def test_nonfinite_feature_cell_propagates_like_the_reference(dev, bad):
+    """One NaN / Inf feature value poisons exactly the HR pixels whose nearest cell has it in its 3x3 window -- the
+    unfold's support -- and leaves every other pixel untouched (the Winograd form of the hoisted conv has the same
+    support: a patch element only enters the outputs whose window holds it)."""
+    import diinn_oracle as orc
+    sd = synth.decoder_state_dict(11)
+    for (h, w, hu, wu, cy, cx) in [(20, 24, 66, 80, 7, 9), (20, 24, 66, 80, 0, 23), (12, 10, 24, 20, 11, 0)]:
+        feat = synth.encoder_features(11, 1, h, w).copy()
+        feat[0, 17, cy, cx] = bad
+        ref = orc.decode_reference_form(sd, feat, (hu, wu), 30000).numpy()
+        got = _decode(sd, feat, (hu, wu), dev)
+        _same_nonfinite(got, ref, f"{bad} at ({cy},{cx}) of {h}x{w}")
+        assert np.isnan(got[~np.isfinite(got)]).all()              # and what comes out is NaN, as in the reference
+
+
+@pytest.mark.parametrize("compute", ["bf16", "bf16_full"])
+def test_nonfinite_feature_cell_bf16(dev, compute):
+    import diinn_oracle as orc
+    sd = synth.decoder_state_dict(11)
+    feat = synth.encoder_features(11, 1, 20, 24).copy()
+    feat[0, 3, 9, 9] = float("nan")
+    ref = orc.decode_reference_form(sd, feat, (80, 96), 30000).numpy()
+    got = _decode(sd, feat, (80, 96), dev, compute=compute)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    fin = ~np.isnan(ref)
+    assert float(np.abs(got[fin] - ref[fin]).max()) <= 3e-3 * float(np.abs(ref[fin]).max())
+
+
+def test_nonfinite_weights_propagate_like_the_reference(dev):
+    """A NaN in a modulation weight, a synthesis weight or a bias makes the reference's whole output NaN; a NaN in one
+    head bias only that colour plane.  (With v_max_f32 as relu a NaN modulation value became k = 0 and the pixel a
+    finite colour: round 2's behaviour.)"""
+    import diinn_oracle as orc
+    feat = synth.encoder_features(3, 1, 10, 12)
+    size = (33, 40)
+    for key, index, whole in [("K.2.0.weight", (5, 300, 0, 0), True), ("K.1.0.weight", (9, 17, 0, 0), True),
+                              ("Q.1.0.weight", (0, 0, 0, 0), True), ("K.0.0.bias", (100,), True),
+                              ("last_layer.bias", (1,), False)]:
+        sd = {k: v.copy() for k, v in synth.decoder_state_dict(3).items()}
+        sd[key][index] = float("nan")
+        ref = orc.decode_reference_form(sd, feat, size, 30000).numpy()
+        got = _decode(sd, feat, size, dev)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), key
+        assert np.isnan(ref).all() == whole, key
+        if not whole:
+            fin = ~np.isnan(ref)
+            assert float(np.abs(got[fin] - ref[fin]).max()) <= _tol(ref[fin]), key
+
+
+def test_image_without_derived_sections_is_refused(dev):
+    """the gather-packed image of a training step has empty derived sections (WPU, WLR, BQR, Q0R, WLB, WPB)
+    and a zero validity word.  The inference entry points read those sections; handed such an image they answer NaN
+    everywhere instead of decoding with empty weights (the launch functions cannot look into device memory).  The
+    entry points of the training path accept the same image."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.decoder as D
+    import diinn_amd.training as T
+    lib = N.load()
+    sd = synth.decoder_state_dict(5)
+    params = [torch.from_numpy(sd[n]).to(dev) for n in T.PARAM_NAMES]
+    gathered = T.pack_on_device(params)
+    host = D.pack_state_dict(sd).to(dev)
+    off, size = C.c_size_t(), C.c_size_t()
+    N.check(lib.diinn_packed_section(6, C.byref(off), C.byref(size)), "section")
+    word = off.value + 3
+    assert gathered[word].item() == 0.0
+    assert host[word:word + 1].view(torch.int32).item() == N.PACKED_MAGIC
+    feat = torch.from_numpy(synth.encoder_features(5, 1, 24, 20)).to(dev)
+    good = D.decode_features(feat, host, (79, 66))
+    assert bool(torch.isfinite(good).all())
+    for compute in ("f32", "bf16", "bf16_full"):
+        out = D.decode_features(feat, gathered, (79, 66), compute=compute)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(out).all()), compute
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = torch.zeros(24 * 20 * 1024, device=dev)
+    for comp in (N.COMPUTE_F32, N.COMPUTE_BF16_FULL):             # the stand-alone P entry points of the inference path
+        P.zero_()
+        N.check(lib.diinn_precompute_P_ex(stream, C.c_void_p(feat.data_ptr()), C.c_void_p(gathered.data_ptr()),
+                                          C.c_void_p(P.data_ptr()), 1, 24, 20, 0, 24, comp), "P_ex")
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(P).all()), comp
+    # the training path's P (direct kernel, permutation sections only) is fine with it
+    N.check(lib.diinn_precompute_P(stream, C.c_void_p(feat.data_ptr()), C.c_void_p(gathered.data_ptr()),
+                                   C.c_void_p(P.data_ptr()), 1, 24, 20, 0, 24), "P")
+    Pg = torch.empty_like(P)
+    N.check(lib.diinn_precompute_P(stream, C.c_void_p(feat.data_ptr()), C.c_void_p(host.data_ptr()),
+                                   C.c_void_p(Pg.data_ptr()), 1, 24, 20, 0, 24), "P")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(P).all()) and torch.equal(P, Pg)

@@ -81,7 +81,11 @@ def _worker(rank, world, port, mode, geom, q):
         ok_rows, band = True, None
         for it in range(2):                       # twice: the pre-allocated buffers are reused
             win, row0 = ex.handoff(feat)
+            if rank == 0 and mode == "halo" and world > 1:
+                # the source only STARTS its sends: it decodes its own band below while they are in flight
+                assert len(ex._pending) == sum(1 for r, b2 in enumerate(bands) if r != 0 and not b2.empty)
             if bd.empty:
+                ex.complete()
                 continue
             if mode == "halo" and rank != 0:
                 assert win.shape[2] == bd.a1 - bd.a0 and row0 == bd.a0       # band-sized, not the whole map
@@ -90,7 +94,12 @@ def _worker(rank, world, port, mode, geom, q):
             # decode the band from ONLY the rows this rank holds -> must equal the same rows of the full decode
             band = orc.decode_reference_form(sd, win[:, :, lo:lo + bd.a1 - bd.a0].contiguous(), (hu, wu), None,
                                              row_range=(bd.y0, bd.y1), feat_row0=bd.a0, full_h=h)
+            ex.complete()
+            assert not ex._pending
         img = ex.gather(band, dst=0)
+        if rank == 0 and world > 1:                # one band-shaped message per sending rank, placed by one copy
+            assert sum(1 for g in ex.gather_stage if g is not None) == sum(1 for r, b2 in enumerate(bands)
+                                                                            if r != 0 and not b2.empty)
         if rank == 0:
             full = orc.decode_reference_form(sd, feat_np, (hu, wu), None).numpy()
             q.put((ok_rows, float(np.abs(img.numpy() - full).max())))
@@ -173,4 +182,44 @@ def _gpu_worker(rank, world, port, mode, geom, q):
 @pytest.mark.gpu
 def test_two_ranks_decode_bands_on_gpu():
     res = _run(2, "halo", (1, 40, 56, 132, 185), target=_gpu_worker, timeout=600)
+    assert all(res)
+
+
+def _gpu_band_decoder_worker(rank, world, port, mode, geom, q):
+    """``BandDecoder`` itself on the device with the host-staged gloo transport (all ranks share cuda:0): side-stream
+    hand-off overlapped with rank 0's own band, band-sized windows, two steps over the same buffers, the
+    one-message gather -- every line of sharded.py that the RCCL run executes except the wire itself."""
+    import diinn_amd.decoder as D
+    import diinn_amd.sharded as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        b, h, w, hu, wu = geom
+        packed = D.pack_state_dict(synth.decoder_state_dict(33)).to(dev)
+        dec = S.BandDecoder((b, 64, h, w), (hu, wu), packed, src=0, mode=mode)
+        assert dec.host_staged and dec.side is not None
+        ok = True
+        for it in range(2):
+            feat_cpu = torch.from_numpy(synth.encoder_features(33 + it, b, h, w))
+            feat = feat_cpu.to(dev) if rank == 0 else None
+            band = dec.step(feat)
+            img = dec.gather(band, dst=0)
+            torch.cuda.synchronize()
+            if rank == 0:
+                full = D.decode_features(feat, packed, (hu, wu))
+                ok = ok and bool(torch.equal(img, full))
+            else:
+                assert img is None
+        q.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,mode", [(2, "halo"), (4, "halo"), (2, "bcast")])
+def test_band_decoder_on_gpu_over_host_staged_gloo(world, mode):
+    res = _run(world, mode, (2, 40, 56, 132, 185), target=_gpu_band_decoder_worker, timeout=600)
     assert all(res)

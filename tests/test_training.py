@@ -77,6 +77,10 @@ def test_pack_gather_index_is_the_host_packer():
     for section in (7, 9, 10, 11, 12, 13):         # inference-only sections: derived values, left zero by the gather
         assert lib.diinn_packed_section(section, C.byref(off), C.byref(size)) == 0
         keep[off.value:off.value + size.value] = False
+    assert lib.diinn_packed_section(6, C.byref(off), C.byref(size)) == 0
+    word = off.value + 3                           # the validity word: the magic in a host-packed image, 0 in a gathered one
+    assert ref[word:word + 1].view(np.uint32)[0] == N.PACKED_MAGIC and got[word] == 0.0
+    keep[word] = False
     assert np.array_equal(got[keep], ref[keep]) and not got[~keep].any()
     total = 0
     for s in range(14):
