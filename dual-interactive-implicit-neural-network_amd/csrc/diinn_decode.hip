@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
             *(f32x4*)(tab + 5 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 2 * HID + 4 * i);
             if (i == 0) {                                        // bL + the image's validity word: inference reads derived
                 const f32x4 bl = *(const f32x4*)(p.Wt + OFF_BL); // sections, so an image without them decodes to NaN
-                const unsigned nanm = (SAVE || __builtin_bit_cast(unsigned, bl[3]) == DIINN_PACKED_MAGIC) ? 0u : 0x7fc00000u;
+                // (the word is read on its own: hipcc 7.2 compiled `bit_cast<unsigned>(bl[3]) == MAGIC` on the scalarised
+                // vector load into a compare of element 0)
+                const unsigned nanm = SAVE ? 0u : derived_nan_mask(p.Wt);
                 *(f32x4*)(tab + 6 * HID) = or_bits(bl, nanm);
             }
         }

@@ -22,7 +22,6 @@ const KnobDef KNOBS[] = {
     {"DIINN_PBF16_KERNEL", &DiinnKnobs::pbf16_kernel, 0, false},
     {"DIINN_P_KERNEL", &DiinnKnobs::p_kernel, 0, false},
     {"DIINN_P_WINO_MIN", &DiinnKnobs::p_wino_min, 0, false},
-    {"DIINN_FUSE_MAX_BLOCKS", &DiinnKnobs::fuse_max_blocks, -1, false},
     {"DIINN_ENC_S1_MIN_BLOCKS", &DiinnKnobs::enc_s1_min_blocks, 128, false},
     {"DIINN_ENC_NO_STREAM1X1", &DiinnKnobs::enc_no_stream1x1, 0, true},
     {"DIINN_ENC_LAT_MAX_TILES", &DiinnKnobs::enc_lat_max_tiles, 256, false},

@@ -13,7 +13,6 @@ struct DiinnKnobs {
     std::atomic<long long> pbf16_kernel;        // DIINN_PBF16_KERNEL: 1 narrow, 2 wide bf16 P kernel (0: auto)
     std::atomic<long long> p_kernel;            // DIINN_P_KERNEL: 1 direct, 2 Winograd fp32 P kernel (0: auto)
     std::atomic<long long> p_wino_min;          // DIINN_P_WINO_MIN: cells from which the Winograd P kernel runs (default 0)
-    std::atomic<long long> fuse_max_blocks;     // DIINN_FUSE_MAX_BLOCKS: largest launch (16x8 blocks) for the one-launch P+decode
     std::atomic<long long> enc_s1_min_blocks;   // DIINN_ENC_S1_MIN_BLOCKS (default 128)
     std::atomic<long long> enc_no_stream1x1;    // DIINN_ENC_NO_STREAM1X1 (default 0)
     std::atomic<long long> enc_lat_max_tiles;   // DIINN_ENC_LAT_MAX_TILES (default 256)

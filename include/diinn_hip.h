@@ -41,7 +41,7 @@ extern "C" {
  *      synthesis branch in revolutions)
  *   5  diinn_sfe1_forward; packed section 13 (WPU: the hoisted 3x3 conv in Winograd form)
  *   6  the packed image carries a validity word for its derived sections (DIINN_PACKED_MAGIC, below);
- *      diinn_p_launch_info; diinn_debug_set / diinn_debug_get; the one-launch form of diinn_decode* for small maps;
+ *      diinn_p_launch_info; diinn_debug_set / diinn_debug_get;
  *      bf16 kernel choice taken from the full image, not the band */
 
 /* status codes */
@@ -361,7 +361,7 @@ int diinn_p_launch_info(int B, int H, int W, int r0, int r1, int compute, int* a
 /* ---- diagnostic overrides (tests, A/B timing; never needed in production) -------------------------------------
  * The launch functions pick kernel variants by launch size; each choice can be forced.  The knobs are named like the
  * environment variables that seed them -- DIINN_F32_KERNEL, DIINN_BF16_KERNEL, DIINN_PBF16_KERNEL, DIINN_P_KERNEL,
- * DIINN_P_WINO_MIN, DIINN_FUSE_MAX_BLOCKS, DIINN_ENC_S1_MIN_BLOCKS, DIINN_ENC_NO_STREAM1X1, DIINN_ENC_LAT_MAX_TILES,
+ * DIINN_P_WINO_MIN, DIINN_ENC_S1_MIN_BLOCKS, DIINN_ENC_NO_STREAM1X1, DIINN_ENC_LAT_MAX_TILES,
  * DIINN_ENC_WINO_MIN, DIINN_ENC_WINO_HALF_MAX, DIINN_ENC_WINO_PERSIST (csrc/diinn_knobs.h lists values and
  * defaults).  The environment is read ONCE, at the first launch or the first call of either function; afterwards
  * only diinn_debug_set changes a knob (process-wide, atomic stores: safe against concurrent launches, which see

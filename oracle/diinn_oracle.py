@@ -252,7 +252,7 @@ def _bf16_round(t: torch.Tensor) -> torch.Tensor:
 @torch.no_grad()
 def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = False, bf16_p: bool = False,
                         row_range: Optional[Tuple[int, int]] = None, feat_row0: int = 0,
-                        full_h: Optional[int] = None) -> torch.Tensor:
+                        full_h: Optional[int] = None, bf16_p_storage: bool = False) -> torch.Tensor:
     """Same function evaluated the way the HIP kernels do: per-cell P, then the
     per-pixel 256->512 stacked layers.  Not reference-faithful in summation
     order; agrees with decode_reference_form to ~1e-7.
@@ -262,6 +262,8 @@ def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = Fal
     P, biases, sine, layer 0 and the head (on the unrounded last activation) stay fp32.
     ``bf16_p=True`` additionally rounds the features and the 3x3 conv weights of P to bf16 (fp32 accumulate,
     fp32 bias): the DIINN_COMPUTE_BF16_FULL mode.
+    ``bf16_p_storage=True`` rounds the finished P image (bias included) to bf16, as a kernel that kept P in HBM as
+    bf16 would: an experiment switch, measured by tools/bf16_p_storage_error.py; no kernel does it.
     ``row_range`` / ``feat_row0`` / ``full_h``: an HR row band from a feature crop, as in decode_reference_form."""
     sw = split_weights(sd)
     feat = _as_t(feat)
@@ -280,6 +282,8 @@ def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = Fal
         p = (p + sw["bK"].view(1, -1, 1, 1)).permute(0, 2, 3, 1).contiguous()
     else:
         p = precompute_P(sd, feat)  # [B,hc,W,1024]
+    if bf16_p_storage:
+        p = _bf16_round(p)
     pp = p[:, torch.from_numpy(rows - feat_row0)][:, :, torch.from_numpy(idx_w.astype(np.int64))]
     nh = y1 - y0
     pp = pp.view(b, nh, wu, 4, HIDDEN)

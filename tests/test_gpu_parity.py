@@ -421,7 +421,6 @@ def test_latency_kernel_is_bit_identical_to_throughput_kernel(golden, dev, knobs
         outs = {}
         for k in ("1", "2"):
             knobs("DIINN_F32_KERNEL", int(k))
-            knobs("DIINN_FUSE_MAX_BLOCKS", 0)                      # two launches: the kernels under test
             outs[k] = _decode(sd, feat, (hu, wu), dev)
         assert np.array_equal(outs["1"], outs["2"]), name
         ref = golden[f"out/{name}"]
