@@ -1065,6 +1065,398 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8_kernel(const DecodeP
     CO_STAMP(12);
 }
 
+// ---------------------------------------------------------------------------------
+// decode_bf16_coop8p_kernel: decode_bf16_coop8_kernel with PERSISTENT workgroups (r03).  Stamps of the one-block-per-
+// workgroup form (profiles/r02_bf16_coop8_stamps.txt) put a quarter of a wave's life into the prologue, and more than
+// half of that into waiting for loads: the first 256 KiB of weights alone are 4 k cycles of L1 time, requested by a
+// workgroup that has nothing else to do yet.  Here 256 workgroups (8 XCDs x 32) each walk a list of blocks, and
+// everything the NEXT block's start needs is requested inside the LAST layer of the current one, where it hides
+// behind MFMAs: the first layer's weight fragments (refilled as the last pixel tile consumes the old ones, exactly
+// like the refill between layers), the P_0 / P_1 rows of the next block's cells, the Q0 table.  The second
+// activation image, free during the last layer, receives the next block's layer-0 tables meanwhile.  bias / head
+// tables are staged once per workgroup.
+// Block order: the 32 workgroups of an XCD (= one L2) work on one SUPER-TILE of 8 x 4 neighbouring blocks at a
+// time and walk a contiguous run of super-tiles.  At non-integer scales neighbouring blocks stage the same P rows
+// (c5, x3.3: a block's footprint is ~5 x 3.4 cells, each cell is wanted by up to 4 blocks); with the plain dispatch
+// order those blocks ran in 8 different L2s (measured 6.28 GB of HBM traffic against 3.9 GB algorithmic).
+// Arithmetic, k-order and results are decode_bf16_coop8_kernel's, bit for bit.
+// ---------------------------------------------------------------------------------
+constexpr int CO_ST_X = 8, CO_ST_Y = 4;                      // blocks per super-tile (32 = workgroups per XCD)
+constexpr int CO_PGRID = 8 * CO_ST_X * CO_ST_Y;              // persistent workgroups of a launch
+
+template <int SIN_MODE>
+__global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const DecodeParams p) {
+    constexpr int TILES = CO_TILES;
+    __shared__ __attribute__((aligned(16))) bf16x8 qa[2][TILES][16][64];       // 128 KiB: B fragments, double-buffered
+    __shared__ __attribute__((aligned(16))) float seed[CO_SEED_CELLS * CO_SEED_PITCH];   // P slice of the block's cells
+    __shared__ __attribute__((aligned(16))) float bias[3 * HID];               // bQ1..3 in revolutions
+    __shared__ __attribute__((aligned(16))) float ltab[3 * HID];               // head rows L0..L2
+    float (*red)[TILES * 32][3] = reinterpret_cast<float (*)[TILES * 32][3]>(seed);   // partial RGB per (wave, lane half)
+    static_assert(sizeof(seed) >= 16 * TILES * 32 * 3 * sizeof(float), "red aliases the seed slab");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..7 = this wave's M-tile
+    const int grp = wave >> 2;                                    // waves w and w + 4 share a SIMD
+    const int h = lane >> 5, j = lane & 31;
+    const float* __restrict__ Wt = p.Wt;
+    const int ncx = p.seed_cols;
+    const int ncx_inv = 65536 / ncx + 1;
+
+    // ---- this workgroup's blocks: position (dx, dy) inside every super-tile of its XCD's run
+    const int gx = p.pg[0], gy = p.pg[1], stx = p.pg[3], sty = p.pg[4], per = p.pg[5];
+    const int nst = stx * sty * p.pg[2];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int dx = slot & (CO_ST_X - 1), dy = slot / CO_ST_X;
+    int stile = xcd * per;
+    const int st_end = stile + per < nst ? stile + per : nst;
+    struct Blk { int x, y, z; };
+    auto locate = [&](const int st_, Blk& bk) {                   // block (dx, dy) of super-tile st_; false: outside the grid
+        const int z = st_ / (stx * sty), r = st_ - z * stx * sty;
+        const int sy = r / stx, sx = r - sy * stx;
+        bk.x = sx * CO_ST_X + dx; bk.y = sy * CO_ST_Y + dy; bk.z = z;
+        return bk.x < gx && bk.y < gy;
+    };
+    auto next_block = [&](int& st_, Blk& bk) {                    // first super-tile >= st_ that holds a block for us
+        while (st_ < st_end && !locate(st_, bk)) ++st_;
+        return st_ < st_end;
+    };
+    Blk blk;
+    if (!next_block(stile, blk)) return;                          // uniform over the workgroup; no barrier yet
+
+    // ---- per-block coordinates
+    int ixs[2], iys[2];
+    float relws[2], relhs[2];
+    int ix0, iy0;
+    int srow[TILES], qoff[TILES];
+#pragma unroll
+    for (int ti = 0; ti < TILES; ++ti) qoff[ti] = (grp ? (ti ^ 2) : ti) * 16 * 64;   // tile order of this wave's group
+    auto coords = [&](const Blk& bk) {
+        const int x0 = bk.x * (2 * TILE_W) + (j & (TILE_W - 1));
+        const int yb = p.y0 + bk.y * (2 * TILE_H) + (j / TILE_W);
+#pragma unroll
+        for (int tx = 0; tx < 2; ++tx) {
+            const int x = x0 + tx * TILE_W;
+            axis_eval(p.aw, x < p.Wu ? x : p.Wu - 1, ixs[tx], relws[tx]);
+        }
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty) {
+            const int y = yb + ty * TILE_H;
+            axis_eval(p.ah, y < p.y1 ? y : p.y1 - 1, iys[ty], relhs[ty]);
+        }
+        ix0 = __builtin_amdgcn_readfirstlane(ixs[0]);
+        iy0 = __builtin_amdgcn_readfirstlane(iys[0]);
+#pragma unroll
+        for (int ti = 0; ti < TILES; ++ti) {
+            const int ta = ti, tb2 = ti ^ 2;
+            const int sa = (((iys[ta >> 1] - iy0) * ncx + (ixs[ta & 1] - ix0)) * CO_SEED_PITCH + 4 * h) * (int)sizeof(float);
+            const int sb = (((iys[tb2 >> 1] - iy0) * ncx + (ixs[tb2 & 1] - ix0)) * CO_SEED_PITCH + 4 * h) * (int)sizeof(float);
+            srow[ti] = grp ? sb : sa;
+        }
+    };
+    // first LR cell of a block (wave-uniform): the lane-0 pixel's indices
+    auto first_cell = [&](const Blk& bk, int& cx0, int& cy0) {
+        const int x = bk.x * (2 * TILE_W), y = p.y0 + bk.y * (2 * TILE_H);
+        int a, b2;
+        float rel;
+        axis_eval(p.aw, x < p.Wu ? x : p.Wu - 1, a, rel);
+        axis_eval(p.ah, y < p.y1 ? y : p.y1 - 1, b2, rel);
+        cx0 = __builtin_amdgcn_readfirstlane(a);
+        cy0 = __builtin_amdgcn_readfirstlane(b2);
+    };
+    // element offsets of the P rows this wave stages (slab rows wave, wave + 8, wave + 16) for a block whose first cell is
+    // (cx0, cy0) of batch item z; wave-uniform, the lane adds its 16 bytes
+    size_t scell[CO_SEED_CELLS / 8];
+    auto cells_of = [&](const int cx0, const int cy0, const int z) {
+#pragma unroll
+        for (int i = 0; i < CO_SEED_CELLS / 8; ++i) {
+            const int c = wave + 8 * i;
+            const int cq = (c * ncx_inv) >> 16;
+            int cy = cy0 + cq, cx = cx0 + (c - cq * ncx);
+            const int ylast = p.Prow0 + p.Prows - 1;
+            cy = cy < ylast ? cy : ylast;
+            cx = cx < p.W - 1 ? cx : p.W - 1;
+            scell[i] = ((size_t)(z * p.Prows + (cy - p.Prow0)) * p.W + cx) * PCH;
+        }
+    };
+    f32x4 st[CO_SEED_CELLS / 8];
+    auto stage_load = [&](const int slice) {
+#pragma unroll
+        for (int i = 0; i < CO_SEED_CELLS / 8; ++i) st[i] = *(const f32x4*)(p.P + scell[i] + slice * HID + 4 * lane);
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < CO_SEED_CELLS / 8; ++i)
+            *(f32x4*)(seed + (wave + 8 * i) * CO_SEED_PITCH + 4 * lane) = st[i];
+    };
+
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);
+    const int lane_off = lane * 16;
+    auto ld_w = [&](const int mt, const int pc) {
+        return ld_piece(wrs, lane_off + (pc & 3) * PIECE_BYTES, mt + (pc >> 2) * 4 * PIECE_BYTES);
+    };
+    f32x4 Ak[16], As[16];
+    const int wp0 = (int)(OFF_WLB * sizeof(float)) + wave * CO_MT_BYTES;   // this wave's M-tile of the first stacked layer
+    int wp = wp0;
+
+    // the tables of layer 0 live in the second activation image: free until layer 1's epilogue starts writing it, and
+    // free again during the whole last layer (whose results go to the head, not to an image)
+    float* const q0tab = reinterpret_cast<float*>(&qa[1][0][0][0]);          // [3][256]: Q0h, Q0w, fma(Q0r, ratio, bQ0)
+    float* const seed0 = q0tab + 4 * HID;                                     // P_0 rows of the block's cells
+    float* const seed1n = seed0 + CO_SEED_CELLS * CO_SEED_PITCH;              // the NEXT block's P_1 rows, parked until the slab is free
+    static_assert((4 * HID + 2 * CO_SEED_CELLS * CO_SEED_PITCH) * sizeof(float) <= sizeof(qa) / 2, "layer-0 tables fit in qa[1]");
+    const int tix = threadIdx.x;
+    // the Q0 rows of thread tix (192 threads x 16 B), row 2 folded with the ratio: identical for every block
+    auto q0_load = [&](f32x4& tq, f32x4& bq0) {
+        tq = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        bq0 = tq;
+        if (tix < 192) tq = *(const f32x4*)(Wt + OFF_Q0R + 4 * tix);
+        if (tix >= 128 && tix < 192) bq0 = *(const f32x4*)(Wt + OFF_Q0R + HID + 4 * tix);
+    };
+    auto q0_store = [&](f32x4 tq, const f32x4 bq0) {
+        if (tix < 192) {
+            if (tix >= 128) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tq[e] = __builtin_fmaf(tq[e], p.ratio, bq0[e]);
+            }
+            *(f32x4*)(q0tab + 4 * tix) = tq;
+        }
+    };
+
+    // ---- prologue of the FIRST block (later blocks are prepared inside the previous block's last layer)
+    {
+        int cx0, cy0;
+        first_cell(blk, cx0, cy0);
+        cells_of(cx0, cy0, blk.z);
+        f32x4 s0[CO_SEED_CELLS / 8];
+#pragma unroll
+        for (int i = 0; i < CO_SEED_CELLS / 8; ++i) s0[i] = *(const f32x4*)(p.P + scell[i] + 4 * lane);
+        stage_load(1);
+        f32x4 tq, bq0;
+        q0_load(tq, bq0);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            Ak[ks] = ld_w(wp, 2 * ks + 0);
+            As[ks] = ld_w(wp, 2 * ks + 1);
+        }
+        asm volatile("" ::: "memory");
+        q0_store(tq, bq0);
+        if (tix >= 192 && tix < 384) {
+            *(f32x4*)(bias + 4 * (tix - 192)) = *(const f32x4*)(Wt + OFF_BQR + 4 * (tix - 192));
+        } else if (tix >= 384) {
+            const int k = tix - 384;                                         // 128 threads: 192 pieces of L, two rounds
+            *(f32x4*)(ltab + 4 * k) = *(const f32x4*)(Wt + OFF_L + 4 * k);
+            if (k < 64) *(f32x4*)(ltab + 4 * (k + 128)) = *(const f32x4*)(Wt + OFF_L + 4 * (k + 128));
+        }
+#pragma unroll
+        for (int i = 0; i < CO_SEED_CELLS / 8; ++i)
+            *(f32x4*)(seed0 + (wave + 8 * i) * CO_SEED_PITCH + 4 * lane) = s0[i];
+        stage_store();
+    }
+    const unsigned nanm = derived_nan_mask(Wt);
+    const float bl0 = or_bits(Wt[OFF_BL + 0], nanm), bl1 = or_bits(Wt[OFF_BL + 1], nanm), bl2 = or_bits(Wt[OFF_BL + 2], nanm);
+
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    float o[TILES][3];
+    bool has_next = false;
+    Blk nblk = blk;
+
+    auto layer_body = [&](auto last_tag, auto cur_tag, const int layer) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        constexpr int CUR = decltype(cur_tag)::value ? 1 : 0;
+        constexpr int NXT = 1 - CUR;
+        const bf16x8* __restrict__ qin = &qa[CUR][0][0][lane];
+        const float* __restrict__ bl = bias + layer * HID + 32 * wave + 4 * h;
+        const float* __restrict__ hl = ltab + 32 * wave + 4 * h;
+        if (LAST) {
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) o[t][0] = o[t][1] = o[t][2] = 0.0f;
+        }
+        // LAST: what the next block's start reads is requested here, two rows per pixel tile, and parked in the free
+        // second image at the end of the tile: tile 0: P_0 rows 0, 1; tile 1: P_0 row 2, P_1 row 0; tile 2: P_1 rows 1, 2;
+        // tile 3: the Q0 table (and, fragment by fragment, the first layer's weights)
+        static_assert(CO_SEED_CELLS / 8 == 3, "prefetch schedule of the last layer");
+        f32x4 na, nb;
+        auto nrow = [&](const int r) -> const float* {            // row r = 0..5: (slice r / 3, cell row r % 3)
+            return p.P + scell[r % 3] + (r / 3) * HID + 4 * lane;
+        };
+        auto nslot = [&](const int r) -> float* {
+            return (r < 3 ? seed0 : seed1n) + (wave + 8 * (r % 3)) * CO_SEED_PITCH + 4 * lane;
+        };
+        bf16x8 bq[CO_BRING];
+#pragma unroll
+        for (int i = 0; i < CO_BRING; ++i) bq[i] = qin[qoff[0] + i * 64];
+#pragma unroll
+        for (int ti = 0; ti < TILES; ++ti) {
+            f32x16 ak, as;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const f32x4 sk = *(const f32x4*)((const char*)seed + srow[ti] + (32 * wave + 8 * gg) * (int)sizeof(float));
+                const f32x4 sq = *(const f32x4*)(bl + 8 * gg);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ak[4 * gg + e] = sk[e];
+                    as[4 * gg + e] = sq[e];
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const bf16x8 bv = bq[ks % CO_BRING];
+                ak = MFMA_BF16(__builtin_bit_cast(bf16x8, Ak[ks]), bv, ak);
+                as = MFMA_BF16(__builtin_bit_cast(bf16x8, As[ks]), bv, as);
+                if (ks + CO_BRING < 16) bq[ks % CO_BRING] = qin[qoff[ti] + (ks + CO_BRING) * 64];
+                else if (ti + 1 < TILES) bq[ks % CO_BRING] = qin[qoff[ti + 1] + (ks + CO_BRING - 16) * 64];
+                if (ti == TILES - 1) {                            // last use of this fragment: fetch the next layer's --
+                    const int nwp = LAST ? wp0 : wp + (int)(WLB_LAYER * sizeof(float));   // or the next block's first layer
+                    if (!LAST || has_next) {
+                        Ak[ks] = ld_w(nwp, 2 * ks + 0);
+                        As[ks] = ld_w(nwp, 2 * ks + 1);
+                    }
+                }
+                if (!LAST && ti == 1 && ks == 8) stage_load(layer + 2);   // next layer's P slice, into registers
+                if (LAST && ks == 0 && has_next) {
+                    if (ti < 3) {
+                        na = *(const f32x4*)nrow(2 * ti);
+                        nb = *(const f32x4*)nrow(2 * ti + 1);
+                    } else {
+                        q0_load(na, nb);
+                    }
+                }
+                if ((ks & 3) == 3) asm volatile("" ::: "memory");
+            }
+            // epilogue of this tile (the other wave of the SIMD has the matrix pipe): q = relu(k) * sin(s)
+            u32x4 fragw;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 v;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    v[i] = relu0(ak[r + i]) * co_sin_fin<SIN_MODE>(co_sin_prep<SIN_MODE>(as[r + i]));
+                if (LAST) {                                       // head rows of this element's channel, from the LDS table
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int c = 8 * ((r + i) >> 2) + ((r + i) & 3);
+                        o[ti][0] = __builtin_fmaf(hl[0 * HID + c], v[i], o[ti][0]);
+                        o[ti][1] = __builtin_fmaf(hl[1 * HID + c], v[i], o[ti][1]);
+                        o[ti][2] = __builtin_fmaf(hl[2 * HID + c], v[i], o[ti][2]);
+                    }
+                } else {
+                    fragw[(r >> 1) & 3] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+                    if ((r & 7) == 6)
+                        *(bf16x8*)(&qa[NXT][0][0][lane] + qoff[ti] + (2 * wave + (r >> 3)) * 64) = __builtin_bit_cast(bf16x8, fragw);
+                }
+            }
+            if (LAST) asm volatile("" : "+v"(o[ti][0]), "+v"(o[ti][1]), "+v"(o[ti][2]));
+            if (LAST && has_next) {                               // ... parked in the free image
+                if (ti < 3) {
+                    *(f32x4*)nslot(2 * ti) = na;
+                    *(f32x4*)nslot(2 * ti + 1) = nb;
+                } else {
+                    q0_store(na, nb);
+                }
+            }
+        }
+        __syncthreads();                                          // layer output complete; input and seed slab are free
+        if (!LAST) {
+            stage_store();
+            __syncthreads();
+        }
+    };
+
+    for (;;) {
+        coords(blk);
+        __syncthreads();                                          // the block's tables and P_0 / P_1 slices are in LDS
+        // ---- layer 0 (fp32): wave w evaluates tile w & 3, channels 128 grp .. 128 grp + 127 (k-steps 8 grp .. 8 grp + 7)
+        {
+            const float* __restrict__ Q0 = q0tab + 4 * h;
+            const int t = wave & 3;
+            const int ix = (t & 1) ? ixs[1] : ixs[0], iy = (t >> 1) ? iys[1] : iys[0];
+            const float relw = (t & 1) ? relws[1] : relws[0], relh = (t >> 1) ? relhs[1] : relhs[0];
+            const float* __restrict__ Pc = seed0 + ((iy - iy0) * ncx + (ix - ix0)) * CO_SEED_PITCH + 4 * h;
+            const int g0 = 16 * grp;
+            f32x4 cpv, cwh, cww, ctq, npv, nwh, nww, ntq2;
+            auto fetch = [&](const int i, f32x4& pv, f32x4& wh, f32x4& ww, f32x4& tq) {
+                const int c0 = 8 * (g0 + i);
+                pv = *(const f32x4*)(Pc + c0);
+                wh = *(const f32x4*)(Q0 + 0 * HID + c0);
+                ww = *(const f32x4*)(Q0 + 1 * HID + c0);
+                tq = *(const f32x4*)(Q0 + 2 * HID + c0);
+            };
+            fetch(0, cpv, cwh, cww, ctq);
+            u32x4 fragw;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i + 1 < 16) fetch(i + 1, npv, nwh, nww, ntq2);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = __builtin_fmaf(cww[e], relw, ctq[e]);
+                    a = __builtin_fmaf(cwh[e], relh, a);
+                    v[e] = relu0(cpv[e]) * dsin_rev<SIN_MODE>(a);
+                }
+                const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+                fragw[2 * (i & 1) + 0] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+                fragw[2 * (i & 1) + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+                if (i & 1) qa[0][t][8 * grp + (i >> 1)][lane] = __builtin_bit_cast(bf16x8, fragw);
+                cpv = npv; cwh = nwh; cww = nww; ctq = ntq2;
+                asm volatile("" ::: "memory");
+            }
+        }
+        // the block after this one (wave-uniform scalar work, overlaps the barrier)
+        int nst_i = stile + 1;
+        has_next = next_block(nst_i, nblk);
+        __syncthreads();
+
+        wp = wp0;
+        layer_body(CoopTagFalse{}, CoopTagFalse{}, 0);
+        wp += (int)(WLB_LAYER * sizeof(float));
+        layer_body(CoopTagFalse{}, CoopTagTrue{}, 1);
+        wp += (int)(WLB_LAYER * sizeof(float));
+        if (has_next) {                                           // P rows of the next block's cells: read by the last layer's prefetch
+            int cx0, cy0;
+            first_cell(nblk, cx0, cy0);
+            cells_of(cx0, cy0, nblk.z);
+        }
+        layer_body(CoopTagTrue{}, CoopTagFalse{}, 2);
+
+        // ---- head: the 16 partial sums of a pixel (8 waves x 2 lane halves) meet in LDS (diinn.py:138).
+        // o[ti] belongs to tile ti ^ (2 grp)
+#pragma unroll
+        for (int ti = 0; ti < TILES; ++ti) {
+            const int t = ti ^ (2 * grp);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) red[2 * wave + h][t * 32 + j][k] = o[ti][k];
+        }
+        __syncthreads();
+        if (threadIdx.x < TILES * 32) {
+            const int t = threadIdx.x >> 5, jj = threadIdx.x & 31;
+            const int x = blk.x * (2 * TILE_W) + (t & 1) * TILE_W + (jj & (TILE_W - 1));
+            const int y = p.y0 + blk.y * (2 * TILE_H) + (t >> 1) * TILE_H + (jj / TILE_W);
+            float acc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int w16 = 0; w16 < 16; ++w16)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc[k] += red[w16][threadIdx.x][k];
+            if (x < p.Wu && y < p.y1) {
+                const size_t plane = (size_t)p.Orows * p.Wu;
+                float* op = p.out + (size_t)blk.z * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
+                op[0] = acc[0] + bl0;
+                op[plane] = acc[1] + bl1;
+                op[2 * plane] = acc[2] + bl2;
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();                                          // the partial sums have been read: the seed slab is free
+#pragma unroll
+        for (int i = 0; i < CO_SEED_CELLS / 8; ++i)               // the next block's P_1 slice, from where the last layer parked it
+            *(f32x4*)(seed + (wave + 8 * i) * CO_SEED_PITCH + 4 * lane) =
+                *(const f32x4*)(seed1n + (wave + 8 * i) * CO_SEED_PITCH + 4 * lane);
+        blk = nblk;
+        stile = nst_i;
+    }
+}
+
 // cells of the LR footprint of the widest 16 x 8 pixel block: (columns, rows).  Rows: the maximum over EVERY start
 // row of the full image, not over the blocks of the band at hand (they are anchored at y0), so that the kernel choice
 // below is the same for a band and for the whole image.
@@ -1117,8 +1509,21 @@ int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int 
         // a 16 x 8 block covers whole cells iff 16 / scale_x and 8 / scale_y are integers
         pc.xcd_runs = !((16LL * p.W) % p.Wu == 0 && (8LL * p.H) % p.Hu == 0);
         const bool coop_ok = ncx * ncy <= CO_SEED_CELLS;
-        const bool coop = coop_ok && (force ? (force == 4 || force == 8) : (long long)gx * full_gy * gz >= 1024);
-        if (coop && force != 4) {                                 // 16 x 8 pixel blocks, 8 waves: the grid of the one-tile kernel
+        const bool coop = coop_ok && (force ? (force == 4 || force == 8 || force == 9) : (long long)gx * full_gy * gz >= 1024);
+        if (coop && force != 4 && force != 8) {                   // 8 waves, persistent workgroups over super-tiles of 8 x 4 blocks
+            pc.pg[0] = gx; pc.pg[1] = gy; pc.pg[2] = gz;
+            pc.pg[3] = (gx + CO_ST_X - 1) / CO_ST_X; pc.pg[4] = (gy + CO_ST_Y - 1) / CO_ST_Y;
+            const long long nst = (long long)pc.pg[3] * pc.pg[4] * gz;
+            if (nst > 0x7fffffffLL) return DIINN_ERR_TOO_LARGE;
+            pc.pg[5] = (int)((nst + 7) / 8);
+            const dim3 gridp(CO_PGRID);
+            if (sin_mode == DIINN_SIN_HW)
+                hipLaunchKernelGGL(decode_bf16_coop8p_kernel<DIINN_SIN_HW>, gridp, dim3(512), 0, (hipStream_t)stream, pc);
+            else if (sin_mode == DIINN_SIN_HW_REDUCED)
+                hipLaunchKernelGGL(decode_bf16_coop8p_kernel<DIINN_SIN_HW_REDUCED>, gridp, dim3(512), 0, (hipStream_t)stream, pc);
+            else
+                hipLaunchKernelGGL(decode_bf16_coop8p_kernel<DIINN_SIN_ACCURATE>, gridp, dim3(512), 0, (hipStream_t)stream, pc);
+        } else if (coop && force != 4) {                          // one block per workgroup (DIINN_BF16_KERNEL=8)
             if (sin_mode == DIINN_SIN_HW)
                 hipLaunchKernelGGL(decode_bf16_coop8_kernel<DIINN_SIN_HW>, grid, dim3(512), 0, (hipStream_t)stream, pc);
             else if (sin_mode == DIINN_SIN_HW_REDUCED)

@@ -612,6 +612,7 @@ static int decode_band_impl(void* stream, const float* P_dev, const float* packe
     p.ratio = (float)(((double)H * (double)W) / ((double)Hu * (double)Wu));
     p.Prow0 = pw.row0; p.Prows = pw.rows; p.Orow0 = ow.row0; p.Orows = ow.rows;
     p.acts = nullptr; p.npix = 0; p.seed_cols = 0; p.xcd_runs = 0;
+    for (int i = 0; i < 6; ++i) p.pg[i] = 0;
 #ifdef DIINN_STAMPS
     p.stamps = g_stamps;
 #endif
@@ -730,6 +731,7 @@ int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed
     p.ratio = (float)(((double)H * (double)W) / ((double)Hu * (double)Wu));
     p.Prow0 = 0; p.Prows = H; p.Orow0 = 0; p.Orows = Hu;
     p.acts = acts_dev; p.npix = npix; p.seed_cols = 0; p.xcd_runs = 0;
+    for (int i = 0; i < 6; ++i) p.pg[i] = 0;
 #ifdef DIINN_STAMPS
     p.stamps = nullptr;
 #endif

@@ -109,6 +109,7 @@ struct DecodeParams {
     int Prow0, Prows, Orow0, Orows;
     int seed_cols;         // decode_bf16_coop_kernel: LR columns of a block's footprint (row length of its LDS seed slab)
     int xcd_runs;          // decode_bf16_coop8_kernel: walk the blocks XCD by XCD (set when neighbouring blocks share P rows)
+    int pg[6];             // decode_bf16_coop8p_kernel: block grid (x, y, z), super-tile grid (x, y), super-tiles per XCD
     float ratio;           // fp32(H*W / (Hu*Wu))   (diinn.py:166)
     Axis ah, aw;
     float* acts;           // training forward only (SAVE): saved activations, tiled planes [4 layers][ntiles][512][32]
