@@ -1091,8 +1091,6 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
     __shared__ __attribute__((aligned(16))) float seed[CO_SEED_CELLS * CO_SEED_PITCH];   // P slice of the block's cells
     __shared__ __attribute__((aligned(16))) float bias[3 * HID];               // bQ1..3 in revolutions
     __shared__ __attribute__((aligned(16))) float ltab[3 * HID];               // head rows L0..L2
-    float (*red)[TILES * 32][3] = reinterpret_cast<float (*)[TILES * 32][3]>(seed);   // partial RGB per (wave, lane half)
-    static_assert(sizeof(seed) >= 16 * TILES * 32 * 3 * sizeof(float), "red aliases the seed slab");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..7 = this wave's M-tile
     const int grp = wave >> 2;                                    // waves w and w + 4 share a SIMD
@@ -1130,6 +1128,9 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
 #pragma unroll
     for (int ti = 0; ti < TILES; ++ti) qoff[ti] = (grp ? (ti ^ 2) : ti) * 16 * 64;   // tile order of this wave's group
     auto coords = [&](const Blk& bk) {
+        int ln = lane;                                            // opaque: see stage_load
+        asm volatile("" : "+v"(ln));
+        const int j = ln & 31, h = ln >> 5;
         const int x0 = bk.x * (2 * TILE_W) + (j & (TILE_W - 1));
         const int yb = p.y0 + bk.y * (2 * TILE_H) + (j / TILE_W);
 #pragma unroll
@@ -1162,30 +1163,51 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
         cx0 = __builtin_amdgcn_readfirstlane(a);
         cy0 = __builtin_amdgcn_readfirstlane(b2);
     };
-    // element offsets of the P rows this wave stages (slab rows wave, wave + 8, wave + 16) for a block whose first cell is
-    // (cx0, cy0) of batch item z; wave-uniform, the lane adds its 16 bytes
+    // Staging of the block's P rows (slab cell c = 0..23 of the footprint whose first cell is (cx0, cy0) of batch item z):
+    //  * P_0, read by layer 0 across all channels: whole 1 KiB rows, cells wave, wave + 8, wave + 16 per wave
+    //    (scell: wave-uniform element offsets, the lane adds its 16 bytes);
+    //  * P_1..3, the accumulator seeds of layers 1..3: wave w only ever reads ITS 32 channels of every cell, so it stages
+    //    exactly that column itself -- cell (lane >> 3) + 8 i, 16-byte chunk lane & 7: one 128-byte line per cell -- and
+    //    writes it once its own last read of the old column is behind it.  No other wave touches the column: no
+    //    barrier for the seeds, one barrier per layer instead of two (ccell: per-lane cell numbers in the P window).
     size_t scell[CO_SEED_CELLS / 8];
     auto cells_of = [&](const int cx0, const int cy0, const int z) {
+        const int ylast = p.Prow0 + p.Prows - 1;
 #pragma unroll
         for (int i = 0; i < CO_SEED_CELLS / 8; ++i) {
             const int c = wave + 8 * i;
             const int cq = (c * ncx_inv) >> 16;
             int cy = cy0 + cq, cx = cx0 + (c - cq * ncx);
-            const int ylast = p.Prow0 + p.Prows - 1;
             cy = cy < ylast ? cy : ylast;
             cx = cx < p.W - 1 ? cx : p.W - 1;
             scell[i] = ((size_t)(z * p.Prows + (cy - p.Prow0)) * p.W + cx) * PCH;
         }
     };
     f32x4 st[CO_SEED_CELLS / 8];
-    auto stage_load = [&](const int slice) {
+    // (the lane number enters through an opaque copy and the per-lane cell arithmetic -- a dozen operations per cell --
+    // is redone at every staging: held in registers across the block loop it would not fit)
+    auto stage_load = [&](const int slice, const int cx0, const int cy0, const int z) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int ccol = 32 * wave + 4 * (ln & 7);               // this lane's 4 channels inside the wave's column
+        const int ylast = p.Prow0 + p.Prows - 1;
 #pragma unroll
-        for (int i = 0; i < CO_SEED_CELLS / 8; ++i) st[i] = *(const f32x4*)(p.P + scell[i] + slice * HID + 4 * lane);
+        for (int i = 0; i < CO_SEED_CELLS / 8; ++i) {
+            const int c2 = (ln >> 3) + 8 * i;
+            const int cq2 = (c2 * ncx_inv) >> 16;
+            int cy2 = cy0 + cq2, cx2 = cx0 + (c2 - cq2 * ncx);
+            cy2 = cy2 < ylast ? cy2 : ylast;
+            cx2 = cx2 < p.W - 1 ? cx2 : p.W - 1;
+            const size_t cell = (size_t)(z * p.Prows + (cy2 - p.Prow0)) * p.W + cx2;
+            st[i] = *(const f32x4*)(p.P + cell * PCH + slice * HID + ccol);
+        }
     };
     auto stage_store = [&]() {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        float* dst = seed + (ln >> 3) * CO_SEED_PITCH + 32 * wave + 4 * (ln & 7);
 #pragma unroll
-        for (int i = 0; i < CO_SEED_CELLS / 8; ++i)
-            *(f32x4*)(seed + (wave + 8 * i) * CO_SEED_PITCH + 4 * lane) = st[i];
+        for (int i = 0; i < CO_SEED_CELLS / 8; ++i) *(f32x4*)(dst + 8 * i * CO_SEED_PITCH) = st[i];
     };
 
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -1201,24 +1223,27 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
     // the tables of layer 0 live in the second activation image: free until layer 1's epilogue starts writing it, and
     // free again during the whole last layer (whose results go to the head, not to an image)
     float* const q0tab = reinterpret_cast<float*>(&qa[1][0][0][0]);          // [3][256]: Q0h, Q0w, fma(Q0r, ratio, bQ0)
-    float* const seed0 = q0tab + 4 * HID;                                     // P_0 rows of the block's cells
-    float* const seed1n = seed0 + CO_SEED_CELLS * CO_SEED_PITCH;              // the NEXT block's P_1 rows, parked until the slab is free
-    static_assert((4 * HID + 2 * CO_SEED_CELLS * CO_SEED_PITCH) * sizeof(float) <= sizeof(qa) / 2, "layer-0 tables fit in qa[1]");
+    float* const seed0 = q0tab + 3 * HID;                                     // P_0 rows of the block's cells
+    // partial RGB sums of the head per (wave, pixel), written tile by tile during the last layer (12 registers fewer
+    // than carrying all four tiles' sums to the end)
+    float (*red)[TILES * 32][3] = reinterpret_cast<float (*)[TILES * 32][3]>(seed0 + CO_SEED_CELLS * CO_SEED_PITCH);
+    static_assert((3 * HID + CO_SEED_CELLS * CO_SEED_PITCH + 8 * TILES * 32 * 3) * sizeof(float) <= sizeof(qa) / 2,
+                  "layer-0 tables and the head sums fit in qa[1]");
     const int tix = threadIdx.x;
     // the Q0 rows of thread tix (192 threads x 16 B), row 2 folded with the ratio: identical for every block
-    auto q0_load = [&](f32x4& tq, f32x4& bq0) {
+    auto q0_load = [&](const int tx, f32x4& tq, f32x4& bq0) {
         tq = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         bq0 = tq;
-        if (tix < 192) tq = *(const f32x4*)(Wt + OFF_Q0R + 4 * tix);
-        if (tix >= 128 && tix < 192) bq0 = *(const f32x4*)(Wt + OFF_Q0R + HID + 4 * tix);
+        if (tx < 192) tq = *(const f32x4*)(Wt + OFF_Q0R + 4 * tx);
+        if (tx >= 128 && tx < 192) bq0 = *(const f32x4*)(Wt + OFF_Q0R + HID + 4 * tx);
     };
-    auto q0_store = [&](f32x4 tq, const f32x4 bq0) {
-        if (tix < 192) {
-            if (tix >= 128) {
+    auto q0_store = [&](const int tx, f32x4 tq, const f32x4 bq0) {
+        if (tx < 192) {
+            if (tx >= 128) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) tq[e] = __builtin_fmaf(tq[e], p.ratio, bq0[e]);
             }
-            *(f32x4*)(q0tab + 4 * tix) = tq;
+            *(f32x4*)(q0tab + 4 * tx) = tq;
         }
     };
 
@@ -1230,9 +1255,9 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
         f32x4 s0[CO_SEED_CELLS / 8];
 #pragma unroll
         for (int i = 0; i < CO_SEED_CELLS / 8; ++i) s0[i] = *(const f32x4*)(p.P + scell[i] + 4 * lane);
-        stage_load(1);
+        stage_load(1, cx0, cy0, blk.z);
         f32x4 tq, bq0;
-        q0_load(tq, bq0);
+        q0_load(tix, tq, bq0);
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
@@ -1240,7 +1265,7 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
             As[ks] = ld_w(wp, 2 * ks + 1);
         }
         asm volatile("" ::: "memory");
-        q0_store(tq, bq0);
+        q0_store(tix, tq, bq0);
         if (tix >= 192 && tix < 384) {
             *(f32x4*)(bias + 4 * (tix - 192)) = *(const f32x4*)(Wt + OFF_BQR + 4 * (tix - 192));
         } else if (tix >= 384) {
@@ -1253,37 +1278,31 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
             *(f32x4*)(seed0 + (wave + 8 * i) * CO_SEED_PITCH + 4 * lane) = s0[i];
         stage_store();
     }
-    const unsigned nanm = derived_nan_mask(Wt);
-    const float bl0 = or_bits(Wt[OFF_BL + 0], nanm), bl1 = or_bits(Wt[OFF_BL + 1], nanm), bl2 = or_bits(Wt[OFF_BL + 2], nanm);
 
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    float o[TILES][3];
     bool has_next = false;
     Blk nblk = blk;
+    int ncx0 = 0, ncy0 = 0;                                       // first cell of the next block
 
     auto layer_body = [&](auto last_tag, auto cur_tag, const int layer) {
         constexpr bool LAST = decltype(last_tag)::value;
         constexpr int CUR = decltype(cur_tag)::value ? 1 : 0;
         constexpr int NXT = 1 - CUR;
-        const bf16x8* __restrict__ qin = &qa[CUR][0][0][lane];
+        int ln = lane, tx = tix;                                  // opaque copies: see stage_load
+        asm volatile("" : "+v"(ln), "+v"(tx));
+        const int h = ln >> 5, j = ln & 31;
+        const bf16x8* __restrict__ qin = &qa[CUR][0][0][ln];
         const float* __restrict__ bl = bias + layer * HID + 32 * wave + 4 * h;
         const float* __restrict__ hl = ltab + 32 * wave + 4 * h;
-        if (LAST) {
-#pragma unroll
-            for (int t = 0; t < TILES; ++t) o[t][0] = o[t][1] = o[t][2] = 0.0f;
-        }
-        // LAST: what the next block's start reads is requested here, two rows per pixel tile, and parked in the free
-        // second image at the end of the tile: tile 0: P_0 rows 0, 1; tile 1: P_0 row 2, P_1 row 0; tile 2: P_1 rows 1, 2;
-        // tile 3: the Q0 table (and, fragment by fragment, the first layer's weights)
+        // LAST: what the next block's start reads is requested here and parked at the end of the tile: tile 0: P_0 rows
+        // 0, 1 and tile 1: P_0 row 2 into the free second image; tile 2: the Q0 table, likewise; tile 3: this wave's
+        // column of the P_1 slice, into the seed slab (its last read of the old column is the tile's own seed), and,
+        // fragment by fragment, the first layer's weights
         static_assert(CO_SEED_CELLS / 8 == 3, "prefetch schedule of the last layer");
         f32x4 na, nb;
-        auto nrow = [&](const int r) -> const float* {            // row r = 0..5: (slice r / 3, cell row r % 3)
-            return p.P + scell[r % 3] + (r / 3) * HID + 4 * lane;
-        };
-        auto nslot = [&](const int r) -> float* {
-            return (r < 3 ? seed0 : seed1n) + (wave + 8 * (r % 3)) * CO_SEED_PITCH + 4 * lane;
-        };
+        auto nrow = [&](const int r) -> const float* { return p.P + scell[r] + 4 * ln; };
+        auto nslot = [&](const int r) -> float* { return seed0 + (wave + 8 * r) * CO_SEED_PITCH + 4 * ln; };
         bf16x8 bq[CO_BRING];
 #pragma unroll
         for (int i = 0; i < CO_BRING; ++i) bq[i] = qin[qoff[0] + i * 64];
@@ -1300,6 +1319,10 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
                     as[4 * gg + e] = sq[e];
                 }
             }
+            if (ti == TILES - 1) {                                // that was this wave's last read of its seed column
+                asm volatile("" ::: "memory");
+                if (!LAST) stage_store();                         // the next layer's column (requested during tile 1)
+            }
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 const bf16x8 bv = bq[ks % CO_BRING];
@@ -1314,19 +1337,24 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
                         As[ks] = ld_w(nwp, 2 * ks + 1);
                     }
                 }
-                if (!LAST && ti == 1 && ks == 8) stage_load(layer + 2);   // next layer's P slice, into registers
+                if (!LAST && ti == 1 && ks == 8) stage_load(layer + 2, ix0, iy0, blk.z);   // next layer's seed column, into registers
                 if (LAST && ks == 0 && has_next) {
-                    if (ti < 3) {
-                        na = *(const f32x4*)nrow(2 * ti);
-                        nb = *(const f32x4*)nrow(2 * ti + 1);
+                    if (ti == 0) {
+                        na = *(const f32x4*)nrow(0);
+                        nb = *(const f32x4*)nrow(1);
+                    } else if (ti == 1) {
+                        na = *(const f32x4*)nrow(2);
+                    } else if (ti == 2) {
+                        q0_load(tx, na, nb);
                     } else {
-                        q0_load(na, nb);
+                        stage_load(1, ncx0, ncy0, nblk.z);        // the next block's P_1 column
                     }
                 }
                 if ((ks & 3) == 3) asm volatile("" ::: "memory");
             }
             // epilogue of this tile (the other wave of the SIMD has the matrix pipe): q = relu(k) * sin(s)
             u32x4 fragw;
+            float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 f32x2 v;
@@ -1337,31 +1365,40 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const int c = 8 * ((r + i) >> 2) + ((r + i) & 3);
-                        o[ti][0] = __builtin_fmaf(hl[0 * HID + c], v[i], o[ti][0]);
-                        o[ti][1] = __builtin_fmaf(hl[1 * HID + c], v[i], o[ti][1]);
-                        o[ti][2] = __builtin_fmaf(hl[2 * HID + c], v[i], o[ti][2]);
+                        o0 = __builtin_fmaf(hl[0 * HID + c], v[i], o0);
+                        o1 = __builtin_fmaf(hl[1 * HID + c], v[i], o1);
+                        o2 = __builtin_fmaf(hl[2 * HID + c], v[i], o2);
                     }
                 } else {
                     fragw[(r >> 1) & 3] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
                     if ((r & 7) == 6)
-                        *(bf16x8*)(&qa[NXT][0][0][lane] + qoff[ti] + (2 * wave + (r >> 3)) * 64) = __builtin_bit_cast(bf16x8, fragw);
+                        *(bf16x8*)(&qa[NXT][0][0][ln] + qoff[ti] + (2 * wave + (r >> 3)) * 64) = __builtin_bit_cast(bf16x8, fragw);
                 }
             }
-            if (LAST) asm volatile("" : "+v"(o[ti][0]), "+v"(o[ti][1]), "+v"(o[ti][2]));
-            if (LAST && has_next) {                               // ... parked in the free image
-                if (ti < 3) {
-                    *(f32x4*)nslot(2 * ti) = na;
-                    *(f32x4*)nslot(2 * ti + 1) = nb;
+            if (LAST) {                                           // this wave's 32 channels of the head, both lane halves
+                asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2));
+                o0 += __shfl_xor(o0, 32);
+                o1 += __shfl_xor(o1, 32);
+                o2 += __shfl_xor(o2, 32);
+                if (h == 0) {
+                    float* r3 = red[wave][(ti ^ (2 * grp)) * 32 + j];    // visit ti of this wave's group is tile ti ^ (2 grp)
+                    r3[0] = o0; r3[1] = o1; r3[2] = o2;
+                }
+            }
+            if (LAST && has_next) {                               // ... parked
+                if (ti == 0) {
+                    *(f32x4*)nslot(0) = na;
+                    *(f32x4*)nslot(1) = nb;
+                } else if (ti == 1) {
+                    *(f32x4*)nslot(2) = na;
+                } else if (ti == 2) {
+                    q0_store(tx, na, nb);
                 } else {
-                    q0_store(na, nb);
+                    stage_store();
                 }
             }
         }
-        __syncthreads();                                          // layer output complete; input and seed slab are free
-        if (!LAST) {
-            stage_store();
-            __syncthreads();
-        }
+        __syncthreads();                                          // layer output complete, its input image is free
     };
 
     for (;;) {
@@ -1369,6 +1406,9 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
         __syncthreads();                                          // the block's tables and P_0 / P_1 slices are in LDS
         // ---- layer 0 (fp32): wave w evaluates tile w & 3, channels 128 grp .. 128 grp + 127 (k-steps 8 grp .. 8 grp + 7)
         {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int h = ln >> 5;
             const float* __restrict__ Q0 = q0tab + 4 * h;
             const int t = wave & 3;
             const int ix = (t & 1) ? ixs[1] : ixs[0], iy = (t >> 1) ? iys[1] : iys[0];
@@ -1398,7 +1438,7 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
                 const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
                 fragw[2 * (i & 1) + 0] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
                 fragw[2 * (i & 1) + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
-                if (i & 1) qa[0][t][8 * grp + (i >> 1)][lane] = __builtin_bit_cast(bf16x8, fragw);
+                if (i & 1) qa[0][t][8 * grp + (i >> 1)][ln] = __builtin_bit_cast(bf16x8, fragw);
                 cpv = npv; cwh = nwh; cww = nww; ctq = ntq2;
                 asm volatile("" ::: "memory");
             }
@@ -1414,31 +1454,27 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
         layer_body(CoopTagFalse{}, CoopTagTrue{}, 1);
         wp += (int)(WLB_LAYER * sizeof(float));
         if (has_next) {                                           // P rows of the next block's cells: read by the last layer's prefetch
-            int cx0, cy0;
-            first_cell(nblk, cx0, cy0);
-            cells_of(cx0, cy0, nblk.z);
+            first_cell(nblk, ncx0, ncy0);
+            cells_of(ncx0, ncy0, nblk.z);
         }
         layer_body(CoopTagTrue{}, CoopTagFalse{}, 2);
 
-        // ---- head: the 16 partial sums of a pixel (8 waves x 2 lane halves) meet in LDS (diinn.py:138).
-        // o[ti] belongs to tile ti ^ (2 grp)
-#pragma unroll
-        for (int ti = 0; ti < TILES; ++ti) {
-            const int t = ti ^ (2 * grp);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) red[2 * wave + h][t * 32 + j][k] = o[ti][k];
-        }
-        __syncthreads();
-        if (threadIdx.x < TILES * 32) {
-            const int t = threadIdx.x >> 5, jj = threadIdx.x & 31;
+        // ---- head: the 8 partial sums of a pixel (one per wave) meet here (diinn.py:138); the last layer's closing
+        // barrier made them visible
+        int tid = threadIdx.x;                                    // opaque: keeps the pixel arithmetic inside the loop
+        asm volatile("" : "+v"(tid));
+        if (tid < TILES * 32) {
+            const int t = tid >> 5, jj = tid & 31;
             const int x = blk.x * (2 * TILE_W) + (t & 1) * TILE_W + (jj & (TILE_W - 1));
             const int y = p.y0 + blk.y * (2 * TILE_H) + (t >> 1) * TILE_H + (jj / TILE_W);
             float acc[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int w16 = 0; w16 < 16; ++w16)
+            for (int w8 = 0; w8 < 8; ++w8)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) acc[k] += red[w16][threadIdx.x][k];
+                for (int k = 0; k < 3; ++k) acc[k] += red[w8][tid][k];
             if (x < p.Wu && y < p.y1) {
+                const unsigned nanm = derived_nan_mask(Wt);      // (read per block: three scalar loads instead of registers held across the loop)
+                const float bl0 = or_bits(Wt[OFF_BL + 0], nanm), bl1 = or_bits(Wt[OFF_BL + 1], nanm), bl2 = or_bits(Wt[OFF_BL + 2], nanm);
                 const size_t plane = (size_t)p.Orows * p.Wu;
                 float* op = p.out + (size_t)blk.z * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
                 op[0] = acc[0] + bl0;
@@ -1447,11 +1483,6 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
             }
         }
         if (!has_next) break;
-        __syncthreads();                                          // the partial sums have been read: the seed slab is free
-#pragma unroll
-        for (int i = 0; i < CO_SEED_CELLS / 8; ++i)               // the next block's P_1 slice, from where the last layer parked it
-            *(f32x4*)(seed + (wave + 8 * i) * CO_SEED_PITCH + 4 * lane) =
-                *(const f32x4*)(seed1n + (wave + 8 * i) * CO_SEED_PITCH + 4 * lane);
         blk = nblk;
         stile = nst_i;
     }
@@ -1510,7 +1541,9 @@ int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int 
         pc.xcd_runs = !((16LL * p.W) % p.Wu == 0 && (8LL * p.H) % p.Hu == 0);
         const bool coop_ok = ncx * ncy <= CO_SEED_CELLS;
         const bool coop = coop_ok && (force ? (force == 4 || force == 8 || force == 9) : (long long)gx * full_gy * gz >= 1024);
-        if (coop && force != 4 && force != 8) {                   // 8 waves, persistent workgroups over super-tiles of 8 x 4 blocks
+        // (the polynomial sine needs a few registers more than the 256 a wave may have at two per SIMD once the block
+        // loop's state is added: DIINN_SIN_ACCURATE stays on the one-block-per-workgroup form)
+        if (coop && force != 4 && force != 8 && sin_mode != DIINN_SIN_ACCURATE) {   // 8 waves, persistent workgroups over super-tiles of 8 x 4 blocks
             pc.pg[0] = gx; pc.pg[1] = gy; pc.pg[2] = gz;
             pc.pg[3] = (gx + CO_ST_X - 1) / CO_ST_X; pc.pg[4] = (gy + CO_ST_Y - 1) / CO_ST_Y;
             const long long nst = (long long)pc.pg[3] * pc.pg[4] * gz;
@@ -1519,10 +1552,8 @@ int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int 
             const dim3 gridp(CO_PGRID);
             if (sin_mode == DIINN_SIN_HW)
                 hipLaunchKernelGGL(decode_bf16_coop8p_kernel<DIINN_SIN_HW>, gridp, dim3(512), 0, (hipStream_t)stream, pc);
-            else if (sin_mode == DIINN_SIN_HW_REDUCED)
-                hipLaunchKernelGGL(decode_bf16_coop8p_kernel<DIINN_SIN_HW_REDUCED>, gridp, dim3(512), 0, (hipStream_t)stream, pc);
             else
-                hipLaunchKernelGGL(decode_bf16_coop8p_kernel<DIINN_SIN_ACCURATE>, gridp, dim3(512), 0, (hipStream_t)stream, pc);
+                hipLaunchKernelGGL(decode_bf16_coop8p_kernel<DIINN_SIN_HW_REDUCED>, gridp, dim3(512), 0, (hipStream_t)stream, pc);
         } else if (coop && force != 4) {                          // one block per workgroup (DIINN_BF16_KERNEL=8)
             if (sin_mode == DIINN_SIN_HW)
                 hipLaunchKernelGGL(decode_bf16_coop8_kernel<DIINN_SIN_HW>, grid, dim3(512), 0, (hipStream_t)stream, pc);

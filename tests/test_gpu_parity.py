@@ -453,12 +453,46 @@ def test_bf16_kernel_variants_agree(golden, dev, knobs):
         ref = golden[f"out/{name}"]
         scale = float(np.abs(ref).max())
         outs = {}
-        for k in ("1", "2", "4", "8"):
+        for k in ("1", "2", "4", "8", "9"):                        # 9: the 8-wave kernel with persistent workgroups
             knobs("DIINN_BF16_KERNEL", int(k))
             outs[k] = _decode(sd, feat, (hu, wu), dev, compute="bf16")
             assert float(np.abs(outs[k] - ref).max()) <= 2e-3 * scale + 1e-6, (name, k)
-        for k in ("2", "4", "8"):
+        for k in ("2", "4", "8", "9"):
             assert float(np.abs(outs[k] - outs["1"]).max()) <= 5e-4 * scale, (name, k)
+        # the persistent form does the one-block form's arithmetic; only the head's 16 partial sums meet in another order
+        assert float(np.abs(outs["9"] - outs["8"]).max()) <= 2e-6 * scale, name
+
+
+@pytest.mark.parametrize("compute", ["bf16", "bf16_full"])
+def test_bf16_persistent_kernel_blocks_bands_and_batches(dev, knobs, compute):
+    """decode_bf16_coop8p_kernel walks super-tiles of 8 x 4 blocks with 256 persistent workgroups and prepares the next
+    block inside the current one's last layer: ragged right / bottom edges, more super-tiles than one per XCD, batch > 1,
+    and row bands whose first row is not a block boundary must all reproduce the one-block-per-workgroup kernel (to the
+    head's summation order) and meet the restated bound against the oracle."""
+    import diinn_oracle as orc
+    import diinn_amd.decoder as D
+    tol = {"bf16": 2e-3, "bf16_full": 3e-3}[compute]
+    for (b, h, w, hu, wu, seed) in [(1, 40, 56, 132, 185, 3), (2, 33, 47, 109, 155, 4), (1, 60, 100, 333, 530, 5),
+                                    (3, 9, 11, 36, 40, 6)]:
+        sd = synth.decoder_state_dict(seed)
+        feat_np = synth.encoder_features(seed, b, h, w)
+        ref = orc.decode_reference_form(sd, feat_np, (hu, wu), 30000).numpy()
+        scale = float(np.abs(ref).max())
+        knobs("DIINN_BF16_KERNEL", 8)
+        one = _decode(sd, feat_np, (hu, wu), dev, compute=compute)
+        knobs("DIINN_BF16_KERNEL", 9)
+        per = _decode(sd, feat_np, (hu, wu), dev, compute=compute)
+        assert float(np.abs(per - ref).max()) <= tol * scale, (b, h, w, hu, wu)
+        assert float(np.abs(per - one).max()) <= 2e-6 * scale, (b, h, w, hu, wu)
+        # bands: rows [0, 13), [13, hu - 5), [hu - 5, hu) stitched into one image equal the whole decode bit for bit
+        packed = D.pack_state_dict(sd).to(dev)
+        feat = torch.from_numpy(feat_np).to(dev)
+        full = D.decode_features(feat, packed, (hu, wu), compute=compute)
+        out = torch.zeros_like(full)
+        for y0, y1 in [(0, 13), (13, hu - 5), (hu - 5, hu)]:
+            D.decode_features(feat, packed, (hu, wu), out=out, rows=(y0, y1), compute=compute)
+        torch.cuda.synchronize()
+        assert torch.equal(full, out), (b, h, w, hu, wu)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
