@@ -2,13 +2,19 @@
 // sine variants, the weight-stream load, tile geometry, the tiled-plane helpers of the training
 // path, and the small host-side helpers of the C ABI launch functions.
 //
-// Translation units (all built with hipcc --offload-arch=gfx950 -O3 -ffp-contract=off):
-//   diinn_decode.hip      decode_kernel (+ modes 1/2 chain, training forward) and the decode entry points
-//   diinn_precompute.hip  precompute_P_kernel, precompute_P_bf16_kernel
-//   diinn_bf16.hip        decode_bf16_kernel, decode_bf16x2_kernel
-//   diinn_training.hip    backward pass: bwd_head/bwd_layer, plane_gemm, plane_rowdot, cell_sum
-//   diinn_baselines.hip   LIIF and MetaSR comparison decoders
-//   diinn_misc.hip        device sine / axis-table test hooks, error state
+// Translation units (all built with hipcc --offload-arch=gfx950 -O3 -ffp-contract=off; build.py: HIP_SOURCES + HOST_SOURCES):
+//   diinn_decode.hip           decode_kernel (+ modes 1/2 chain, training forward), decode_coop_kernel (latency form),
+//                              and the decode entry points of the C ABI
+//   diinn_precompute.hip       precompute_P_kernel (direct fp32), precompute_P_bf16_kernel / _bf16_wide_kernel, launch_P
+//   diinn_precompute_wino.hip  precompute_P_wino_kernel (the fp32 hoisted conv in Winograd F(2x2,3x3) form: inference)
+//   diinn_bf16.hip             decode_bf16_kernel, decode_bf16x2_kernel, decode_bf16_coop_kernel (4 waves),
+//                              decode_bf16_coop8_kernel (8 waves), decode_bf16_coop8p_kernel (8 waves, persistent)
+//   diinn_training.hip         backward pass: bwd_head / bwd_layer, plane_gemm, plane_rowdot, cell_sum
+//   diinn_baselines.hip        LIIF and MetaSR comparison decoders
+//   diinn_encoder.hip          RDN trunk: conv_ksplit kernels (small maps), conv1x1_stream_kernel, sfe1_conv_kernel
+//   diinn_winograd.hip         RDN trunk: conv_wino_kernel / conv_wino_half_kernel (3x3 layers, Winograd F(2x2,3x3))
+//   diinn_misc.hip             device sine / axis-table test hooks, error state
+//   diinn_host.cpp (host only) weight packing, coordinate tables, size queries, the knob table (diinn_knobs.h)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

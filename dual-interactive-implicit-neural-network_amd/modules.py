@@ -471,15 +471,20 @@ class SRLitModule(nn.Module):
         """Lightning checkpoint dict: ``hyper_parameters`` (ctor kwargs saved by save_hyperparameters,
         sr_module.py:91) and ``state_dict`` (keys ``net.encoder.*``, ``net.decoder.*``, ``sub``, ``div``)."""
         # plain tensors + a dict of primitives load under weights_only=True; a checkpoint that pickles other
-        # classes (Lightning's AttributeDict, callbacks) executes code on load and needs an explicit opt-in
+        # classes (Lightning's AttributeDict, callbacks, LightningCLI namespaces) executes code on load and needs an
+        # explicit opt-in: DIINN_TRUST_CKPT=1 (README "Checkpoints")
+        import os
         try:
             ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=True)
         except Exception as e:
-            import os
-            import pickle
-            if not isinstance(e, pickle.UnpicklingError) or os.environ.get("DIINN_TRUST_CKPT") != "1":
-                raise
-            ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+            if os.environ.get("DIINN_TRUST_CKPT") == "1":
+                ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+            else:
+                raise RuntimeError(
+                    f"{checkpoint_path} did not load as plain tensors (torch.load(weights_only=True): "
+                    f"{type(e).__name__}: {e}).  Checkpoints written by Lightning / LightningCLI can pickle their own "
+                    f"classes; unpickling those runs code from the file.  If you trust this file, set "
+                    f"DIINN_TRUST_CKPT=1 to load it with weights_only=False.") from e
         hp = dict(ckpt.get("hyper_parameters", {}))
         hp.update(overrides)
         known = ("arch", "mode", "init_q", "lr", "lr_gamma", "lr_step", "eval_bsize")

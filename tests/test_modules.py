@@ -147,3 +147,25 @@ def test_graph_replay_survives_larger_shape_and_knob_changes():
         net.decoder.sin_mode = N.SIN_ACCURATE
         net(xa, (40, 40), 30000)
         assert len(net._graph_cache) == n_graphs + 1
+
+
+def test_untrusted_checkpoint_is_refused_with_the_opt_in_named(tmp_path, monkeypatch):
+    """A checkpoint that pickles a class outside torch's allow-list (what Lightning / LightningCLI runs can write) is
+    not unpickled silently: the error names DIINN_TRUST_CKPT, and with the opt-in the same file loads."""
+    import collections
+    import diinn_amd.modules as M
+    path = tmp_path / "cli.ckpt"
+    lit = M.SRLitModule(arch="diinn", mode=3, init_q=False)
+    torch.save({"state_dict": lit.state_dict(), "callbacks": collections.OrderedDict(a=_Opaque()),
+                "hyper_parameters": {"arch": "diinn", "mode": 3, "init_q": False}}, str(path))
+    monkeypatch.delenv("DIINN_TRUST_CKPT", raising=False)
+    with pytest.raises(RuntimeError, match="DIINN_TRUST_CKPT=1"):
+        M.SRLitModule.load_from_checkpoint(str(path))
+    monkeypatch.setenv("DIINN_TRUST_CKPT", "1")
+    again = M.SRLitModule.load_from_checkpoint(str(path))
+    assert all(torch.equal(a, b) for a, b in zip(lit.state_dict().values(), again.state_dict().values()))
+
+
+class _Opaque:
+    """stands in for a Lightning callback state object"""
+    x = 1
