@@ -402,7 +402,7 @@ def run_workload(job, name, scaling, steps, warmup, solo=False, check=True, gath
         lo = bd.a0 - row0
         win_cpu = win[:, :, lo:lo + bd.a1 - bd.a0].cpu()       # the rows this rank actually decoded from
         out_cpu = dec.out_band.cpu()
-        torch.set_num_threads(effective_cores())
+        torch.set_num_threads(max(1, effective_cores() // job.world))   # every rank checks at once on the one host
         err, ok = check_band_rows(job.sd, win_cpu, bd.a0, H, (HU, WU), out_cpu, bd.y0, rows_list, args.compute)
         ok = ok and handoff_ok
         err, bad = job.reduce_max([err, 0.0 if ok else 1.0])
