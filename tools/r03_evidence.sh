@@ -1,0 +1,56 @@
+#!/bin/bash
+# round 3 evidence run (one MI355X box): gpu tests, bench lines of every BASELINE workload, rocprofv3 kernel stats and
+# PMC passes (separate, as the guide prescribes) of the c2 fp32 step and the c5 bf16_full step.
+#   gpurun --timeout 2400 -- 'bash tools/r03_evidence.sh TAG'
+set -u
+TAG=${1:-r03}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
+python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
+for wl in c1 c3 tgt c4 c5; do
+  python bench.py --workload $wl --steps 12 --warmup 3 --no-cpu-baseline --no-target > $O/bench_$wl.json 2> $O/bench_$wl.err
+done
+python bench.py --workload c1 --steps 200 --warmup 20 --no-cpu-baseline --no-target > $O/bench_c1_200.json 2> $O/bench_c1_200.err
+python bench.py --workload c5 --compute bf16 --no-cpu-baseline --no-target > $O/bench_c5_bf16.json 2> $O/bench_c5_bf16.err
+python bench.py --workload c5 --compute bf16_full --no-cpu-baseline --no-target > $O/bench_c5_bf16_full.json 2> $O/bench_c5_bf16_full.err
+python bench.py --workload c2 --compute bf16_full --no-cpu-baseline --no-target > $O/bench_c2_bf16_full.json 2> $O/bench_c2_bf16_full.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --workload c3 --scaling strong --gather --no-cpu-baseline --no-target > $O/bench_c3_strong_torchrun.json 2> $O/bench_c3_strong_torchrun.err
+DIINN_BENCH_ONE_DEVICE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 --strong-legs c3 > $O/bench_2ranks_one_device_gloo.json 2> $O/bench_2ranks_one_device_gloo.err
+python - <<PY
+import json, glob
+for f in sorted(glob.glob("$O/bench_*.json")):
+    try:
+        r = json.loads(open(f).readline())
+    except Exception as e:
+        print(f, "UNREADABLE", e); continue
+    print("%-38s %9.2f Mpix/s  step %8.3f ms  decode %8.3f ms frac %.3f  P %7.3f ms (%.3f)  err %.2e ok=%s" % (
+        f.split("/")[-1], r["value"], r["ms_per_step"], r["roofline"]["kernel_ms"], r["roofline"]["frac"],
+        r["roofline"]["p_kernel"]["ms"], r["roofline"]["p_kernel"]["frac"], r["checked"]["max_err"], r["checked"]["ok"]))
+PY
+cd /tmp
+C2="python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-check --no-target"
+C5="python3 $R/bench.py --workload c5 --compute bf16_full --steps 10 --warmup 3 --no-cpu-baseline --no-check --no-target"
+C1="python3 $R/bench.py --workload c1 --steps 50 --warmup 5 --no-cpu-baseline --no-check --no-target"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -- $C2 > $O/stats_c2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5bf -- $C5 > $O/stats_c5bf.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c1 -- $C1 > $O/stats_c1.log 2>&1
+cd $R
+python tools/summarize_rocprof.py $O/stats_c2 $O/r03_c2_kernel_stats.csv "bench.py (c2 f32) --steps 10 --warmup 3" > /dev/null 2>&1
+python tools/summarize_rocprof.py $O/stats_c5bf $O/r03_c5_bf16_full_kernel_stats.csv "bench.py --workload c5 --compute bf16_full --steps 10 --warmup 3" > /dev/null 2>&1
+python tools/summarize_rocprof.py $O/stats_c1 $O/r03_c1_kernel_stats.csv "bench.py --workload c1 --steps 50 --warmup 5" > /dev/null 2>&1
+cd /tmp
+SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
+SQ2="SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
+B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-check --no-target"
+timeout 300 rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $O/pmc_c2_sq1 -- $B > $O/pmc_c2_sq1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d $O/pmc_c2_sq2 -- $B > $O/pmc_c2_sq2.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_c2_fetch -- $B > $O/pmc_c2_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_c2_write -- $B > $O/pmc_c2_write.log 2>&1
+cd $R
+python tools/pmc_summary.py $O/pmc_c2_sq1 $O/pmc_c2_sq2 $O/pmc_c2_fetch $O/pmc_c2_write > $O/r03_c2_pmc_summary.txt 2>&1
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -delete
+du -sh $O
