@@ -468,6 +468,12 @@ def strong_legs(job):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result: the collective libraries print banners to stdout when they
+    # initialise ("RCCL version : ...", "[Gloo] Rank 0 is connected to ..."), so file descriptor 1 points at stderr
+    # until the line is written
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     job = Job(args)
     world, rank = job.world, job.rank
     N = job.N
@@ -597,7 +603,7 @@ def main():
             res["strong"] = strong
         if feat_cpu is not None:
             res["cpu_baseline"] = cpu_baseline(job.sd, feat_cpu, (HU, WU), args.workload)
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res), file=result_out, flush=True)
     if job.use_dist:
         dist.barrier()
         dist.destroy_process_group()

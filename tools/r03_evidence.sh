@@ -24,7 +24,7 @@ python - <<PY
 import json, glob
 for f in sorted(glob.glob("$O/bench_*.json")):
     try:
-        r = json.loads(open(f).readline())
+        r = json.loads([ln for ln in open(f) if ln.startswith("{")][-1])
     except Exception as e:
         print(f, "UNREADABLE", e); continue
     print("%-38s %9.2f Mpix/s  step %8.3f ms  decode %8.3f ms frac %.3f  P %7.3f ms (%.3f)  err %.2e ok=%s" % (
