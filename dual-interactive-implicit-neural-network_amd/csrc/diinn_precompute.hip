@@ -323,6 +323,9 @@ constexpr int PW_PIX = PW_LR * PT_LC;                         // 340 staged pixe
 constexpr int PW_LDS = PW_PIX * PB_PITCH;                     // bf16 elements: 48,960 B
 constexpr int PW_XQ = 10;                                     // 16-byte pieces per staged row: columns x0-4 .. x0+35
 constexpr int PW_TR_PITCH = 36;                               // floats per cell in the store transpose (32 + 4: rotates banks)
+#ifndef PWB_RING_N
+#define PWB_RING_N 4                                          // B-fragment ring of the wide kernel (register slots; read-ahead = slots - 1)
+#endif
 
 __global__ __launch_bounds__(256, 2) void precompute_P_bf16_wide_kernel(const PParams p) {
     __shared__ __attribute__((aligned(16))) __bf16 tile[PW_LDS];
@@ -343,6 +346,9 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_wide_kernel(const PP
     // the launch requires W % 4 == 0); the tile keeps columns x0-1 .. x0+32, i.e. lx = 4q - 3 + e
     constexpr int ITEMS = C_IN * PW_LR * PW_XQ;                  // 6,400 = 25 per thread
     static_assert(ITEMS % 256 == 0, "staging loop has a fixed trip count");
+#ifdef ABL_PW_NOSTAGE
+    if (p.W < 0)                                                 // timing ablation: the staging loop is skipped (wrong results)
+#endif
 #pragma unroll 5
     for (int it = 0; it < ITEMS / 256; ++it) {
         const int idx = it * 256 + threadIdx.x;
@@ -384,20 +390,21 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_wide_kernel(const PP
     // groups straight from the accumulator layout writes 32 bytes per line per instruction and leaves the merging to
     // L2: 1.66 ms against 0.88 ms without stores at c5.)
     float* const trw = tr[wave];
-    f32x16 pacc = {};                                            // the previous tile's result, stored under this tile's MFMAs
     int pmo = 0, prow = 0;
     bool prowok = false;
-    auto tr_write = [&]() {
+    auto tr_write = [&](const f32x16& r) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = pacc[4 * g + e];
+            for (int e = 0; e < 4; ++e) v[e] = r[4 * g + e];
             *(f32x4*)(trw + j * PW_TR_PITCH + 4 * (2 * g + h)) = v;
         }
     };
     auto store_i = [&](const int i) {
-        const int cell = 8 * i + (lane >> 3), q = lane & 7;
+        int ln = lane;                                           // opaque: the address arithmetic stays at the store (with the row
+        asm volatile("" : "+v"(ln));                             // loop unrolled, 8 x 4 destination pointers would be hoisted and spilled)
+        const int cell = 8 * i + (ln >> 3), q = ln & 7;
         const f32x4 v = *(const f32x4*)(trw + cell * PW_TR_PITCH + 4 * q);
         if (prowok && x0 + cell < p.W) {
             float* dst = p.P + (((size_t)b * p.Prows + prow) * p.W + x0 + cell) * PCH + 32 * pmo + 4 * q;
@@ -406,42 +413,82 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_wide_kernel(const PP
 #else
             // streaming store: P is hundreds of MB and is read back by the next launch only after all of it has been
             // written, so the lines need not stay in L2 (1.43 -> 1.20 ms at c5; the packed weights stay resident)
+#ifdef ABL_PW_PLAINSTORE
+            *(f32x4*)dst = v;
+#else
             __builtin_nontemporal_store(v, (f32x4*)dst);
+#endif
 #endif
         }
     };
+    // r03: the staged halo tile is walked ROW by row and every B fragment feeds up to THREE MFMAs -- halo row r is
+    // tap row ky of output row r - ky -- into a rolling window of three accumulators (output rows r, r - 1, r - 2).
+    // Round 2 read one 1 KiB fragment from LDS per MFMA (8 waves per CU x 1 KiB per 32-cycle MFMA = twice the 128 B/clk
+    // of the LDS) into ONE dependent accumulation chain; now 120 LDS reads per 288 MFMAs and three independent chains.
+    // Per output value the products are added in the same order as before (ky, kx, channel group = ascending k-step):
+    // bit-identical results.  Measured effect on the kernel's time: none (DESIGN.md section 4.3 has the ablations: the
+    // loop alone 0.66-0.83 ms, staging +0.1-0.2, stores +0.1-0.25 at c5, and they add instead of overlapping) -- kept for
+    // the LDS traffic it removes.  The HBM write stream is NOT the bound it was taken for in round 2: a plain fill of the
+    // same 3.7 GB runs at 6.8 TB/s on the same box (tools/hbm_write_roof.py), this kernel writes at ~3.
 #pragma unroll 1
     for (int mi = 0; mi < 8; ++mi) {
         const int mo = wave + 4 * mi;                            // this wave's M-tile: channels 32 mo .. 32 mo + 31
-        f32x4 sd[4];
+        f32x16 acc[3];
+        auto seed = [&](f32x16& a) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) sd[g] = *(const f32x4*)(bk + 32 * mo + 4 * h + 8 * g);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 sd = *(const f32x4*)(bk + 32 * mo + 4 * h + 8 * g);
 #pragma unroll
-        for (int t = 0; t < PW_ROWS; ++t) {
-            f32x16 acc;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[4 * g + e] = sd[g][e];
-#pragma unroll
-            for (int ks = 0; ks < WPB_KS; ++ks) {
-                const int tap = ks >> 2, cg = ks & 3;
-                const bf16x8 bv = *(const bf16x8*)(tb + ((t + tap / 3) * PT_LC + (tap % 3)) * PB_PITCH + 16 * cg);
-                acc = MFMA_BF16(__builtin_bit_cast(bf16x8, A[ks]), bv, acc);
-#ifndef ABL_PW_NOREFILL
-                if (t == PW_ROWS - 1 && mi < 7) A[ks] = ld_piece(wrs, lane_off, piece(mo + 4, ks));
-#endif
-                if (ks == 2) tr_write();                         // the previous tile: transpose ..
-                if ((ks & 7) == 6) store_i(ks >> 3);             // .. and its four stores, spread out
-                if ((ks & 3) == 3) asm volatile("" ::: "memory");   // memory operations stay inside a 4-step window
+                for (int e = 0; e < 4; ++e) a[4 * g + e] = sd[e];
             }
-            pacc = acc;
-            pmo = mo;
-            prow = y0 + t - p.Prow0;
-            prowok = y0 + t < p.r1;
+        };
+        seed(acc[0]);
+        // the B fragments of the 120 (halo row, kx, channel group) steps pass through a register ring, read PWB_AHEAD
+        // steps before their MFMAs (an LDS read takes ~100 cycles, three MFMAs)
+        constexpr int PWB_RING = PWB_RING_N, PWB_AHEAD = PWB_RING_N - 1, NSTEP = PW_LR * 12;
+        bf16x8 bv[PWB_RING];
+        auto bfrag = [&](const int n) -> bf16x8 {
+            const int r = n / 12, kc = n % 12;
+            return *(const bf16x8*)(tb + (r * PT_LC + (kc >> 2)) * PB_PITCH + 16 * (kc & 3));
+        };
+#pragma unroll
+        for (int n = 0; n < PWB_AHEAD; ++n) bv[n % PWB_RING] = bfrag(n);
+#pragma unroll
+        for (int r = 0; r < PW_LR; ++r)                          // halo row r = map row y0 - 1 + r
+#pragma unroll
+        for (int kc = 0; kc < 12; ++kc) {                        // (kx, channel group)
+            const int n = 12 * r + kc;
+            const int kx = kc >> 2, cg = kc & 3;
+            if (n + PWB_AHEAD < NSTEP) bv[(n + PWB_AHEAD) % PWB_RING] = bfrag(n + PWB_AHEAD);
+            __builtin_amdgcn_sched_barrier(0);                   // the read is issued HERE (left free it sinks to its use and every
+            const bf16x8 cur = bv[n % PWB_RING];                 // step waits out the LDS latency)
+#pragma unroll
+            for (int ky = 2; ky >= 0; --ky) {                    // the oldest output row first: it finishes with this halo row
+                const int t = r - ky;
+                if (t < 0 || t >= PW_ROWS) continue;
+                const int ks = 4 * (3 * ky + kx) + cg;
+                acc[t % 3] = MFMA_BF16(__builtin_bit_cast(bf16x8, A[ks]), cur, acc[t % 3]);
+#ifndef ABL_PW_NOREFILL
+                if (t == PW_ROWS - 1 && mi < 7) A[ks] = ld_piece(wrs, lane_off, piece(mo + 4, ks));   // last use of this fragment
+#endif
+            }
+            // the previous output row leaves under this halo row's MFMAs: its four stores, spread out
+            if (r >= 3 || (r == 0 && mi > 0)) {                  // (row 0: the last output row of the previous M-tile)
+                if ((kc % 3) == 1) store_i(kc / 3);
+            }
+            asm volatile("" ::: "memory");                       // memory operations stay where they are written
+            if (kc == 11) {                                      // end of halo row r
+                if (r >= 2) {                                    // output row t = r - 2 is complete: into the transpose buffer
+                    const int t = r - 2;
+                    tr_write(acc[t % 3]);
+                    pmo = mo;
+                    prow = y0 + t - p.Prow0;
+                    prowok = y0 + t < p.r1;
+                }
+                if (r + 1 < PW_ROWS) seed(acc[(r + 1) % 3]);     // output row r + 1 starts with the next halo row, in the slot just freed
+            }
         }
     }
-    tr_write();
 #pragma unroll
     for (int i = 0; i < 4; ++i) store_i(i);
 }
