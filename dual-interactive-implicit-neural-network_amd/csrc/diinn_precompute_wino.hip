@@ -32,6 +32,7 @@ struct PWinoParams {
     int bx_n, by_n;      // blocks of 8 x 4 tiles
     int msplit;          // the 32 M-tiles are divided over `msplit` workgroups per block (small maps: fills the chip)
     int stream_stores;
+    int warm_l2;         // touch the Winograd weight section first (maps whose P image has flushed it out of the L2s)
 };
 
 constexpr int PWN_TX = 8, PWN_TY = 4;
@@ -43,7 +44,8 @@ constexpr int PWN_MT_BYTES = 4 * 8 * 4 * PIECE_BYTES;            // bytes of WPU
 #define PWN_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <bool EDGE>
-__device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, float* __restrict__ zs, int b, int tx0, int ty0, int mt0, int mtn) {
+__device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, float* __restrict__ zs, int b, int tx0, int ty0, int mt0, int mtn,
+                                                       const float (&warm)[4]) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = row i of the transformed tile
     const int h = lane >> 5, m = lane & 31;
@@ -99,6 +101,9 @@ __device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, flo
         }
     }
 
+#ifndef PWN_NO_WARMUP
+    asm volatile("" :: "v"(warm[0]), "v"(warm[1]), "v"(warm[2]), "v"(warm[3]));   // the warm-up loads are older than the patch rows just waited for
+#endif
     // ---- output side: wave = output row pr of the 2x2 block and tile half th; store group k, lane L: cell n = 8k + (L >> 3)
     // of the wave's 32 cells (tile 16 th + (n >> 1), column q = n & 1), chunk c = L & 7 (channels 4c .. 4c+3 of the M-tile)
     const int pr = wave & 1, th = wave >> 1;
@@ -166,8 +171,12 @@ __device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, flo
         for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf(s2, z2[e], __builtin_fmaf(s2, z1[e], z0[e])) + bias4[e];
         if (pdst[k]) {
             f32x4* dst = reinterpret_cast<f32x4*>(pdst[k] + 32 * mprev);
+#ifdef ABL_PWN_NOSTORE
+            asm volatile("" :: "v"(y), "v"(dst));                // timing ablation (wrong results)
+#else
             if (p.stream_stores) __builtin_nontemporal_store(y, dst);
             else *dst = y;
+#endif
         }
     };
     // one M-tile: 8 k-groups x (4 k-steps x 4 columns) MFMAs into acc[PAR]; PREV: finish M-tile mt - 1 meanwhile
@@ -245,6 +254,32 @@ __global__ __launch_bounds__(256, 1) void precompute_P_wino_kernel(const PWinoPa
     int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     const int per_b = p.bx_n * p.by_n;
     if (t >= p.B * per_b * p.msplit) return;
+    // L2 warm-up (r03; the direct kernel has had it since r02).  Inside a decode step this kernel starts right after
+    // decode_kernel has streamed hundreds of MB of P through every L2, so the 4 MiB Winograd weight section is gone;
+    // the workgroups of an XCD then walk it in lock-step and the first round advances at HBM-latency pace (a block takes
+    // 167 us in the two rounds of c2 against 142 us in the eight of a 512 x 512 map).  Every workgroup of the first
+    // round touches its share of the section's 128-byte lines first; the values are dead.  In the c2 step: 0.325 ->
+    // 0.293 ms (same box, A/B); c5: neutral; on maps whose whole working set stays in the L2s (c1: +1.6 us on 26) it is
+    // pure overhead, so the host switches it on from 8,192 cells (a P image of 32 MiB = the eight L2s) on.
+    float warm[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#ifndef PWN_NO_WARMUP
+    {
+        const unsigned slot = blockIdx.x >> 3;                   // this workgroup's index inside its XCD
+        const unsigned first = (unsigned)per_xcd < 32u ? (unsigned)per_xcd : 32u;   // workgroups of an XCD's first round (one per CU)
+        constexpr unsigned LINES = (unsigned)(SZ_WPU * sizeof(float) / 128);
+        const unsigned share = (LINES + first - 1) / first;      // <= 1024 once 32 workgroups share the section
+        if (p.warm_l2 && slot < first) {
+            const char* wpu = (const char*)(p.Wt + OFF_WPU);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned k = threadIdx.x + 256 * i;
+                unsigned line = slot * share + k;
+                line = (k < share && line < LINES) ? line : 0;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(warm[i]) : "v"(wpu + (size_t)line * 128) : "memory");
+            }
+        }
+    }
+#endif
     const int part = __builtin_amdgcn_readfirstlane(t % p.msplit);   // the parts of a block are neighbours: they share its patch rows
     t /= p.msplit;
     const int mtn = 32 / p.msplit, mt0 = part * mtn;
@@ -253,8 +288,8 @@ __global__ __launch_bounds__(256, 1) void precompute_P_wino_kernel(const PWinoPa
     const int by = __builtin_amdgcn_readfirstlane(t / p.bx_n), bx = t - by * p.bx_n;
     const int tx0 = bx * PWN_TX, ty0 = p.ty_first + by * PWN_TY;
     const bool edge = tx0 == 0 || 2 * (tx0 + PWN_TX - 1) + 2 >= p.W;
-    if (edge) precompute_P_wino_body<true>(p, zs, b, tx0, ty0, mt0, mtn);
-    else      precompute_P_wino_body<false>(p, zs, b, tx0, ty0, mt0, mtn);
+    if (edge) precompute_P_wino_body<true>(p, zs, b, tx0, ty0, mt0, mtn, warm);
+    else      precompute_P_wino_body<false>(p, zs, b, tx0, ty0, mt0, mtn, warm);
 }
 
 // Winograd form of launch_P for the fp32 hoisted convolution of all 1024 channels (diinn_precompute.hip decides when)
@@ -286,6 +321,7 @@ int launch_P_wino(void* stream, const float* feat_dev, const float* packed_dev, 
     if (blocks > 2147483000LL) return DIINN_ERR_TOO_LARGE;
     if ((long long)C_IN * fw.rows * W * 4 > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;   // the feature window is addressed with 32-bit byte offsets
     p.stream_stores = (double)B * (r1 - r0) * W * PCH * 4.0 >= 128.0 * 1024 * 1024;
+    p.warm_l2 = (long long)B * (r1 - r0) * W >= 8192;
     hipLaunchKernelGGL(precompute_P_wino_kernel, dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
