@@ -1,4 +1,4 @@
-for i in 1 2 3; do for v in shipped nowarm; do
+for i in 1 2 3; do for v in shipped ${VARIANT:-nowarm}; do
   if [ $v = shipped ]; then L=""; else L=variants/libdiinn_$v.so; fi
   DIINN_HIP_LIB=$L python bench.py $BARGS --no-cpu-baseline --no-target 2>/dev/null | python -c "
 import sys, json
