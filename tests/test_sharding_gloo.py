@@ -223,3 +223,42 @@ def _gpu_band_decoder_worker(rank, world, port, mode, geom, q):
 def test_band_decoder_on_gpu_over_host_staged_gloo(world, mode):
     res = _run(world, mode, (2, 40, 56, 132, 185), target=_gpu_band_decoder_worker, timeout=600)
     assert all(res)
+
+
+_RCCL_SELF = r'''
+import os, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+dist.barrier()
+a = torch.randn(2, 64, 66, 256, device=dev); stage = torch.empty_like(a[:, :, 3:40]); win = torch.zeros_like(stage)
+big = torch.randn(4096, 4096, device=dev)
+side = torch.cuda.Stream(device=dev); cur = torch.cuda.current_stream()
+for it in range(3):                               # the buffers are reused, as in a step loop
+    a.normal_()
+    side.wait_stream(cur)                         # BandExchange.handoff on the source rank, with itself as the peer
+    with torch.cuda.stream(side):
+        stage.copy_(a[:, :, 3:40])
+        reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, stage, 0), dist.P2POp(dist.irecv, win, 0)])
+        for r in reqs:
+            r.wait()
+    c = big @ big                                 # the rank's own band, queued while the message is on the wire
+    cur.wait_stream(side)                         # BandExchange.complete
+    torch.cuda.synchronize()
+    assert torch.equal(win, a[:, :, 3:40]) and bool(torch.isfinite(c).all())
+print("RCCL-SELF-OK")
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_rccl_point_to_point_on_a_side_stream_with_itself_as_peer():
+    """No test box has two GPUs, and RCCL refuses two ranks on one.  What CAN run on the real backend is the exact call
+    sequence of the overlapped hand-off -- strided stage copy, `batch_isend_irecv` and `wait()` inside a side-stream
+    context, the caller's kernels queued meanwhile, `wait_stream` -- with the rank itself as the peer (RCCL supports a
+    send and a receive to oneself inside one group)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_SELF], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL-SELF-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
