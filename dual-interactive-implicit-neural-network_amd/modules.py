@@ -278,6 +278,37 @@ class DIINN(nn.Module, _GraphReplay):
             return self._forward_graphed(x, size, bsize)
         return self._forward_eager(x, size, bsize)
 
+    @torch.no_grad()
+    def forward_sharded(self, x, size, src: int = 0, gather_to: Optional[int] = 0, group=None, mode: str = "halo"):
+        """The same forward with the HR grid cut into row bands, one per rank of the process group (one process per
+        GPU under ``torch.distributed``): rank ``src`` runs the encoder, every rank receives the
+        LR feature rows its band reads (+ a one-row halo) and decodes its band, and the image is assembled on
+        ``gather_to`` (returned there, ``None`` elsewhere) -- or, with ``gather_to=None``, every rank gets
+        ``(band, (y0, y1))``.  Every rank passes ``x`` (only its shape is used away from ``src``).  Inference, mode 3.
+        With one rank this is ``forward``.  The reference has no multi-GPU inference (benchmarks.py:13: devices=1)."""
+        import torch.distributed as dist
+        from . import sharded as S
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            out = self._forward_eager(x, size, None)
+            return out if gather_to is not None else (out, (0, int(size[0])))
+        if self.decoder.mode != 3 or self.decoder.init_q:
+            raise NotImplementedError("forward_sharded covers the mode-3 decoder")
+        hu, wu = size
+        b, _, h, w = x.shape
+        shape = (int(b), 64, int(h), int(w))
+        packed = self.decoder.packed_weights(x.device)
+        key = (shape, int(hu), int(wu), packed.data_ptr(), src, mode, id(group))
+        if getattr(self, "_band_key", None) != key:           # band-sized buffers are allocated once per geometry
+            self._band_dec = S.BandDecoder(shape, (int(hu), int(wu)), packed, group=group, src=src, mode=mode,
+                                           sin_mode=self.decoder.sin_mode, compute=self.decoder.compute)
+            self._band_key = key
+        dec = self._band_dec
+        feat = self.encoder(x).contiguous() if dist.get_rank(group) == src else None
+        band = dec.step(feat)
+        if gather_to is None:
+            return band, (dec.band.y0, dec.band.y1)
+        return dec.gather(band, dst=gather_to)
+
 
 class MLP(nn.Module):
     """Linear/ReLU stack with the reference's parameter names ``layers.{0,2,4,...}`` (mlp.py:3-20)."""
@@ -410,6 +441,12 @@ class SRLitModule(nn.Module):
 
     def forward(self, x: torch.Tensor, size, eval_bsize=None):
         return self.net(x, size, eval_bsize)
+
+    def forward_sharded(self, x: torch.Tensor, size, **kw):
+        """``forward`` with the HR grid sharded by row bands over the ranks of ``torch.distributed`` (DIINN only)."""
+        if not hasattr(self.net, "forward_sharded"):
+            raise NotImplementedError(f"arch {self.hparams.arch}: only DIINN has a sharded forward")
+        return self.net.forward_sharded(x, size, **kw)
 
     def step(self, batch: Any, eval_bsize=None):
         """sr_module.py:113-125: ``batch`` maps scale -> (lr, hr, name); normalise, decode, L1, de-normalise."""

@@ -8,6 +8,10 @@ Behaviour kept from the reference (demo2.py:29-41): no (x-0.5)/0.5 normalisation
 goes to <dir(lr_path)>/<model_name>/<model_name>_<file>_<H>x<W>.png.  Differences: the model and
 the image are moved to the GPU (the reference leaves them on the CPU), and image I/O uses PIL
 because torchvision is not part of the target image.
+
+Several GPUs: the same command line under ``python -m torch.distributed.run --nproc-per-node N`` cuts
+the HR grid into N row bands, one per GPU (rank 0 runs the encoder and writes the file; DESIGN.md
+section 7).  DIINN_DIST_BACKEND=gloo with DIINN_BENCH_ONE_DEVICE=1 is the one-GPU test transport.
 """
 import os
 import sys
@@ -33,22 +37,50 @@ def save_rgb(t, path):
     Image.fromarray(arr).save(path)
 
 
+def _dist_setup():
+    """(rank, world, device) -- a process group when launched by torch.distributed.run with more than one rank."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1, torch.device("cuda:0")
+    import torch.distributed as dist
+    rank = int(os.environ["RANK"])
+    local = 0 if os.environ.get("DIINN_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("DIINN_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, dev
+
+
 @torch.no_grad()
 def demo2(args):
-    dev = torch.device("cuda:0")
+    rank, world, dev = _dist_setup()
     if args.model_name == "bicubic":
         model = SRLitModule(arch="bicubic")
     else:
         model = SRLitModule.load_from_checkpoint(args.ckpt_path)
     model = model.to(dev).eval()
-    print(args.lr_path)
+    if rank == 0:
+        print(args.lr_path)
     filename, _ = os.path.splitext(os.path.basename(args.lr_path))
     lr = read_rgb(args.lr_path).to(dev)
     out_dir = os.path.join(os.path.dirname(args.lr_path) or ".", args.model_name)
-    Path(out_dir).mkdir(parents=True, exist_ok=True)
-    sr = model(lr, args.output_size)
-    save_rgb(sr, os.path.join(out_dir, "{}_{}_{}x{}.png".format(args.model_name, filename,
-                                                               args.output_size[0], args.output_size[1])))
+    if world > 1 and args.model_name != "bicubic":
+        sr = model.forward_sharded(lr, args.output_size, src=0, gather_to=0)      # None away from rank 0
+    else:
+        sr = model(lr, args.output_size) if rank == 0 else None
+    if sr is not None:
+        Path(out_dir).mkdir(parents=True, exist_ok=True)
+        save_rgb(sr, os.path.join(out_dir, "{}_{}_{}x{}.png".format(args.model_name, filename,
+                                                                   args.output_size[0], args.output_size[1])))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
