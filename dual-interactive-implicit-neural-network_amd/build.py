@@ -33,6 +33,14 @@ DEPS = SOURCES + ["diinn_device.h", "diinn_layout.h", os.path.join("..", "..", "
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-x", "c++"]
+# per translation unit.  -amdgpu-mfma-vgpr-form lets the register allocator keep MFMA accumulators in VGPRs (the
+# activations go to AGPRs instead): decode_kernel's epilogue then reads them without v_accvgpr_read -- 988 -> 801 VALU
+# instructions per layer, 5.803 -> 5.782 ms at c2 (same-box A/B, r03).  The same flag makes precompute_P_wino_kernel 8 %
+# SLOWER (0.294 -> 0.319 ms), so it is not a library-wide setting.
+# Measured TU by TU (tools/r03_vgprform_ab.sh): encoder trunk 11.88 -> 11.78 ms at 256x256 (kept); LIIF 12.73 -> 12.60 but
+# MetaSR 6.50 -> 8.52 in the same TU, training step 16.4 -> 16.6 (not applied).
+_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+PER_FILE_FLAGS = {"diinn_decode.hip": _VGPR_FORM, "diinn_winograd.hip": _VGPR_FORM, "diinn_encoder.hip": _VGPR_FORM}
 
 
 def find_hipcc() -> str:
@@ -67,7 +75,7 @@ def build(force: bool = False, verbose: bool = True, extra_flags=(), out: str = 
         src_path = os.path.join(CSRC, src)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(newest_header, os.path.getmtime(src_path)):
             continue
-        flags = [*HIPCC_FLAGS, *extra_flags] if src in HIP_SOURCES else HOST_FLAGS
+        flags = [*HIPCC_FLAGS, *PER_FILE_FLAGS.get(src, []), *extra_flags] if src in HIP_SOURCES else HOST_FLAGS
         cmds.append([hipcc, *flags, "-c", src_path, "-o", obj])
     running = []
     for cmd in cmds:

@@ -1094,7 +1094,6 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..7 = this wave's M-tile
     const int grp = wave >> 2;                                    // waves w and w + 4 share a SIMD
-    const int h = lane >> 5, j = lane & 31;
     const float* __restrict__ Wt = p.Wt;
     const int ncx = p.seed_cols;
     const int ncx_inv = 65536 / ncx + 1;
