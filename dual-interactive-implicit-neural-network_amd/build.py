@@ -35,12 +35,15 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-cont
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-x", "c++"]
 # per translation unit.  -amdgpu-mfma-vgpr-form lets the register allocator keep MFMA accumulators in VGPRs (the
 # activations go to AGPRs instead): decode_kernel's epilogue then reads them without v_accvgpr_read -- 988 -> 801 VALU
-# instructions per layer, 5.803 -> 5.782 ms at c2 (same-box A/B, r03).  The same flag makes precompute_P_wino_kernel 8 %
+# instructions per layer, 5.802 -> 5.783 ms at c2 (same box, order-balanced runs, r03).  The same flag makes precompute_P_wino_kernel 8 %
 # SLOWER (0.294 -> 0.319 ms), so it is not a library-wide setting.
-# Measured TU by TU (tools/r03_vgprform_ab.sh): encoder trunk 11.88 -> 11.78 ms at 256x256 (kept); LIIF 12.73 -> 12.60 but
-# MetaSR 6.50 -> 8.52 in the same TU, training step 16.4 -> 16.6 (not applied).
+# Measured TU by TU (tools/r03_vgprform_ab.sh): encoder trunk unchanged in order-balanced runs (11.83-11.88 either way);
+# LIIF 12.73 -> 12.60 but MetaSR 6.50 -> 8.52 in the same TU, training step 16.4 -> 16.6: applied to the decode file only.
 _VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
-PER_FILE_FLAGS = {"diinn_decode.hip": _VGPR_FORM, "diinn_winograd.hip": _VGPR_FORM, "diinn_encoder.hip": _VGPR_FORM}
+# Compared in order-balanced runs (tools/r03_ab_abba.sh; a run's position in a sequence biases it by ~0.4 %): no flag 5.802,
+# vgpr-form 5.783, vgpr-form + -amdgpu-use-amdgpu-trackers 5.800 (noisy), trackers alone 6.05 ms.
+# NOT to be used: -amdgpu-disable-unclustered-high-rp-reschedule produced WRONG results (bench.py's oracle check failed).
+PER_FILE_FLAGS = {"diinn_decode.hip": _VGPR_FORM}
 
 
 def find_hipcc() -> str:
