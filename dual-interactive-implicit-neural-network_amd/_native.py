@@ -29,7 +29,9 @@ COMPUTE_F32 = 0
 COMPUTE_BF16 = 1
 COMPUTE_F32_QONLY = 2
 COMPUTE_BF16_FULL = 3
-COMPUTE = {"f32": COMPUTE_F32, "fp32": COMPUTE_F32, "bf16": COMPUTE_BF16, "bf16_full": COMPUTE_BF16_FULL}
+COMPUTE_BF16X3 = 4
+COMPUTE = {"f32": COMPUTE_F32, "fp32": COMPUTE_F32, "bf16": COMPUTE_BF16, "bf16_full": COMPUTE_BF16_FULL,
+           "bf16x3": COMPUTE_BF16X3}
 
 _f = C.POINTER(C.c_float)
 _i32 = C.POINTER(C.c_int32)

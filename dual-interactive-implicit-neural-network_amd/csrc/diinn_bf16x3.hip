@@ -1,0 +1,243 @@
+// diinn_bf16x3.hip -- the optional split-bf16 decode kernel (DIINN_COMPUTE_BF16X3)
+// (part of libdiinn_hip.so; shared definitions in diinn_device.h, layout in diinn_layout.h)
+#include "diinn_device.h"
+
+// ---------------------------------------------------------------------------------
+// decode_bf16x3_kernel: the per-pixel layers 1..3 (diinn.py:128-137) on v_mfma_f32_32x32x16_bf16 at fp32 accuracy.
+// Every operand of the two 256 x 256 products of a layer is carried as TWO bf16 numbers, hi = bf16(v) and
+// lo = bf16(v - hi) (16 significant bits together), and a product is evaluated as
+//     w . q  ~=  w_hi . q_hi  +  w_lo . q_hi  +  w_hi . q_lo          (fp32 accumulation in the MFMA)
+// -- the dropped term w_lo . q_lo is 2^-16 of the result, below the fp32 rounding of the 256-term sum itself.
+// Three bf16 MFMAs (32 cycles each) replace the eight fp32 MFMAs (64 cycles each) of the same k-range: 5.3x fewer
+// matrix-core cycles than decode_kernel.  Measured error against the reference form (tools/bf16x3_error.py, the
+// GPU parity tests): that of the fp32 kernels at default-init weights, 3e-5 x |out| on the x3 stress weights.
+// Structure: decode_bf16_kernel's -- one wave owns 32 pixels, packs its activation to B fragments straight from
+// the epilogue (accumulator registers 8s..8s+7 of a tile are the fragment of k-step 2m+s) -- with
+//   * weights: hi parts from packed section 7 (WLB), lo parts from section 14 (WLBL), the same piece order; four
+//     1 KiB pieces per k-step through a register ring (0.67 KiB per MFMA: less L1 traffic per MFMA than the
+//     one-tile bf16 kernel's 1 KiB);
+//   * the next layer's hi/lo fragments parked in a wave-private LDS slab (each lane re-reads only what it wrote:
+//     no barrier), as in decode_bf16x2_kernel;
+//   * P, seeds, biases, sine, layer 0 and the RGB head in fp32; the head is accumulated in the last layer's
+//     epilogue on the unsplit activation.
+// ---------------------------------------------------------------------------------
+#ifndef DECODE_BF16X3_PREFETCH
+#define DECODE_BF16X3_PREFETCH 4                // ring depth in k-steps (4 pieces, 6 MFMAs each)
+#endif
+
+__device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)v;
+    lo = (__bf16)(v - (float)hi);               // exact difference: v and hi share sign and exponent range
+}
+
+template <int SIN_MODE>
+__global__ __launch_bounds__(256, 1) void decode_bf16x3_kernel(const DecodeParams p) {
+    __shared__ __attribute__((aligned(16))) bf16x8 park[4][2][16][64];     // [wave][hi, lo][fragment][lane] = 128 KiB
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int x = blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
+    const int y = p.y0 + blockIdx.y * (TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
+    const int b = blockIdx.z;
+    const bool valid = (x < p.Wu) && (y < p.y1);
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
+    const int xc = x < p.Wu ? x : p.Wu - 1;
+    const int yc = y < p.y1 ? y : p.y1 - 1;
+    int iy, ix;
+    float relh, relw;
+    axis_eval(p.ah, yc, iy, relh);
+    axis_eval(p.aw, xc, ix, relw);
+    const float* __restrict__ Wt = p.Wt;
+    const float* __restrict__ Pc = p.P + (((size_t)b * p.Prows + (iy - p.Prow0)) * p.W + ix) * PCH + 4 * h;
+
+    // ---- layer 0 (fp32), split into hi/lo fragments: register r = 4g+e of tile m -> q[2m + (r>>3)][r&7]
+    bf16x8 qh[16], ql[16];
+    {
+        const float* __restrict__ Q0 = Wt + OFF_Q0 + 4 * h;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * m + 8 * g;
+                const f32x4 pv = *(const f32x4*)(Pc + c0);
+                const f32x4 wh = *(const f32x4*)(Q0 + 0 * HID + c0);
+                const f32x4 ww = *(const f32x4*)(Q0 + 1 * HID + c0);
+                const f32x4 wr = *(const f32x4*)(Q0 + 2 * HID + c0);
+                const f32x4 bq = *(const f32x4*)(Q0 + 3 * HID + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = __builtin_fmaf(wr[e], p.ratio, bq[e]);
+                    a = __builtin_fmaf(ww[e], relw, a);
+                    a = __builtin_fmaf(wh[e], relh, a);
+                    __bf16 vh, vl;
+                    split_bf16(relu0(pv[e]) * dsin<SIN_MODE>(a), vh, vl);
+                    qh[2 * m + (g >> 1)][4 * (g & 1) + e] = vh;
+                    ql[2 * m + (g >> 1)][4 * (g & 1) + e] = vl;
+                }
+            }
+        }
+    }
+
+    constexpr int PF = DECODE_BF16X3_PREFETCH;
+    static_assert(16 % PF == 0, "ring index must be static");
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);
+    const int lane_off = lane * 16;
+    constexpr int LO = (int)((OFF_WLBL - OFF_WLB) * sizeof(float));      // hi piece -> its lo piece
+    int wp = (int)(OFF_WLB * sizeof(float));
+    f32x4 rkh[PF], rkl[PF], rqh[PF], rql[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        rkh[d] = ld_piece(wrs, lane_off, wp + (2 * d + 0) * PIECE_BYTES);
+        rqh[d] = ld_piece(wrs, lane_off, wp + (2 * d + 1) * PIECE_BYTES);
+        rkl[d] = ld_piece(wrs, lane_off, wp + LO + (2 * d + 0) * PIECE_BYTES);
+        rql[d] = ld_piece(wrs, lane_off, wp + LO + (2 * d + 1) * PIECE_BYTES);
+    }
+    f32x4 sk[4], sq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        sk[g] = *(const f32x4*)(Pc + HID + 8 * g);
+        sq[g] = *(const f32x4*)(Wt + OFF_BQR + 4 * h + 8 * g);
+    }
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+    bf16x8 (*mine)[16][64] = park[wave];
+
+    // the layer loop is fully unrolled: LAST is a compile-time constant per copy and fuses the RGB head
+    // (diinn.py:138) into the epilogue, on the unsplit activation
+#pragma unroll
+    for (int layer = 0; layer < 3; ++layer) {
+        const bool LAST = layer == 2;
+        const int nl = layer < 2 ? layer + 1 : 2;
+        const float* __restrict__ Pl = Pc + (layer + 1) * HID;
+        const float* __restrict__ Bq = Wt + OFF_BQR + layer * HID + 4 * h;
+        const float* __restrict__ Pn = Pc + (nl + 1) * HID;
+        const float* __restrict__ Bn = Wt + OFF_BQR + nl * HID + 4 * h;
+        const float* __restrict__ L = Wt + OFF_L + 4 * h;
+        f32x16 pk, ps;
+        bf16x8 fh, fl;
+        f32x4 l0[4], l1[4], l2[4];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            f32x16 ak, as;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ak[4 * g + e] = sk[g][e];
+                    as[4 * g + e] = sq[g][e];
+                }
+            }
+            if (LAST && m > 0) {                                  // head rows of the tile being finished
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    l0[g] = *(const f32x4*)(L + 0 * HID + 32 * (m - 1) + 8 * g);
+                    l1[g] = *(const f32x4*)(L + 1 * HID + 32 * (m - 1) + 8 * g);
+                    l2[g] = *(const f32x4*)(L + 2 * HID + 32 * (m - 1) + 8 * g);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int s = m * 16 + ks;
+                const bf16x8 wkh = __builtin_bit_cast(bf16x8, rkh[s % PF]);
+                const bf16x8 wqh = __builtin_bit_cast(bf16x8, rqh[s % PF]);
+                // the two small products first, the leading one last (the order the oracle's emulation adds them in)
+                ak = MFMA_BF16(__builtin_bit_cast(bf16x8, rkl[s % PF]), qh[ks], ak);
+                as = MFMA_BF16(__builtin_bit_cast(bf16x8, rql[s % PF]), qh[ks], as);
+                ak = MFMA_BF16(wkh, ql[ks], ak);
+                as = MFMA_BF16(wqh, ql[ks], as);
+                ak = MFMA_BF16(wkh, qh[ks], ak);
+                as = MFMA_BF16(wqh, qh[ks], as);
+#ifndef ABL_X3_NOLOAD
+                rkh[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF) + 0) * PIECE_BYTES);
+                rqh[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF) + 1) * PIECE_BYTES);
+                rkl[s % PF] = ld_piece(wrs, lane_off, wp + LO + (2 * (s + PF) + 0) * PIECE_BYTES);
+                rql[s % PF] = ld_piece(wrs, lane_off, wp + LO + (2 * (s + PF) + 1) * PIECE_BYTES);
+#endif
+                if (ks == 2) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        sk[g] = *(const f32x4*)((m < 7 ? Pl + 32 * (m + 1) : Pn) + 8 * g);
+                        sq[g] = *(const f32x4*)((m < 7 ? Bq + 32 * (m + 1) : Bn) + 8 * g);
+                    }
+                }
+                if (m > 0) {                                      // one epilogue element of tile m-1 per k-step
+                    float v = relu0(pk[ks]) * dsin_rev<SIN_MODE>(ps[ks]);
+                    asm volatile("" : "+v"(v));                   // the element stays behind its k-step (see decode_bf16x2_kernel)
+                    if (LAST) {
+                        o0 = __builtin_fmaf(l0[ks >> 2][ks & 3], v, o0);
+                        o1 = __builtin_fmaf(l1[ks >> 2][ks & 3], v, o1);
+                        o2 = __builtin_fmaf(l2[ks >> 2][ks & 3], v, o2);
+                    } else {
+                        __bf16 vh, vl;
+                        split_bf16(v, vh, vl);
+                        fh[ks & 7] = vh;
+                        fl[ks & 7] = vl;
+                        if ((ks & 7) == 7) {
+                            mine[0][2 * (m - 1) + (ks >> 3)][lane] = fh;
+                            mine[1][2 * (m - 1) + (ks >> 3)][lane] = fl;
+                        }
+                    }
+                }
+            }
+            pk = ak;
+            ps = as;
+        }
+        if (LAST) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                l0[g] = *(const f32x4*)(L + 0 * HID + 32 * 7 + 8 * g);
+                l1[g] = *(const f32x4*)(L + 1 * HID + 32 * 7 + 8 * g);
+                l2[g] = *(const f32x4*)(L + 2 * HID + 32 * 7 + 8 * g);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = relu0(pk[r]) * dsin_rev<SIN_MODE>(ps[r]);
+            if (LAST) {
+                o0 = __builtin_fmaf(l0[r >> 2][r & 3], v, o0);
+                o1 = __builtin_fmaf(l1[r >> 2][r & 3], v, o1);
+                o2 = __builtin_fmaf(l2[r >> 2][r & 3], v, o2);
+            } else {
+                __bf16 vh, vl;
+                split_bf16(v, vh, vl);
+                fh[r & 7] = vh;
+                fl[r & 7] = vl;
+                if ((r & 7) == 7) {
+                    mine[0][14 + (r >> 3)][lane] = fh;
+                    mine[1][14 + (r >> 3)][lane] = fl;
+                }
+            }
+        }
+        if (!LAST) {                                              // the parked activation becomes the next layer's B operand
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                qh[i] = mine[0][i][lane];
+                ql[i] = mine[1][i][lane];
+            }
+        }
+        wp += (int)(WLB_LAYER * sizeof(float));
+    }
+
+    o0 += __shfl_xor(o0, 32);
+    o1 += __shfl_xor(o1, 32);
+    o2 += __shfl_xor(o2, 32);
+    if (valid && h == 0) {
+        const size_t plane = (size_t)p.Orows * p.Wu;
+        float* o = p.out + (size_t)b * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
+        const unsigned nanm = derived_nan_mask(Wt);
+        o[0] = o0 + or_bits(Wt[OFF_BL + 0], nanm);
+        o[plane] = o1 + or_bits(Wt[OFF_BL + 1], nanm);
+        o[2 * plane] = o2 + or_bits(Wt[OFF_BL + 2], nanm);
+    }
+}
+
+int launch_decode_bf16x3(void* stream, const DecodeParams& p, int gx, int gy, int gz, int sin_mode) {
+    const dim3 grid(gx, gy, gz);
+    if (sin_mode == DIINN_SIN_HW)
+        hipLaunchKernelGGL(decode_bf16x3_kernel<DIINN_SIN_HW>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (sin_mode == DIINN_SIN_HW_REDUCED)
+        hipLaunchKernelGGL(decode_bf16x3_kernel<DIINN_SIN_HW_REDUCED>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(decode_bf16x3_kernel<DIINN_SIN_ACCURATE>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}

@@ -585,8 +585,7 @@ static int cell_chain_impl(void* stream, float* P_dev, const float* packed_dev, 
 static int decode_band_impl(void* stream, const float* P_dev, const float* packed_dev,
                             float* out_dev, int B, int H, int W, int Hu, int Wu,
                             int y0, int y1, int sin_mode, int compute, RowWin pw, RowWin ow) {
-    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY &&
-        compute != DIINN_COMPUTE_BF16_FULL)
+    if (!compute_ok(compute))
         return DIINN_ERR_UNSUPPORTED;
     if (!P_dev || !packed_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
@@ -622,6 +621,8 @@ static int decode_band_impl(void* stream, const float* P_dev, const float* packe
     const dim3 grid(gx, gy, gz);
     if (compute == DIINN_COMPUTE_BF16 || compute == DIINN_COMPUTE_BF16_FULL)
         return launch_decode_bf16(stream, p, gx, gy, gz, sin_mode);
+    if (compute == DIINN_COMPUTE_BF16X3)
+        return launch_decode_bf16x3(stream, p, gx, gy, gz, sin_mode);
     if (compute == DIINN_COMPUTE_F32_QONLY) {
         if (sin_mode == DIINN_SIN_HW)
             hipLaunchKernelGGL((decode_kernel<DIINN_SIN_HW, false>), grid, dim3(blk), 0, (hipStream_t)stream, p);
@@ -662,8 +663,7 @@ static int decode_impl(void* stream, const float* feat_dev, const float* packed_
     int r0, r1;
     int st = diinn_lr_rows_for_band(H, Hu, Wu, y0, y1, &r0, &r1);
     if (st) return st;
-    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY &&
-        compute != DIINN_COMPUTE_BF16_FULL)
+    if (!compute_ok(compute))
         return DIINN_ERR_UNSUPPORTED;
     st = launch_P(stream, feat_dev, packed_dev, workspace_dev, B, H, W, r0, r1, 16, compute == DIINN_COMPUTE_BF16_FULL,
                   &fw, &pw, true);

@@ -268,6 +268,12 @@ static inline int hip_status(hipError_t e) {
     return DIINN_ERR_HIP;
 }
 
+// the arithmetic modes of the C ABI (include/diinn_hip.h)
+static inline bool compute_ok(int compute) {
+    return compute == DIINN_COMPUTE_F32 || compute == DIINN_COMPUTE_BF16 || compute == DIINN_COMPUTE_F32_QONLY ||
+           compute == DIINN_COMPUTE_BF16_FULL || compute == DIINN_COMPUTE_BF16X3;
+}
+
 static inline int check_dims(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return DIINN_ERR_INVALID_ARG;
     if ((double)B * H * W * PCH >= 9.0e18 || B > 65535 || H > 65535) return DIINN_ERR_TOO_LARGE;
@@ -300,3 +306,6 @@ int launch_P_wino(void* stream, const float* feat_dev, const float* packed_dev, 
 // diinn_bf16.hip: the bf16 decode of HR rows [p.y0, p.y1) (grid of the one-tile kernel: gx, gy, gz)
 __attribute__((visibility("hidden")))
 int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int gz, int sin_mode);
+// diinn_bf16.hip: the split-bf16 decode (DIINN_COMPUTE_BF16X3) of HR rows [p.y0, p.y1)
+__attribute__((visibility("hidden")))
+int launch_decode_bf16x3(void* stream, const DecodeParams& p, int gx, int gy, int gz, int sin_mode);

@@ -54,6 +54,13 @@ static inline uint16_t f32_to_bf16(float f) {
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
+static inline float bf16_to_f32(uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
 extern "C" {
 
 int diinn_abi_version(void) { return DIINN_ABI_VERSION; }
@@ -135,11 +142,11 @@ size_t diinn_metasr_workspace_bytes(int B, int H, int W) {
 }
 
 int diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats) {
-    static const size_t off[14] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT, OFF_WPB, OFF_BQR,
-                                   OFF_Q0R, OFF_WLR, OFF_WPU};
-    static const size_t sz[14]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT, SZ_WPB, 3 * HID,
-                                   4 * HID, SZ_WL, SZ_WPU};
-    if (section < 0 || section > 13 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
+    static const size_t off[15] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT, OFF_WPB, OFF_BQR,
+                                   OFF_Q0R, OFF_WLR, OFF_WPU, OFF_WLBL};
+    static const size_t sz[15]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT, SZ_WPB, 3 * HID,
+                                   4 * HID, SZ_WL, SZ_WPU, SZ_WLB};
+    if (section < 0 || section > 14 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
     *offset_floats = off[section];
     *size_floats = sz[section];
     return DIINN_OK;
@@ -273,13 +280,15 @@ int diinn_pack_weights(const float* K0w, const float* K0b,
     bl[0] = Lb[0]; bl[1] = Lb[1]; bl[2] = Lb[2];
     const uint32_t magic = DIINN_PACKED_MAGIC;                  // validity word: this image holds its derived sections
     std::memcpy(bl + 3, &magic, 4);
-    // WLB: [layer][m][ks][part][lane][j] bf16
+    // WLB: [layer][m][ks][part][lane][j] bf16; WLBL: the low parts, bf16(w - bf16(w)) (split-bf16 arithmetic)
     uint16_t* wlb = reinterpret_cast<uint16_t*>(packed + OFF_WLB);
+    uint16_t* wlbl = reinterpret_cast<uint16_t*>(packed + OFF_WLBL);
     for (int i = 0; i < 3; ++i)
         for (int m = 0; m < 8; ++m)
             for (int ks = 0; ks < 16; ++ks)
                 for (int part = 0; part < 2; ++part) {
                     uint16_t* dst = wlb + ((((size_t)i * 8 + m) * 16 + ks) * 2 + part) * (64 * 8);
+                    uint16_t* dlo = wlbl + ((((size_t)i * 8 + m) * 16 + ks) * 2 + part) * (64 * 8);
                     for (int lane = 0; lane < 64; ++lane) {
                         const int out = 32 * m + (lane & 31);
                         const int h = lane >> 5;
@@ -288,7 +297,9 @@ int diinn_pack_weights(const float* K0w, const float* K0b,
                             // synthesis rows in revolutions (one fp32 multiply, then the bf16 rounding)
                             const float w = part == 0 ? Kw[i][(size_t)out * (HID + UNF) + in]
                                                       : Qw[i][(size_t)out * HID + in] * INV_2PI;
-                            dst[lane * 8 + j] = f32_to_bf16(w);
+                            const uint16_t hi = f32_to_bf16(w);
+                            dst[lane * 8 + j] = hi;
+                            dlo[lane * 8 + j] = f32_to_bf16(w - bf16_to_f32(hi));   // exact difference, then one rounding
                         }
                     }
                 }

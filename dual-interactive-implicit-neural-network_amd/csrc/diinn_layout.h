@@ -86,7 +86,11 @@ constexpr size_t OFF_WLR    = OFF_Q0R + 4 * HID;
 //     negated), else 1.  Derived (float64, rounded once): an inference-only section like WLR.
 constexpr size_t OFF_WPU    = OFF_WLR + SZ_WL;
 constexpr size_t SZ_WPU     = (size_t)32 * 4 * 8 * 4 * WL_PIECE;   // 1,048,576 floats = 4 MiB
-constexpr size_t PACKED_FLOATS = OFF_WPU + SZ_WPU;         // 3,314,948
+// WLBL: the LOW parts of WLB for the split-bf16 arithmetic (DIINN_COMPUTE_BF16X3): every weight w (synthesis rows: w / (2 pi))
+//     is carried as hi + lo with hi = bf16(w) (section WLB) and lo = bf16(w - hi) (here, same shape and order as WLB); the
+//     kernel adds hi*hi + hi*lo + lo*hi on the bf16 MFMA.  Derived, inference only.
+constexpr size_t OFF_WLBL   = OFF_WPU + SZ_WPU;
+constexpr size_t PACKED_FLOATS = OFF_WLBL + SZ_WLB;        // 3,511,556
 
 // channel held by activation register (m, r) of lane-half h
 DIINN_HD int chan_of(int kk /* = 16*m + r */, int h) {

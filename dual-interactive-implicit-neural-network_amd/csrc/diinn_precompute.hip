@@ -552,8 +552,7 @@ int diinn_p_launch_info(int B, int H, int W, int r0, int r1, int compute, int* a
     if (!algorithm || r0 < 0 || r1 > H || r0 >= r1) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
     if (st) return st;
-    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY &&
-        compute != DIINN_COMPUTE_BF16_FULL)
+    if (!compute_ok(compute))
         return DIINN_ERR_UNSUPPORTED;
     const bool bf16 = compute == DIINN_COMPUTE_BF16_FULL;
     *algorithm = p_uses_winograd(B, H, W, 16, bf16, true) ? DIINN_P_ALGO_WINOGRAD
@@ -568,8 +567,7 @@ int diinn_precompute_P(void* stream, const float* feat_dev, const float* packed_
 
 int diinn_precompute_P_ex(void* stream, const float* feat_dev, const float* packed_dev,
                           float* P_dev, int B, int H, int W, int r0, int r1, int compute) {
-    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY &&
-        compute != DIINN_COMPUTE_BF16_FULL)
+    if (!compute_ok(compute))
         return DIINN_ERR_UNSUPPORTED;
     return launch_P(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, 16, compute == DIINN_COMPUTE_BF16_FULL, nullptr, nullptr, true);
 }
@@ -577,8 +575,7 @@ int diinn_precompute_P_ex(void* stream, const float* feat_dev, const float* pack
 int diinn_precompute_P_win(void* stream, const float* feat_win_dev, int feat_row0, int feat_rows,
                            const float* packed_dev, float* P_win_dev, int p_row0, int p_rows,
                            int B, int H, int W, int r0, int r1, int compute) {
-    if (compute != DIINN_COMPUTE_F32 && compute != DIINN_COMPUTE_BF16 && compute != DIINN_COMPUTE_F32_QONLY &&
-        compute != DIINN_COMPUTE_BF16_FULL)
+    if (!compute_ok(compute))
         return DIINN_ERR_UNSUPPORTED;
     const RowWin fw{feat_row0, feat_rows}, pw{p_row0, p_rows};
     return launch_P(stream, feat_win_dev, packed_dev, P_win_dev, B, H, W, r0, r1, 16, compute == DIINN_COMPUTE_BF16_FULL,

@@ -42,7 +42,7 @@ extern "C" {
  *   5  diinn_sfe1_forward; packed section 13 (WPU: the hoisted 3x3 conv in Winograd form)
  *   6  the packed image carries a validity word for its derived sections (DIINN_PACKED_MAGIC, below);
  *      diinn_p_launch_info; diinn_debug_set / diinn_debug_get;
- *      bf16 kernel choice taken from the full image, not the band */
+ *      bf16 kernel choice taken from the full image, not the band; DIINN_COMPUTE_BF16X3 and packed section 14 */
 
 /* status codes */
 #define DIINN_OK                 0
@@ -80,6 +80,11 @@ extern "C" {
 #define DIINN_COMPUTE_BF16_FULL 3  /* DIINN_COMPUTE_BF16 plus the hoisted 3x3 conv (P) on bf16 operands too (features and
                                    weights rounded to bf16, fp32 accumulate): ~1.6e-3 relative at default-init
                                    weights; the fastest path, BASELINE config 5 */
+#define DIINN_COMPUTE_BF16X3 4     /* split bf16 (r03, optional): the per-pixel layers 1..3 on the bf16 MFMA with every operand
+                                  carried as hi + lo bf16 parts -- hi*hi + hi*lo + lo*hi, fp32 accumulation (packed
+                                  sections 7 and 14); P, seeds, biases, sine, layer 0 and the head stay fp32.  As
+                                  accurate as DIINN_COMPUTE_F32 on every fixture at default-init weights (5e-8) and
+                                  inside the 1e-4 x max(1,|ref|) tolerance on the x3 stress set (2e-4 of |out| 6.8) */
 #define DIINN_COMPUTE_F32_QONLY 2 /* decoder modes 1 and 2 (diinn.py:116-131): fp32, synthesis GEMM only; the
                                   workspace slots 1..3 hold the per-cell modulation k_i (>= 0) produced by
                                   diinn_cell_chain from P (diinn_decode_ex runs P, the chain and the decode) */
@@ -109,9 +114,10 @@ size_t diinn_packed_weight_floats(void);
  * sine on revolutions, and the synthesis rows inside section 7 are pre-multiplied by 1/(2 pi) to match), 11 Q0R
  * (section 3 / (2 pi)), 12 WLR (section 0 with its synthesis pieces / (2 pi): the fp32 inference kernels evaluate the
  * sine on revolutions as well), 13 WPU (section 1 in Winograd F(2x2,3x3) form, U = G Wx G^T: what the fp32 inference
- * entry points -- everything but diinn_precompute_P -- read, at every map size).  Every section but 7 and
- * 9..13 is a pure permutation (plus zero padding) of the reference tensors, so a training loop can re-pack on the
- * device with one gather; sections 7 and 9..13 hold derived values, read by the inference kernels only (the
+ * entry points -- everything but diinn_precompute_P -- read, at every map size), 14 WLBL (the low parts
+ * bf16(w - bf16(w)) of section 7, for DIINN_COMPUTE_BF16X3).  Every section but 7 and
+ * 9..14 is a pure permutation (plus zero padding) of the reference tensors, so a training loop can re-pack on the
+ * device with one gather; sections 7 and 9..14 hold derived values, read by the inference kernels only (the
  * training forward and LIIF read sections 0, 1 and 4; diinn_precompute_P reads section 1 whatever the map size).
  *
  * VALIDITY WORD.  The pad word behind bL (float index 3 of section 6) holds the bit pattern DIINN_PACKED_MAGIC in an

@@ -252,7 +252,8 @@ def _bf16_round(t: torch.Tensor) -> torch.Tensor:
 @torch.no_grad()
 def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = False, bf16_p: bool = False,
                         row_range: Optional[Tuple[int, int]] = None, feat_row0: int = 0,
-                        full_h: Optional[int] = None, bf16_p_storage: bool = False) -> torch.Tensor:
+                        full_h: Optional[int] = None, bf16_p_storage: bool = False,
+                        bf16x3: bool = False) -> torch.Tensor:
     """Same function evaluated the way the HIP kernels do: per-cell P, then the
     per-pixel 256->512 stacked layers.  Not reference-faithful in summation
     order; agrees with decode_reference_form to ~1e-7.
@@ -264,7 +265,12 @@ def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = Fal
     fp32 bias): the DIINN_COMPUTE_BF16_FULL mode.
     ``bf16_p_storage=True`` rounds the finished P image (bias included) to bf16, as a kernel that kept P in HBM as
     bf16 would: an experiment switch, measured by tools/bf16_p_storage_error.py; no kernel does it.
+    ``bf16x3=True`` emulates the split-bf16 mode (DIINN_COMPUTE_BF16X3, decode_bf16x3_kernel): weights and
+    activation of layers 1..3 as hi = bf16(v), lo = bf16(v - hi); a product is w_lo.q_hi + w_hi.q_lo + w_hi.q_hi with
+    fp32 accumulation; the synthesis branch in revolutions as in the bf16 mode; everything else fp32.
     ``row_range`` / ``feat_row0`` / ``full_h``: an HR row band from a feature crop, as in decode_reference_form."""
+    if bf16x3 and (bf16_operands or bf16_p):
+        raise ValueError("bf16x3 is a mode of its own")
     sw = split_weights(sd)
     feat = _as_t(feat)
     b, c, hc, w = feat.shape
@@ -294,7 +300,19 @@ def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = Fal
     q = torch.relu(pp[:, :, :, 0]) * torch.sin(syn @ sw["Q0"].t() + sw["bQ"][0])
     rnd = _bf16_round if bf16_operands else (lambda t: t)
     inv_2pi = torch.tensor(0.15915494309189533577, dtype=torch.float32)
+    def mm3(a, wgt):                                   # a [.., K] x wgt [M, K]: three bf16 products
+        ah = _bf16_round(a)
+        al = _bf16_round(a - ah)
+        wh = _bf16_round(wgt)
+        wl = _bf16_round(wgt - wh)
+        return (ah @ wl.t() + al @ wh.t()) + ah @ wh.t()
+
     for i in range(1, 4):
+        if bf16x3:
+            k = torch.relu(mm3(q, sw["Wq"][i - 1]) + pp[:, :, :, i])
+            rev = mm3(q, sw["Qw"][i - 1] * inv_2pi) + sw["bQ"][i] * inv_2pi
+            q = k * torch.sin(rev.double() * (2.0 * np.pi)).float()
+            continue
         qi = rnd(q)
         k = torch.relu(qi @ rnd(sw["Wq"][i - 1]).t() + pp[:, :, :, i])
         if bf16_operands:

@@ -496,6 +496,70 @@ def test_bf16_persistent_kernel_blocks_bands_and_batches(dev, knobs, compute):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# split bf16 (DIINN_COMPUTE_BF16X3, decode_bf16x3_kernel): the bf16 matrix cores at the fp32 path's tolerance
+
+
+def test_bf16x3_meets_the_fp32_tolerance_on_every_fixture(golden, dev):
+    """hi/lo bf16 operands, three products per term: the kernel is held to the SAME bound as the fp32 kernels,
+    1e-4 x max(1, |ref|) against the reference's own outputs (tests/golden), stress weights included, and to the
+    oracle's emulation of its roundings (decode_hoisted_form(bf16x3=True))."""
+    import diinn_oracle as orc
+    for name, b, h, w, hu, wu, gain in golden_cases(golden):
+        sd = synth.decoder_state_dict(123, gain)
+        feat = synth.encoder_features(123, b, h, w)
+        ref = golden[f"out/{name}"]
+        for sin_mode in (0, 1, 2):
+            got = _decode(sd, feat, (hu, wu), dev, compute="bf16x3", sin_mode=sin_mode)
+            err = float(np.abs(got - ref).max())
+            assert got.shape == ref.shape and err <= _tol(ref), f"{name}/{sin_mode}: bf16x3 {err:.3e} > {_tol(ref):.3e}"
+        emu = orc.decode_hoisted_form(sd, feat, (hu, wu), bf16x3=True).numpy()
+        err2 = float(np.abs(got - emu).max())
+        assert err2 <= _tol(ref), f"{name}: bf16x3 kernel vs emulation {err2:.3e}"
+        f32 = _decode(sd, feat, (hu, wu), dev)
+        print(f"bf16x3 {name}: max|ref| {float(np.abs(ref).max()):.3f}  vs reference {err:.2e}  vs emulation {err2:.2e}  "
+              f"(fp32 kernel vs reference {float(np.abs(f32 - ref).max()):.2e}; bound {_tol(ref):.1e})")
+
+
+def test_bf16x3_ragged_shapes_batches_and_bands(dev):
+    """Fresh seeds, non-integer scales, batch > 1, ragged edges; row bands stitch bit-exactly into the whole image."""
+    import diinn_oracle as orc
+    import diinn_amd.decoder as D
+    for (b, h, w, hu, wu, seed) in [(1, 40, 56, 132, 185, 3), (2, 33, 47, 109, 155, 4), (3, 9, 11, 36, 40, 6), (1, 5, 3, 9, 4, 8)]:
+        sd = synth.decoder_state_dict(seed)
+        feat_np = synth.encoder_features(seed, b, h, w)
+        ref = orc.decode_reference_form(sd, feat_np, (hu, wu), 30000).numpy()
+        packed = D.pack_state_dict(sd).to(dev)
+        feat = torch.from_numpy(feat_np).to(dev)
+        full = D.decode_features(feat, packed, (hu, wu), compute="bf16x3")
+        assert float(np.abs(full.cpu().numpy() - ref).max()) <= _tol(ref), (b, h, w, hu, wu)
+        out = torch.zeros_like(full)
+        cuts = sorted({0, min(13, hu), max(hu - 5, 0), hu})
+        for y0, y1 in zip(cuts[:-1], cuts[1:]):
+            D.decode_features(feat, packed, (hu, wu), out=out, rows=(y0, y1), compute="bf16x3")
+        torch.cuda.synchronize()
+        assert torch.equal(full, out), (b, h, w, hu, wu)
+
+
+def test_bf16x3_full_size_config2_band_vs_oracle(dev):
+    """BASELINE config 2 at full size in the split-bf16 mode: HR row bands against the oracle at the fp32 bound."""
+    import diinn_amd.decoder as D
+    import diinn_oracle as orc
+    sd = synth.decoder_state_dict(123)
+    feat_np = synth.encoder_features(123, 1, 256, 256)
+    feat = torch.from_numpy(feat_np).to(dev)
+    packed = D.pack_state_dict(sd).to(dev)
+    full = D.decode_features(feat, packed, (1024, 1024), compute="bf16x3")
+    again = D.decode_features(feat, packed, (1024, 1024), compute="bf16x3")
+    torch.cuda.synchronize()
+    assert torch.equal(full, again)
+    full_np = full.cpu().numpy()
+    for y0, y1 in [(0, 8), (508, 524), (1016, 1024)]:
+        ref = orc.decode_reference_form(sd, feat_np, (1024, 1024), 30000, row_range=(y0, y1)).numpy()
+        err = float(np.abs(full_np[:, :, y0:y1] - ref).max())
+        assert err <= _tol(ref), f"rows {y0}:{y1} err {err:.3e}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # non-finite inputs (VERDICT r02 item 5): the reference's relu / conv / sin propagate NaN (diinn.py:133-138), and so
 # does the HIP path: relu0 is the NaN-propagating v_maximum3_f32 (csrc/diinn_device.h)
 # ---------------------------------------------------------------------------------------------------------------------
@@ -523,7 +587,7 @@ def test_nonfinite_feature_cell_propagates_like_the_reference(dev, bad):
         assert np.isnan(got[~np.isfinite(got)]).all()              # and what comes out is NaN, as in the reference
 
 
-@pytest.mark.parametrize("compute", ["bf16", "bf16_full"])
+@pytest.mark.parametrize("compute", ["bf16", "bf16_full", "bf16x3"])
 def test_nonfinite_feature_cell_bf16(dev, compute):
     import diinn_oracle as orc
     sd = synth.decoder_state_dict(11)
@@ -579,7 +643,7 @@ def test_image_without_derived_sections_is_refused(dev):
     feat = torch.from_numpy(synth.encoder_features(5, 1, 24, 20)).to(dev)
     good = D.decode_features(feat, host, (79, 66))
     assert bool(torch.isfinite(good).all())
-    for compute in ("f32", "bf16", "bf16_full"):
+    for compute in ("f32", "bf16", "bf16_full", "bf16x3"):
         out = D.decode_features(feat, gathered, (79, 66), compute=compute)
         torch.cuda.synchronize()
         assert bool(torch.isnan(out).all()), compute
