@@ -1,6 +1,7 @@
 // diinn_bf16x3.hip -- the optional split-bf16 decode kernel (DIINN_COMPUTE_BF16X3)
 // (part of libdiinn_hip.so; shared definitions in diinn_device.h, layout in diinn_layout.h)
 #include "diinn_device.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------
 // decode_bf16x3_kernel: the per-pixel layers 1..3 (diinn.py:128-137) on v_mfma_f32_32x32x16_bf16 at fp32 accuracy.
@@ -24,6 +25,19 @@
 #ifndef DECODE_BF16X3_PREFETCH
 #define DECODE_BF16X3_PREFETCH 4                // ring depth in k-steps (4 pieces, 6 MFMAs each)
 #endif
+
+// issue order of a k-step (one wave per SIMD: whatever sits between two MFMAs delays the second): a weight load
+// behind each of the first four MFMAs, the epilogue's VALU spread over all six; the region ends at the k-step
+// (a scheduling region over the whole unrolled layer does not finish compiling).  A/B on one box: -2.7 %.
+#define X3_KSTEP_ORDER()                                                              \
+    do {                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
+            if (i_ < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                        \
+        }                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+    } while (0)
 
 __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
     hi = (__bf16)v;
@@ -50,6 +64,14 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x3_kernel(const DecodeParam
     const float* __restrict__ Wt = p.Wt;
     const float* __restrict__ Pc = p.P + (((size_t)b * p.Prows + (iy - p.Prow0)) * p.W + ix) * PCH + 4 * h;
 
+#ifdef X3_WARM
+    // the seeds of layers 1..3 (3 KiB of the cell's P row) are first touched in the main loop, where a miss to HBM
+    // holds up every weight piece behind it (one in-order vmcnt): fetch their 24 lines into the L2 now
+    float warm[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+        asm volatile("global_load_dword %0, %1, off" : "=v"(warm[i]) : "v"((const char*)(Pc - 4 * h) + 1024 + (2 * i + h) * 128) : "memory");
+#endif
     // ---- layer 0 (fp32), split into hi/lo fragments: register r = 4g+e of tile m -> q[2m + (r>>3)][r&7]
     bf16x8 qh[16], ql[16];
     {
@@ -78,6 +100,10 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x3_kernel(const DecodeParam
         }
     }
 
+#ifdef X3_WARM
+    asm volatile("" :: "v"(warm[0]), "v"(warm[1]), "v"(warm[2]), "v"(warm[3]), "v"(warm[4]), "v"(warm[5]), "v"(warm[6]),
+                 "v"(warm[7]), "v"(warm[8]), "v"(warm[9]), "v"(warm[10]), "v"(warm[11]));   // older than layer 0's loads: arrived
+#endif
     constexpr int PF = DECODE_BF16X3_PREFETCH;
     static_assert(16 % PF == 0, "ring index must be static");
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -153,6 +179,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x3_kernel(const DecodeParam
                 rkl[s % PF] = ld_piece(wrs, lane_off, wp + LO + (2 * (s + PF) + 0) * PIECE_BYTES);
                 rql[s % PF] = ld_piece(wrs, lane_off, wp + LO + (2 * (s + PF) + 1) * PIECE_BYTES);
 #endif
+#ifndef ABL_X3_NOSEED
                 if (ks == 2) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -160,6 +187,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x3_kernel(const DecodeParam
                         sq[g] = *(const f32x4*)((m < 7 ? Bq + 32 * (m + 1) : Bn) + 8 * g);
                     }
                 }
+#endif
                 if (m > 0) {                                      // one epilogue element of tile m-1 per k-step
                     float v = relu0(pk[ks]) * dsin_rev<SIN_MODE>(ps[ks]);
                     asm volatile("" : "+v"(v));                   // the element stays behind its k-step (see decode_bf16x2_kernel)
@@ -178,6 +206,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x3_kernel(const DecodeParam
                         }
                     }
                 }
+                X3_KSTEP_ORDER();
             }
             pk = ak;
             ps = as;
@@ -231,8 +260,310 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x3_kernel(const DecodeParam
     }
 }
 
+// ---------------------------------------------------------------------------------
+// decode_bf16x3p_kernel: the same arithmetic with PERSISTENT workgroups.  Layer 0 is pure VALU work (128 sines per
+// lane, ~13 % of decode_bf16x3_kernel's time at one wave per SIMD, where nothing else can cover it); here a workgroup
+// walks blocks blockIdx.x, + gridDim.x, ... and evaluates the NEXT block's layer 0 inside the current block's last
+// layer -- one element per k-step in the issue slots the six MFMAs of a k-step leave free -- into the LDS slab, which
+// no activation occupies during a last layer.  The weight ring runs on across the block boundary (the refills of the
+// last layer's final k-steps fetch the first layer's pieces) and the first seeds of the next block are loaded in the
+// last M-tile.  Per pixel the operations and their order are those of decode_bf16x3_kernel: bit-identical output.
+// ---------------------------------------------------------------------------------
+struct X3Pixel {
+    int x, y, b;
+    bool valid;
+    const float* Pc;       // P row of the pixel's LR cell (+ 4 * lane half)
+    float relh, relw;
+};
+
+__device__ __forceinline__ X3Pixel x3_locate(const DecodeParams& p, const int blk, const int wave, const int j, const int h) {
+    const int bx = blk % p.pg[0], t = blk / p.pg[0], by = t % p.pg[1], bz = t / p.pg[1];
+    X3Pixel r;
+    r.x = bx * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
+    r.y = p.y0 + by * (TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
+    r.b = bz;
+    r.valid = (r.x < p.Wu) && (r.y < p.y1);
+    const int xc = r.x < p.Wu ? r.x : p.Wu - 1;
+    const int yc = r.y < p.y1 ? r.y : p.y1 - 1;
+    int iy, ix;
+    axis_eval(p.ah, yc, iy, r.relh);
+    axis_eval(p.aw, xc, ix, r.relw);
+    r.Pc = p.P + (((size_t)bz * p.Prows + (iy - p.Prow0)) * p.W + ix) * PCH + 4 * h;
+    return r;
+}
+
+constexpr int X3_PGRID = 256;                   // persistent workgroups of a launch: one per CU (128 KiB of LDS each)
+
+template <int SIN_MODE>
+__global__ __launch_bounds__(256, 1) void decode_bf16x3p_kernel(const DecodeParams p) {
+    __shared__ __attribute__((aligned(16))) bf16x8 park[4][2][16][64];     // [wave][hi, lo][fragment][ln] = 128 KiB
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));              // opaque: per-lane addresses are rebuilt per block, not hoisted and spilled
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int nblk = p.pg[0] * p.pg[1] * p.pg[2];
+    int blk = blockIdx.x;
+    X3Pixel cur = x3_locate(p, blk, wave, j, h);
+    const float* __restrict__ Wt = p.Wt;
+    auto l0_value = [&](const float pv, const float wh, const float ww, const float wr, const float bq,
+                        const float relh, const float relw) -> float {
+        float a = __builtin_fmaf(wr, p.ratio, bq);
+        a = __builtin_fmaf(ww, relw, a);
+        a = __builtin_fmaf(wh, relh, a);
+        return relu0(pv) * dsin<SIN_MODE>(a);
+    };
+
+    // ---- layer 0 of the first block, as in decode_bf16x3_kernel
+    bf16x8 qh[16], ql[16];
+    const float* __restrict__ Q0 = Wt + OFF_Q0 + 4 * h;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = 32 * m + 8 * g;
+            const f32x4 pv = *(const f32x4*)(cur.Pc + c0);
+            const f32x4 wh = *(const f32x4*)(Q0 + 0 * HID + c0);
+            const f32x4 ww = *(const f32x4*)(Q0 + 1 * HID + c0);
+            const f32x4 wr = *(const f32x4*)(Q0 + 2 * HID + c0);
+            const f32x4 bq = *(const f32x4*)(Q0 + 3 * HID + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 vh, vl;
+                split_bf16(l0_value(pv[e], wh[e], ww[e], wr[e], bq[e], cur.relh, cur.relw), vh, vl);
+                qh[2 * m + (g >> 1)][4 * (g & 1) + e] = vh;
+                ql[2 * m + (g >> 1)][4 * (g & 1) + e] = vl;
+            }
+        }
+    }
+
+    constexpr int PF = DECODE_BF16X3_PREFETCH;
+    static_assert(16 % PF == 0, "ring index must be static");
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);
+    constexpr int LO = (int)((OFF_WLBL - OFF_WLB) * sizeof(float));      // hi piece -> its lo piece
+    constexpr int WP0 = (int)(OFF_WLB * sizeof(float));
+    f32x4 rkh[PF], rkl[PF], rqh[PF], rql[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        rkh[d] = ld_piece(wrs, lane * 16, WP0 + (2 * d + 0) * PIECE_BYTES);
+        rqh[d] = ld_piece(wrs, lane * 16, WP0 + (2 * d + 1) * PIECE_BYTES);
+        rkl[d] = ld_piece(wrs, lane * 16, WP0 + LO + (2 * d + 0) * PIECE_BYTES);
+        rql[d] = ld_piece(wrs, lane * 16, WP0 + LO + (2 * d + 1) * PIECE_BYTES);
+    }
+    f32x4 sk[4], sq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        sk[g] = *(const f32x4*)(cur.Pc + HID + 8 * g);
+        sq[g] = *(const f32x4*)(Wt + OFF_BQR + 4 * h + 8 * g);
+    }
+    bf16x8 (*mine)[16][64] = park[wave];
+    const unsigned nanm = derived_nan_mask(Wt);
+
+    for (;;) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                              // (the same for the LDS and weight-ring addresses)
+        const int lane_off = ln * 16;
+        const int nb = blk + (int)gridDim.x;
+        const bool more = nb < nblk;                              // the same for every wave of the launch's workgroup
+        X3Pixel nxt = cur;
+        float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+        // three copies of the layer body (a generic lambda: `#pragma unroll` on a loop of this size inside the block
+        // loop is declined): the layer and LAST are compile-time constants per copy
+        auto do_layer = [&](auto layer_tag) {
+            constexpr int layer = decltype(layer_tag)::value;
+            constexpr bool LAST = layer == 2;
+            constexpr int nl = layer < 2 ? layer + 1 : 0;         // layer whose first seeds the last M-tile fetches
+            constexpr int wp = WP0 + layer * (int)(WLB_LAYER * sizeof(float));
+            // table addresses are rebuilt from an opaque lane half in every layer copy: as invariants of the block loop
+            // they would be hoisted in front of it, sixty-odd 64-bit values, and spilled
+            int hb = h;
+            asm volatile("" : "+v"(hb));
+            const float* __restrict__ Q0 = Wt + OFF_Q0 + 4 * hb;
+            const float* __restrict__ Pl = cur.Pc + (layer + 1) * HID;
+            const float* __restrict__ Bq = Wt + OFF_BQR + layer * HID + 4 * hb;
+            const float* __restrict__ Bn = Wt + OFF_BQR + nl * HID + 4 * hb;
+            const float* __restrict__ L = Wt + OFF_L + 4 * hb;
+            f32x16 pk, ps;
+            bf16x8 fh, fl, nh, nw;
+            f32x4 l0[4], l1[4], l2[4];
+            f32x4 cpv, cwh, cww, cwr, cbq, npv, nwh, nww, nwr, nbq;   // LAST: layer-0 inputs of the next block, a group ahead
+            if (LAST) {
+                nxt = x3_locate(p, more ? nb : blk, wave, j, h);
+                cpv = *(const f32x4*)(nxt.Pc);
+                cwh = *(const f32x4*)(Q0 + 0 * HID);
+                cww = *(const f32x4*)(Q0 + 1 * HID);
+                cwr = *(const f32x4*)(Q0 + 2 * HID);
+                cbq = *(const f32x4*)(Q0 + 3 * HID);
+            }
+            const float* __restrict__ Pn = LAST ? nxt.Pc + HID : cur.Pc + (nl + 1) * HID;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                f32x16 ak, as;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ak[4 * g + e] = sk[g][e];
+                        as[4 * g + e] = sq[g][e];
+                    }
+                }
+                if (LAST && m > 0) {                              // head rows of the tile being finished
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        l0[g] = *(const f32x4*)(L + 0 * HID + 32 * (m - 1) + 8 * g);
+                        l1[g] = *(const f32x4*)(L + 1 * HID + 32 * (m - 1) + 8 * g);
+                        l2[g] = *(const f32x4*)(L + 2 * HID + 32 * (m - 1) + 8 * g);
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    const int s = m * 16 + ks;
+                    const bf16x8 wkh = __builtin_bit_cast(bf16x8, rkh[s % PF]);
+                    const bf16x8 wqh = __builtin_bit_cast(bf16x8, rqh[s % PF]);
+                    ak = MFMA_BF16(__builtin_bit_cast(bf16x8, rkl[s % PF]), qh[ks], ak);
+                    as = MFMA_BF16(__builtin_bit_cast(bf16x8, rql[s % PF]), qh[ks], as);
+                    ak = MFMA_BF16(wkh, ql[ks], ak);
+                    as = MFMA_BF16(wqh, ql[ks], as);
+                    ak = MFMA_BF16(wkh, qh[ks], ak);
+                    as = MFMA_BF16(wqh, qh[ks], as);
+                    {   // refill: k-step s + PF of this layer; past the last layer's end, the first layer's (next block)
+                        const int rp = (LAST && s + PF >= 128) ? WP0 + 2 * (s + PF - 128) * PIECE_BYTES : wp + 2 * (s + PF) * PIECE_BYTES;
+                        rkh[s % PF] = ld_piece(wrs, lane_off, rp);
+                        rqh[s % PF] = ld_piece(wrs, lane_off, rp + PIECE_BYTES);
+                        rkl[s % PF] = ld_piece(wrs, lane_off, rp + LO);
+                        rql[s % PF] = ld_piece(wrs, lane_off, rp + LO + PIECE_BYTES);
+                    }
+                    if (ks == 2) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            sk[g] = *(const f32x4*)((m < 7 ? Pl + 32 * (m + 1) : Pn) + 8 * g);
+                            sq[g] = *(const f32x4*)((m < 7 ? Bq + 32 * (m + 1) : Bn) + 8 * g);
+                        }
+                    }
+                    if (m > 0) {                                  // one epilogue element of tile m-1 per k-step
+                        float v = relu0(pk[ks]) * dsin_rev<SIN_MODE>(ps[ks]);
+                        asm volatile("" : "+v"(v));               // the element stays behind its k-step (see decode_bf16x2_kernel)
+                        if (LAST) {
+                            o0 = __builtin_fmaf(l0[ks >> 2][ks & 3], v, o0);
+                            o1 = __builtin_fmaf(l1[ks >> 2][ks & 3], v, o1);
+                            o2 = __builtin_fmaf(l2[ks >> 2][ks & 3], v, o2);
+                        } else {
+                            __bf16 vh, vl;
+                            split_bf16(v, vh, vl);
+                            fh[ks & 7] = vh;
+                            fl[ks & 7] = vl;
+                            if ((ks & 7) == 7) {
+                                mine[0][2 * (m - 1) + (ks >> 3)][ln] = fh;
+                                mine[1][2 * (m - 1) + (ks >> 3)][ln] = fl;
+                            }
+                        }
+                    }
+                    if (LAST) {                                   // layer 0 of the next block: element ks of tile m
+                        if ((ks & 3) == 0 && s + 4 < 128) {       // inputs of the next group of four
+                            const int c0 = 32 * ((s + 4) >> 4) + 8 * (((s + 4) >> 2) & 3);
+#ifdef ABL_X3P_WARMP
+                            npv = *(const f32x4*)(cur.Pc + c0);
+#else
+                            npv = *(const f32x4*)(nxt.Pc + c0);
+#endif
+                            nwh = *(const f32x4*)(Q0 + 0 * HID + c0);
+                            nww = *(const f32x4*)(Q0 + 1 * HID + c0);
+                            nwr = *(const f32x4*)(Q0 + 2 * HID + c0);
+                            nbq = *(const f32x4*)(Q0 + 3 * HID + c0);
+                        }
+                        const int e = ks & 3;
+                        float v0 = l0_value(cpv[e], cwh[e], cww[e], cwr[e], cbq[e], nxt.relh, nxt.relw);
+                        asm volatile("" : "+v"(v0));
+                        __bf16 vh, vl;
+                        split_bf16(v0, vh, vl);
+                        nh[ks & 7] = vh;
+                        nw[ks & 7] = vl;
+                        if ((ks & 7) == 7) {
+                            mine[0][2 * m + (ks >> 3)][ln] = nh;
+                            mine[1][2 * m + (ks >> 3)][ln] = nw;
+                        }
+                        if (e == 3) {
+                            cpv = npv; cwh = nwh; cww = nww; cwr = nwr; cbq = nbq;
+                        }
+                    }
+                    X3_KSTEP_ORDER();
+                }
+                pk = ak;
+                ps = as;
+            }
+            if (LAST) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    l0[g] = *(const f32x4*)(L + 0 * HID + 32 * 7 + 8 * g);
+                    l1[g] = *(const f32x4*)(L + 1 * HID + 32 * 7 + 8 * g);
+                    l2[g] = *(const f32x4*)(L + 2 * HID + 32 * 7 + 8 * g);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = relu0(pk[r]) * dsin_rev<SIN_MODE>(ps[r]);
+                if (LAST) {
+                    o0 = __builtin_fmaf(l0[r >> 2][r & 3], v, o0);
+                    o1 = __builtin_fmaf(l1[r >> 2][r & 3], v, o1);
+                    o2 = __builtin_fmaf(l2[r >> 2][r & 3], v, o2);
+                } else {
+                    __bf16 vh, vl;
+                    split_bf16(v, vh, vl);
+                    fh[r & 7] = vh;
+                    fl[r & 7] = vl;
+                    if ((r & 7) == 7) {
+                        mine[0][14 + (r >> 3)][ln] = fh;
+                        mine[1][14 + (r >> 3)][ln] = fl;
+                    }
+                }
+            }
+            // the parked activation -- the next layer's, or after a last layer the next block's layer 0 -- becomes
+            // the B operand
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                qh[i] = mine[0][i][ln];
+                ql[i] = mine[1][i][ln];
+            }
+        };
+        do_layer(std::integral_constant<int, 0>{});
+        do_layer(std::integral_constant<int, 1>{});
+        do_layer(std::integral_constant<int, 2>{});
+
+        o0 += __shfl_xor(o0, 32);
+        o1 += __shfl_xor(o1, 32);
+        o2 += __shfl_xor(o2, 32);
+        if (cur.valid && h == 0) {
+            const size_t plane = (size_t)p.Orows * p.Wu;
+            float* o = p.out + (size_t)cur.b * 3 * plane + (size_t)(cur.y - p.Orow0) * p.Wu + cur.x;
+            o[0] = o0 + or_bits(Wt[OFF_BL + 0], nanm);
+            o[plane] = o1 + or_bits(Wt[OFF_BL + 1], nanm);
+            o[2 * plane] = o2 + or_bits(Wt[OFF_BL + 2], nanm);
+        }
+        if (!more) break;
+        cur = nxt;
+        blk = nb;
+    }
+}
+
 int launch_decode_bf16x3(void* stream, const DecodeParams& p, int gx, int gy, int gz, int sin_mode) {
     const dim3 grid(gx, gy, gz);
+    const long long nblk = (long long)gx * gy * gz;
+    if (nblk > 0x7fffffffLL) return DIINN_ERR_TOO_LARGE;
+    // persistent workgroups from two blocks per CU up (below that there is no next block whose layer 0 could be
+    // overlapped); DIINN_X3_KERNEL = 1 / 2 forces the one-block / the persistent form.  Bit-identical results.
+    const int force = (int)knob(diinn_knobs().x3_kernel);
+    if (force ? force == 2 : nblk >= 2 * X3_PGRID) {
+        DecodeParams pc = p;
+        pc.pg[0] = gx; pc.pg[1] = gy; pc.pg[2] = gz;
+        const dim3 gridp((unsigned)(nblk < X3_PGRID ? nblk : X3_PGRID));
+        if (sin_mode == DIINN_SIN_HW)
+            hipLaunchKernelGGL(decode_bf16x3p_kernel<DIINN_SIN_HW>, gridp, dim3(256), 0, (hipStream_t)stream, pc);
+        else if (sin_mode == DIINN_SIN_HW_REDUCED)
+            hipLaunchKernelGGL(decode_bf16x3p_kernel<DIINN_SIN_HW_REDUCED>, gridp, dim3(256), 0, (hipStream_t)stream, pc);
+        else
+            hipLaunchKernelGGL(decode_bf16x3p_kernel<DIINN_SIN_ACCURATE>, gridp, dim3(256), 0, (hipStream_t)stream, pc);
+        return hip_status(hipGetLastError());
+    }
     if (sin_mode == DIINN_SIN_HW)
         hipLaunchKernelGGL(decode_bf16x3_kernel<DIINN_SIN_HW>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else if (sin_mode == DIINN_SIN_HW_REDUCED)

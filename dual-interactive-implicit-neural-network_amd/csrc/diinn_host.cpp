@@ -19,6 +19,7 @@ struct KnobDef { const char* name; std::atomic<long long> DiinnKnobs::*field; lo
 const KnobDef KNOBS[] = {
     {"DIINN_F32_KERNEL", &DiinnKnobs::f32_kernel, 0, false},
     {"DIINN_BF16_KERNEL", &DiinnKnobs::bf16_kernel, 0, false},
+    {"DIINN_X3_KERNEL", &DiinnKnobs::x3_kernel, 0, false},
     {"DIINN_PBF16_KERNEL", &DiinnKnobs::pbf16_kernel, 0, false},
     {"DIINN_P_KERNEL", &DiinnKnobs::p_kernel, 0, false},
     {"DIINN_P_WINO_MIN", &DiinnKnobs::p_wino_min, 0, false},

@@ -10,6 +10,7 @@
 struct DiinnKnobs {
     std::atomic<long long> f32_kernel;          // DIINN_F32_KERNEL: 1 throughput, 2 latency decode kernel (0: by launch size)
     std::atomic<long long> bf16_kernel;         // DIINN_BF16_KERNEL: 1 / 2 tiles per wave, 4 / 8 cooperative waves (0: auto)
+    std::atomic<long long> x3_kernel;           // DIINN_X3_KERNEL: 1 one block per workgroup, 2 persistent split-bf16 decode (0: auto)
     std::atomic<long long> pbf16_kernel;        // DIINN_PBF16_KERNEL: 1 narrow, 2 wide bf16 P kernel (0: auto)
     std::atomic<long long> p_kernel;            // DIINN_P_KERNEL: 1 direct, 2 Winograd fp32 P kernel (0: auto)
     std::atomic<long long> p_wino_min;          // DIINN_P_WINO_MIN: cells from which the Winograd P kernel runs (default 0)

@@ -47,7 +47,7 @@ def test_abi_version_and_status_strings(lib):
 def test_debug_knobs_roundtrip(lib):
     """The diagnostic overrides live in one table behind diinn_debug_set / diinn_debug_get (no getenv per launch)."""
     import diinn_amd._native as N
-    for name, dflt in [("DIINN_F32_KERNEL", 0), ("DIINN_BF16_KERNEL", 0), ("DIINN_PBF16_KERNEL", 0), ("DIINN_P_KERNEL", 0),
+    for name, dflt in [("DIINN_F32_KERNEL", 0), ("DIINN_BF16_KERNEL", 0), ("DIINN_X3_KERNEL", 0), ("DIINN_PBF16_KERNEL", 0), ("DIINN_P_KERNEL", 0),
                        ("DIINN_P_WINO_MIN", 0), ("DIINN_ENC_S1_MIN_BLOCKS", 128), ("DIINN_ENC_NO_STREAM1X1", 0),
                        ("DIINN_ENC_LAT_MAX_TILES", 256), ("DIINN_ENC_WINO_MIN", 8192), ("DIINN_ENC_WINO_HALF_MAX", -1),
                        ("DIINN_ENC_WINO_PERSIST", 256)]:

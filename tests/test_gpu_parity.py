@@ -540,6 +540,37 @@ def test_bf16x3_ragged_shapes_batches_and_bands(dev):
         assert torch.equal(full, out), (b, h, w, hu, wu)
 
 
+def test_bf16x3_persistent_kernel_is_bit_identical(dev, knobs):
+    """decode_bf16x3p_kernel (persistent workgroups, the next block's layer 0 evaluated inside the current block's last
+    layer) does decode_bf16x3_kernel's arithmetic pixel by pixel: equal bit for bit on ragged edges, batches, fewer
+    blocks than workgroups, many blocks per workgroup, and row bands that do not start on a block boundary."""
+    import diinn_oracle as orc
+    import diinn_amd.decoder as D
+    for (b, h, w, hu, wu, seed) in [(1, 60, 100, 333, 530, 5), (2, 33, 47, 109, 155, 4), (3, 9, 11, 36, 40, 6),
+                                    (1, 5, 3, 9, 4, 8), (1, 64, 64, 256, 256, 9)]:
+        sd = synth.decoder_state_dict(seed)
+        feat_np = synth.encoder_features(seed, b, h, w)
+        packed = D.pack_state_dict(sd).to(dev)
+        feat = torch.from_numpy(feat_np).to(dev)
+        outs = {}
+        for k in (1, 2):
+            knobs("DIINN_X3_KERNEL", k)
+            for sin_mode in (0, 2):
+                outs[k, sin_mode] = D.decode_features(feat, packed, (hu, wu), compute="bf16x3", sin_mode=sin_mode)
+        torch.cuda.synchronize()
+        for sin_mode in (0, 2):
+            assert torch.equal(outs[1, sin_mode], outs[2, sin_mode]), (b, h, w, hu, wu, sin_mode)
+        ref = orc.decode_reference_form(sd, feat_np, (hu, wu), 30000).numpy()
+        assert float(np.abs(outs[2, 2].cpu().numpy() - ref).max()) <= _tol(ref), (b, h, w, hu, wu)
+        knobs("DIINN_X3_KERNEL", 2)
+        out = torch.zeros_like(outs[2, 2])
+        cuts = sorted({0, min(13, hu), max(hu - 5, 0), hu})
+        for y0, y1 in zip(cuts[:-1], cuts[1:]):
+            D.decode_features(feat, packed, (hu, wu), out=out, rows=(y0, y1), compute="bf16x3")
+        torch.cuda.synchronize()
+        assert torch.equal(outs[2, 2], out), (b, h, w, hu, wu)
+
+
 def test_bf16x3_full_size_config2_band_vs_oracle(dev):
     """BASELINE config 2 at full size in the split-bf16 mode: HR row bands against the oracle at the fp32 bound."""
     import diinn_amd.decoder as D
