@@ -553,16 +553,17 @@ def test_bf16x3_persistent_kernel_is_bit_identical(dev, knobs):
         packed = D.pack_state_dict(sd).to(dev)
         feat = torch.from_numpy(feat_np).to(dev)
         outs = {}
-        for k in (1, 2):
+        for k in (1, 2, 3):                                       # one block per workgroup, persistent, shared weight stream
             knobs("DIINN_X3_KERNEL", k)
             for sin_mode in (0, 2):
                 outs[k, sin_mode] = D.decode_features(feat, packed, (hu, wu), compute="bf16x3", sin_mode=sin_mode)
         torch.cuda.synchronize()
         for sin_mode in (0, 2):
             assert torch.equal(outs[1, sin_mode], outs[2, sin_mode]), (b, h, w, hu, wu, sin_mode)
+            assert torch.equal(outs[1, sin_mode], outs[3, sin_mode]), (b, h, w, hu, wu, sin_mode)
         ref = orc.decode_reference_form(sd, feat_np, (hu, wu), 30000).numpy()
         assert float(np.abs(outs[2, 2].cpu().numpy() - ref).max()) <= _tol(ref), (b, h, w, hu, wu)
-        knobs("DIINN_X3_KERNEL", 2)
+        knobs("DIINN_X3_KERNEL", 3)
         out = torch.zeros_like(outs[2, 2])
         cuts = sorted({0, min(13, hu), max(hu - 5, 0), hu})
         for y0, y1 in zip(cuts[:-1], cuts[1:]):
