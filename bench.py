@@ -75,6 +75,7 @@ def parse():
                     help="arithmetic of the per-pixel layers; f32 is the reference's precision and the only "
                          "valid headline (bf16 is BASELINE config 5's optional path, 2e-3 relative; bf16x3 = split "
                          "bf16, three bf16 MFMA products per term, held to f32's 1e-4)")
+    ap.add_argument("--no-split", action="store_true", help="skip the split-bf16 side leg of the default run")
     ap.add_argument("--dist-mode", choices=["halo", "bcast"], default="halo")
     ap.add_argument("--gather", action="store_true", help="also time assembling the image on rank 0 (reported "
                                                            "as gather_ms, never part of value)")
@@ -294,11 +295,13 @@ class Job:
         torch.cuda.synchronize()
 
 
-def run_workload(job, name, scaling, steps, warmup, solo=False, check=True, gather=False):
+def run_workload(job, name, scaling, steps, warmup, solo=False, check=True, gather=False, compute=None):
     """Time ``steps`` steps of one workload.  ``solo``: rank 0 decodes the whole image alone (the same-run one-GPU
     reference of a strong-scaling leg) while the other ranks wait at the barriers.  Returns a dict on every rank
     (timings are this rank's, ``elapsed`` the max over ranks)."""
     args, N, S, lib, dev = job.args, job.N, job.S, job.lib, job.dev
+    compute = compute or args.compute                      # (the split-bf16 side leg overrides the run's mode)
+    comp = N.COMPUTE[compute]
     world = 1 if solo else job.world
     rank = job.rank
     idle = solo and rank != 0
@@ -322,7 +325,7 @@ def run_workload(job, name, scaling, steps, warmup, solo=False, check=True, gath
         gen.manual_seed(123)
         feat = torch.randn(shape, device=dev, generator=gen)
     dec = S.BandDecoder(shape, (HU, WU), job.packed, src=0, mode=args.dist_mode, sin_mode=job.sin_mode,
-                        compute=args.compute, solo=solo)
+                        compute=compute, solo=solo)
     bd = dec.band
     if bd.empty:
         raise SystemExit("more ranks than HR rows")
@@ -347,12 +350,12 @@ def run_workload(job, name, scaling, steps, warmup, solo=False, check=True, gath
             ev[i][1].record()
         N.check(lib.diinn_precompute_P_win(C.c_void_p(stream), C.c_void_p(win.data_ptr()), row0, win.shape[2],
                                            C.c_void_p(packed.data_ptr()), C.c_void_p(dec.p_win.data_ptr()),
-                                           bd.r0, bd.r1 - bd.r0, 1, H, W, bd.r0, bd.r1, job.comp), "diinn_precompute_P_win")
+                                           bd.r0, bd.r1 - bd.r0, 1, H, W, bd.r0, bd.r1, comp), "diinn_precompute_P_win")
         if i is not None:
             ev[i][2].record()
         N.check(lib.diinn_decode_band_win(C.c_void_p(stream), C.c_void_p(dec.p_win.data_ptr()), bd.r0, bd.r1 - bd.r0,
                                           C.c_void_p(packed.data_ptr()), C.c_void_p(dec.out_band.data_ptr()),
-                                          bd.y0, bd.y1 - bd.y0, 1, H, W, HU, WU, bd.y0, bd.y1, job.sin_mode, job.comp),
+                                          bd.y0, bd.y1 - bd.y0, 1, H, W, HU, WU, bd.y0, bd.y1, job.sin_mode, comp),
                 "diinn_decode_band_win")
         if i is not None:
             ev[i][3].record()
@@ -404,10 +407,10 @@ def run_workload(job, name, scaling, steps, warmup, solo=False, check=True, gath
         win_cpu = win[:, :, lo:lo + bd.a1 - bd.a0].cpu()       # the rows this rank actually decoded from
         out_cpu = dec.out_band.cpu()
         torch.set_num_threads(max(1, effective_cores() // job.world))   # every rank checks at once on the one host
-        err, ok = check_band_rows(job.sd, win_cpu, bd.a0, H, (HU, WU), out_cpu, bd.y0, rows_list, args.compute)
+        err, ok = check_band_rows(job.sd, win_cpu, bd.a0, H, (HU, WU), out_cpu, bd.y0, rows_list, compute)
         ok = ok and handoff_ok
         err, bad = job.reduce_max([err, 0.0 if ok else 1.0])
-        tol = CHECK_TOL[args.compute]
+        tol = CHECK_TOL[compute]
         res["checked"] = {"rows": [list(r) for r in rows_list], "rows_of": "rank 0's band; every rank checks its own",
                           "max_err": err, "tol": f"{tol[0]:g} x max(1,|ref|)" if tol[1] else f"{tol[0]:g} x max|ref|",
                           "handoff_exact": handoff_ok, "ok": bad == 0.0}
@@ -496,6 +499,21 @@ def main():
     del r
     torch.cuda.empty_cache()
 
+    split = None
+    if world == 1 and args.workload == "c2" and args.compute == "f32" and not args.no_split:
+        # the same workload in the optional split-bf16 mode (DIINN_COMPUTE_BF16X3: bf16 MFMAs, three products per term,
+        # held to the fp32 bound by the same post-run check): reported beside the fp32 line, never as `value`
+        t = run_workload(job, "c2", "weak", args.steps, args.warmup, compute="bf16x3")
+        t_k = sum(t["k_ms_all"]) / len(t["k_ms_all"])
+        split = {"compute": "bf16x3", "mpix_s": round(t["HU"] * t["WU"] * args.steps / t["elapsed"] / 1e6, 2),
+                 "ms_per_step": round(t["elapsed"] / args.steps * 1e3, 4), "kernel": "decode_bf16x3 kernel",
+                 "kernel_ms": round(t_k, 4), "p_kernel_ms": round(sum(t["p_ms"]) / len(t["p_ms"]), 4),
+                 "issued_bf16_tflops": round((3 * 786_432.0 + 3_072.0) * t["HU"] * t["WU"] / (t_k * 1e-3) / 1e12, 1),
+                 "checked": t.get("checked"),
+                 "note": "hi/lo bf16 operands, hi*hi + hi*lo + lo*hi with fp32 accumulation; same workload, same "
+                         "1e-4 x max(1,|ref|) check against the oracle as the fp32 line"}
+        del t
+        torch.cuda.empty_cache()
     strong = None
     if world > 1 and not args.no_strong:
         strong = strong_legs(job)
@@ -605,6 +623,8 @@ def main():
             res["checked"] = checked
         if gather_ms is not None:
             res["gather_ms"] = round(gather_ms, 4)
+        if split is not None:
+            res["split_bf16"] = split
         if target is not None:
             res["target_shape"] = target
         if strong is not None:

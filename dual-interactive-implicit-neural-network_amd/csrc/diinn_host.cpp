@@ -144,9 +144,9 @@ size_t diinn_metasr_workspace_bytes(int B, int H, int W) {
 
 int diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats) {
     static const size_t off[15] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT, OFF_WPB, OFF_BQR,
-                                   OFF_Q0R, OFF_WLR, OFF_WPU, OFF_WLBL};
+                                   OFF_Q0R, OFF_WLR, OFF_WPU, OFF_WLX};
     static const size_t sz[15]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT, SZ_WPB, 3 * HID,
-                                   4 * HID, SZ_WL, SZ_WPU, SZ_WLB};
+                                   4 * HID, SZ_WL, SZ_WPU, SZ_WLX};
     if (section < 0 || section > 14 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
     *offset_floats = off[section];
     *size_floats = sz[section];
@@ -281,15 +281,17 @@ int diinn_pack_weights(const float* K0w, const float* K0b,
     bl[0] = Lb[0]; bl[1] = Lb[1]; bl[2] = Lb[2];
     const uint32_t magic = DIINN_PACKED_MAGIC;                  // validity word: this image holds its derived sections
     std::memcpy(bl + 3, &magic, 4);
-    // WLB: [layer][m][ks][part][lane][j] bf16; WLBL: the low parts, bf16(w - bf16(w)) (split-bf16 arithmetic)
+    // WLB: [layer][m][ks][part][lane][j] bf16; WLX (split-bf16 arithmetic): [layer][m][ks][k_hi, q_hi, k_lo, q_lo][lane][j],
+    // hi as in WLB, lo = bf16(w - hi)
     uint16_t* wlb = reinterpret_cast<uint16_t*>(packed + OFF_WLB);
-    uint16_t* wlbl = reinterpret_cast<uint16_t*>(packed + OFF_WLBL);
+    uint16_t* wlx = reinterpret_cast<uint16_t*>(packed + OFF_WLX);
     for (int i = 0; i < 3; ++i)
         for (int m = 0; m < 8; ++m)
             for (int ks = 0; ks < 16; ++ks)
                 for (int part = 0; part < 2; ++part) {
                     uint16_t* dst = wlb + ((((size_t)i * 8 + m) * 16 + ks) * 2 + part) * (64 * 8);
-                    uint16_t* dlo = wlbl + ((((size_t)i * 8 + m) * 16 + ks) * 2 + part) * (64 * 8);
+                    uint16_t* xhi = wlx + ((((size_t)i * 8 + m) * 16 + ks) * 4 + part) * (64 * 8);
+                    uint16_t* xlo = xhi + 2 * (64 * 8);
                     for (int lane = 0; lane < 64; ++lane) {
                         const int out = 32 * m + (lane & 31);
                         const int h = lane >> 5;
@@ -300,7 +302,8 @@ int diinn_pack_weights(const float* K0w, const float* K0b,
                                                       : Qw[i][(size_t)out * HID + in] * INV_2PI;
                             const uint16_t hi = f32_to_bf16(w);
                             dst[lane * 8 + j] = hi;
-                            dlo[lane * 8 + j] = f32_to_bf16(w - bf16_to_f32(hi));   // exact difference, then one rounding
+                            xhi[lane * 8 + j] = hi;
+                            xlo[lane * 8 + j] = f32_to_bf16(w - bf16_to_f32(hi));   // exact difference, then one rounding
                         }
                     }
                 }

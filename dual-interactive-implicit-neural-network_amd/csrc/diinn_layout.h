@@ -86,11 +86,16 @@ constexpr size_t OFF_WLR    = OFF_Q0R + 4 * HID;
 //     negated), else 1.  Derived (float64, rounded once): an inference-only section like WLR.
 constexpr size_t OFF_WPU    = OFF_WLR + SZ_WL;
 constexpr size_t SZ_WPU     = (size_t)32 * 4 * 8 * 4 * WL_PIECE;   // 1,048,576 floats = 4 MiB
-// WLBL: the LOW parts of WLB for the split-bf16 arithmetic (DIINN_COMPUTE_BF16X3): every weight w (synthesis rows: w / (2 pi))
-//     is carried as hi + lo with hi = bf16(w) (section WLB) and lo = bf16(w - hi) (here, same shape and order as WLB); the
-//     kernel adds hi*hi + hi*lo + lo*hi on the bf16 MFMA.  Derived, inference only.
-constexpr size_t OFF_WLBL   = OFF_WPU + SZ_WPU;
-constexpr size_t PACKED_FLOATS = OFF_WLBL + SZ_WLB;        // 3,511,556
+// WLX: the per-pixel layers for the split-bf16 arithmetic (DIINN_COMPUTE_BF16X3): every weight w (synthesis rows:
+//     w / (2 pi)) is carried as hi + lo with hi = bf16(w) (the value section WLB holds) and lo = bf16(w - hi); the kernel
+//     adds hi*hi + hi*lo + lo*hi on the bf16 MFMA.  [layer 3][m 8][ks 16][piece 4][lane 64][j 8] bf16 with the pieces of
+//     a k-step -- k_hi, q_hi, k_lo, q_lo -- contiguous (4 KiB: one scalar offset per k-step, the pieces by immediate
+//     offsets); lane / j as in WLB.  Derived, inference only.
+constexpr size_t WLX_KSTEP  = 4 * WLB_PIECE;               // floats per k-step
+constexpr size_t WLX_LAYER  = (size_t)8 * 16 * WLX_KSTEP;
+constexpr size_t OFF_WLX    = OFF_WPU + SZ_WPU;
+constexpr size_t SZ_WLX     = 3 * WLX_LAYER;               // 393,216 floats = 1.5 MiB
+constexpr size_t PACKED_FLOATS = OFF_WLX + SZ_WLX;         // 3,708,164
 
 // channel held by activation register (m, r) of lane-half h
 DIINN_HD int chan_of(int kk /* = 16*m + r */, int h) {

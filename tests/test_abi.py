@@ -115,7 +115,7 @@ def test_packed_image_layout(lib):
     import diinn_amd.decoder as D
     sd = synth.decoder_state_dict(11)
     packed = D.pack_state_dict(sd).numpy()
-    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608 + 393_216 + 294_912 + 768 + 1024 + 393_216 + 1_048_576 + 196_608
+    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608 + 393_216 + 294_912 + 768 + 1024 + 393_216 + 1_048_576 + 393_216
     lane = np.arange(64)
     out_l, h_l = lane & 31, lane >> 5
     # WL section
@@ -206,18 +206,21 @@ def test_packed_image_layout(lib):
         g = sd[f"K.{layer}.0.weight"][ch, col0 + 9 * c: col0 + 9 * c + 9, 0, 0].astype(np.float64).reshape(3, 3)
         u = (G @ g @ G.T)[i, jj]
         assert WPU[mt, i, sg, jj, l, e] == np.float32(-u if jj == 2 else u)
-    # WLBL (split-bf16 mode): the low parts of WLB, bf16(w - bf16(w)), same piece order; hi + lo carries w to 2^-17
+    # WLX (split-bf16 mode): [layer][m][ks][k_hi, q_hi, k_lo, q_lo][lane][j]; hi = the WLB value, lo = bf16(w - hi);
+    # hi + lo carries w to 2^-17
     def bf16_val(bits):
         return np.array([bits << 16], dtype=np.uint32).view(np.float32)[0]
-    WLBL = tail[1792 + 393_216 + 1_048_576:].view(np.uint16).reshape(3, 8, 16, 2, 64, 8)
+    WLX = tail[1792 + 393_216 + 1_048_576:].view(np.uint16).reshape(3, 8, 16, 4, 64, 8)
     for _ in range(300):
         i, m, ks, part, l, jj = (int(rng.integers(n)) for n in (3, 8, 16, 2, 64, 8))
         hh = l >> 5
         o, cin = 32 * m + (l & 31), 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (jj >> 2) + 4 * hh + (jj & 3)
         w = sd[f"K.{i + 1}.0.weight"][o, cin, 0, 0] if part == 0 else np.float32(sd[f"Q.{i + 1}.0.weight"][o, cin, 0, 0] * inv2pi)
-        hi = bf16_val(int(WLB[i, m, ks, part, l, jj]))
-        assert int(WLBL[i, m, ks, part, l, jj]) == bf16_bits(np.float32(w) - hi)
-        assert abs(float(hi) + float(bf16_val(int(WLBL[i, m, ks, part, l, jj]))) - float(w)) <= 2.0 ** -16 * abs(float(w))
+        assert int(WLX[i, m, ks, part, l, jj]) == int(WLB[i, m, ks, part, l, jj])
+        hi = bf16_val(int(WLX[i, m, ks, part, l, jj]))
+        lo_bits = int(WLX[i, m, ks, 2 + part, l, jj])
+        assert lo_bits == bf16_bits(np.float32(w) - hi)
+        assert abs(float(hi) + float(bf16_val(lo_bits)) - float(w)) <= 2.0 ** -16 * abs(float(w))
     # every channel appears exactly once per lane-half in the activation register order
     seen = sorted(_chan_of(kk, h) for kk in range(128) for h in range(2))
     assert seen == list(range(256))

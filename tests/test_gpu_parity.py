@@ -541,9 +541,10 @@ def test_bf16x3_ragged_shapes_batches_and_bands(dev):
 
 
 def test_bf16x3_persistent_kernel_is_bit_identical(dev, knobs):
-    """decode_bf16x3p_kernel (persistent workgroups, the next block's layer 0 evaluated inside the current block's last
-    layer) does decode_bf16x3_kernel's arithmetic pixel by pixel: equal bit for bit on ragged edges, batches, fewer
-    blocks than workgroups, many blocks per workgroup, and row bands that do not start on a block boundary."""
+    """decode_bf16x3h_kernel (persistent workgroups, hi weight pieces shared through an LDS ring with a barrier per stage,
+    the next block's layer 0 evaluated inside the current block's last layer) does decode_bf16x3_kernel's arithmetic
+    pixel by pixel: equal bit for bit on ragged edges, batches, fewer blocks than workgroups, many blocks per workgroup,
+    and row bands that do not start on a block boundary."""
     import diinn_oracle as orc
     import diinn_amd.decoder as D
     for (b, h, w, hu, wu, seed) in [(1, 60, 100, 333, 530, 5), (2, 33, 47, 109, 155, 4), (3, 9, 11, 36, 40, 6),
@@ -553,17 +554,16 @@ def test_bf16x3_persistent_kernel_is_bit_identical(dev, knobs):
         packed = D.pack_state_dict(sd).to(dev)
         feat = torch.from_numpy(feat_np).to(dev)
         outs = {}
-        for k in (1, 2, 3):                                       # one block per workgroup, persistent, shared weight stream
+        for k in (1, 2):                                          # one block per workgroup, persistent
             knobs("DIINN_X3_KERNEL", k)
-            for sin_mode in (0, 2):
+            for sin_mode in (0, 1, 2):
                 outs[k, sin_mode] = D.decode_features(feat, packed, (hu, wu), compute="bf16x3", sin_mode=sin_mode)
         torch.cuda.synchronize()
-        for sin_mode in (0, 2):
+        for sin_mode in (0, 1, 2):
             assert torch.equal(outs[1, sin_mode], outs[2, sin_mode]), (b, h, w, hu, wu, sin_mode)
-            assert torch.equal(outs[1, sin_mode], outs[3, sin_mode]), (b, h, w, hu, wu, sin_mode)
         ref = orc.decode_reference_form(sd, feat_np, (hu, wu), 30000).numpy()
         assert float(np.abs(outs[2, 2].cpu().numpy() - ref).max()) <= _tol(ref), (b, h, w, hu, wu)
-        knobs("DIINN_X3_KERNEL", 3)
+        knobs("DIINN_X3_KERNEL", 2)
         out = torch.zeros_like(outs[2, 2])
         cuts = sorted({0, min(13, hu), max(hu - 5, 0), hu})
         for y0, y1 in zip(cuts[:-1], cuts[1:]):
