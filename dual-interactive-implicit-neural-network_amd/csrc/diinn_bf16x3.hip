@@ -314,6 +314,9 @@ constexpr int X3H_NSTAGE = 384 / X3H_STAGE;     // stages per block: a multiple 
 #define X3H_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // issue order of a k-step: the two A reads of the NEXT k-step at once behind the first MFMA -- they have the whole
 // k-step to arrive, so the lgkmcnt(0) in front of a stage's barrier finds nothing outstanding
+#ifdef X3H_NO_ORDER
+#define X3H_KSTEP_ORDER() __builtin_amdgcn_sched_barrier(0)
+#else
 #define X3H_KSTEP_ORDER()                                                             \
     do {                                                                              \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
@@ -326,6 +329,7 @@ constexpr int X3H_NSTAGE = 384 / X3H_STAGE;     // stages per block: a multiple 
         }                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                            \
     } while (0)
+#endif
 
 template <int SIN_MODE>
 __global__ __launch_bounds__(256, 1) void decode_bf16x3h_kernel(const DecodeParams p) {

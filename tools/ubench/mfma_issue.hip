@@ -81,75 +81,6 @@ void run(const char* name, const float* w, unsigned long long* out, float* sink,
     printf("%-34s grid %3d  counter/k-step %8.2f   event ns/k-step %7.2f\n", name, grid, s / h.size() / (iters * 4.0), ms * 1e6 / (iters * 4.0));
 }
 
-// hand-interleaved: behind each MFMA a slice of the other work, fenced (sched_barrier) so the order is the source's
-template <int NLOAD, int NLDS, int VPER, int NSIN>
-__global__ __launch_bounds__(256, 1) void ki(const float* __restrict__ w, unsigned long long* out, int iters, float* sink) {
-    __shared__ f32x4 lds[32][64];
-    __shared__ float pad[24 * 1024];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 32 * 64; i += 256) lds[i >> 6][i & 63] = f32x4{1.f, 2.f, 3.f, 4.f};
-    pad[threadIdx.x] = 0.f;
-    __syncthreads();
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 1 << 20, 0x00020000);
-    f32x16 ak = {}, as = {};
-    f32x4 R[16];
-    for (int i = 0; i < 16; ++i) R[i] = f32x4{1, 1, 1, 1};
-    bf16x8 qh = __builtin_bit_cast(bf16x8, f32x4{1, 1, 1, 1}), ql = qh;
-    float v[16];
-    for (int i = 0; i < 16; ++i) v[i] = lane * 0.001f + i;
-    int off = 0;
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            // operands: loaded two k-steps ago (slots of k-step u: 4u..4u+3 mod 16 hold what (u+2)'s loads brought)
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, R[(4 * u) & 15]), a1 = __builtin_bit_cast(bf16x8, R[(4 * u + 1) & 15]);
-            const bf16x8 a2 = __builtin_bit_cast(bf16x8, R[(4 * u + 2) & 15]), a3 = __builtin_bit_cast(bf16x8, R[(4 * u + 3) & 15]);
-#pragma unroll
-            for (int mi = 0; mi < 6; ++mi) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (mi == 0) ak = MFMA(a2, qh, ak);
-                if (mi == 1) as = MFMA(a3, qh, as);
-                if (mi == 2) ak = MFMA(a0, ql, ak);
-                if (mi == 3) as = MFMA(a1, ql, as);
-                if (mi == 4) ak = MFMA(a0, qh, ak);
-                if (mi == 5) as = MFMA(a1, qh, as);
-                __builtin_amdgcn_sched_barrier(0);
-                // refill the slots of the previous k-step
-                if (mi < NLOAD) R[(4 * (u + 3) + mi) & 15] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, off + (4 * u + mi) * 1024, 0));
-                if (mi < NLDS) R[(4 * (u + 3) + mi) & 15] = lds[(4 * u + mi + off) & 31][lane];
-#pragma unroll
-                for (int i = 0; i < VPER; ++i) v[(mi * VPER + i) & 15] = __builtin_fmaf(v[(mi * VPER + i) & 15], 1.0001f, 0.5f);
-                if (mi >= 4 && mi - 4 < NSIN) v[mi] = __builtin_amdgcn_sinf(v[mi]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        off = (off + 16 * 1024) & (256 * 1024 - 1);
-    }
-    const unsigned long long t1 = __builtin_readcyclecounter();
-    float sum = 0;
-    for (int i = 0; i < 16; ++i) sum += ak[i] + as[i] + v[i] + R[i][0];
-    if (sum == 1234.5f) sink[0] = sum;
-    if (lane == 0) out[blockIdx.x * 4 + wave] = t1 - t0;
-}
-
-template <int NLOAD, int NLDS, int VPER, int NSIN>
-void runi(const char* name, const float* w, unsigned long long* out, float* sink, int grid) {
-    const int iters = 2000;
-    hipLaunchKernelGGL((ki<NLOAD, NLDS, VPER, NSIN>), dim3(grid), dim3(256), 0, 0, w, out, iters, sink);
-    hipDeviceSynchronize();
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0);
-    hipLaunchKernelGGL((ki<NLOAD, NLDS, VPER, NSIN>), dim3(grid), dim3(256), 0, 0, w, out, iters, sink);
-    hipEventRecord(e1);
-    hipDeviceSynchronize();
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    std::vector<unsigned long long> h(grid * 4);
-    hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
-    double s = 0; for (auto x : h) s += (double)x;
-    printf("%-44s grid %3d  clocks/k-step %8.2f   event ns/k-step %7.2f\n", name, grid, s / h.size() / (iters * 4.0), ms * 1e6 / (iters * 4.0));
-}
 
 int main() {
     float *w, *sink; unsigned long long* out;
@@ -167,17 +98,6 @@ int main() {
         run<4, 0, 16, 0, 2>("6 MFMA + 4 vmem + 16 valu + 2 sin", w, out, sink, grid);
         run<0, 4, 16, 0, 2>("6 MFMA + 4 lds + 16 valu + 2 sin", w, out, sink, grid);
         run<1, 4, 16, 0, 2>("6 MFMA + 1 vmem + 4 lds + 16 valu + 2 sin", w, out, sink, grid);
-    }
-    for (int grid : {1, 256}) {
-        runi<4, 0, 0, 0>("interleaved: 4 vmem", w, out, sink, grid);
-        runi<4, 0, 2, 2>("interleaved: 4 vmem + 12 valu + 2 sin", w, out, sink, grid);
-        runi<4, 0, 3, 2>("interleaved: 4 vmem + 18 valu + 2 sin", w, out, sink, grid);
-        runi<4, 0, 4, 2>("interleaved: 4 vmem + 24 valu + 2 sin", w, out, sink, grid);
-        runi<0, 4, 3, 2>("interleaved: 4 lds + 18 valu + 2 sin", w, out, sink, grid);
-        runi<0, 4, 4, 2>("interleaved: 4 lds + 24 valu + 2 sin", w, out, sink, grid);
-        runi<0, 0, 5, 2>("interleaved: 30 valu + 2 sin", w, out, sink, grid);
-        runi<0, 0, 6, 2>("interleaved: 36 valu + 2 sin", w, out, sink, grid);
-        runi<0, 0, 7, 2>("interleaved: 42 valu + 2 sin", w, out, sink, grid);
     }
     return 0;
 }
