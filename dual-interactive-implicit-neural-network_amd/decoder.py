@@ -121,8 +121,9 @@ def decode_features(feat: torch.Tensor, packed: torch.Tensor, size: Sequence[int
 
     ``rows=(y0,y1)`` computes only that HR row band (tile sharding across GPUs);
     the rest of ``out`` is left untouched.  ``workspace`` is the P image
-    [B,H,W,1024] fp32 (allocated if None).  ``compute`` = "f32" (reference precision) or "bf16"
-    (bf16 operands in layers 1..3, fp32 accumulate; ~2e-3 relative).  ``mode`` 3 (default) is the
+    [B,H,W,1024] fp32 (allocated if None).  ``compute`` = "f32" (reference precision), "bf16" /
+    "bf16_full" (bf16 operands in layers 1..3 / also in the hoisted conv, fp32 accumulate; ~2e-3 relative) or
+    "bf16x3" (split bf16: hi + lo bf16 operands, three bf16 MFMA products per term; held to f32's 1e-4 bound).  ``mode`` 3 (default) is the
     reference's final model; modes 1 and 2 (packed with ``pack_state_dict(..., mode=...)``) run fp32
     only.  Enqueues two kernels (three for modes 1/2: + the per-cell modulation chain) on the
     current stream; never synchronises."""
@@ -358,7 +359,7 @@ class ImplicitDecoder(nn.Module):
         self.in_channels = in_channels
         self.hidden_dims = list(hidden_dims)
         self.sin_mode = sin_mode
-        self.compute = compute            # "f32" (default, reference precision) or "bf16"
+        self.compute = compute            # "f32" (default, reference precision), "bf16", "bf16_full" or "bf16x3"
         unfolded = in_channels * 9
         if init_q:
             self.first_layer = nn.Sequential(nn.Conv2d(3, unfolded, 1), SineAct())

@@ -78,20 +78,20 @@ def _window_equals_full(feat, packed, size, full, y0, y1, compute="f32"):
     assert torch.equal(band, full[:, :, y0:y1]), f"window decode of rows {y0}:{y1} differs from the full decode"
 
 
-def _full_size_case(dev, weights, h, w, hu, wu, seed, bands, win_band):
+def _full_size_case(dev, weights, h, w, hu, wu, seed, bands, win_band, compute="f32"):
     import diinn_amd.decoder as D
     sd, packed = weights
     feat = _features(dev, h, w, seed)
     ws = torch.empty(h * w * 1024, device=dev)
-    full = D.decode_features(feat, packed, (hu, wu), workspace=ws)
-    again = D.decode_features(feat, packed, (hu, wu), workspace=ws)
+    full = D.decode_features(feat, packed, (hu, wu), workspace=ws, compute=compute)
+    again = D.decode_features(feat, packed, (hu, wu), workspace=ws, compute=compute)
     torch.cuda.synchronize()
     assert torch.equal(full, again), "decode is not deterministic"
     assert bool(torch.isfinite(full).all())
     del again, ws
-    worst = _check_bands(sd, feat, full, (hu, wu), bands, TOL)
-    _window_equals_full(feat, packed, (hu, wu), full, *win_band)
-    print(f"{h}x{w} -> {hu}x{wu}: worst band error = {worst:.3f} of the 1e-4 bound")
+    worst = _check_bands(sd, feat, full, (hu, wu), bands, TOL, emu={"bf16x3": True} if compute == "bf16x3" else None)
+    _window_equals_full(feat, packed, (hu, wu), full, *win_band, compute=compute)
+    print(f"{h}x{w} -> {hu}x{wu} ({compute}): worst band error = {worst:.3f} of the 1e-4 bound")
 
 
 def test_config3_512_x4(dev, weights):
@@ -102,6 +102,13 @@ def test_config3_512_x4(dev, weights):
 def test_target_1024_x4(dev, weights):
     """north_star target shape: 1024x1024 LR x4 -> 4096x4096 (16.8 Mpixel, P workspace 4.3 GB)."""
     _full_size_case(dev, weights, 1024, 1024, 4096, 4096, 4, [(0, 4), (2046, 2050), (4092, 4096)], (1536, 2048))
+
+
+def test_target_1024_x4_split_bf16(dev, weights):
+    """The same shape in the optional split-bf16 mode (DIINN_COMPUTE_BF16X3; 131,072 blocks over 256 persistent
+    workgroups), held to the SAME 1e-4 bound as fp32, and to the oracle's emulation of its roundings."""
+    _full_size_case(dev, weights, 1024, 1024, 4096, 4096, 4, [(0, 4), (2046, 2050), (4092, 4096)], (1536, 2048),
+                    compute="bf16x3")
 
 
 def test_config4_1024_x8(dev, weights):
@@ -133,7 +140,7 @@ def test_size_limits_just_past_config4(dev, weights):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("compute,rel", [("f32", None), ("bf16", 2e-3), ("bf16_full", 3e-3)])
+@pytest.mark.parametrize("compute,rel", [("f32", None), ("bf16x3", None), ("bf16", 2e-3), ("bf16_full", 3e-3)])
 def test_config5_720p_x3p3(dev, weights, compute, rel):
     """BASELINE config 5: 720x1280 LR -> 2376x4224 HR (x3.3, non-integer) in fp32 and on both bf16 MFMA paths.
     bf16 bands are checked against the fp32 oracle at the restated tolerance and against the oracle's emulation
@@ -151,6 +158,8 @@ def test_config5_720p_x3p3(dev, weights, compute, rel):
     bands = [(0, 4), (1187, 1191), (2372, 2376)]
     if compute == "f32":
         worst = _check_bands(sd, feat, full, (hu, wu), bands, TOL)
+    elif compute == "bf16x3":                                     # split bf16: the fp32 bound
+        worst = _check_bands(sd, feat, full, (hu, wu), bands, TOL, emu={"bf16x3": True})
     else:
         emu = {"bf16_operands": True, "bf16_p": compute == "bf16_full"}
         worst = _check_bands(sd, feat, full, (hu, wu), bands, rel, floor_one=False, emu=emu)

@@ -198,8 +198,10 @@ def _gpu_band_decoder_worker(rank, world, port, mode, geom, q):
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
         b, h, w, hu, wu = geom
+        mode, _, compute = mode.partition(":")                    # "halo:bf16x3" = hand-off mode : arithmetic
+        compute = compute or "f32"
         packed = D.pack_state_dict(synth.decoder_state_dict(33)).to(dev)
-        dec = S.BandDecoder((b, 64, h, w), (hu, wu), packed, src=0, mode=mode)
+        dec = S.BandDecoder((b, 64, h, w), (hu, wu), packed, src=0, mode=mode, compute=compute)
         assert dec.host_staged and dec.side is not None
         ok = True
         for it in range(2):
@@ -209,7 +211,7 @@ def _gpu_band_decoder_worker(rank, world, port, mode, geom, q):
             img = dec.gather(band, dst=0)
             torch.cuda.synchronize()
             if rank == 0:
-                full = D.decode_features(feat, packed, (hu, wu))
+                full = D.decode_features(feat, packed, (hu, wu), compute=compute)
                 ok = ok and bool(torch.equal(img, full))
             else:
                 assert img is None
@@ -219,7 +221,7 @@ def _gpu_band_decoder_worker(rank, world, port, mode, geom, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,mode", [(2, "halo"), (4, "halo"), (2, "bcast")])
+@pytest.mark.parametrize("world,mode", [(2, "halo"), (4, "halo"), (2, "bcast"), (2, "halo:bf16x3"), (2, "halo:bf16_full")])
 def test_band_decoder_on_gpu_over_host_staged_gloo(world, mode):
     res = _run(world, mode, (2, 40, 56, 132, 185), target=_gpu_band_decoder_worker, timeout=600)
     assert all(res)
