@@ -48,6 +48,14 @@ def test_demo2_and_benchmarks_run_end_to_end(tmp_path, golden):
     out = tmp_path / "diinn_hip" / "diinn_hip_img_50x61.png"      # reference naming, demo2.py:41
     assert out.exists()
     assert Image.open(out).size == (61, 50)
+    # the split-bf16 decoder writes the same 8-bit image to within one grey level
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "demo2.py"), "--lr_path", str(lr_png),
+                        "--output_size", "50", "61", "--ckpt_path", str(ckpt), "--model_name", "diinn_x3",
+                        "--compute", "bf16x3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = np.asarray(Image.open(out)).astype(np.int32)
+    b = np.asarray(Image.open(tmp_path / "diinn_x3" / "diinn_x3_img_50x61.png")).astype(np.int32)
+    assert a.shape == b.shape and int(np.abs(a - b).max()) <= 1
     # benchmarks.py: a one-image "Set5"
     hr_dir = tmp_path / "data" / "benchmark" / "Set5" / "HR"
     hr_dir.mkdir(parents=True)
