@@ -33,5 +33,10 @@ for lr, s in ((48, 2), (128, 4), (256, 4), (512, 4)):
         net.graphs = True
         tg = t_ms(lambda: net(x, (lr * s, lr * s), 30000))
         net.graphs = False
+        net.decoder.compute = "bf16x3"                       # the optional split-bf16 decoder (fp32 tolerance)
+        td3 = t_ms(lambda: net.decoder(feat, (lr * s, lr * s), 30000))
+        te3 = t_ms(lambda: net(x, (lr * s, lr * s), 30000))
+        net.decoder.compute = "f32"
     print(f"LR {lr}x{lr} x{s}: encoder HIP trunk {t_hip:.2f} ms ({43.9e6*lr*lr/t_hip/1e9:.1f} TFLOP/s) | MIOpen {t_mi:.2f} ms; "
-          f"decoder {td:.2f} ms; whole model eager {te:.2f} ms, hipGraph {tg:.2f} ms", flush=True)
+          f"decoder {td:.2f} ms; whole model eager {te:.2f} ms, hipGraph {tg:.2f} ms; "
+          f"with the split-bf16 decoder: decoder {td3:.2f} ms, whole model {te3:.2f} ms", flush=True)
