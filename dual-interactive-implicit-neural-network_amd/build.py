@@ -24,7 +24,9 @@ HIP_SOURCES = ["diinn_decode.hip", "diinn_precompute.hip", "diinn_precompute_win
                "diinn_baselines.hip", "diinn_encoder.hip", "diinn_winograd.hip", "diinn_misc.hip"]
 HOST_SOURCES = ["diinn_host.cpp"]
 SOURCES = HIP_SOURCES + HOST_SOURCES
-DEPS = SOURCES + ["diinn_device.h", "diinn_layout.h", os.path.join("..", "..", "include", "diinn_hip.h")]
+# (build.py itself counts as a header: it holds the compiler flags of every translation unit)
+DEPS = SOURCES + ["diinn_device.h", "diinn_layout.h", "diinn_knobs.h", os.path.join("..", "..", "include", "diinn_hip.h"),
+                  os.path.join("..", "build.py")]
 
 # -ffp-contract=off: the coordinate formulas must round every fp32 op separately
 # (diinn_layout.h axis_eval); the kernels spell out fmaf where fusion is wanted.
@@ -38,12 +40,13 @@ HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-x", 
 # instructions per layer, 5.802 -> 5.783 ms at c2 (same box, order-balanced runs, r03).  The same flag makes precompute_P_wino_kernel 8 %
 # SLOWER (0.294 -> 0.319 ms), so it is not a library-wide setting.
 # Measured TU by TU (tools/r03_vgprform_ab.sh): encoder trunk unchanged in order-balanced runs (11.83-11.88 either way);
-# LIIF 12.73 -> 12.60 but MetaSR 6.50 -> 8.52 in the same TU, training step 16.4 -> 16.6: applied to the decode file only.
+# LIIF 12.73 -> 12.60 but MetaSR 6.50 -> 8.52 in the same TU, training step 16.4 -> 16.6: applied to the decode file and to
+# the split-bf16 decode (832 -> 260 accumulator moves per layer copy, 2.022 -> 1.995 ms at c2, order-balanced).
 _VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 # Compared in order-balanced runs (tools/r03_ab_abba.sh; a run's position in a sequence biases it by ~0.4 %): no flag 5.802,
 # vgpr-form 5.783, vgpr-form + -amdgpu-use-amdgpu-trackers 5.800 (noisy), trackers alone 6.05 ms.
 # NOT to be used: -amdgpu-disable-unclustered-high-rp-reschedule produced WRONG results (bench.py's oracle check failed).
-PER_FILE_FLAGS = {"diinn_decode.hip": _VGPR_FORM}
+PER_FILE_FLAGS = {"diinn_decode.hip": _VGPR_FORM, "diinn_bf16x3.hip": _VGPR_FORM}
 
 
 def find_hipcc() -> str:

@@ -7,7 +7,7 @@ echo "# hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Rpass-analysis=kernel
 for f in "$CSRC"/diinn_*.hip; do
   echo "## $(basename "$f")"
   EXTRA=""                                                     # the per-file flags of build.py (PER_FILE_FLAGS)
-  case "$(basename "$f")" in diinn_decode.hip) EXTRA="-mllvm -amdgpu-mfma-vgpr-form";; esac
+  case "$(basename "$f")" in diinn_decode.hip|diinn_bf16x3.hip) EXTRA="-mllvm -amdgpu-mfma-vgpr-form";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-gpu-rdc $EXTRA -Rpass-analysis=kernel-resource-usage \
       -c "$f" -o /dev/null 2>&1 |
     grep -oE "(Function Name: [^ ]+|VGPRs: [0-9]+|AGPRs: [0-9]+|ScratchSize \[bytes/lane\]: [0-9]+|VGPRs Spill: [0-9]+|Occupancy \[waves/SIMD\]: [0-9]+|LDS Size \[bytes/block\]: [0-9]+)" |
