@@ -18,6 +18,8 @@ python bench.py --workload c1 --steps 200 --warmup 20 --no-cpu-baseline --no-tar
 python bench.py --workload c5 --compute bf16 --no-cpu-baseline --no-target > $O/bench_c5_bf16.json 2> $O/bench_c5_bf16.err
 python bench.py --workload c5 --compute bf16_full --no-cpu-baseline --no-target > $O/bench_c5_bf16_full.json 2> $O/bench_c5_bf16_full.err
 python bench.py --workload c2 --compute bf16_full --no-cpu-baseline --no-target > $O/bench_c2_bf16_full.json 2> $O/bench_c2_bf16_full.err
+python bench.py --workload c2 --compute bf16x3 --no-cpu-baseline > $O/bench_c2_bf16x3.json 2> $O/bench_c2_bf16x3.err
+python bench.py --workload c5 --compute bf16x3 --no-cpu-baseline > $O/bench_c5_bf16x3.json 2> $O/bench_c5_bf16x3.err
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --workload c3 --scaling strong --gather --no-cpu-baseline --no-target > $O/bench_c3_strong_torchrun.json 2> $O/bench_c3_strong_torchrun.err
 DIINN_BENCH_ONE_DEVICE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 --strong-legs c3 > $O/bench_2ranks_one_device_gloo.json 2> $O/bench_2ranks_one_device_gloo.err
 python - <<PY
@@ -30,6 +32,9 @@ for f in sorted(glob.glob("$O/bench_*.json")):
     print("%-38s %9.2f Mpix/s  step %8.3f ms  decode %8.3f ms frac %.3f  P %7.3f ms (%.3f)  err %.2e ok=%s" % (
         f.split("/")[-1], r["value"], r["ms_per_step"], r["roofline"]["kernel_ms"], r["roofline"]["frac"],
         r["roofline"]["p_kernel"]["ms"], r["roofline"]["p_kernel"]["frac"], r["checked"]["max_err"], r["checked"]["ok"]))
+    if "split_bf16" in r:
+        sp = r["split_bf16"]
+        print("%-38s %9.2f Mpix/s  step %8.3f ms  decode %8.3f ms  (split_bf16 side leg) ok=%s" % ("", sp["mpix_s"], sp["ms_per_step"], sp["kernel_ms"], sp["checked"]["ok"]))
 PY
 cd /tmp
 C2="python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-check --no-target"
