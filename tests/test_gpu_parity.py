@@ -572,6 +572,41 @@ def test_bf16x3_persistent_kernel_is_bit_identical(dev, knobs):
         assert torch.equal(outs[2, 2], out), (b, h, w, hu, wu)
 
 
+def test_bf16x3_random_geometries_track_the_fp32_kernels(dev):
+    """Forty seeded random geometries -- up- and down-scaling, non-integer ratios, batches, sizes on both sides of the
+    one-block / persistent switch (512 blocks), a random row band each -- decoded in split bf16 and in fp32: the two
+    agree to 2e-6 at default-init weights (both are within 1e-7 of the reference there), every value finite, the band
+    bit-equal to the same rows of the whole image."""
+    import diinn_amd.decoder as D
+    rng = np.random.default_rng(20260)
+    sd = synth.decoder_state_dict(41)
+    packed = D.pack_state_dict(sd).to(dev)
+    seen_persistent = seen_one_block = 0
+    for it in range(40):
+        b = int(rng.integers(1, 4))
+        h, w = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+        sy, sx = rng.uniform(0.6, 9.0), rng.uniform(0.6, 9.0)
+        hu, wu = max(1, int(h * sy)), max(1, int(w * sx))
+        if b * hu * wu > 1_500_000:
+            hu, wu = min(hu, 600), min(wu, 600)
+        blocks = b * ((wu + 15) // 16) * ((hu + 7) // 8)
+        seen_persistent += blocks >= 512
+        seen_one_block += blocks < 512
+        feat = torch.from_numpy(synth.encoder_features(100 + it, b, h, w)).to(dev)
+        x3 = D.decode_features(feat, packed, (hu, wu), compute="bf16x3")
+        f32 = D.decode_features(feat, packed, (hu, wu))
+        y0 = int(rng.integers(0, hu))
+        y1 = int(rng.integers(y0 + 1, hu + 1))
+        band = torch.full_like(x3, float("nan"))
+        D.decode_features(feat, packed, (hu, wu), out=band, rows=(y0, y1), compute="bf16x3")
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(x3).all()), (b, h, w, hu, wu)
+        assert float((x3 - f32).abs().max()) <= 2e-6, (b, h, w, hu, wu, float((x3 - f32).abs().max()))
+        assert torch.equal(band[:, :, y0:y1], x3[:, :, y0:y1]), (b, h, w, hu, wu, y0, y1)
+        assert bool(torch.isnan(band[:, :, :y0]).all()) and bool(torch.isnan(band[:, :, y1:]).all())   # rows outside untouched
+    assert seen_persistent >= 5 and seen_one_block >= 5
+
+
 def test_bf16x3_full_size_config2_band_vs_oracle(dev):
     """BASELINE config 2 at full size in the split-bf16 mode: HR row bands against the oracle at the fp32 bound."""
     import diinn_amd.decoder as D
