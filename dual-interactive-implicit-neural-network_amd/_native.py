@@ -94,6 +94,11 @@ SIGNATURES = {
                                     C.c_int, C.c_int, C.c_int]),
     "diinn_conv_wino": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "diinn_conv3x3_x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "diinn_rdn_x3_packed_floats": (C.c_size_t, []),
+    "diinn_rdn_forward_x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "diinn_rdn_wino_packed_floats": (C.c_size_t, []),
     "diinn_rdn_forward_wino": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_int, C.c_int, C.c_int]),

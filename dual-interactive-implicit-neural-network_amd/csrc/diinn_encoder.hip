@@ -621,7 +621,15 @@ size_t diinn_rdn_wino_packed_floats(void) {
     return n;
 }
 
+size_t diinn_rdn_x3_packed_floats(void) {
+    // the 3x3 layers only, 9 taps x (hi + lo) bf16 = 9 floats per (output, input) pair: SFENet2, 16 x 8 dense convs, GFF.1
+    size_t n = (size_t)2 * 64 * 64 * 9;
+    for (int c = 0; c < 8; ++c) n += (size_t)16 * 64 * (64 + 64 * c) * 9;
+    return n;
+}
+
 static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
+                            const float* packed_x3_dev,
                             const float* biases_dev, float* workspace_dev, float* out_dev, int B, int H, int W) {
     if (!sfe1_dev || !packed_dev || !biases_dev || !workspace_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
@@ -634,16 +642,23 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     float* buf[2] = {workspace_dev, workspace_dev + (size_t)B * 576 * hw};     // dense buffers [B,576,H,W]
     float* gff_in = workspace_dev + (size_t)2 * B * 576 * hw;                    // [B,1024,H,W]
     float* tmp = gff_in + (size_t)B * 1024 * hw;                                 // [B,64,H,W]
+    // split-bf16 3x3 layers (csrc/diinn_conv_x3.hip; optional): they pay from about two workgroups of 32 x 8 pixels per CU
+    // (measured per trunk: 256x256 11.9 vs 11.8 ms, 384x384 25.1 vs 28.2, 512x512 35.8 vs 46.8)
+    const bool x3 = packed_x3_dev && (long long)B * hw >= knob(diinn_knobs().enc_x3_min);
     const float* w = packed_dev;
     const float* wu = packed_wino_dev;
+    const float* wx = packed_x3_dev;
     const float* bias = biases_dev;
     auto conv = [&](const float* in, long long in_bs, int cin, int taps, const float* res, long long res_bs,
                     float* o0, long long o0_bs, float* o1, long long o1_bs, int relu) {
-        const int s = (wino && taps == 9 && !o1)
+        const int s = (x3 && taps == 9 && !o1)
+            ? diinn_conv3x3_x3(stream, in, in_bs, cin, wx, bias, res, res_bs, o0, o0_bs, relu, B, H, W)
+            : (wino && taps == 9 && !o1)
             ? diinn_conv_wino(stream, in, in_bs, cin, wu, bias, res, res_bs, o0, o0_bs, relu, B, H, W)
             : diinn_conv_ksplit(stream, in, in_bs, cin, taps, w, bias, res, res_bs, o0, o0_bs, o1, o1_bs, relu, B, H, W);
         w += (size_t)64 * cin * taps;
         if (taps == 9 && wu) wu += (size_t)64 * cin * 16;
+        if (taps == 9 && wx) wx += (size_t)64 * cin * 9;
         bias += 64;
         return s;
     };
@@ -669,13 +684,20 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
 
 int diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packed_dev, const float* biases_dev,
                       float* workspace_dev, float* out_dev, int B, int H, int W) {
-    return rdn_forward_impl(stream, sfe1_dev, packed_dev, nullptr, biases_dev, workspace_dev, out_dev, B, H, W);
+    return rdn_forward_impl(stream, sfe1_dev, packed_dev, nullptr, nullptr, biases_dev, workspace_dev, out_dev, B, H, W);
 }
 
 int diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
                            const float* biases_dev, float* workspace_dev, float* out_dev, int B, int H, int W) {
     if (!packed_wino_dev) return DIINN_ERR_INVALID_ARG;
-    return rdn_forward_impl(stream, sfe1_dev, packed_dev, packed_wino_dev, biases_dev, workspace_dev, out_dev, B, H, W);
+    return rdn_forward_impl(stream, sfe1_dev, packed_dev, packed_wino_dev, nullptr, biases_dev, workspace_dev, out_dev, B, H, W);
+}
+
+int diinn_rdn_forward_x3(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
+                         const float* packed_x3_dev, const float* biases_dev, float* workspace_dev, float* out_dev,
+                         int B, int H, int W) {
+    if (!packed_wino_dev || !packed_x3_dev) return DIINN_ERR_INVALID_ARG;
+    return rdn_forward_impl(stream, sfe1_dev, packed_dev, packed_wino_dev, packed_x3_dev, biases_dev, workspace_dev, out_dev, B, H, W);
 }
 
 }  // extern "C"

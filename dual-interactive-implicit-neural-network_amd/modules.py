@@ -98,6 +98,22 @@ def pack_conv_wino(weight: torch.Tensor) -> torch.Tensor:
     return u.permute(5, 2, 6, 0, 4, 1, 3).reshape(-1)           # [i, chunk, j, half, h, m, e]
 
 
+def pack_conv_x3(weight: torch.Tensor) -> torch.Tensor:
+    """3x3 conv weight [64, Cin, 3, 3] (Cin % 16 == 0) -> the split-bf16 image ``diinn_conv3x3_x3`` reads
+    (include/diinn_hip.h): every weight as hi = bf16(w), lo = bf16(w - hi), laid out
+    [group Cin/16][tap 9][M-tile 2][hi, lo][lane 64][8 bf16] with cout = 32 mt + (lane & 31) and input channel =
+    16 group + 8 (lane >> 5) + j; returned as float32 words (two bf16 each), 9 * 64 * Cin of them."""
+    co, cin, kh, kw = weight.shape
+    if co != 64 or cin % 16 or (kh, kw) != (3, 3):
+        raise ValueError(f"unsupported convolution shape {tuple(weight.shape)}")
+    w = weight.detach().to(torch.float32)
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+    parts = torch.stack([hi, lo], 0).reshape(2, 2, 32, cin // 16, 2, 8, 9)          # [part, mt, m, g, h, j, tap]
+    img = parts.permute(3, 6, 1, 0, 4, 2, 5).contiguous()                           # [g, tap, mt, part, h, m, j]
+    return img.view(torch.int16).reshape(-1, 2).view(torch.int32).reshape(-1).view(torch.float32)
+
+
 class RDN(nn.Module):
     _CONFIGS = {"A": (20, 6, 32), "B": (16, 8, 64)}
     # Inference (no autograd, fp32, config 'B') runs the whole encoder on the library's kernels (DESIGN.md section 4.8):
@@ -110,6 +126,11 @@ class RDN(nn.Module):
     # 3x3 layers as Winograd F(2x2, 3x3) (csrc/diinn_winograd.hip) on maps of >= 8192 pixels: 2.25x fewer MFMAs, fp32,
     # equal to the direct sum up to reassociation (~1e-6 relative).  False keeps every layer on the direct kernel.
     hip_winograd: bool = True
+    # optional: the 3x3 layers in split-bf16 arithmetic on the bf16 MFMA (csrc/diinn_conv_x3.hip) on maps of >= 131,072
+    # pixels: hi + lo bf16 operands, three products per term, fp32 accumulation.  Per layer ~4e-6 of max|out| against
+    # float64; the whole trunk differs from the fp32 one by ~3e-6 of max|feat| and the decoded image by ~2e-8 (DESIGN.md
+    # 4.8).  Measured per trunk: 384x384 28.2 -> 25.1 ms, 512x512 46.8 -> 35.8 ms; no gain at 256x256 (stays on Winograd).
+    hip_split_bf16: bool = False
 
     def __init__(self, G0: int = 64, RDNkSize: int = 3, RDNconfig: str = "B", n_colors: int = 3):
         super().__init__()
@@ -140,8 +161,16 @@ class RDN(nn.Module):
             w = torch.cat([pack_conv_ksplit(l.weight) for l in layers]).to(device)
             b = torch.cat([l.bias.detach().to(torch.float32) for l in layers]).to(device)
             wu = torch.cat([pack_conv_wino(l.weight) for l in layers if l.kernel_size == (3, 3)]).to(device)
-            self._hip_pack, self._hip_key = (w, b, wu), key
+            self._hip_pack, self._hip_key, self._hip_x3 = (w, b, wu), key, None
         return self._hip_pack
+
+    def _hip_packed_x3(self, device):
+        """The split-bf16 image of the 130 3x3 weights, built on first use (and again when a weight changes)."""
+        self._hip_packed(device)
+        if getattr(self, "_hip_x3", None) is None:
+            layers = self._trunk_layers()
+            self._hip_x3 = torch.cat([pack_conv_x3(l.weight.to(device)) for l in layers if l.kernel_size == (3, 3)]).to(device)
+        return self._hip_x3
 
     def _forward_hip_trunk(self, shallow):
         import ctypes as C
@@ -154,7 +183,13 @@ class RDN(nn.Module):
         out = torch.empty_like(shallow)
         with torch.cuda.device(shallow.device):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            if self.hip_winograd:
+            if self.hip_winograd and self.hip_split_bf16:
+                px3 = self._hip_packed_x3(shallow.device)
+                _native.check(lib.diinn_rdn_forward_x3(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                                       C.c_void_p(packed_wino.data_ptr()), C.c_void_p(px3.data_ptr()),
+                                                       C.c_void_p(biases.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                                       C.c_void_p(out.data_ptr()), b, h, w), "diinn_rdn_forward_x3")
+            elif self.hip_winograd:
                 _native.check(lib.diinn_rdn_forward_wino(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
                                                          C.c_void_p(packed_wino.data_ptr()), C.c_void_p(biases.data_ptr()),
                                                          C.c_void_p(ws.data_ptr()), C.c_void_p(out.data_ptr()), b, h, w),

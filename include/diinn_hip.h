@@ -42,7 +42,8 @@ extern "C" {
  *   5  diinn_sfe1_forward; packed section 13 (WPU: the hoisted 3x3 conv in Winograd form)
  *   6  the packed image carries a validity word for its derived sections (DIINN_PACKED_MAGIC, below);
  *      diinn_p_launch_info; diinn_debug_set / diinn_debug_get;
- *      bf16 kernel choice taken from the full image, not the band; DIINN_COMPUTE_BF16X3 and packed section 14 */
+ *      bf16 kernel choice taken from the full image, not the band; DIINN_COMPUTE_BF16X3 and packed section 14;
+ *      split-bf16 encoder layers (diinn_conv3x3_x3, diinn_rdn_forward_x3) */
 
 /* status codes */
 #define DIINN_OK                 0
@@ -354,6 +355,25 @@ size_t diinn_rdn_wino_packed_floats(void);
 int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
                               const float* biases_dev, float* workspace_dev, float* out_dev, int B, int H, int W);
 
+/* Split-bf16 arithmetic for the trunk's 3x3 convolutions (csrc/diinn_conv_x3.hip; optional, large maps): the direct sum
+ * on v_mfma_f32_32x32x16_bf16 with every operand as hi + lo bf16 parts (hi = bf16(v), lo = bf16(v - hi)), a product as
+ * w_lo.x_hi + w_hi.x_lo + w_hi.x_hi, fp32 accumulation.  Per layer ~4e-6 of max|out| against float64 (fp32 Winograd:
+ * ~5e-7); through the whole trunk 7e-6 of max|feat| and 1e-7 in the decoded image.
+ * diinn_conv3x3_x3: one 3x3 zero-padded 64-output convolution over Cin % 16 == 0 input planes (addressing and epilogue as
+ *   diinn_conv_wino).  packed_x3_dev: [group Cin/16][tap 9][M-tile 2][hi, lo][lane 64][8 bf16] with
+ *   value = part(W[32 mt + (lane&31)][16 group + 8 (lane>>5) + j][tap / 3][tap % 3])   (9 * 64 * Cin floats).
+ * diinn_rdn_x3_packed_floats: floats of the 130 such weights of the trunk, in execution order.
+ * diinn_rdn_forward_x3: diinn_rdn_forward_wino with the 3x3 layers on diinn_conv3x3_x3 from B*H*W >= 131072 pixels on
+ *   (DIINN_ENC_X3_MIN); smaller maps run exactly as diinn_rdn_forward_wino. */
+int    diinn_conv3x3_x3(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
+                        const float* packed_x3_dev, const float* bias_dev,
+                        const float* res_dev, long long res_batch_stride,
+                        float* out_dev, long long out_batch_stride, int relu, int B, int H, int W);
+size_t diinn_rdn_x3_packed_floats(void);
+int    diinn_rdn_forward_x3(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
+                            const float* packed_x3_dev, const float* biases_dev, float* workspace_dev, float* out_dev,
+                            int B, int H, int W);
+
 /* Dominant-kernel launch geometry, for benchmarks/roofline accounting. */
 int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,
                              int* grid_x, int* grid_y, int* grid_z, int* block);
@@ -366,7 +386,7 @@ int diinn_p_launch_info(int B, int H, int W, int r0, int r1, int compute, int* a
 
 /* ---- diagnostic overrides (tests, A/B timing; never needed in production) -------------------------------------
  * The launch functions pick kernel variants by launch size; each choice can be forced.  The knobs are named like the
- * environment variables that seed them -- DIINN_F32_KERNEL, DIINN_BF16_KERNEL, DIINN_X3_KERNEL, DIINN_PBF16_KERNEL, DIINN_P_KERNEL,
+ * environment variables that seed them -- DIINN_F32_KERNEL, DIINN_BF16_KERNEL, DIINN_X3_KERNEL, DIINN_PBF16_KERNEL, DIINN_P_KERNEL, DIINN_ENC_X3_MIN, DIINN_ENC_X3_ROWS,
  * DIINN_P_WINO_MIN, DIINN_ENC_S1_MIN_BLOCKS, DIINN_ENC_NO_STREAM1X1, DIINN_ENC_LAT_MAX_TILES,
  * DIINN_ENC_WINO_MIN, DIINN_ENC_WINO_HALF_MAX, DIINN_ENC_WINO_PERSIST (csrc/diinn_knobs.h lists values and
  * defaults).  The environment is read ONCE, at the first launch or the first call of either function; afterwards

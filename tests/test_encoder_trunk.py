@@ -261,3 +261,75 @@ def test_rdn_hip_trunk_matches_the_reference_on_big_maps():
         assert err <= 2e-5 * scale, (key, err)
         sums = y.astype(np.float64).sum(axis=(0, 2, 3))
         assert float(np.abs(sums - gold[f"rdn/{key}/channel_sums"]).max()) <= 1e-6 * b * h * w * scale, key
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# split-bf16 3x3 layers (csrc/diinn_conv_x3.hip; optional, RDN.hip_split_bf16)
+
+
+@pytest.mark.gpu
+def test_conv3x3_split_bf16_matches_float64(knobs):
+    """diinn_conv3x3_x3 against a float64 convolution: both kernel forms (1 / 2 pixel rows per wave), ragged map sizes
+    (zero padding at every border, partial tiles), batches, ReLU, the residual input, a strided destination.  Bound:
+    2e-5 of max|out| (measured 2e-6 .. 5e-6: hi + lo bf16 operands carry 16 bits)."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    lib = N.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for rows in (1, 2):
+        knobs("DIINN_ENC_X3_ROWS", rows)
+        for (b, cin, h, w, relu, use_res) in [(1, 64, 48, 48, 1, 0), (2, 320, 13, 21, 1, 0), (1, 512, 5, 3, 0, 1),
+                                              (1, 128, 33, 70, 1, 0), (3, 16, 9, 65, 0, 1), (1, 576, 1, 1, 1, 0)]:
+            x = torch.randn(b, cin, h, w, device=dev)
+            wt = (torch.rand(64, cin, 3, 3, device=dev) * 2 - 1) / (cin * 9) ** 0.5 * 1.7
+            bias = torch.randn(64, device=dev) * 0.1
+            res = torch.randn(b, 64, h, w, device=dev) if use_res else None
+            ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+            if relu:
+                ref = ref.relu()
+            if use_res:
+                ref = ref + res.double()
+            wx = M.pack_conv_x3(wt).to(dev)
+            assert wx.numel() == 9 * 64 * cin
+            big = torch.full((b, 96, h, w), float("nan"), device=dev)          # destination: channels 16..79 of a wider buffer
+            out = big[:, 16:80]
+            N.check(lib.diinn_conv3x3_x3(st, C.c_void_p(x.data_ptr()), cin * h * w, cin, C.c_void_p(wx.data_ptr()),
+                                         C.c_void_p(bias.data_ptr()), C.c_void_p(res.data_ptr()) if use_res else None,
+                                         64 * h * w, C.c_void_p(out.data_ptr()), 96 * h * w, relu, b, h, w), "diinn_conv3x3_x3")
+            torch.cuda.synchronize()
+            scale = float(ref.abs().max())
+            err = float((out.double() - ref).abs().max())
+            assert err <= 2e-5 * scale, (rows, b, cin, h, w, err / scale)
+            assert bool(torch.isnan(big[:, :16]).all()) and bool(torch.isnan(big[:, 80:]).all())   # nothing outside the 64 planes
+    # shapes it does not cover are refused
+    assert lib.diinn_conv3x3_x3(st, C.c_void_p(x.data_ptr()), 0, 24, C.c_void_p(wx.data_ptr()), C.c_void_p(bias.data_ptr()),
+                                None, 0, C.c_void_p(out.data_ptr()), 0, 0, 1, 8, 8) == N.ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+def test_trunk_with_split_bf16_layers_tracks_the_fp32_trunk(knobs):
+    """RDN.hip_split_bf16: the whole encoder with its 130 3x3 layers on diinn_conv3x3_x3 (forced on at a small map through
+    DIINN_ENC_X3_MIN) against the fp32 trunk: features within 3e-5 of max|feat| (measured 3e-6), and the image decoded
+    from them within 1e-6 (measured 2e-8; the north_star bound is 1e-4) -- the per-layer 4e-6 does not pile up."""
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    net = M.DIINN(mode=3, init_q=False).to(dev).eval()
+    enc = net.encoder
+    knobs("DIINN_ENC_X3_MIN", 0)
+    with torch.no_grad():
+        for (b, h, w) in [(1, 96, 100), (2, 40, 72)]:
+            x = torch.rand(b, 3, h, w, device=dev)
+            enc.hip_split_bf16 = False
+            f32 = enc(x)
+            enc.hip_split_bf16 = True
+            f3 = enc(x)
+            assert float((f3 - f32).abs().max()) <= 3e-5 * float(f32.abs().max()), (b, h, w)
+            assert not torch.equal(f3, f32)                          # the other kernel did run
+            size = (2 * h + 3, 3 * w - 1)
+            img32, img3 = net.decoder(f32, size, 30000), net.decoder(f3, size, 30000)
+            assert float((img3 - img32).abs().max()) <= 1e-6, (b, h, w)
+    enc.hip_split_bf16 = False
