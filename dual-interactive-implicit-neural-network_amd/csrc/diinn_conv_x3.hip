@@ -29,13 +29,25 @@ struct ConvX3Params {
     float* out;              // out + b*out_bs + co*H*W
     long long in_bs, out_bs, res_bs;
     int Cin, B, H, W, relu;
+    // the SPLIT activation format (optional): [b][group of 8 channels][hi, lo][H][W] x 16 bytes -- 8 bf16 per pixel, the
+    // same 4 bytes per element as fp32, already in B-fragment order: staging a pixel is two 16-byte copies, no
+    // conversion.  xs_in != null: the layer reads ALL its inputs from there (`in` is not touched); xs_out != null: the
+    // outputs are written there as well (channel groups xs_out_g8 .. + 7) for the 3x3 layers that follow in the block
+    const u32x4* xs_in;
+    u32x4* xs_out;
+    long long xs_bs;         // batch stride of both, in 16-byte units
+    int xs_out_g8;
 };
 
 // CX_ROWS = pixel rows per wave.  2: every weight piece feeds 3 MFMAs on average (L1: 43 B/clk per CU), 256 workgroups
 // on a 256x256 map; 1: twice the workgroups (two per CU there, which cover each other's patch loads), 1.5 MFMAs per
 // piece.  Measured per layer at 256x256 (tools/conv_x3_time.py): 64 inputs 25.9 / 29.5 us, 512 inputs 131.4 / 124.0 us.
-template <int CX_ROWS>
-__global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const ConvX3Params p) {
+// WAHEAD: a whole group's 36 weight pieces live in registers (144) and each tap's are replaced by the next group's right
+// behind their MFMAs -- for launches of about one workgroup per CU, where no other workgroup covers a wait: the
+// vector-memory counter is in order, so a weight piece requested behind the patch loads is usable only once the patch
+// (HBM latency) has arrived; one tap ahead that stalls every group, a group ahead it never does.
+template <int CX_ROWS, bool SPLIT_IN, bool WAHEAD>
+__global__ __launch_bounds__(256, WAHEAD ? 1 : 2) void conv3x3_x3_kernel(const ConvX3Params p) {
     constexpr int CX_TY = 4 * CX_ROWS, CX_PH = CX_TY + 2;
     constexpr int CX_TASKS = CX_PH * CX_PW * 2;           // staging tasks per group: (pixel, k-half) -> 8 channels
     constexpr int CX_ITERS = (CX_TASKS + 255) / 256;
@@ -65,13 +77,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const ConvX3Params p
         t_lds[i] = has ? (kh * CX_PH + row) * CX_PW + col : -1;
         t_half[i] = kh;
     }
-    float sv[CX_ITERS][8];
+    float sv[SPLIT_IN ? 1 : CX_ITERS][8];
+    u32x4 xh_[SPLIT_IN ? CX_ITERS : 1], xl_[SPLIT_IN ? CX_ITERS : 1];
+    const u32x4* __restrict__ xs_b = SPLIT_IN ? p.xs_in + (size_t)b * p.xs_bs : nullptr;
     auto stage_load = [&](const int g) {
+        if constexpr (SPLIT_IN) {
 #pragma unroll
-        for (int i = 0; i < CX_ITERS; ++i) {
-            const float* __restrict__ src = in_b + (size_t)(16 * g + 8 * t_half[i]) * plane;
+            for (int i = 0; i < CX_ITERS; ++i) {
+                const u32x4* __restrict__ src = xs_b + (size_t)(2 * (2 * g + t_half[i])) * plane;     // group 2g + k-half, hi plane
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                xh_[i] = t_off[i] >= 0 ? src[t_off[i]] : z;
+                xl_[i] = t_off[i] >= 0 ? src[plane + t_off[i]] : z;
+            }
+        } else {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) sv[i][c] = t_off[i] >= 0 ? src[(size_t)c * plane + t_off[i]] : 0.0f;
+            for (int i = 0; i < CX_ITERS; ++i) {
+                const float* __restrict__ src = in_b + (size_t)(16 * g + 8 * t_half[i]) * plane;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) sv[i][c] = t_off[i] >= 0 ? src[(size_t)c * plane + t_off[i]] : 0.0f;
+            }
         }
     };
     auto stage_store = [&](const int buf) {
@@ -80,15 +104,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const ConvX3Params p
 #pragma unroll
         for (int i = 0; i < CX_ITERS; ++i) {
             if (t_lds[i] < 0) continue;
-            bf16x8 vh, vl;
+            if constexpr (SPLIT_IN) {
+                hi[t_lds[i]] = __builtin_bit_cast(bf16x8, xh_[i]);
+                lo[t_lds[i]] = __builtin_bit_cast(bf16x8, xl_[i]);
+            } else {
+                bf16x8 vh, vl;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const __bf16 a = (__bf16)sv[i][c];
-                vh[c] = a;
-                vl[c] = (__bf16)(sv[i][c] - (float)a);
+                for (int c = 0; c < 8; ++c) {
+                    const __bf16 a = (__bf16)sv[i][c];
+                    vh[c] = a;
+                    vl[c] = (__bf16)(sv[i][c] - (float)a);
+                }
+                hi[t_lds[i]] = vh;
+                lo[t_lds[i]] = vl;
             }
-            hi[t_lds[i]] = vh;
-            lo[t_lds[i]] = vl;
         }
     };
 
@@ -99,10 +128,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const ConvX3Params p
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.wx, 0, (int)((size_t)ngroups * 9 * 4 * PIECE_BYTES), 0x00020000);
     const int lane_off = lane * 16;
-    f32x4 A[3][4];
+    f32x4 A[WAHEAD ? 1 : 3][4];
+    f32x4 Wg[WAHEAD ? 9 : 1][4];
     auto load_w = [&](const int slot, const int gt) {            // gt = group * 9 + tap
 #pragma unroll
         for (int i = 0; i < 4; ++i) A[slot][i] = ld_piece(wrs, lane_off + i * PIECE_BYTES, gt * 4 * PIECE_BYTES);
+    };
+    auto load_tap = [&](auto tap_tag, const int g) {
+        constexpr int T = decltype(tap_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Wg[WAHEAD ? T : 0][i] = ld_piece(wrs, lane_off + i * PIECE_BYTES, (g * 9 + T) * 4 * PIECE_BYTES);
     };
 
     f32x16 acc[CX_ROWS][2];       // [pixel row of the wave][M-tile]
@@ -113,37 +148,75 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const ConvX3Params p
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[r][mt][e] = 0.0f;
 
-    load_w(0, 0);
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-    const int total = ngroups * 9;
-    for (int g = 0; g < ngroups; ++g) {
-        const int buf = g & 1;
-        load_w(1, g * 9 + 1);
-        if (g + 1 < ngroups) stage_load(g + 1);                  // in flight behind this group's MFMAs
-        const bf16x8* __restrict__ sh = &stage[buf][0][h][CX_ROWS * wave][px];
-        const bf16x8* __restrict__ sl = &stage[buf][1][h][CX_ROWS * wave][px];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            const int gt = g * 9 + tap;
-            if (tap > 0) load_w((tap + 1) % 3, gt + 1 < total ? gt + 1 : gt);
-            const bf16x8 wh0 = __builtin_bit_cast(bf16x8, A[tap % 3][0]), wl0 = __builtin_bit_cast(bf16x8, A[tap % 3][1]);
-            const bf16x8 wh1 = __builtin_bit_cast(bf16x8, A[tap % 3][2]), wl1 = __builtin_bit_cast(bf16x8, A[tap % 3][3]);
-#pragma unroll
-            for (int r = 0; r < CX_ROWS; ++r) {
-                const bf16x8 xh = sh[(r + ky) * CX_PW + kx], xl = sl[(r + ky) * CX_PW + kx];
-                acc[r][0] = MFMA_BF16(wl0, xh, acc[r][0]);
-                acc[r][1] = MFMA_BF16(wl1, xh, acc[r][1]);
-                acc[r][0] = MFMA_BF16(wh0, xl, acc[r][0]);
-                acc[r][1] = MFMA_BF16(wh1, xl, acc[r][1]);
-                acc[r][0] = MFMA_BF16(wh0, xh, acc[r][0]);
-                acc[r][1] = MFMA_BF16(wh1, xh, acc[r][1]);
-            }
-        }
-        if (g + 1 < ngroups) stage_store(buf ^ 1);
+    if constexpr (WAHEAD) {
+        // every tap's weights live in their own registers and are replaced by the NEXT group's right after their MFMAs:
+        // those loads queue up behind the next group's patch loads, but nothing needs them for eight taps
+        load_tap(IC<0>{}, 0); load_tap(IC<1>{}, 0); load_tap(IC<2>{}, 0); load_tap(IC<3>{}, 0); load_tap(IC<4>{}, 0);
+        load_tap(IC<5>{}, 0); load_tap(IC<6>{}, 0); load_tap(IC<7>{}, 0); load_tap(IC<8>{}, 0);
+        stage_load(0);
+        stage_store(0);
         __syncthreads();
+        for (int g = 0; g < ngroups; ++g) {
+            const int buf = g & 1;
+            const bool more = g + 1 < ngroups;
+            if (more) stage_load(g + 1);
+            const bf16x8* __restrict__ sh = &stage[buf][0][h][CX_ROWS * wave][px];
+            const bf16x8* __restrict__ sl = &stage[buf][1][h][CX_ROWS * wave][px];
+            auto tap_step = [&](auto tap_tag) {
+                constexpr int tap = decltype(tap_tag)::value;
+                constexpr int ky = tap / 3, kx = tap - 3 * ky;
+                const bf16x8 wh0 = __builtin_bit_cast(bf16x8, Wg[WAHEAD ? tap : 0][0]), wl0 = __builtin_bit_cast(bf16x8, Wg[WAHEAD ? tap : 0][1]);
+                const bf16x8 wh1 = __builtin_bit_cast(bf16x8, Wg[WAHEAD ? tap : 0][2]), wl1 = __builtin_bit_cast(bf16x8, Wg[WAHEAD ? tap : 0][3]);
+#pragma unroll
+                for (int r = 0; r < CX_ROWS; ++r) {
+                    const bf16x8 xh = sh[(r + ky) * CX_PW + kx], xl = sl[(r + ky) * CX_PW + kx];
+                    acc[r][0] = MFMA_BF16(wl0, xh, acc[r][0]);
+                    acc[r][1] = MFMA_BF16(wl1, xh, acc[r][1]);
+                    acc[r][0] = MFMA_BF16(wh0, xl, acc[r][0]);
+                    acc[r][1] = MFMA_BF16(wh1, xl, acc[r][1]);
+                    acc[r][0] = MFMA_BF16(wh0, xh, acc[r][0]);
+                    acc[r][1] = MFMA_BF16(wh1, xh, acc[r][1]);
+                }
+                load_tap(tap_tag, more ? g + 1 : g);
+            };
+            tap_step(IC<0>{}); tap_step(IC<1>{}); tap_step(IC<2>{}); tap_step(IC<3>{}); tap_step(IC<4>{});
+            tap_step(IC<5>{}); tap_step(IC<6>{}); tap_step(IC<7>{}); tap_step(IC<8>{});
+            if (more) stage_store(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        load_w(0, 0);
+        stage_load(0);
+        stage_store(0);
+        __syncthreads();
+        const int total = ngroups * 9;
+        for (int g = 0; g < ngroups; ++g) {
+            const int buf = g & 1;
+            load_w(1, g * 9 + 1);
+            if (g + 1 < ngroups) stage_load(g + 1);              // in flight behind this group's MFMAs
+            const bf16x8* __restrict__ sh = &stage[buf][0][h][CX_ROWS * wave][px];
+            const bf16x8* __restrict__ sl = &stage[buf][1][h][CX_ROWS * wave][px];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const int gt = g * 9 + tap;
+                if (tap > 0) load_w((tap + 1) % 3, gt + 1 < total ? gt + 1 : gt);
+                const bf16x8 wh0 = __builtin_bit_cast(bf16x8, A[tap % 3][0]), wl0 = __builtin_bit_cast(bf16x8, A[tap % 3][1]);
+                const bf16x8 wh1 = __builtin_bit_cast(bf16x8, A[tap % 3][2]), wl1 = __builtin_bit_cast(bf16x8, A[tap % 3][3]);
+#pragma unroll
+                for (int r = 0; r < CX_ROWS; ++r) {
+                    const bf16x8 xh = sh[(r + ky) * CX_PW + kx], xl = sl[(r + ky) * CX_PW + kx];
+                    acc[r][0] = MFMA_BF16(wl0, xh, acc[r][0]);
+                    acc[r][1] = MFMA_BF16(wl1, xh, acc[r][1]);
+                    acc[r][0] = MFMA_BF16(wh0, xl, acc[r][0]);
+                    acc[r][1] = MFMA_BF16(wh1, xl, acc[r][1]);
+                    acc[r][0] = MFMA_BF16(wh0, xh, acc[r][0]);
+                    acc[r][1] = MFMA_BF16(wh1, xh, acc[r][1]);
+                }
+            }
+            if (g + 1 < ngroups) stage_store(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- bias, ReLU, residual, store: accumulator register e of M-tile mt is output channel 32 mt + 8 (e >> 2) + (e & 3) + 4 h
@@ -162,13 +235,85 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const ConvX3Params p
                 if (p.relu) v = relu0(v);
                 if (p.res) v += p.res[(size_t)b * p.res_bs + (size_t)co * plane + pix];
                 p.out[(size_t)b * p.out_bs + (size_t)co * plane + pix] = v;
+                acc[r][mt][e] = v;
             }
+        if (p.xs_out) {
+            // registers 4q .. 4q+3 of M-tile mt are channels 32 mt + 8 q + 4 h + (0..3): this lane's half (8 bytes hi, 8 bytes
+            // lo) of the pixel's vector in channel group xs_out_g8 + 4 mt + q
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+            u32x2_* __restrict__ dst = reinterpret_cast<u32x2_*>(p.xs_out + (size_t)b * p.xs_bs);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bf16x4 vh, vl;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = acc[r][mt][4 * q + i];
+                        const __bf16 a = (__bf16)v;
+                        vh[i] = a;
+                        vl[i] = (__bf16)(v - (float)a);
+                    }
+                    const size_t g8 = (size_t)(p.xs_out_g8 + 4 * mt + q);
+                    dst[((2 * g8 + 0) * plane + pix) * 2 + h] = __builtin_bit_cast(u32x2_, vh);
+                    dst[((2 * g8 + 1) * plane + pix) * 2 + h] = __builtin_bit_cast(u32x2_, vl);
+                }
+        }
     }
+}
+
+// fp32 planes -> the split format (the block input, written by the 1x1 fusion layer in planes): C / 8 channel groups
+struct SplitParams {
+    const float* in;
+    u32x4* xs;
+    long long in_bs, xs_bs;
+    int C8, B, H, W;
+};
+
+__global__ __launch_bounds__(256) void planes_to_split_kernel(const SplitParams p) {
+    const size_t plane = (size_t)p.H * p.W;
+    const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int g8 = blockIdx.y, b = blockIdx.z;
+    if (pix >= plane) return;
+    const float* __restrict__ src = p.in + (size_t)b * p.in_bs + (size_t)8 * g8 * plane + pix;
+    bf16x8 vh, vl;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float v = src[(size_t)c * plane];
+        const __bf16 a = (__bf16)v;
+        vh[c] = a;
+        vl[c] = (__bf16)(v - (float)a);
+    }
+    u32x4* __restrict__ dst = p.xs + (size_t)b * p.xs_bs + (size_t)2 * g8 * plane + pix;
+    dst[0] = __builtin_bit_cast(u32x4, vh);
+    dst[plane] = __builtin_bit_cast(u32x4, vl);
 }
 
 extern "C" {
 
-// one 3x3 layer (64 outputs, Cin a multiple of 16) in split-bf16 arithmetic; `wx` as diinn_conv_x3_packed_floats describes
+static int launch_conv_x3(void* stream, const ConvX3Params& p) {
+    // two rows per wave where the chip stays full with them or the layer is long; DIINN_ENC_X3_ROWS forces 1 / 2, 3 = two
+    // rows with the weights a group ahead (picked by itself when there is at most about one such workgroup per CU)
+    const long long wg2 = (long long)((p.W + CX_TX - 1) / CX_TX) * ((p.H + 7) / 8) * p.B;
+    const long long force = knob(diinn_knobs().enc_x3_rows);
+    const bool two = force ? force >= 2 : (wg2 >= 512 || p.Cin > 128);
+    const bool ahead = force ? force == 3 : (two && wg2 <= 384);
+    const dim3 grid((unsigned)((p.W + CX_TX - 1) / CX_TX), (unsigned)((p.H + (two ? 7 : 3)) / (two ? 8 : 4)), (unsigned)p.B);
+    const hipStream_t st = (hipStream_t)stream;
+    if (p.xs_in) {
+        if (ahead) hipLaunchKernelGGL((conv3x3_x3_kernel<2, true, true>), grid, dim3(256), 0, st, p);
+        else if (two) hipLaunchKernelGGL((conv3x3_x3_kernel<2, true, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3x3_x3_kernel<1, true, false>), grid, dim3(256), 0, st, p);
+    } else {
+        if (ahead) hipLaunchKernelGGL((conv3x3_x3_kernel<2, false, true>), grid, dim3(256), 0, st, p);
+        else if (two) hipLaunchKernelGGL((conv3x3_x3_kernel<2, false, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3x3_x3_kernel<1, false, false>), grid, dim3(256), 0, st, p);
+    }
+    return hip_status(hipGetLastError());
+}
+
+// one 3x3 layer (64 outputs, Cin a multiple of 16) in split-bf16 arithmetic; `wx` as diinn_rdn_x3_packed_floats describes
 int diinn_conv3x3_x3(void* stream, const float* in_dev, long long in_bs, int Cin, const float* wx_dev, const float* bias_dev,
                      const float* res_dev, long long res_bs, float* out_dev, long long out_bs, int relu, int B, int H, int W) {
     if (!in_dev || !wx_dev || !bias_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
@@ -176,18 +321,30 @@ int diinn_conv3x3_x3(void* stream, const float* in_dev, long long in_bs, int Cin
     if (st) return st;
     if (Cin < 16 || Cin % 16 || Cin > 1024) return DIINN_ERR_UNSUPPORTED;
     if ((long long)H * W > 0x7fffffffLL / 4) return DIINN_ERR_TOO_LARGE;
-    ConvX3Params p{in_dev, wx_dev, bias_dev, res_dev, out_dev, in_bs, out_bs, res_bs, Cin, B, H, W, relu};
-    // two rows per wave where the chip stays full with them or the layer is long; DIINN_ENC_X3_ROWS forces 1 / 2
-    const long long wg2 = (long long)((W + CX_TX - 1) / CX_TX) * ((H + 7) / 8) * B;
-    const long long force = knob(diinn_knobs().enc_x3_rows);
-    const bool two = force ? force == 2 : (wg2 >= 512 || Cin > 192);
-    if (two) {
-        const dim3 grid((unsigned)((W + CX_TX - 1) / CX_TX), (unsigned)((H + 7) / 8), (unsigned)B);
-        hipLaunchKernelGGL(conv3x3_x3_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    } else {
-        const dim3 grid((unsigned)((W + CX_TX - 1) / CX_TX), (unsigned)((H + 3) / 4), (unsigned)B);
-        hipLaunchKernelGGL(conv3x3_x3_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    }
+    ConvX3Params p{in_dev, wx_dev, bias_dev, res_dev, out_dev, in_bs, out_bs, res_bs, Cin, B, H, W, relu, nullptr, nullptr, 0, 0};
+    return launch_conv_x3(stream, p);
+}
+
+// the same layer inside a dense block (diinn_rdn_forward_x3): inputs from the split-format buffer xs (all Cin channels),
+// outputs to the planes and, when xs_out_g8 >= 0, to channel groups xs_out_g8 .. + 7 of the same buffer
+__attribute__((visibility("hidden")))
+int diinn_conv3x3_x3_split(void* stream, float* xs_dev, long long xs_bs16, int xs_out_g8, int Cin, const float* wx_dev,
+                           const float* bias_dev, float* out_dev, long long out_bs, int relu, int B, int H, int W) {
+    if (Cin < 16 || Cin % 16 || Cin > 1024) return DIINN_ERR_UNSUPPORTED;
+    if ((long long)H * W > 0x7fffffffLL / 4) return DIINN_ERR_TOO_LARGE;
+    ConvX3Params p{nullptr, wx_dev, bias_dev, nullptr, out_dev, 0, out_bs, 0, Cin, B, H, W, relu,
+                   reinterpret_cast<const u32x4*>(xs_dev), xs_out_g8 >= 0 ? reinterpret_cast<u32x4*>(xs_dev) : nullptr, xs_bs16,
+                   xs_out_g8 >= 0 ? xs_out_g8 : 0};
+    return launch_conv_x3(stream, p);
+}
+
+__attribute__((visibility("hidden")))
+int diinn_planes_to_split(void* stream, const float* in_dev, long long in_bs, int C, float* xs_dev, long long xs_bs16,
+                          int B, int H, int W) {
+    SplitParams p{in_dev, reinterpret_cast<u32x4*>(xs_dev), in_bs, xs_bs16, C / 8, B, H, W};
+    const long long plane = (long long)H * W;
+    hipLaunchKernelGGL(planes_to_split_kernel, dim3((unsigned)((plane + 255) / 256), (unsigned)(C / 8), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
 

@@ -306,6 +306,14 @@ int launch_P_wino(void* stream, const float* feat_dev, const float* packed_dev, 
 // diinn_bf16.hip: the bf16 decode of HR rows [p.y0, p.y1) (grid of the one-tile kernel: gx, gy, gz)
 __attribute__((visibility("hidden")))
 int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int gz, int sin_mode);
+// diinn_conv_x3.hip: a split-bf16 3x3 layer reading (and optionally extending) the split-format buffer of a dense block;
+// fp32 planes -> that format (diinn_rdn_forward_x3)
+extern "C" __attribute__((visibility("hidden")))
+int diinn_conv3x3_x3_split(void* stream, float* xs_dev, long long xs_bs16, int xs_out_g8, int Cin, const float* wx_dev,
+                           const float* bias_dev, float* out_dev, long long out_bs, int relu, int B, int H, int W);
+extern "C" __attribute__((visibility("hidden")))
+int diinn_planes_to_split(void* stream, const float* in_dev, long long in_bs, int C, float* xs_dev, long long xs_bs16,
+                          int B, int H, int W);
 // diinn_bf16.hip: the split-bf16 decode (DIINN_COMPUTE_BF16X3) of HR rows [p.y0, p.y1)
 __attribute__((visibility("hidden")))
 int launch_decode_bf16x3(void* stream, const DecodeParams& p, int gx, int gy, int gz, int sin_mode);

@@ -621,6 +621,12 @@ size_t diinn_rdn_wino_packed_floats(void) {
     return n;
 }
 
+size_t diinn_rdn_x3_workspace_floats(int B, int H, int W) {
+    // diinn_rdn_workspace_floats + the split-format copy of one dense buffer ([B][72 groups][hi, lo][H][W] x 16 bytes)
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return diinn_rdn_workspace_floats(B, H, W) + (size_t)B * 576 * H * W;
+}
+
 size_t diinn_rdn_x3_packed_floats(void) {
     // the 3x3 layers only, 9 taps x (hi + lo) bf16 = 9 floats per (output, input) pair: SFENet2, 16 x 8 dense convs, GFF.1
     size_t n = (size_t)2 * 64 * 64 * 9;
@@ -642,8 +648,9 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     float* buf[2] = {workspace_dev, workspace_dev + (size_t)B * 576 * hw};     // dense buffers [B,576,H,W]
     float* gff_in = workspace_dev + (size_t)2 * B * 576 * hw;                    // [B,1024,H,W]
     float* tmp = gff_in + (size_t)B * 1024 * hw;                                 // [B,64,H,W]
-    // split-bf16 3x3 layers (csrc/diinn_conv_x3.hip; optional): they pay from about two workgroups of 32 x 8 pixels per CU
-    // (measured per trunk: 256x256 11.9 vs 11.8 ms, 384x384 25.1 vs 28.2, 512x512 35.8 vs 46.8)
+    // split-bf16 3x3 layers (csrc/diinn_conv_x3.hip; optional): blocks of 32 x 8 pixels; they pay from about 0.8 blocks
+    // per CU on (measured per trunk, x3 vs Winograd: 192x192 9.5 vs 9.4 ms, 224x224 9.7 vs 11.5, 256x256 9.8 vs 11.8,
+    // 384x384 22.3 vs 27.9, 512x512 32.8 vs 46.2)
     const bool x3 = packed_x3_dev && (long long)B * hw >= knob(diinn_knobs().enc_x3_min);
     const float* w = packed_dev;
     const float* wu = packed_wino_dev;
@@ -665,9 +672,27 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     // SFENet2: 64 -> 64 into channels [0,64) of the first dense buffer (rdn.py:97)
     st = conv(sfe1_dev, 64 * hw, 64, 9, nullptr, 0, buf[0], 576 * hw, nullptr, 0, 0);
     if (st) return st;
+    float* xs = tmp + (size_t)B * 64 * hw;                                       // x3 only: the block's channels in split format
+    const long long xs_bs16 = 144 * hw;                                          // 72 groups x (hi, lo) planes of 16-byte pixels
     for (int d = 0; d < 16; ++d) {
         float* cur = buf[d & 1];
         float* nxt = buf[(d + 1) & 1];
+        if (x3) {
+            // the block input (fp32 planes, written by the previous fusion layer) once into the split format; every dense conv
+            // then reads ALL its inputs from there (two 16-byte copies per staged pixel instead of eight loads and a
+            // conversion, redone by each of the up to eight layers that read a channel) and appends its own outputs to it
+            st = diinn_planes_to_split(stream, cur, 576 * hw, 64, xs, xs_bs16, B, H, W);
+            if (st) return st;
+            for (int c = 0; c < 8; ++c) {
+                st = diinn_conv3x3_x3_split(stream, xs, xs_bs16, c < 7 ? 8 * (c + 1) : -1, 64 * (c + 1), wx, bias,
+                                            cur + (size_t)64 * (c + 1) * hw, 576 * hw, 1, B, H, W);
+                if (st) return st;
+                w += (size_t)64 * 64 * (c + 1) * 9;
+                wu += (size_t)64 * 64 * (c + 1) * 16;
+                wx += (size_t)64 * 64 * (c + 1) * 9;
+                bias += 64;
+            }
+        } else
         for (int c = 0; c < 8; ++c) {                            // dense 3x3 convs: read channels [0, 64(c+1)), append 64 (rdn.py:15-17)
             st = conv(cur, 576 * hw, 64 * (c + 1), 9, nullptr, 0, cur + (size_t)64 * (c + 1) * hw, 576 * hw, nullptr, 0, 1);
             if (st) return st;

@@ -126,10 +126,11 @@ class RDN(nn.Module):
     # 3x3 layers as Winograd F(2x2, 3x3) (csrc/diinn_winograd.hip) on maps of >= 8192 pixels: 2.25x fewer MFMAs, fp32,
     # equal to the direct sum up to reassociation (~1e-6 relative).  False keeps every layer on the direct kernel.
     hip_winograd: bool = True
-    # optional: the 3x3 layers in split-bf16 arithmetic on the bf16 MFMA (csrc/diinn_conv_x3.hip) on maps of >= 131,072
-    # pixels: hi + lo bf16 operands, three products per term, fp32 accumulation.  Per layer ~4e-6 of max|out| against
-    # float64; the whole trunk differs from the fp32 one by ~3e-6 of max|feat| and the decoded image by ~2e-8 (DESIGN.md
-    # 4.8).  Measured per trunk: 384x384 28.2 -> 25.1 ms, 512x512 46.8 -> 35.8 ms; no gain at 256x256 (stays on Winograd).
+    # optional: the 3x3 layers in split-bf16 arithmetic on the bf16 MFMA (csrc/diinn_conv_x3.hip) on maps of >= 45,056
+    # pixels: hi + lo bf16 operands, three products per term, fp32 accumulation; inside a dense block the activations are
+    # exchanged already split.  Per layer ~4e-6 of max|out| against float64; the whole trunk differs from the fp32 one by
+    # ~3e-6 of max|feat| and the decoded image by ~2e-8.  Measured per trunk: 256x256 11.8 -> 9.8 ms,
+    # 384x384 27.9 -> 22.3 ms, 512x512 46.2 -> 32.8 ms; below ~200x200 the Winograd kernels stay faster and are used.
     hip_split_bf16: bool = False
 
     def __init__(self, G0: int = 64, RDNkSize: int = 3, RDNconfig: str = "B", n_colors: int = 3):
@@ -179,7 +180,9 @@ class RDN(nn.Module):
         b, _, h, w = shallow.shape
         shallow = shallow.contiguous()
         packed, biases, packed_wino = self._hip_packed(shallow.device)
-        ws = torch.empty(lib.diinn_rdn_workspace_floats(b, h, w), dtype=torch.float32, device=shallow.device)
+        x3 = self.hip_winograd and self.hip_split_bf16
+        ws_floats = lib.diinn_rdn_x3_workspace_floats(b, h, w) if x3 else lib.diinn_rdn_workspace_floats(b, h, w)
+        ws = torch.empty(ws_floats, dtype=torch.float32, device=shallow.device)
         out = torch.empty_like(shallow)
         with torch.cuda.device(shallow.device):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -36,7 +36,12 @@ for lr, s in ((48, 2), (128, 4), (256, 4), (512, 4)):
         net.decoder.compute = "bf16x3"                       # the optional split-bf16 decoder (fp32 tolerance)
         td3 = t_ms(lambda: net.decoder(feat, (lr * s, lr * s), 30000))
         te3 = t_ms(lambda: net(x, (lr * s, lr * s), 30000))
+        enc.hip_split_bf16 = True                            # ... and the encoder's 3x3 layers in split bf16 as well
+        t_hip3 = t_ms(lambda: enc(x))
+        te33 = t_ms(lambda: net(x, (lr * s, lr * s), 30000))
+        enc.hip_split_bf16 = False
         net.decoder.compute = "f32"
     print(f"LR {lr}x{lr} x{s}: encoder HIP trunk {t_hip:.2f} ms ({43.9e6*lr*lr/t_hip/1e9:.1f} TFLOP/s) | MIOpen {t_mi:.2f} ms; "
           f"decoder {td:.2f} ms; whole model eager {te:.2f} ms, hipGraph {tg:.2f} ms; "
-          f"with the split-bf16 decoder: decoder {td3:.2f} ms, whole model {te3:.2f} ms", flush=True)
+          f"with the split-bf16 decoder: decoder {td3:.2f} ms, whole model {te3:.2f} ms; "
+          f"with split-bf16 3x3 encoder layers too: encoder {t_hip3:.2f} ms, whole model {te33:.2f} ms", flush=True)
