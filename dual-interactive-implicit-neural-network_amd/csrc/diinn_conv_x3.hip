@@ -40,8 +40,7 @@ struct ConvX3Params {
 };
 
 // CX_ROWS = pixel rows per wave.  2: every weight piece feeds 3 MFMAs on average (L1: 43 B/clk per CU), 256 workgroups
-// on a 256x256 map; 1: twice the workgroups (two per CU there, which cover each other's patch loads), 1.5 MFMAs per
-// piece.  Measured per layer at 256x256 (tools/conv_x3_time.py): 64 inputs 25.9 / 29.5 us, 512 inputs 131.4 / 124.0 us.
+// on a 256x256 map; 1: twice the workgroups, 1.5 MFMAs per piece (maps of a few blocks only).
 // WAHEAD: a whole group's 36 weight pieces live in registers (144) and each tap's are replaced by the next group's right
 // behind their MFMAs -- for launches of about one workgroup per CU, where no other workgroup covers a wait: the
 // vector-memory counter is in order, so a weight piece requested behind the patch loads is usable only once the patch
@@ -320,11 +319,13 @@ __global__ __launch_bounds__(256) void planes_to_split_kernel(const SplitParams 
 extern "C" {
 
 static int launch_conv_x3(void* stream, const ConvX3Params& p) {
-    // two rows per wave where the chip stays full with them or the layer is long; DIINN_ENC_X3_ROWS forces 1 / 2, 3 = two
-    // rows with the weights a group ahead (picked by itself when there is at most about one such workgroup per CU)
+    // two pixel rows per wave (every weight piece feeds 3 MFMAs); with at most ~1.5 such workgroups per CU the form that
+    // keeps a group's weights in registers.  DIINN_ENC_X3_ROWS forces 1 row / 2 rows / 3 = 2 rows + weights a group ahead
+    // (the one-row form -- twice the workgroups -- measured slower at every map size the trunk sends here: 256x256 9.4 vs
+    // 9.0 ms per trunk; it stays for maps of a few blocks)
     const long long wg2 = (long long)((p.W + CX_TX - 1) / CX_TX) * ((p.H + 7) / 8) * p.B;
     const long long force = knob(diinn_knobs().enc_x3_rows);
-    const bool two = force ? force >= 2 : (wg2 >= 512 || p.Cin > 128);
+    const bool two = force ? force >= 2 : wg2 >= 64;
     const bool ahead = force ? force == 3 : (two && wg2 <= 384);
     const dim3 grid((unsigned)((p.W + CX_TX - 1) / CX_TX), (unsigned)((p.H + (two ? 7 : 3)) / (two ? 8 : 4)), (unsigned)p.B);
     const hipStream_t st = (hipStream_t)stream;
