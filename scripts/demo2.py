@@ -68,6 +68,8 @@ def demo2(args):
         # (not in the reference's command line) arithmetic of the implicit decoder's per-pixel layers: "bf16x3" = split
         # bf16, held to the fp32 tolerance at ~2.9x the decode speed; "bf16" / "bf16_full" = reduced precision
         model.net.decoder.compute = args.compute
+    if args.encoder_split_bf16 and args.model_name != "bicubic" and hasattr(model.net, "encoder"):
+        model.net.encoder.hip_split_bf16 = True      # the RDN trunk's 3x3 layers in split bf16 (maps of >= ~210x210 pixels)
     if rank == 0:
         print(args.lr_path)
     filename, _ = os.path.splitext(os.path.basename(args.lr_path))
@@ -95,4 +97,5 @@ if __name__ == "__main__":
     parser.add_argument("--model_name", type=str, default="default_model")
     parser.add_argument("--file_ext", type=str, default=".png")
     parser.add_argument("--compute", type=str, default="f32", choices=["f32", "bf16x3", "bf16", "bf16_full"])
+    parser.add_argument("--encoder_split_bf16", action="store_true")
     demo2(parser.parse_args())
