@@ -9,10 +9,12 @@
 //   diinn_precompute_wino.hip  precompute_P_wino_kernel (the fp32 hoisted conv in Winograd F(2x2,3x3) form: inference)
 //   diinn_bf16.hip             decode_bf16_kernel, decode_bf16x2_kernel, decode_bf16_coop_kernel (4 waves),
 //                              decode_bf16_coop8_kernel (8 waves), decode_bf16_coop8p_kernel (8 waves, persistent)
+//   diinn_bf16x3.hip           decode_bf16x3h_kernel (persistent, hi weight pieces through LDS), decode_bf16x3_kernel: split bf16
 //   diinn_training.hip         backward pass: bwd_head / bwd_layer, plane_gemm, plane_rowdot, cell_sum
 //   diinn_baselines.hip        LIIF and MetaSR comparison decoders
 //   diinn_encoder.hip          RDN trunk: conv_ksplit kernels (small maps), conv1x1_stream_kernel, sfe1_conv_kernel
 //   diinn_winograd.hip         RDN trunk: conv_wino_kernel / conv_wino_half_kernel (3x3 layers, Winograd F(2x2,3x3))
+//   diinn_conv_x3.hip          RDN trunk: conv3x3_x3_kernel (3x3 layers in split-bf16 arithmetic, optional), planes_to_split_kernel
 //   diinn_misc.hip             device sine / axis-table test hooks, error state
 //   diinn_host.cpp (host only) weight packing, coordinate tables, size queries, the knob table (diinn_knobs.h)
 #pragma once
