@@ -365,7 +365,7 @@ int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* 
  * diinn_rdn_x3_packed_floats: floats of the 130 such weights of the trunk, in execution order.
  * diinn_rdn_x3_workspace_floats: floats of diinn_rdn_forward_x3's workspace (diinn_rdn_workspace_floats + one dense
  *   buffer in the split format the dense blocks' 3x3 layers exchange: [B][72 groups of 8 channels][hi, lo][H][W] x 16 B).
- * diinn_rdn_forward_x3: diinn_rdn_forward_wino with the 3x3 layers on diinn_conv3x3_x3 from B*H*W >= 45056 pixels on
+ * diinn_rdn_forward_x3: diinn_rdn_forward_wino with the 3x3 layers on diinn_conv3x3_x3 from B*H*W >= 32768 pixels on
  *   (DIINN_ENC_X3_MIN); smaller maps run exactly as diinn_rdn_forward_wino. */
 int    diinn_conv3x3_x3(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
                         const float* packed_x3_dev, const float* bias_dev,

@@ -69,7 +69,7 @@ def demo2(args):
         # bf16, held to the fp32 tolerance at ~2.9x the decode speed; "bf16" / "bf16_full" = reduced precision
         model.net.decoder.compute = args.compute
     if args.encoder_split_bf16 and args.model_name != "bicubic" and hasattr(model.net, "encoder"):
-        model.net.encoder.hip_split_bf16 = True      # the RDN trunk's 3x3 layers in split bf16 (maps of >= ~210x210 pixels)
+        model.net.encoder.hip_split_bf16 = True      # the RDN trunk's 3x3 layers in split bf16 (maps of >= ~180x180 pixels)
     if rank == 0:
         print(args.lr_path)
     filename, _ = os.path.splitext(os.path.basename(args.lr_path))

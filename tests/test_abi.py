@@ -50,7 +50,7 @@ def test_debug_knobs_roundtrip(lib):
     for name, dflt in [("DIINN_F32_KERNEL", 0), ("DIINN_BF16_KERNEL", 0), ("DIINN_X3_KERNEL", 0), ("DIINN_PBF16_KERNEL", 0), ("DIINN_P_KERNEL", 0),
                        ("DIINN_P_WINO_MIN", 0), ("DIINN_ENC_S1_MIN_BLOCKS", 128), ("DIINN_ENC_NO_STREAM1X1", 0),
                        ("DIINN_ENC_LAT_MAX_TILES", 256), ("DIINN_ENC_WINO_MIN", 8192), ("DIINN_ENC_WINO_HALF_MAX", -1),
-                       ("DIINN_ENC_WINO_PERSIST", 256), ("DIINN_ENC_X3_MIN", 45056), ("DIINN_ENC_X3_ROWS", 0)]:
+                       ("DIINN_ENC_WINO_PERSIST", 256), ("DIINN_ENC_X3_MIN", 32768), ("DIINN_ENC_X3_ROWS", 0)]:
         if name not in os.environ:
             assert N.debug_get(name) == dflt, name
         old = N.debug_get(name)
