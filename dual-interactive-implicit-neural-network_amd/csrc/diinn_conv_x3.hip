@@ -289,6 +289,154 @@ __global__ __launch_bounds__(256, WAHEAD ? 1 : 2) void conv3x3_x3_kernel(const C
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// conv3x3_x3m_kernel: the dense-block form for launches of about one workgroup per CU (256x256: 256 blocks of 32 x 8
+// pixels).  With four waves such a workgroup leaves every SIMD a single wave, whose instruction stream is serial: LDS
+// reads, weight loads and the staging all add to the MFMAs' time (3.0 us per group of 16 channels against 1.65 us of MFMAs).
+// Here the SAME block is worked by EIGHT waves -- waves 0..3 the first 32 outputs, waves 4..7 the other 32, each its two
+// pixel rows -- so every SIMD holds two waves that cover each other's non-MFMA instructions.  Same MFMAs per SIMD, the B
+// fragments are read twice (LDS: 48 B/clk per CU), a wave keeps its own M-tile's weights of a whole group in registers (72)
+// and replaces each tap's behind its MFMAs (as WAHEAD above).  Split-format input only.
+__global__ __launch_bounds__(512, 1) void conv3x3_x3m_kernel(const ConvX3Params p) {
+    constexpr int CX_ROWS = 2, CX_TY = 8, CX_PH = CX_TY + 2;
+    constexpr int CX_TASKS = CX_PH * CX_PW * 2;
+    constexpr int CX_ITERS = (CX_TASKS + 511) / 512;
+    __shared__ __attribute__((aligned(16))) bf16x8 stage[2][2][2][CX_PH][CX_PW];   // [buffer][hi, lo][k-half][row][col]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = wave >> 2, rw = wave & 3;
+    const int h = lane >> 5, px = lane & 31;
+    const int x0 = blockIdx.x * CX_TX, y0 = blockIdx.y * CX_TY, b = blockIdx.z;
+    const size_t plane = (size_t)p.H * p.W;
+    const int ngroups = p.Cin / 16;
+    int t_off[CX_ITERS], t_lds[CX_ITERS], t_half[CX_ITERS];
+#pragma unroll
+    for (int i = 0; i < CX_ITERS; ++i) {
+        const int task = tid + 512 * i;
+        const bool has = task < CX_TASKS;
+        const int kh = task / (CX_PH * CX_PW), rem = task - kh * (CX_PH * CX_PW);
+        const int row = rem / CX_PW, col = rem - row * CX_PW;
+        const int y = y0 + row - 1, x = x0 + col - 1;
+        const bool inside = has && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        t_off[i] = inside ? y * p.W + x : -1;
+        t_lds[i] = has ? (kh * CX_PH + row) * CX_PW + col : -1;
+        t_half[i] = kh;
+    }
+    u32x4 xh_[CX_ITERS], xl_[CX_ITERS];
+    const u32x4* __restrict__ xs_b = p.xs_in + (size_t)b * p.xs_bs;
+    auto stage_load = [&](const int g) {
+#pragma unroll
+        for (int i = 0; i < CX_ITERS; ++i) {
+            const u32x4* __restrict__ src = xs_b + (size_t)(2 * (2 * g + t_half[i])) * plane;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            xh_[i] = t_off[i] >= 0 ? src[t_off[i]] : z;
+            xl_[i] = t_off[i] >= 0 ? src[plane + t_off[i]] : z;
+        }
+    };
+    auto stage_store = [&](const int buf) {
+        bf16x8* __restrict__ hi = &stage[buf][0][0][0][0];
+        bf16x8* __restrict__ lo = &stage[buf][1][0][0][0];
+#pragma unroll
+        for (int i = 0; i < CX_ITERS; ++i) {
+            if (t_lds[i] < 0) continue;
+            hi[t_lds[i]] = __builtin_bit_cast(bf16x8, xh_[i]);
+            lo[t_lds[i]] = __builtin_bit_cast(bf16x8, xl_[i]);
+        }
+    };
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.wx, 0, (int)((size_t)ngroups * 9 * 4 * PIECE_BYTES), 0x00020000);
+    const int lane_off = lane * 16 + mt * 2 * PIECE_BYTES;       // this wave's M-tile: pieces 2 mt (hi), 2 mt + 1 (lo)
+    f32x4 Wg[9][2];
+    auto load_tap = [&](auto tap_tag, const int g) {
+        constexpr int T = decltype(tap_tag)::value;
+        Wg[T][0] = ld_piece(wrs, lane_off, (g * 9 + T) * 4 * PIECE_BYTES);
+        Wg[T][1] = ld_piece(wrs, lane_off + PIECE_BYTES, (g * 9 + T) * 4 * PIECE_BYTES);
+    };
+    f32x16 acc[CX_ROWS];
+#pragma unroll
+    for (int r = 0; r < CX_ROWS; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[r][e] = 0.0f;
+
+    load_tap(IC<0>{}, 0); load_tap(IC<1>{}, 0); load_tap(IC<2>{}, 0); load_tap(IC<3>{}, 0); load_tap(IC<4>{}, 0);
+    load_tap(IC<5>{}, 0); load_tap(IC<6>{}, 0); load_tap(IC<7>{}, 0); load_tap(IC<8>{}, 0);
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int g = 0; g < ngroups; ++g) {
+        const int buf = g & 1;
+        const bool more = g + 1 < ngroups;
+        if (more) stage_load(g + 1);
+        const bf16x8* __restrict__ sh = &stage[buf][0][h][CX_ROWS * rw][px];
+        const bf16x8* __restrict__ sl = &stage[buf][1][h][CX_ROWS * rw][px];
+        bf16x8 Bf[2][CX_ROWS][2];
+        auto read_b = [&](auto tap_tag) {
+            constexpr int tap = decltype(tap_tag)::value;
+            constexpr int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int r = 0; r < CX_ROWS; ++r) {
+                Bf[tap & 1][r][0] = sh[(r + ky) * CX_PW + kx];
+                Bf[tap & 1][r][1] = sl[(r + ky) * CX_PW + kx];
+            }
+        };
+        read_b(IC<0>{});
+        auto tap_step = [&](auto tap_tag) {
+            constexpr int tap = decltype(tap_tag)::value;
+            if constexpr (tap < 8) read_b(IC<tap + 1>{});
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, Wg[tap][0]), wl = __builtin_bit_cast(bf16x8, Wg[tap][1]);
+            acc[0] = MFMA_BF16(wl, Bf[tap & 1][0][0], acc[0]);
+            acc[1] = MFMA_BF16(wl, Bf[tap & 1][1][0], acc[1]);
+            acc[0] = MFMA_BF16(wh, Bf[tap & 1][0][1], acc[0]);
+            acc[1] = MFMA_BF16(wh, Bf[tap & 1][1][1], acc[1]);
+            acc[0] = MFMA_BF16(wh, Bf[tap & 1][0][0], acc[0]);
+            acc[1] = MFMA_BF16(wh, Bf[tap & 1][1][0], acc[1]);
+            load_tap(tap_tag, more ? g + 1 : g);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        tap_step(IC<0>{}); tap_step(IC<1>{}); tap_step(IC<2>{}); tap_step(IC<3>{}); tap_step(IC<4>{});
+        tap_step(IC<5>{}); tap_step(IC<6>{}); tap_step(IC<7>{}); tap_step(IC<8>{});
+        if (more) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int x = x0 + px;
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int r = 0; r < CX_ROWS; ++r) {
+        const int y = y0 + CX_ROWS * rw + r;
+        if (y >= p.H || x >= p.W) continue;
+        const size_t pix = (size_t)y * p.W + x;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = 32 * mt + 8 * (e >> 2) + (e & 3) + 4 * h;
+            float v = acc[r][e] + p.bias[co];
+            if (p.relu) v = relu0(v);
+            if (p.res) v += p.res[(size_t)b * p.res_bs + (size_t)co * plane + pix];
+            p.out[(size_t)b * p.out_bs + (size_t)co * plane + pix] = v;
+            acc[r][e] = v;
+        }
+        if (p.xs_out) {
+            u32x2_* __restrict__ dst = reinterpret_cast<u32x2_*>(p.xs_out + (size_t)b * p.xs_bs);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bf16x4 vh, vl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = acc[r][4 * q + i];
+                    const __bf16 a = (__bf16)v;
+                    vh[i] = a;
+                    vl[i] = (__bf16)(v - (float)a);
+                }
+                const size_t g8 = (size_t)(p.xs_out_g8 + 4 * mt + q);
+                dst[((2 * g8 + 0) * plane + pix) * 2 + h] = __builtin_bit_cast(u32x2_, vh);
+                dst[((2 * g8 + 1) * plane + pix) * 2 + h] = __builtin_bit_cast(u32x2_, vl);
+            }
+        }
+    }
+}
+
 // fp32 planes -> the split format (the block input, written by the 1x1 fusion layer in planes): C / 8 channel groups
 struct SplitParams {
     const float* in;
@@ -319,18 +467,19 @@ __global__ __launch_bounds__(256) void planes_to_split_kernel(const SplitParams 
 extern "C" {
 
 static int launch_conv_x3(void* stream, const ConvX3Params& p) {
-    // two pixel rows per wave (every weight piece feeds 3 MFMAs); with at most ~1.5 such workgroups per CU the form that
-    // keeps a group's weights in registers.  DIINN_ENC_X3_ROWS forces 1 row / 2 rows / 3 = 2 rows + weights a group ahead
-    // (the one-row form -- twice the workgroups -- measured slower at every map size the trunk sends here: 256x256 9.4 vs
-    // 9.0 ms per trunk; it stays for maps of a few blocks)
+    // two pixel rows per wave (every weight piece feeds 3 MFMAs).  Below two such workgroups per CU the eight-wave form
+    // (conv3x3_x3m_kernel; per trunk 192x192 8.2 -> 7.2 ms, 256x256 9.1 -> 8.8, 320x320 16.2 -> 14.7; from 384x384 on the
+    // four-wave ring form is faster: 21.3 vs 22.5, 512x512 32.9 vs 33.7).  DIINN_ENC_X3_ROWS forces 1 row / 2 rows (ring) /
+    // 3 = four waves + a group's weights in registers (layers not in the split format use this one) / 4 = eight waves
     const long long wg2 = (long long)((p.W + CX_TX - 1) / CX_TX) * ((p.H + 7) / 8) * p.B;
     const long long force = knob(diinn_knobs().enc_x3_rows);
     const bool two = force ? force >= 2 : wg2 >= 64;
-    const bool ahead = force ? force == 3 : (two && wg2 <= 384);
+    const bool ahead = force ? force >= 3 : (two && wg2 < 512);
     const dim3 grid((unsigned)((p.W + CX_TX - 1) / CX_TX), (unsigned)((p.H + (two ? 7 : 3)) / (two ? 8 : 4)), (unsigned)p.B);
     const hipStream_t st = (hipStream_t)stream;
     if (p.xs_in) {
-        if (ahead) hipLaunchKernelGGL((conv3x3_x3_kernel<2, true, true>), grid, dim3(256), 0, st, p);
+        if (ahead && force != 3) hipLaunchKernelGGL(conv3x3_x3m_kernel, grid, dim3(512), 0, st, p);   // eight waves: two per SIMD
+        else if (ahead) hipLaunchKernelGGL((conv3x3_x3_kernel<2, true, true>), grid, dim3(256), 0, st, p);
         else if (two) hipLaunchKernelGGL((conv3x3_x3_kernel<2, true, false>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv3x3_x3_kernel<1, true, false>), grid, dim3(256), 0, st, p);
     } else {

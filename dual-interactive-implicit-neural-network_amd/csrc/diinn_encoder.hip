@@ -649,7 +649,7 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     float* gff_in = workspace_dev + (size_t)2 * B * 576 * hw;                    // [B,1024,H,W]
     float* tmp = gff_in + (size_t)B * 1024 * hw;                                 // [B,64,H,W]
     // split-bf16 3x3 layers (csrc/diinn_conv_x3.hip; optional): blocks of 32 x 8 pixels; they pay from about 0.8 blocks
-    // per CU on (measured per trunk, x3 vs Winograd: 160x160 7.8 vs 6.2 ms, 192x192 8.2 vs 9.3, 224x224 8.6 vs 11.4, 256x256 9.1 vs 11.8,
+    // per CU on (measured per trunk, x3 vs Winograd: 160x160 7.8 vs 6.2 ms, 192x192 7.2 vs 9.3, 224x224 7.5 vs 11.4, 256x256 8.6 vs 11.8,
     // 384x384 20.8 vs 28.0, 512x512 32.9 vs 46.5)
     const bool x3 = packed_x3_dev && (long long)B * hw >= knob(diinn_knobs().enc_x3_min);
     const float* w = packed_dev;

@@ -129,8 +129,8 @@ class RDN(nn.Module):
     # optional: the 3x3 layers in split-bf16 arithmetic on the bf16 MFMA (csrc/diinn_conv_x3.hip) on maps of >= 32,768
     # pixels: hi + lo bf16 operands, three products per term, fp32 accumulation; inside a dense block the activations are
     # exchanged already split.  Per layer ~4e-6 of max|out| against float64; the whole trunk differs from the fp32 one by
-    # ~3e-6 of max|feat| and the decoded image by ~2e-8.  Measured per trunk: 256x256 11.8 -> 9.1 ms,
-    # 384x384 28.0 -> 20.8 ms, 512x512 46.5 -> 32.9 ms; 192x192 9.3 -> 8.2 ms; below ~180x180 the Winograd kernels stay faster and are used.
+    # ~3e-6 of max|feat| and the decoded image by ~2e-8.  Measured per trunk: 192x192 9.3 -> 7.2 ms,
+    # 256x256 11.8 -> 8.6 ms, 384x384 28.2 -> 21.4 ms, 512x512 46.7 -> 33.1 ms; below ~180x180 the Winograd kernels stay faster and are used.
     hip_split_bf16: bool = False
 
     def __init__(self, G0: int = 64, RDNkSize: int = 3, RDNconfig: str = "B", n_colors: int = 3):

@@ -279,7 +279,7 @@ def test_conv3x3_split_bf16_matches_float64(knobs):
     dev = torch.device("cuda:0")
     torch.manual_seed(5)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for rows in (1, 2):
+    for rows in (1, 2, 3):                                        # one row / two rows (ring) / two rows + a group's weights in registers
         knobs("DIINN_ENC_X3_ROWS", rows)
         for (b, cin, h, w, relu, use_res) in [(1, 64, 48, 48, 1, 0), (2, 320, 13, 21, 1, 0), (1, 512, 5, 3, 0, 1),
                                               (1, 128, 33, 70, 1, 0), (3, 16, 9, 65, 0, 1), (1, 576, 1, 1, 1, 0)]:
@@ -321,7 +321,8 @@ def test_trunk_with_split_bf16_layers_tracks_the_fp32_trunk(knobs):
     enc = net.encoder
     knobs("DIINN_ENC_X3_MIN", 0)
     with torch.no_grad():
-        for (b, h, w) in [(1, 96, 100), (2, 40, 72)]:
+        for (b, h, w, form) in [(1, 96, 100, 0), (2, 40, 72, 0), (1, 45, 67, 4), (1, 64, 40, 2), (1, 33, 35, 1)]:
+            knobs("DIINN_ENC_X3_ROWS", form)                      # 0: the launcher's choice; every kernel form inside the trunk
             x = torch.rand(b, 3, h, w, device=dev)
             enc.hip_split_bf16 = False
             f32 = enc(x)
