@@ -169,3 +169,13 @@ def test_untrusted_checkpoint_is_refused_with_the_opt_in_named(tmp_path, monkeyp
 class _Opaque:
     """stands in for a Lightning callback state object"""
     x = 1
+
+
+def test_set_split_bf16_switches_both_modes():
+    import diinn_amd.modules as M
+    net = M.DIINN(mode=3, init_q=False)
+    assert net.decoder.compute == "f32" and net.encoder.hip_split_bf16 is False
+    assert net.set_split_bf16() is net
+    assert net.decoder.compute == "bf16x3" and net.encoder.hip_split_bf16 is True
+    net.set_split_bf16(False)
+    assert net.decoder.compute == "f32" and net.encoder.hip_split_bf16 is False
