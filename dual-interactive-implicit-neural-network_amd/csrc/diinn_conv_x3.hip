@@ -353,11 +353,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3m_kernel(const ConvX3Params 
         Wg[T][0] = ld_piece(wrs, lane_off, (g * 9 + T) * 4 * PIECE_BYTES);
         Wg[T][1] = ld_piece(wrs, lane_off + PIECE_BYTES, (g * 9 + T) * 4 * PIECE_BYTES);
     };
+    // the accumulators start from the bias (requested with the first loads of the kernel, not at its end)
     f32x16 acc[CX_ROWS];
 #pragma unroll
-    for (int r = 0; r < CX_ROWS; ++r)
+    for (int e = 0; e < 16; ++e) {
+        const float bv = p.bias[32 * mt + 8 * (e >> 2) + (e & 3) + 4 * h];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[r][e] = 0.0f;
+        for (int r = 0; r < CX_ROWS; ++r) acc[r][e] = bv;
+    }
 
     load_tap(IC<0>{}, 0); load_tap(IC<1>{}, 0); load_tap(IC<2>{}, 0); load_tap(IC<3>{}, 0); load_tap(IC<4>{}, 0);
     load_tap(IC<5>{}, 0); load_tap(IC<6>{}, 0); load_tap(IC<7>{}, 0); load_tap(IC<8>{}, 0);
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3m_kernel(const ConvX3Params 
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int co = 32 * mt + 8 * (e >> 2) + (e & 3) + 4 * h;
-            float v = acc[r][e] + p.bias[co];
+            float v = acc[r][e];
             if (p.relu) v = relu0(v);
             if (p.res) v += p.res[(size_t)b * p.res_bs + (size_t)co * plane + pix];
             __builtin_nontemporal_store(v, &p.out[(size_t)b * p.out_bs + (size_t)co * plane + pix]);
