@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, WAHEAD ? 1 : 2) void conv3x3_x3_kernel(const C
                 float v = acc[r][mt][e] + p.bias[co];
                 if (p.relu) v = relu0(v);
                 if (p.res) v += p.res[(size_t)b * p.res_bs + (size_t)co * plane + pix];
-                __builtin_nontemporal_store(v, &p.out[(size_t)b * p.out_bs + (size_t)co * plane + pix]);
+                if (p.out) __builtin_nontemporal_store(v, &p.out[(size_t)b * p.out_bs + (size_t)co * plane + pix]);
                 acc[r][mt][e] = v;
             }
         if (p.xs_out) {
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3m_kernel(const ConvX3Params 
             float v = acc[r][e];
             if (p.relu) v = relu0(v);
             if (p.res) v += p.res[(size_t)b * p.res_bs + (size_t)co * plane + pix];
-            __builtin_nontemporal_store(v, &p.out[(size_t)b * p.out_bs + (size_t)co * plane + pix]);
+            if (p.out) __builtin_nontemporal_store(v, &p.out[(size_t)b * p.out_bs + (size_t)co * plane + pix]);
             acc[r][e] = v;
         }
         if (p.xs_out) {
@@ -473,6 +473,126 @@ __global__ __launch_bounds__(256) void planes_to_split_kernel(const SplitParams 
 
 extern "C" {
 
+// ---------------------------------------------------------------------------------------------------------------------
+// conv1x1_x3_kernel: a block's 1x1 fusion layer (rdn.py:34, 576 -> 64 plus the block input) in the same arithmetic, reading
+// the split format directly: without a halo the B fragment of pixel x, k-half h, channel group g IS the 16-byte vector
+// stored for it, so a lane loads its fragments straight from memory (512 contiguous bytes per half wave) -- no LDS, no
+// barrier, the waves are independent.  A wave owns 64 consecutive pixels (two N-tiles) x 64 outputs; per group of 16
+// channels 4 fragment loads + 4 weight pieces feed 12 MFMAs, one group ahead in registers (L1-bound: 8 KiB per 12 MFMAs
+// and wave; as fast as the fp32 streaming kernel it replaces -- what it buys is that the dense layers need not write
+// their outputs as fp32 planes any more, half of their store burst).  Outputs: the planes of the next block's input and of
+// the global fusion input (fp32, residual added from the block input's planes), and the next block's channel groups 0..7
+// in the split format IN PLACE (a pixel's vectors are read and written by the same lane only).
+struct Conv1X3Params {
+    u32x4* xs;               // [b][72 groups][hi, lo][H*W] x 16 bytes
+    long long xs_bs;
+    const float* wx;         // [group Cin/16][M-tile 2][hi, lo][lane 64][8 bf16]
+    const float* bias;
+    const float* res;        // block input planes [B,64,H,W] (batch stride res_bs)
+    float* o0;               // next block's input planes
+    float* o1;               // slice of the global fusion input
+    long long res_bs, o0_bs, o1_bs;
+    int G, B, H, W;
+};
+
+__global__ __launch_bounds__(256, 2) void conv1x1_x3_kernel(const Conv1X3Params p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, px = lane & 31;
+    const int b = blockIdx.y;
+    const size_t plane = (size_t)p.H * p.W;
+    const size_t base = (size_t)blockIdx.x * 256 + 64 * wave;
+    if (base >= plane) return;
+    size_t pix[2];
+    bool in[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const size_t q = base + 32 * t + px;
+        in[t] = q < plane;
+        pix[t] = in[t] ? q : plane - 1;
+    }
+    const u32x4* __restrict__ xs_b = p.xs + (size_t)b * p.xs_bs;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wx, 0, p.G * 4 * PIECE_BYTES, 0x00020000);
+    const int lane_off = lane * 16;
+    u32x4 Bf[2][2][2];            // [set][tile][hi, lo]
+    f32x4 Wt[2][4];
+    auto fetch = [&](const int set, const int g) {
+        const u32x4* __restrict__ src = xs_b + (size_t)(2 * (2 * g + h)) * plane;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            Bf[set][t][0] = src[pix[t]];
+            Bf[set][t][1] = src[plane + pix[t]];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Wt[set][i] = ld_piece(wrs, lane_off + i * PIECE_BYTES, g * 4 * PIECE_BYTES);
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float bv = p.bias[32 * mt + 8 * (e >> 2) + (e & 3) + 4 * h];
+            acc[0][mt][e] = bv;
+            acc[1][mt][e] = bv;
+        }
+    auto mma = [&](const int set) {
+        const bf16x8 wh0 = __builtin_bit_cast(bf16x8, Wt[set][0]), wl0 = __builtin_bit_cast(bf16x8, Wt[set][1]);
+        const bf16x8 wh1 = __builtin_bit_cast(bf16x8, Wt[set][2]), wl1 = __builtin_bit_cast(bf16x8, Wt[set][3]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, Bf[set][t][0]), xl = __builtin_bit_cast(bf16x8, Bf[set][t][1]);
+            acc[t][0] = MFMA_BF16(wl0, xh, acc[t][0]);
+            acc[t][1] = MFMA_BF16(wl1, xh, acc[t][1]);
+            acc[t][0] = MFMA_BF16(wh0, xl, acc[t][0]);
+            acc[t][1] = MFMA_BF16(wh1, xl, acc[t][1]);
+            acc[t][0] = MFMA_BF16(wh0, xh, acc[t][0]);
+            acc[t][1] = MFMA_BF16(wh1, xh, acc[t][1]);
+        }
+    };
+    fetch(0, 0);
+    for (int g = 0; g < p.G; g += 2) {                           // G is even (576 / 16 = 36)
+        fetch(1, g + 1);
+        mma(0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(0, g + 2 < p.G ? g + 2 : g + 1);
+        mma(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    u32x2_* __restrict__ dst = reinterpret_cast<u32x2_*>(p.xs + (size_t)b * p.xs_bs);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (!in[t]) continue;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = 32 * mt + 8 * (e >> 2) + (e & 3) + 4 * h;
+                const float v = acc[t][mt][e] + p.res[(size_t)b * p.res_bs + (size_t)co * plane + pix[t]];
+                __builtin_nontemporal_store(v, &p.o0[(size_t)b * p.o0_bs + (size_t)co * plane + pix[t]]);
+                __builtin_nontemporal_store(v, &p.o1[(size_t)b * p.o1_bs + (size_t)co * plane + pix[t]]);
+                acc[t][mt][e] = v;
+            }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bf16x4 vh, vl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = acc[t][mt][4 * q + i];
+                    const __bf16 a = (__bf16)v;
+                    vh[i] = a;
+                    vl[i] = (__bf16)(v - (float)a);
+                }
+                const size_t g8 = (size_t)(4 * mt + q);
+                __builtin_nontemporal_store(__builtin_bit_cast(u32x2_, vh), &dst[((2 * g8 + 0) * plane + pix[t]) * 2 + h]);
+                __builtin_nontemporal_store(__builtin_bit_cast(u32x2_, vl), &dst[((2 * g8 + 1) * plane + pix[t]) * 2 + h]);
+            }
+    }
+}
+
 static int launch_conv_x3(void* stream, const ConvX3Params& p) {
     // two pixel rows per wave (every weight piece feeds 3 MFMAs).  Below two such workgroups per CU the eight-wave form
     // (conv3x3_x3m_kernel; per trunk 192x192 8.2 -> 7.2 ms, 256x256 9.1 -> 8.8, 320x320 16.2 -> 14.7; from 384x384 on the
@@ -509,17 +629,32 @@ int diinn_conv3x3_x3(void* stream, const float* in_dev, long long in_bs, int Cin
     return launch_conv_x3(stream, p);
 }
 
-// the same layer inside a dense block (diinn_rdn_forward_x3): inputs from the split-format buffer xs (all Cin channels),
-// outputs to the planes and, when xs_out_g8 >= 0, to channel groups xs_out_g8 .. + 7 of the same buffer
+// the same layer inside the trunk (diinn_rdn_forward_x3): inputs from the planes `in_dev`, or -- in_dev null -- all Cin channels
+// from the split-format buffer xs; outputs to the planes `out_dev` (may be null) and, when xs_out_g8 >= 0, to channel groups
+// xs_out_g8 .. + 7 of xs
 __attribute__((visibility("hidden")))
-int diinn_conv3x3_x3_split(void* stream, float* xs_dev, long long xs_bs16, int xs_out_g8, int Cin, const float* wx_dev,
-                           const float* bias_dev, float* out_dev, long long out_bs, int relu, int B, int H, int W) {
+int diinn_conv3x3_x3_split(void* stream, const float* in_dev, long long in_bs, float* xs_dev, long long xs_bs16, int xs_out_g8,
+                           int Cin, const float* wx_dev, const float* bias_dev, float* out_dev, long long out_bs, int relu,
+                           int B, int H, int W) {
     if (Cin < 16 || Cin % 16 || Cin > 1024) return DIINN_ERR_UNSUPPORTED;
     if ((long long)H * W > 0x7fffffffLL / 4) return DIINN_ERR_TOO_LARGE;
-    ConvX3Params p{nullptr, wx_dev, bias_dev, nullptr, out_dev, 0, out_bs, 0, Cin, B, H, W, relu,
-                   reinterpret_cast<const u32x4*>(xs_dev), xs_out_g8 >= 0 ? reinterpret_cast<u32x4*>(xs_dev) : nullptr, xs_bs16,
-                   xs_out_g8 >= 0 ? xs_out_g8 : 0};
+    ConvX3Params p{in_dev, wx_dev, bias_dev, nullptr, out_dev, in_bs, out_bs, 0, Cin, B, H, W, relu,
+                   in_dev ? nullptr : reinterpret_cast<const u32x4*>(xs_dev),
+                   xs_out_g8 >= 0 ? reinterpret_cast<u32x4*>(xs_dev) : nullptr, xs_bs16, xs_out_g8 >= 0 ? xs_out_g8 : 0};
     return launch_conv_x3(stream, p);
+}
+
+// a block's 1x1 fusion layer from the split-format buffer (Cin % 32 == 0): see conv1x1_x3_kernel
+__attribute__((visibility("hidden")))
+int diinn_conv1x1_x3_split(void* stream, float* xs_dev, long long xs_bs16, int Cin, const float* wx_dev, const float* bias_dev,
+                           const float* res_dev, long long res_bs, float* o0_dev, long long o0_bs, float* o1_dev, long long o1_bs,
+                           int B, int H, int W) {
+    if (Cin < 32 || Cin % 32 || Cin > 1024) return DIINN_ERR_UNSUPPORTED;
+    Conv1X3Params p{reinterpret_cast<u32x4*>(xs_dev), xs_bs16, wx_dev, bias_dev, res_dev, o0_dev, o1_dev, res_bs, o0_bs, o1_bs,
+                    Cin / 16, B, H, W};
+    const long long plane = (long long)H * W;
+    hipLaunchKernelGGL(conv1x1_x3_kernel, dim3((unsigned)((plane + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
 }
 
 __attribute__((visibility("hidden")))

@@ -311,8 +311,13 @@ int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int 
 // diinn_conv_x3.hip: a split-bf16 3x3 layer reading (and optionally extending) the split-format buffer of a dense block;
 // fp32 planes -> that format (diinn_rdn_forward_x3)
 extern "C" __attribute__((visibility("hidden")))
-int diinn_conv3x3_x3_split(void* stream, float* xs_dev, long long xs_bs16, int xs_out_g8, int Cin, const float* wx_dev,
-                           const float* bias_dev, float* out_dev, long long out_bs, int relu, int B, int H, int W);
+int diinn_conv3x3_x3_split(void* stream, const float* in_dev, long long in_bs, float* xs_dev, long long xs_bs16, int xs_out_g8,
+                           int Cin, const float* wx_dev, const float* bias_dev, float* out_dev, long long out_bs, int relu,
+                           int B, int H, int W);
+extern "C" __attribute__((visibility("hidden")))
+int diinn_conv1x1_x3_split(void* stream, float* xs_dev, long long xs_bs16, int Cin, const float* wx_dev, const float* bias_dev,
+                           const float* res_dev, long long res_bs, float* o0_dev, long long o0_bs, float* o1_dev, long long o1_bs,
+                           int B, int H, int W);
 extern "C" __attribute__((visibility("hidden")))
 int diinn_planes_to_split(void* stream, const float* in_dev, long long in_bs, int C, float* xs_dev, long long xs_bs16,
                           int B, int H, int W);

@@ -628,10 +628,11 @@ size_t diinn_rdn_x3_workspace_floats(int B, int H, int W) {
 }
 
 size_t diinn_rdn_x3_packed_floats(void) {
-    // the 3x3 layers only, 9 taps x (hi + lo) bf16 = 9 floats per (output, input) pair: SFENet2, 16 x 8 dense convs, GFF.1
+    // the 3x3 layers, 9 taps x (hi + lo) bf16 = 9 floats per (output, input) pair: SFENet2, 16 x 8 dense convs, GFF.1 in
+    // execution order; then the 16 local-fusion 1x1 layers, 1 float per pair
     size_t n = (size_t)2 * 64 * 64 * 9;
     for (int c = 0; c < 8; ++c) n += (size_t)16 * 64 * (64 + 64 * c) * 9;
-    return n;
+    return n + (size_t)16 * 64 * 576;
 }
 
 static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
@@ -669,29 +670,44 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
         bias += 64;
         return s;
     };
-    // SFENet2: 64 -> 64 into channels [0,64) of the first dense buffer (rdn.py:97)
-    st = conv(sfe1_dev, 64 * hw, 64, 9, nullptr, 0, buf[0], 576 * hw, nullptr, 0, 0);
-    if (st) return st;
     float* xs = tmp + (size_t)B * 64 * hw;                                       // x3 only: the block's channels in split format
     const long long xs_bs16 = 144 * hw;                                          // 72 groups x (hi, lo) planes of 16-byte pixels
+    size_t n3 = (size_t)2 * 64 * 64 * 9;
+    for (int c = 0; c < 8; ++c) n3 += (size_t)16 * 64 * (64 + 64 * c) * 9;
+    const float* wx1 = packed_x3_dev ? packed_x3_dev + n3 : nullptr;             // the fusion layers' split-bf16 weights
+    // SFENet2: 64 -> 64 into channels [0,64) of the first dense buffer (rdn.py:97); x3: also groups 0..7 of the split buffer
+    if (x3) {
+        st = diinn_conv3x3_x3_split(stream, sfe1_dev, 64 * hw, xs, xs_bs16, 0, 64, wx, bias, buf[0], 576 * hw, 0, B, H, W);
+        w += (size_t)64 * 64 * 9; wu += (size_t)64 * 64 * 16; wx += (size_t)64 * 64 * 9; bias += 64;
+    } else {
+        st = conv(sfe1_dev, 64 * hw, 64, 9, nullptr, 0, buf[0], 576 * hw, nullptr, 0, 0);
+    }
+    if (st) return st;
     for (int d = 0; d < 16; ++d) {
         float* cur = buf[d & 1];
         float* nxt = buf[(d + 1) & 1];
         if (x3) {
-            // the block input (fp32 planes, written by the previous fusion layer) once into the split format; every dense conv
-            // then reads ALL its inputs from there (two 16-byte copies per staged pixel instead of eight loads and a
-            // conversion, redone by each of the up to eight layers that read a channel) and appends its own outputs to it
-            st = diinn_planes_to_split(stream, cur, 576 * hw, 64, xs, xs_bs16, B, H, W);
-            if (st) return st;
+            // inside the trunk the layers exchange their activations already split (csrc/diinn_conv_x3.hip): every dense conv
+            // reads ALL its inputs from the split buffer (two 16-byte copies per staged pixel instead of eight loads and a
+            // conversion, redone by each of the up to eight layers that read a channel) and appends its outputs to it --
+            // ONLY to it: the fp32 planes of the dense channels have no reader left, which halves the store burst at the end
+            // of every layer (at 256x256 the epilogue's 33 MB were 10 of a layer's 23-92 us); the fusion layer reads the
+            // split buffer whole and writes the next block's first 64 channels back in place, next to the planes
             for (int c = 0; c < 8; ++c) {
-                st = diinn_conv3x3_x3_split(stream, xs, xs_bs16, c < 7 ? 8 * (c + 1) : -1, 64 * (c + 1), wx, bias,
-                                            cur + (size_t)64 * (c + 1) * hw, 576 * hw, 1, B, H, W);
+                st = diinn_conv3x3_x3_split(stream, nullptr, 0, xs, xs_bs16, 8 * (c + 1), 64 * (c + 1), wx, bias,
+                                            nullptr, 0, 1, B, H, W);
                 if (st) return st;
                 w += (size_t)64 * 64 * (c + 1) * 9;
                 wu += (size_t)64 * 64 * (c + 1) * 16;
                 wx += (size_t)64 * 64 * (c + 1) * 9;
                 bias += 64;
             }
+            st = diinn_conv1x1_x3_split(stream, xs, xs_bs16, 576, wx1 + (size_t)d * 64 * 576, bias, cur, 576 * hw, nxt, 576 * hw,
+                                        gff_in + (size_t)64 * d * hw, 1024 * hw, B, H, W);
+            if (st) return st;
+            w += (size_t)64 * 576;
+            bias += 64;
+            continue;
         } else
         for (int c = 0; c < 8; ++c) {                            // dense 3x3 convs: read channels [0, 64(c+1)), append 64 (rdn.py:15-17)
             st = conv(cur, 576 * hw, 64 * (c + 1), 9, nullptr, 0, cur + (size_t)64 * (c + 1) * hw, 576 * hw, nullptr, 0, 1);

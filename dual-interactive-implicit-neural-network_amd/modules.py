@@ -99,17 +99,18 @@ def pack_conv_wino(weight: torch.Tensor) -> torch.Tensor:
 
 
 def pack_conv_x3(weight: torch.Tensor) -> torch.Tensor:
-    """3x3 conv weight [64, Cin, 3, 3] (Cin % 16 == 0) -> the split-bf16 image ``diinn_conv3x3_x3`` reads
-    (include/diinn_hip.h): every weight as hi = bf16(w), lo = bf16(w - hi), laid out
-    [group Cin/16][tap 9][M-tile 2][hi, lo][lane 64][8 bf16] with cout = 32 mt + (lane & 31) and input channel =
-    16 group + 8 (lane >> 5) + j; returned as float32 words (two bf16 each), 9 * 64 * Cin of them."""
+    """Conv weight [64, Cin, k, k] (k = 3 or 1, Cin % 16 == 0) -> the split-bf16 image ``diinn_conv3x3_x3`` and the trunk's
+    split-bf16 fusion layer read (include/diinn_hip.h): every weight as hi = bf16(w), lo = bf16(w - hi), laid out
+    [group Cin/16][tap k*k][M-tile 2][hi, lo][lane 64][8 bf16] with cout = 32 mt + (lane & 31) and input channel =
+    16 group + 8 (lane >> 5) + j; returned as float32 words (two bf16 each), k*k * 64 * Cin of them."""
     co, cin, kh, kw = weight.shape
-    if co != 64 or cin % 16 or (kh, kw) != (3, 3):
+    if co != 64 or cin % 16 or (kh, kw) not in ((3, 3), (1, 1)):
         raise ValueError(f"unsupported convolution shape {tuple(weight.shape)}")
+    taps = kh * kw
     w = weight.detach().to(torch.float32)
     hi = w.to(torch.bfloat16)
     lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
-    parts = torch.stack([hi, lo], 0).reshape(2, 2, 32, cin // 16, 2, 8, 9)          # [part, mt, m, g, h, j, tap]
+    parts = torch.stack([hi, lo], 0).reshape(2, 2, 32, cin // 16, 2, 8, taps)       # [part, mt, m, g, h, j, tap]
     img = parts.permute(3, 6, 1, 0, 4, 2, 5).contiguous()                           # [g, tap, mt, part, h, m, j]
     return img.view(torch.int16).reshape(-1, 2).view(torch.int32).reshape(-1).view(torch.float32)
 
@@ -170,7 +171,9 @@ class RDN(nn.Module):
         self._hip_packed(device)
         if getattr(self, "_hip_x3", None) is None:
             layers = self._trunk_layers()
-            self._hip_x3 = torch.cat([pack_conv_x3(l.weight.to(device)) for l in layers if l.kernel_size == (3, 3)]).to(device)
+            # the 130 3x3 layers in execution order, then the 16 local-fusion 1x1 layers
+            self._hip_x3 = torch.cat([pack_conv_x3(l.weight.to(device)) for l in layers if l.kernel_size == (3, 3)] +
+                                     [pack_conv_x3(rdb.LFF.weight.to(device)) for rdb in self.RDBs]).to(device)
         return self._hip_x3
 
     def _forward_hip_trunk(self, shallow):

@@ -362,10 +362,12 @@ int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* 
  * diinn_conv3x3_x3: one 3x3 zero-padded 64-output convolution over Cin % 16 == 0 input planes (addressing and epilogue as
  *   diinn_conv_wino).  packed_x3_dev: [group Cin/16][tap 9][M-tile 2][hi, lo][lane 64][8 bf16] with
  *   value = part(W[32 mt + (lane&31)][16 group + 8 (lane>>5) + j][tap / 3][tap % 3])   (9 * 64 * Cin floats).
- * diinn_rdn_x3_packed_floats: floats of the 130 such weights of the trunk, in execution order.
+ * diinn_rdn_x3_packed_floats: floats of the 130 such weights of the trunk in execution order, followed by the 16 local-fusion
+ *   1x1 weights (64 x 576 each) in the same format with one tap: [group 36][M-tile 2][hi, lo][lane 64][8 bf16].
  * diinn_rdn_x3_workspace_floats: floats of diinn_rdn_forward_x3's workspace (diinn_rdn_workspace_floats + one dense
  *   buffer in the split format the dense blocks' 3x3 layers exchange: [B][72 groups of 8 channels][hi, lo][H][W] x 16 B).
- * diinn_rdn_forward_x3: diinn_rdn_forward_wino with the 3x3 layers on diinn_conv3x3_x3 from B*H*W >= 32768 pixels on
+ * diinn_rdn_forward_x3: diinn_rdn_forward_wino with the 3x3 layers and the local-fusion 1x1 layers in this arithmetic (inside
+ *   the trunk they exchange their activations already split, through the workspace's last buffer) from B*H*W >= 32768 pixels on
  *   (DIINN_ENC_X3_MIN); smaller maps run exactly as diinn_rdn_forward_wino. */
 int    diinn_conv3x3_x3(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
                         const float* packed_x3_dev, const float* bias_dev,
