@@ -471,8 +471,6 @@ __global__ __launch_bounds__(256) void planes_to_split_kernel(const SplitParams 
     dst[plane] = __builtin_bit_cast(u32x4, vl);
 }
 
-extern "C" {
-
 // ---------------------------------------------------------------------------------------------------------------------
 // conv1x1_x3_kernel: a block's 1x1 fusion layer (rdn.py:34, 576 -> 64 plus the block input) in the same arithmetic, reading
 // the split format directly: without a halo the B fragment of pixel x, k-half h, channel group g IS the 16-byte vector
@@ -592,6 +590,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x3_kernel(const Conv1X3Params 
             }
     }
 }
+
+extern "C" {
 
 static int launch_conv_x3(void* stream, const ConvX3Params& p) {
     // two pixel rows per wave (every weight piece feeds 3 MFMAs).  Below two such workgroups per CU the eight-wave form
