@@ -444,33 +444,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3m_kernel(const ConvX3Params 
 // kernel's end-of-kernel write-back -- per trunk at 256x256 8.30 -> 8.00 ms, 512x512 32.5 -> 32.2.  The fp32 Winograd kernel
 // does not gain from the same change: 11.77 vs 11.75 ms.)
 
-// fp32 planes -> the split format (the block input, written by the 1x1 fusion layer in planes): C / 8 channel groups
-struct SplitParams {
-    const float* in;
-    u32x4* xs;
-    long long in_bs, xs_bs;
-    int C8, B, H, W;
-};
-
-__global__ __launch_bounds__(256) void planes_to_split_kernel(const SplitParams p) {
-    const size_t plane = (size_t)p.H * p.W;
-    const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int g8 = blockIdx.y, b = blockIdx.z;
-    if (pix >= plane) return;
-    const float* __restrict__ src = p.in + (size_t)b * p.in_bs + (size_t)8 * g8 * plane + pix;
-    bf16x8 vh, vl;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const float v = src[(size_t)c * plane];
-        const __bf16 a = (__bf16)v;
-        vh[c] = a;
-        vl[c] = (__bf16)(v - (float)a);
-    }
-    u32x4* __restrict__ dst = p.xs + (size_t)b * p.xs_bs + (size_t)2 * g8 * plane + pix;
-    dst[0] = __builtin_bit_cast(u32x4, vh);
-    dst[plane] = __builtin_bit_cast(u32x4, vl);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // conv1x1_x3_kernel: a block's 1x1 fusion layer (rdn.py:34, 576 -> 64 plus the block input) in the same arithmetic, reading
 // the split format directly: without a halo the B fragment of pixel x, k-half h, channel group g IS the 16-byte vector
@@ -654,16 +627,6 @@ int diinn_conv1x1_x3_split(void* stream, float* xs_dev, long long xs_bs16, int C
                     Cin / 16, B, H, W};
     const long long plane = (long long)H * W;
     hipLaunchKernelGGL(conv1x1_x3_kernel, dim3((unsigned)((plane + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, p);
-    return hip_status(hipGetLastError());
-}
-
-__attribute__((visibility("hidden")))
-int diinn_planes_to_split(void* stream, const float* in_dev, long long in_bs, int C, float* xs_dev, long long xs_bs16,
-                          int B, int H, int W) {
-    SplitParams p{in_dev, reinterpret_cast<u32x4*>(xs_dev), in_bs, xs_bs16, C / 8, B, H, W};
-    const long long plane = (long long)H * W;
-    hipLaunchKernelGGL(planes_to_split_kernel, dim3((unsigned)((plane + 255) / 256), (unsigned)(C / 8), (unsigned)B), dim3(256), 0,
-                       (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
 

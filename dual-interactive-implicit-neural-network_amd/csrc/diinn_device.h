@@ -14,7 +14,7 @@
 //   diinn_baselines.hip        LIIF and MetaSR comparison decoders
 //   diinn_encoder.hip          RDN trunk: conv_ksplit kernels (small maps), conv1x1_stream_kernel, sfe1_conv_kernel
 //   diinn_winograd.hip         RDN trunk: conv_wino_kernel / conv_wino_half_kernel (3x3 layers, Winograd F(2x2,3x3))
-//   diinn_conv_x3.hip          RDN trunk: conv3x3_x3_kernel (3x3 layers in split-bf16 arithmetic, optional), planes_to_split_kernel
+//   diinn_conv_x3.hip          RDN trunk, optional split-bf16 arithmetic: conv3x3_x3m_kernel / conv3x3_x3_kernel (3x3 layers), conv1x1_x3_kernel (fusion)
 //   diinn_misc.hip             device sine / axis-table test hooks, error state
 //   diinn_host.cpp (host only) weight packing, coordinate tables, size queries, the knob table (diinn_knobs.h)
 #pragma once
@@ -308,8 +308,8 @@ int launch_P_wino(void* stream, const float* feat_dev, const float* packed_dev, 
 // diinn_bf16.hip: the bf16 decode of HR rows [p.y0, p.y1) (grid of the one-tile kernel: gx, gy, gz)
 __attribute__((visibility("hidden")))
 int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int gz, int sin_mode);
-// diinn_conv_x3.hip: a split-bf16 3x3 layer reading (and optionally extending) the split-format buffer of a dense block;
-// fp32 planes -> that format (diinn_rdn_forward_x3)
+// diinn_conv_x3.hip: a split-bf16 3x3 layer reading planes or the trunk's split-format buffer (and optionally extending it);
+// a block's 1x1 fusion layer from that buffer (diinn_rdn_forward_x3)
 extern "C" __attribute__((visibility("hidden")))
 int diinn_conv3x3_x3_split(void* stream, const float* in_dev, long long in_bs, float* xs_dev, long long xs_bs16, int xs_out_g8,
                            int Cin, const float* wx_dev, const float* bias_dev, float* out_dev, long long out_bs, int relu,
@@ -318,9 +318,6 @@ extern "C" __attribute__((visibility("hidden")))
 int diinn_conv1x1_x3_split(void* stream, float* xs_dev, long long xs_bs16, int Cin, const float* wx_dev, const float* bias_dev,
                            const float* res_dev, long long res_bs, float* o0_dev, long long o0_bs, float* o1_dev, long long o1_bs,
                            int B, int H, int W);
-extern "C" __attribute__((visibility("hidden")))
-int diinn_planes_to_split(void* stream, const float* in_dev, long long in_bs, int C, float* xs_dev, long long xs_bs16,
-                          int B, int H, int W);
 // diinn_bf16.hip: the split-bf16 decode (DIINN_COMPUTE_BF16X3) of HR rows [p.y0, p.y1)
 __attribute__((visibility("hidden")))
 int launch_decode_bf16x3(void* stream, const DecodeParams& p, int gx, int gy, int gz, int sin_mode);

@@ -130,8 +130,8 @@ class RDN(nn.Module):
     # optional: the 3x3 layers in split-bf16 arithmetic on the bf16 MFMA (csrc/diinn_conv_x3.hip) on maps of >= 32,768
     # pixels: hi + lo bf16 operands, three products per term, fp32 accumulation; inside a dense block the activations are
     # exchanged already split.  Per layer ~4e-6 of max|out| against float64; the whole trunk differs from the fp32 one by
-    # ~3e-6 of max|feat| and the decoded image by ~2e-8.  Measured per trunk: 192x192 9.4 -> 7.0 ms,
-    # 256x256 11.8 -> 8.2 ms, 384x384 28.4 -> 20.9 ms, 512x512 46.7 -> 32.5 ms; below ~180x180 the Winograd kernels stay faster and are used.
+    # ~3e-6 of max|feat| and the decoded image by ~3e-8.  Measured per trunk: 192x192 9.4 -> 6.7 ms,
+    # 256x256 11.85 -> 7.9 ms, 384x384 28.1 -> 20.1 ms, 512x512 46.6 -> 31.4 ms; below ~180x180 the Winograd kernels stay faster and are used.
     hip_split_bf16: bool = False
 
     def __init__(self, G0: int = 64, RDNkSize: int = 3, RDNconfig: str = "B", n_colors: int = 3):
@@ -317,7 +317,7 @@ class DIINN(nn.Module, _GraphReplay):
     def set_split_bf16(self, enabled: bool = True) -> "DIINN":
         """Switch both optional split-bf16 modes (not in the reference; DESIGN.md sections 4.3b and 4.8): the decoder's
         per-pixel layers (``decoder.compute = "bf16x3"``) and the encoder's 3x3 layers (``encoder.hip_split_bf16``).  The
-        output stays within the reference tolerance (1e-4 x max(1, |ref|)); 256x256 x4: 17.9 -> 10.5 ms per forward."""
+        output stays within the reference tolerance (1e-4 x max(1, |ref|)); 256x256 x4: 17.9 -> 10.1 ms per forward."""
         self.decoder.compute = "bf16x3" if enabled else "f32"
         self.encoder.hip_split_bf16 = bool(enabled)
         return self
