@@ -496,6 +496,7 @@ def main():
     p_algo = C.c_int(0)
     N.check(job.lib.diinn_p_launch_info(1, H, W, bd.r0, bd.r1, job.comp, C.byref(p_algo)), "diinn_p_launch_info")
     p_wino = p_algo.value == N.P_ALGO_WINOGRAD
+    p_x3 = p_algo.value == N.P_ALGO_DIRECT_BF16X3
     del r
     torch.cuda.empty_cache()
 
@@ -543,7 +544,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         bf = args.compute != "f32"
         peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
-        p_peak = PEAK_BF16_MFMA_TFLOPS if args.compute == "bf16_full" else PEAK_F32_MFMA_TFLOPS
+        p_peak = PEAK_BF16_MFMA_TFLOPS if (args.compute == "bf16_full" or p_x3) else PEAK_F32_MFMA_TFLOPS
         if args.scaling == "weak":
             wl = (f"{wl_label} per GPU, {HU}x{WU} HR total ({world} row band(s) of {hu1}x{WU}), B=1, mode=3")
         else:
@@ -591,8 +592,8 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_source,
                 "p_kernel": {"ms": round(p_mean, 4), "ms_min": round(min(p_ms), 4),
-                             "algorithm": "winograd F(2x2,3x3)" if p_wino else "direct",
-                             "frac": round(p_tflops / (2.25 if p_wino else 1.0) / p_peak, 4),
+                             "algorithm": "winograd F(2x2,3x3)" if p_wino else ("direct, split bf16" if p_x3 else "direct"),
+                             "frac": round(p_tflops * (3.0 if p_x3 else 1.0) / (2.25 if p_wino else 1.0) / p_peak, 4),
                              "direct_equiv_tflops": round(p_tflops, 2),
                              "direct_equiv_frac": round(p_tflops / p_peak, 4),
                              "note": "frac = MFMA work actually issued / peak (the roofline fraction); direct_equiv_* "

@@ -24,7 +24,7 @@ SIN_HW_REDUCED = 2
 SIN_DEFAULT = SIN_HW_REDUCED
 ABI_VERSION = 6
 PACKED_MAGIC = 0x44493036
-P_ALGO_DIRECT, P_ALGO_WINOGRAD, P_ALGO_DIRECT_BF16 = 0, 1, 2
+P_ALGO_DIRECT, P_ALGO_WINOGRAD, P_ALGO_DIRECT_BF16, P_ALGO_DIRECT_BF16X3 = 0, 1, 2, 3
 COMPUTE_F32 = 0
 COMPUTE_BF16 = 1
 COMPUTE_F32_QONLY = 2

@@ -665,7 +665,7 @@ static int decode_impl(void* stream, const float* feat_dev, const float* packed_
     if (st) return st;
     if (!compute_ok(compute))
         return DIINN_ERR_UNSUPPORTED;
-    st = launch_P(stream, feat_dev, packed_dev, workspace_dev, B, H, W, r0, r1, 16, compute == DIINN_COMPUTE_BF16_FULL,
+    st = launch_P(stream, feat_dev, packed_dev, workspace_dev, B, H, W, r0, r1, 16, p_arith(compute),
                   &fw, &pw, true);
     if (st) return st;
     if (compute == DIINN_COMPUTE_F32_QONLY) {                   // modes 1 and 2: per-cell modulation chain

@@ -7,6 +7,7 @@
 //                              and the decode entry points of the C ABI
 //   diinn_precompute.hip       precompute_P_kernel (direct fp32), precompute_P_bf16_kernel / _bf16_wide_kernel, launch_P
 //   diinn_precompute_wino.hip  precompute_P_wino_kernel (the fp32 hoisted conv in Winograd F(2x2,3x3) form: inference)
+//   diinn_precompute_x3.hip    precompute_P_x3_kernel (the hoisted conv in split-bf16 arithmetic: DIINN_COMPUTE_BF16X3, large maps)
 //   diinn_bf16.hip             decode_bf16_kernel, decode_bf16x2_kernel, decode_bf16_coop_kernel (4 waves),
 //                              decode_bf16_coop8_kernel (8 waves), decode_bf16_coop8p_kernel (8 waves, persistent)
 //   diinn_bf16x3.hip           decode_bf16x3h_kernel (persistent, hi weight pieces through LDS), decode_bf16x3_kernel: split bf16
@@ -299,8 +300,14 @@ static inline int check_npix(long long npix) {
 struct RowWin { int row0, rows; };             // rows [row0, row0+rows) of a full-size tensor, stored on their own
 __attribute__((visibility("hidden")))
 int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,
-             int B, int H, int W, int r0, int r1, int mp_total, bool bf16 = false,
+             int B, int H, int W, int r0, int r1, int mp_total, int arith = 0,
              const RowWin* feat_win = nullptr, const RowWin* p_win = nullptr, bool derived_ok = false);
+// `arith` of launch_P: 0 fp32, 1 bf16 operands (DIINN_COMPUTE_BF16_FULL), 2 split bf16 (DIINN_COMPUTE_BF16X3)
+static inline int p_arith(int compute) { return compute == DIINN_COMPUTE_BF16_FULL ? 1 : compute == DIINN_COMPUTE_BF16X3 ? 2 : 0; }
+// diinn_precompute_x3.hip: the hoisted conv of all 1024 channels in split-bf16 arithmetic (needs section WPX)
+__attribute__((visibility("hidden")))
+int launch_P_x3(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,
+                int B, int H, int W, int r0, int r1, RowWin fw, RowWin pw);
 // diinn_precompute_wino.hip: the fp32 hoisted conv of all 1024 channels as Winograd F(2x2,3x3) (needs section WPU)
 __attribute__((visibility("hidden")))
 int launch_P_wino(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,

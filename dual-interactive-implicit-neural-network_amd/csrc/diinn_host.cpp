@@ -22,6 +22,7 @@ const KnobDef KNOBS[] = {
     {"DIINN_X3_KERNEL", &DiinnKnobs::x3_kernel, 0, false},
     {"DIINN_PBF16_KERNEL", &DiinnKnobs::pbf16_kernel, 0, false},
     {"DIINN_P_KERNEL", &DiinnKnobs::p_kernel, 0, false},
+    {"DIINN_P_X3_MIN", &DiinnKnobs::p_x3_min, 32768, false},
     {"DIINN_P_WINO_MIN", &DiinnKnobs::p_wino_min, 0, false},
     {"DIINN_ENC_S1_MIN_BLOCKS", &DiinnKnobs::enc_s1_min_blocks, 128, false},
     {"DIINN_ENC_NO_STREAM1X1", &DiinnKnobs::enc_no_stream1x1, 0, true},
@@ -145,11 +146,11 @@ size_t diinn_metasr_workspace_bytes(int B, int H, int W) {
 }
 
 int diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats) {
-    static const size_t off[15] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT, OFF_WPB, OFF_BQR,
-                                   OFF_Q0R, OFF_WLR, OFF_WPU, OFF_WLX};
-    static const size_t sz[15]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT, SZ_WPB, 3 * HID,
-                                   4 * HID, SZ_WL, SZ_WPU, SZ_WLX};
-    if (section < 0 || section > 14 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
+    static const size_t off[16] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT, OFF_WPB, OFF_BQR,
+                                   OFF_Q0R, OFF_WLR, OFF_WPU, OFF_WLX, OFF_WPX};
+    static const size_t sz[16]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT, SZ_WPB, 3 * HID,
+                                   4 * HID, SZ_WL, SZ_WPU, SZ_WLX, SZ_WPX};
+    if (section < 0 || section > 15 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
     *offset_floats = off[section];
     *size_floats = sz[section];
     return DIINN_OK;
@@ -327,6 +328,30 @@ int diinn_pack_weights(const float* K0w, const float* K0b,
                 }
             }
         }
+    }
+    // WPX: [og][group][tap][mt][hi, lo][lane][j] bf16 (split-bf16 hoisted conv)
+    uint16_t* wpx = reinterpret_cast<uint16_t*>(packed + OFF_WPX);
+    for (int og = 0; og < 16; ++og) {
+        const int i = og >> 2;                                   // 256 channels per layer = 4 output groups of 64
+        const float* w = (i == 0) ? K0w : Kw[i - 1];
+        const size_t ld = (i == 0) ? (size_t)UNF : (size_t)(HID + UNF);
+        const size_t col0 = (i == 0) ? 0 : (size_t)HID;
+        for (int g = 0; g < 4; ++g)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int mt = 0; mt < 2; ++mt) {
+                    uint16_t* dhi = wpx + (((((size_t)og * 4 + g) * 9 + tap) * 2 + mt) * 2 + 0) * (64 * 8);
+                    uint16_t* dlo = dhi + 64 * 8;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int ch = 64 * (og & 3) + 32 * mt + (lane & 31);
+                        for (int j = 0; j < 8; ++j) {
+                            const int c = 16 * g + 8 * (lane >> 5) + j;
+                            const float v = w[(size_t)ch * ld + col0 + (size_t)c * 9 + tap];
+                            const uint16_t hi = f32_to_bf16(v);
+                            dhi[lane * 8 + j] = hi;
+                            dlo[lane * 8 + j] = f32_to_bf16(v - bf16_to_f32(hi));
+                        }
+                    }
+                }
     }
     return DIINN_OK;
 }

@@ -13,6 +13,7 @@ struct DiinnKnobs {
     std::atomic<long long> x3_kernel;           // DIINN_X3_KERNEL: 1 one block per workgroup, 2 persistent split-bf16 decode (0: auto)
     std::atomic<long long> pbf16_kernel;        // DIINN_PBF16_KERNEL: 1 narrow, 2 wide bf16 P kernel (0: auto)
     std::atomic<long long> p_kernel;            // DIINN_P_KERNEL: 1 direct, 2 Winograd fp32 P kernel (0: auto)
+    std::atomic<long long> p_x3_min;            // DIINN_P_X3_MIN: cells from which DIINN_COMPUTE_BF16X3 runs the split-bf16 P kernel (default 32768)
     std::atomic<long long> p_wino_min;          // DIINN_P_WINO_MIN: cells from which the Winograd P kernel runs (default 0)
     std::atomic<long long> enc_s1_min_blocks;   // DIINN_ENC_S1_MIN_BLOCKS (default 128)
     std::atomic<long long> enc_no_stream1x1;    // DIINN_ENC_NO_STREAM1X1 (default 0)

@@ -95,7 +95,12 @@ constexpr size_t WLX_KSTEP  = 4 * WLB_PIECE;               // floats per k-step
 constexpr size_t WLX_LAYER  = (size_t)8 * 16 * WLX_KSTEP;
 constexpr size_t OFF_WLX    = OFF_WPU + SZ_WPU;
 constexpr size_t SZ_WLX     = 3 * WLX_LAYER;               // 393,216 floats = 1.5 MiB
-constexpr size_t PACKED_FLOATS = OFF_WLX + SZ_WLX;         // 3,708,164
+// WPX: the hoisted 3x3 conv for the split-bf16 arithmetic (DIINN_COMPUTE_BF16X3): [og 16][group 4][tap 9][M-tile 2][hi, lo]
+//     [lane 64][j 8] bf16: output channel 64 og + 32 mt + (lane&31) of the 1024, input channel 16 group + 8 (lane>>5) + j,
+//     hi = bf16(w), lo = bf16(w - hi).  Derived, inference only.
+constexpr size_t OFF_WPX    = OFF_WLX + SZ_WLX;
+constexpr size_t SZ_WPX     = (size_t)16 * 4 * 9 * 2 * 2 * WLB_PIECE;   // 589,824 floats = 2.25 MiB
+constexpr size_t PACKED_FLOATS = OFF_WPX + SZ_WPX;         // 4,297,988
 
 // channel held by activation register (m, r) of lane-half h
 DIINN_HD int chan_of(int kk /* = 16*m + r */, int h) {

@@ -501,9 +501,16 @@ static bool p_uses_winograd(int B, int H, int W, int mp_total, bool bf16, bool d
     return derived_ok && !bf16 && mp_total == 16 && forcep != 1 && (forcep == 2 || (long long)B * H * W >= wino_min);
 }
 
+// the split-bf16 form of the hoisted conv: blocks of 32 x 8 cells, so from about half a block per CU on; like the Winograd
+// choice it depends on the whole map, never on the band (bands stay bit-identical to the same rows of a full launch)
+static bool p_uses_x3(int B, int H, int W, int mp_total, int arith, bool derived_ok) {
+    return derived_ok && arith == 2 && mp_total == 16 && (long long)B * H * W >= knob(diinn_knobs().p_x3_min);
+}
+
 int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,
-             int B, int H, int W, int r0, int r1, int mp_total, bool bf16, const RowWin* feat_win, const RowWin* p_win,
+             int B, int H, int W, int r0, int r1, int mp_total, int arith, const RowWin* feat_win, const RowWin* p_win,
              bool derived_ok) {
+    const bool bf16 = arith == 1;
     if (!feat_dev || !packed_dev || !P_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
     if (st) return st;
@@ -520,6 +527,7 @@ int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float
     // full launch.  derived_ok: the caller's packed image holds the
     // derived sections (the gather-packed image of a training step does not).  DIINN_P_KERNEL = 1 direct, 2 Winograd.
     {
+        if (p_uses_x3(B, H, W, mp_total, arith, derived_ok)) return launch_P_x3(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, fw, pw);
         if (p_uses_winograd(B, H, W, mp_total, bf16, derived_ok)) return launch_P_wino(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, fw, pw);
     }
     // Small maps: split the 1024 output channels over up to 16 workgroups per cell block so the
@@ -555,7 +563,8 @@ int diinn_p_launch_info(int B, int H, int W, int r0, int r1, int compute, int* a
     if (!compute_ok(compute))
         return DIINN_ERR_UNSUPPORTED;
     const bool bf16 = compute == DIINN_COMPUTE_BF16_FULL;
-    *algorithm = p_uses_winograd(B, H, W, 16, bf16, true) ? DIINN_P_ALGO_WINOGRAD
+    *algorithm = p_uses_x3(B, H, W, 16, p_arith(compute), true) ? DIINN_P_ALGO_DIRECT_BF16X3
+                 : p_uses_winograd(B, H, W, 16, bf16, true) ? DIINN_P_ALGO_WINOGRAD
                  : bf16 ? DIINN_P_ALGO_DIRECT_BF16 : DIINN_P_ALGO_DIRECT;
     return DIINN_OK;
 }
@@ -569,7 +578,7 @@ int diinn_precompute_P_ex(void* stream, const float* feat_dev, const float* pack
                           float* P_dev, int B, int H, int W, int r0, int r1, int compute) {
     if (!compute_ok(compute))
         return DIINN_ERR_UNSUPPORTED;
-    return launch_P(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, 16, compute == DIINN_COMPUTE_BF16_FULL, nullptr, nullptr, true);
+    return launch_P(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, 16, p_arith(compute), nullptr, nullptr, true);
 }
 
 int diinn_precompute_P_win(void* stream, const float* feat_win_dev, int feat_row0, int feat_rows,
@@ -578,7 +587,7 @@ int diinn_precompute_P_win(void* stream, const float* feat_win_dev, int feat_row
     if (!compute_ok(compute))
         return DIINN_ERR_UNSUPPORTED;
     const RowWin fw{feat_row0, feat_rows}, pw{p_row0, p_rows};
-    return launch_P(stream, feat_win_dev, packed_dev, P_win_dev, B, H, W, r0, r1, 16, compute == DIINN_COMPUTE_BF16_FULL,
+    return launch_P(stream, feat_win_dev, packed_dev, P_win_dev, B, H, W, r0, r1, 16, p_arith(compute),
                     &fw, &pw, true);
 }
 

@@ -83,7 +83,8 @@ extern "C" {
                                    weights; the fastest path, BASELINE config 5 */
 #define DIINN_COMPUTE_BF16X3 4     /* split bf16 (r03, optional): the per-pixel layers 1..3 on the bf16 MFMA with every operand
                                   carried as hi + lo bf16 parts -- hi*hi + hi*lo + lo*hi, fp32 accumulation (packed
-                                  section 14); P, seeds, biases, sine, layer 0 and the head stay fp32.  As
+                                  section 14); on maps of >= 32,768 cells the hoisted 3x3 conv P as well (section 15;
+                                  smaller maps: the fp32 Winograd form); seeds, biases, sine, layer 0 and the head stay fp32.  As
                                   accurate as DIINN_COMPUTE_F32 on every fixture at default-init weights (5e-8) and
                                   inside the 1e-4 x max(1,|ref|) tolerance on the x3 stress set (2e-4 of |out| 6.8) */
 #define DIINN_COMPUTE_F32_QONLY 2 /* decoder modes 1 and 2 (diinn.py:116-131): fp32, synthesis GEMM only; the
@@ -116,9 +117,10 @@ size_t diinn_packed_weight_floats(void);
  * (section 3 / (2 pi)), 12 WLR (section 0 with its synthesis pieces / (2 pi): the fp32 inference kernels evaluate the
  * sine on revolutions as well), 13 WPU (section 1 in Winograd F(2x2,3x3) form, U = G Wx G^T: what the fp32 inference
  * entry points -- everything but diinn_precompute_P -- read, at every map size), 14 WLX (the per-pixel
- * layers as hi + lo bf16 parts, hi = bf16(w), lo = bf16(w - hi), for DIINN_COMPUTE_BF16X3).  Every section but 7 and
- * 9..14 is a pure permutation (plus zero padding) of the reference tensors, so a training loop can re-pack on the
- * device with one gather; sections 7 and 9..14 hold derived values, read by the inference kernels only (the
+ * layers as hi + lo bf16 parts, hi = bf16(w), lo = bf16(w - hi), for DIINN_COMPUTE_BF16X3), 15 WPX (the hoisted 3x3 conv
+ * in the same form).  Every section but 7 and
+ * 9..15 is a pure permutation (plus zero padding) of the reference tensors, so a training loop can re-pack on the
+ * device with one gather; sections 7 and 9..15 hold derived values, read by the inference kernels only (the
  * training forward and LIIF read sections 0, 1 and 4; diinn_precompute_P reads section 1 whatever the map size).
  *
  * VALIDITY WORD.  The pad word behind bL (float index 3 of section 6) holds the bit pattern DIINN_PACKED_MAGIC in an
@@ -387,6 +389,7 @@ int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,
 #define DIINN_P_ALGO_DIRECT      0   /* implicit-im2col GEMM, fp32 (1,179,648 FLOP per cell)                 */
 #define DIINN_P_ALGO_WINOGRAD    1   /* Winograd F(2x2,3x3), fp32: 2.25x fewer MFMAs                          */
 #define DIINN_P_ALGO_DIRECT_BF16 2   /* implicit-im2col GEMM on bf16 operands (DIINN_COMPUTE_BF16_FULL)       */
+#define DIINN_P_ALGO_DIRECT_BF16X3 3 /* direct sum in split-bf16 arithmetic (DIINN_COMPUTE_BF16X3, maps >= 32,768 cells) */
 int diinn_p_launch_info(int B, int H, int W, int r0, int r1, int compute, int* algorithm);
 
 /* ---- diagnostic overrides (tests, A/B timing; never needed in production) -------------------------------------

@@ -253,7 +253,7 @@ def _bf16_round(t: torch.Tensor) -> torch.Tensor:
 def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = False, bf16_p: bool = False,
                         row_range: Optional[Tuple[int, int]] = None, feat_row0: int = 0,
                         full_h: Optional[int] = None, bf16_p_storage: bool = False,
-                        bf16x3: bool = False) -> torch.Tensor:
+                        bf16x3: bool = False, bf16x3_p: bool = False) -> torch.Tensor:
     """Same function evaluated the way the HIP kernels do: per-cell P, then the
     per-pixel 256->512 stacked layers.  Not reference-faithful in summation
     order; agrees with decode_reference_form to ~1e-7.
@@ -268,6 +268,8 @@ def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = Fal
     ``bf16x3=True`` emulates the split-bf16 mode (DIINN_COMPUTE_BF16X3, decode_bf16x3_kernel): weights and
     activation of layers 1..3 as hi = bf16(v), lo = bf16(v - hi); a product is w_lo.q_hi + w_hi.q_lo + w_hi.q_hi with
     fp32 accumulation; the synthesis branch in revolutions as in the bf16 mode; everything else fp32.
+    ``bf16x3_p=True`` (with ``bf16x3``): the hoisted conv P in the same split arithmetic (features and Wx as hi + lo, three
+    products, fp32 accumulation, fp32 bias): what the mode runs on maps of >= 32,768 cells (precompute_P_x3_kernel).
     ``row_range`` / ``feat_row0`` / ``full_h``: an HR row band from a feature crop, as in decode_reference_form."""
     if bf16x3 and (bf16_operands or bf16_p):
         raise ValueError("bf16x3 is a mode of its own")
@@ -283,7 +285,15 @@ def decode_hoisted_form(sd, feat, size: Sequence[int], bf16_operands: bool = Fal
     rows = idx_h[y0:y1].astype(np.int64)
     if not (feat_row0 <= max(int(rows.min()) - 1, 0) and min(int(rows.max()) + 1, h - 1) <= feat_row0 + hc - 1):
         raise ValueError("feature crop does not cover the band's cells + halo")
-    if bf16_p:
+    if bf16x3 and bf16x3_p:
+        wx = sw["Wx"].view(4 * HIDDEN, IN_CHANNELS, 3, 3)
+        fh = _bf16_round(feat)
+        fl = _bf16_round(feat - fh)
+        wh = _bf16_round(wx)
+        wl = _bf16_round(wx - wh)
+        p = (F.conv2d(fh, wl, None, padding=1) + F.conv2d(fl, wh, None, padding=1)) + F.conv2d(fh, wh, None, padding=1)
+        p = (p + sw["bK"].view(1, -1, 1, 1)).permute(0, 2, 3, 1).contiguous()
+    elif bf16_p:
         p = F.conv2d(_bf16_round(feat), _bf16_round(sw["Wx"].view(4 * HIDDEN, IN_CHANNELS, 3, 3)), None, padding=1)
         p = (p + sw["bK"].view(1, -1, 1, 1)).permute(0, 2, 3, 1).contiguous()
     else:

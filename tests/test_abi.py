@@ -48,7 +48,7 @@ def test_debug_knobs_roundtrip(lib):
     """The diagnostic overrides live in one table behind diinn_debug_set / diinn_debug_get (no getenv per launch)."""
     import diinn_amd._native as N
     for name, dflt in [("DIINN_F32_KERNEL", 0), ("DIINN_BF16_KERNEL", 0), ("DIINN_X3_KERNEL", 0), ("DIINN_PBF16_KERNEL", 0), ("DIINN_P_KERNEL", 0),
-                       ("DIINN_P_WINO_MIN", 0), ("DIINN_ENC_S1_MIN_BLOCKS", 128), ("DIINN_ENC_NO_STREAM1X1", 0),
+                       ("DIINN_P_WINO_MIN", 0), ("DIINN_P_X3_MIN", 32768), ("DIINN_ENC_S1_MIN_BLOCKS", 128), ("DIINN_ENC_NO_STREAM1X1", 0),
                        ("DIINN_ENC_LAT_MAX_TILES", 256), ("DIINN_ENC_WINO_MIN", 8192), ("DIINN_ENC_WINO_HALF_MAX", -1),
                        ("DIINN_ENC_WINO_PERSIST", 256), ("DIINN_ENC_X3_MIN", 32768), ("DIINN_ENC_X3_ROWS", 0)]:
         if name not in os.environ:
@@ -115,7 +115,7 @@ def test_packed_image_layout(lib):
     import diinn_amd.decoder as D
     sd = synth.decoder_state_dict(11)
     packed = D.pack_state_dict(sd).numpy()
-    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608 + 393_216 + 294_912 + 768 + 1024 + 393_216 + 1_048_576 + 393_216
+    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608 + 393_216 + 294_912 + 768 + 1024 + 393_216 + 1_048_576 + 393_216 + 589_824
     lane = np.arange(64)
     out_l, h_l = lane & 31, lane >> 5
     # WL section
@@ -210,7 +210,7 @@ def test_packed_image_layout(lib):
     # hi + lo carries w to 2^-17
     def bf16_val(bits):
         return np.array([bits << 16], dtype=np.uint32).view(np.float32)[0]
-    WLX = tail[1792 + 393_216 + 1_048_576:].view(np.uint16).reshape(3, 8, 16, 4, 64, 8)
+    WLX = tail[1792 + 393_216 + 1_048_576:1792 + 393_216 + 1_048_576 + 393_216].view(np.uint16).reshape(3, 8, 16, 4, 64, 8)
     for _ in range(300):
         i, m, ks, part, l, jj = (int(rng.integers(n)) for n in (3, 8, 16, 2, 64, 8))
         hh = l >> 5
@@ -221,6 +221,18 @@ def test_packed_image_layout(lib):
         lo_bits = int(WLX[i, m, ks, 2 + part, l, jj])
         assert lo_bits == bf16_bits(np.float32(w) - hi)
         assert abs(float(hi) + float(bf16_val(lo_bits)) - float(w)) <= 2.0 ** -16 * abs(float(w))
+    # WPX (split-bf16 hoisted conv): [og 16][group 4][tap 9][mt 2][hi, lo][lane][j]: output channel 64 og + 32 mt + (lane & 31) of
+    # the 1024 (layer og >> 2), input channel 16 group + 8 (lane >> 5) + j
+    WPX = tail[1792 + 393_216 + 1_048_576 + 393_216:].view(np.uint16).reshape(16, 4, 9, 2, 2, 64, 8)
+    for _ in range(300):
+        og, g, tap, mt, l, jj = (int(rng.integers(n)) for n in (16, 4, 9, 2, 64, 8))
+        i, ch = og >> 2, 64 * (og & 3) + 32 * mt + (l & 31)
+        c = 16 * g + 8 * (l >> 5) + jj
+        col = c * 9 + tap + (0 if i == 0 else 256)
+        w = np.float32(sd[f"K.{i}.0.weight"][ch, col, 0, 0])
+        hi_bits = bf16_bits(w)
+        assert int(WPX[og, g, tap, mt, 0, l, jj]) == hi_bits
+        assert int(WPX[og, g, tap, mt, 1, l, jj]) == bf16_bits(w - bf16_val(hi_bits))
     # every channel appears exactly once per lane-half in the activation register order
     seen = sorted(_chan_of(kk, h) for kk in range(128) for h in range(2))
     assert seen == list(range(256))

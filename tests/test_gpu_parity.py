@@ -520,6 +520,46 @@ def test_bf16x3_meets_the_fp32_tolerance_on_every_fixture(golden, dev):
               f"(fp32 kernel vs reference {float(np.abs(f32 - ref).max()):.2e}; bound {_tol(ref):.1e})")
 
 
+def test_bf16x3_with_the_split_bf16_hoisted_conv_on_every_fixture(golden, dev, knobs):
+    """On maps of >= 32,768 cells the mode also evaluates the hoisted 3x3 conv P in split bf16 (precompute_P_x3_kernel).
+    Forced on for the fixtures (DIINN_P_X3_MIN = 0): the SAME fp32 bound against the reference's outputs, stress weights
+    included, and the oracle's emulation of both roundings; the P image itself within 2e-5 of max|P| of the fp32 kernel's,
+    full launches and row bands (nothing written outside the band)."""
+    import ctypes as C
+    import diinn_oracle as orc
+    import diinn_amd._native as N
+    import diinn_amd.decoder as D
+    knobs("DIINN_P_X3_MIN", 0)
+    for name, b, h, w, hu, wu, gain in golden_cases(golden):
+        sd = synth.decoder_state_dict(123, gain)
+        feat = synth.encoder_features(123, b, h, w)
+        ref = golden[f"out/{name}"]
+        got = _decode(sd, feat, (hu, wu), dev, compute="bf16x3")
+        err = float(np.abs(got - ref).max())
+        assert err <= _tol(ref), f"{name}: bf16x3 + split-bf16 P {err:.3e} > {_tol(ref):.3e}"
+        emu = orc.decode_hoisted_form(sd, feat, (hu, wu), bf16x3=True, bf16x3_p=True).numpy()
+        assert float(np.abs(got - emu).max()) <= _tol(ref), name
+        print(f"bf16x3 + split-bf16 P {name}: vs reference {err:.2e} (bound {_tol(ref):.1e})")
+    lib = N.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    packed = D.pack_state_dict(synth.decoder_state_dict(5)).to(dev)
+    for (b, h, w, r0, r1) in [(2, 45, 67, 0, 45), (1, 100, 33, 13, 77), (3, 8, 32, 2, 7), (1, 1, 1, 0, 1), (1, 64, 96, 0, 64)]:
+        feat = torch.from_numpy(synth.encoder_features(9, b, h, w)).to(dev)
+        outs = []
+        for comp in (N.COMPUTE_F32, N.COMPUTE_BF16X3):
+            P = torch.full((b, h, w, 1024), float("nan"), device=dev)
+            N.check(lib.diinn_precompute_P_ex(st, C.c_void_p(feat.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                              C.c_void_p(P.data_ptr()), b, h, w, r0, r1, comp), "P")
+            outs.append(P)
+        torch.cuda.synchronize()
+        a, x = outs
+        assert float((x[:, r0:r1] - a[:, r0:r1]).abs().max()) <= 2e-5 * float(a[:, r0:r1].abs().max()), (b, h, w)
+        assert bool(torch.isnan(x[:, :r0]).all()) and bool(torch.isnan(x[:, r1:]).all())
+        algo = C.c_int(-1)
+        N.check(lib.diinn_p_launch_info(b, h, w, r0, r1, N.COMPUTE_BF16X3, C.byref(algo)), "info")
+        assert algo.value == N.P_ALGO_DIRECT_BF16X3
+
+
 def test_bf16x3_ragged_shapes_batches_and_bands(dev):
     """Fresh seeds, non-integer scales, batch > 1, ragged edges; row bands stitch bit-exactly into the whole image."""
     import diinn_oracle as orc
