@@ -394,7 +394,7 @@ int diinn_p_launch_info(int B, int H, int W, int r0, int r1, int compute, int* a
 
 /* ---- diagnostic overrides (tests, A/B timing; never needed in production) -------------------------------------
  * The launch functions pick kernel variants by launch size; each choice can be forced.  The knobs are named like the
- * environment variables that seed them -- DIINN_F32_KERNEL, DIINN_BF16_KERNEL, DIINN_X3_KERNEL, DIINN_PBF16_KERNEL, DIINN_P_KERNEL, DIINN_ENC_X3_MIN, DIINN_ENC_X3_ROWS,
+ * environment variables that seed them -- DIINN_F32_KERNEL, DIINN_BF16_KERNEL, DIINN_X3_KERNEL, DIINN_PBF16_KERNEL, DIINN_P_KERNEL, DIINN_P_X3_MIN, DIINN_ENC_X3_MIN, DIINN_ENC_X3_ROWS,
  * DIINN_P_WINO_MIN, DIINN_ENC_S1_MIN_BLOCKS, DIINN_ENC_NO_STREAM1X1, DIINN_ENC_LAT_MAX_TILES,
  * DIINN_ENC_WINO_MIN, DIINN_ENC_WINO_HALF_MAX, DIINN_ENC_WINO_PERSIST (csrc/diinn_knobs.h lists values and
  * defaults).  The environment is read ONCE, at the first launch or the first call of either function; afterwards
