@@ -42,7 +42,7 @@ extern "C" {
  *   5  diinn_sfe1_forward; packed section 13 (WPU: the hoisted 3x3 conv in Winograd form)
  *   6  the packed image carries a validity word for its derived sections (DIINN_PACKED_MAGIC, below);
  *      diinn_p_launch_info; diinn_debug_set / diinn_debug_get;
- *      bf16 kernel choice taken from the full image, not the band; DIINN_COMPUTE_BF16X3 and packed section 14;
+ *      bf16 kernel choice taken from the full image, not the band; DIINN_COMPUTE_BF16X3 and packed sections 14-15 (DIINN_P_ALGO_DIRECT_BF16X3);
  *      split-bf16 encoder layers (diinn_conv3x3_x3, diinn_rdn_forward_x3) */
 
 /* status codes */
