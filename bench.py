@@ -89,6 +89,7 @@ def parse():
                                                           "(default by N: tgt+c3 at 2/4, tgt+c4 at 8)")
     ap.add_argument("--strong-steps", type=int, default=3)
     ap.add_argument("--no-target", action="store_true", help="N=1: skip the two extra steps at the target shape")
+    ap.add_argument("--no-side-legs", action="store_true", help="N=1: skip the c5 fp32 / c5 bf16_full / c1 side legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args()
@@ -448,6 +449,7 @@ def strong_legs(job):
         hand = job.reduce_max([statistics.median(many["hand_ms"])])[0]       # the slowest receiver
         kern = job.reduce_max([statistics.median(many["step_ms"])])[0]
         checked = many.get("checked")
+        g_ok = many.get("gather_ok")
         ms_n = many["elapsed"] / steps * 1e3
         del many
         torch.cuda.empty_cache()
@@ -466,8 +468,37 @@ def strong_legs(job):
         if checked is not None:
             leg["checked_ok"] = checked["ok"]
             leg["max_err"] = checked["max_err"]
+        if g_ok is not None:
+            leg["gather_ok"] = g_ok
         legs.append(leg)
     return legs
+
+
+# Driver-timed side legs of the default N = 1 run: the other single-GPU BASELINE configs, a few
+# steps each, so that their numbers are measured by the same run that produces the headline -- never part of `value`.
+SIDE_LEGS = [("c5", "f32", 2, 1), ("c5", "bf16_full", 5, 2), ("c1", "f32", 40, 10)]
+
+
+def side_leg(job, name, compute, steps, warmup, check=True):
+    t = run_workload(job, name, "strong", steps, warmup, check=check, compute=compute)
+    (h, w), (hu, wu), label = WORKLOADS[name]
+    t_k = sum(t["k_ms_all"]) / len(t["k_ms_all"])
+    p_ms = sum(t["p_ms"]) / len(t["p_ms"])
+    bf = compute != "f32"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
+    ach = FLOP_DECODE_PER_PX * hu * wu / (t_k * 1e-3) / 1e12
+    leg = {"workload": label, "name": name, "compute": compute, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(t["elapsed"] / steps * 1e3, 4),
+           "mpix_s": round(hu * wu * steps / t["elapsed"] / 1e6, 2),
+           "kernel_ms": round(t_k, 4), "kernel_ms_min": round(min(t["k_ms_all"]), 4), "p_kernel_ms": round(p_ms, 4),
+           "achieved": round(ach, 2), "peak": peak, "frac": round(ach / peak, 4),
+           "of": f"decode kernel, HIP events on {t['event_steps']} of the {steps} steps; frac = 789,504 FLOP/px x pixels / "
+                 f"kernel time / the dense {'bf16' if bf else 'fp32'} MFMA peak"}
+    if "checked" in t:
+        leg["checked"] = t["checked"]
+    del t
+    torch.cuda.empty_cache()
+    return leg
 
 
 def main():
@@ -489,7 +520,7 @@ def main():
     (h1, w1), (hu1, wu1), _ = WORKLOADS[args.workload]
     step_ms, hand_ms, p_ms, k_ms_all = r["step_ms"], r["hand_ms"], r["p_ms"], r["k_ms_all"]
     event_steps = r["event_steps"]
-    checked, gather_ms = r.get("checked"), r.get("gather_ms")
+    checked, gather_ms, gather_ok = r.get("checked"), r.get("gather_ms"), r.get("gather_ok")
     feat_cpu = r["feat"].cpu() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     hand_max = job.reduce_max([statistics.median(hand_ms)])[0]
     # which form of the hoisted conv the library ran for this launch (diinn_p_launch_info: env overrides included)
@@ -532,6 +563,10 @@ def main():
                           "tests/test_gpu_configs.py::test_target_1024_x4"}
         del t
         torch.cuda.empty_cache()
+
+    side = None
+    if world == 1 and args.workload == "c2" and args.compute == "f32" and not args.no_side_legs:
+        side = [side_leg(job, n, c, st, wu_, check=not args.no_check) for (n, c, st, wu_) in SIDE_LEGS]
 
     k_ms = sum(k_ms_all) / max(len(k_ms_all), 1)
     px_launch = (bd.y1 - bd.y0) * WU
@@ -624,10 +659,14 @@ def main():
             res["checked"] = checked
         if gather_ms is not None:
             res["gather_ms"] = round(gather_ms, 4)
+        if gather_ok is not None:
+            res["gather_ok"] = gather_ok
         if split is not None:
             res["split_bf16"] = split
         if target is not None:
             res["target_shape"] = target
+        if side is not None:
+            res["side_legs"] = side
         if strong is not None:
             res["strong"] = strong
         if feat_cpu is not None:
@@ -636,10 +675,16 @@ def main():
     if job.use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    failed = (checked is not None and not checked["ok"]) or \
-        any(not leg.get("checked_ok", True) for leg in (strong or []))
+    # every check the run made decides its exit status: the headline, the split-bf16 and side legs, the strong legs,
+    # the gather
+    def _bad(c):
+        return c is not None and not c["ok"]
+    failed = _bad(checked) or (gather_ok is False) or \
+        _bad((split or {}).get("checked")) or any(_bad(leg.get("checked")) for leg in (side or [])) or \
+        any(not leg.get("checked_ok", True) or leg.get("gather_ok") is False for leg in (strong or []))
     if failed:
-        raise SystemExit(f"bench.py: timed output failed the oracle check: {checked} {strong}")
+        raise SystemExit(f"bench.py: timed output failed a check: headline {checked} gather_ok {gather_ok} "
+                         f"split {(split or {}).get('checked')} side {[l.get('checked') for l in (side or [])]} strong {strong}")
 
 
 if __name__ == "__main__":

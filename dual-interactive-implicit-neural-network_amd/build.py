@@ -30,8 +30,10 @@ DEPS = SOURCES + ["diinn_device.h", "diinn_layout.h", "diinn_knobs.h", os.path.j
 
 # -ffp-contract=off: the coordinate formulas must round every fp32 op separately
 # (diinn_layout.h axis_eval); the kernels spell out fmaf where fusion is wanted.
-# NaNs are honoured (no -fno-honor-nans): relu is the NaN-propagating v_maximum3_f32 (diinn_device.h: relu0), so a
-# non-finite feature or weight reaches the output as it does in the reference.
+# NaNs are honoured: -fno-honor-nans / -ffast-math / -ffinite-math-only must NOT be (re)introduced here or per file.
+# relu is the NaN-propagating v_maximum3_f32 (diinn_device.h: relu0), so a non-finite feature or weight reaches the
+# output as it does in the reference; under -fno-honor-nans the compiler may fold that maximum back to v_max_f32 (NaN ->
+# 0) and tests/test_gpu_parity.py::test_nonfinite_* fail.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-x", "c++"]

@@ -171,7 +171,9 @@ constexpr int TILE_W = 8, TILE_H = 4;           // one wave: 8x4 HR pixels
 // Validity word of the packed image (include/diinn_hip.h "VALIDITY WORD"): 0 when the derived sections are filled, the
 // quiet-NaN bit pattern otherwise.  OR-ing it into the bits of a float leaves the float alone or turns it into a NaN;
 // the inference kernels that read a derived section fold it into a bias they add to every output, outside their
-// inner loops.  Integer operations only: the translation units are built with -fno-honor-nans.
+// inner loops.  Integer operations because they are the cheapest way to force a NaN, not because float NaN handling is
+// unreliable: the translation units are built WITHOUT -fno-honor-nans (relu0 below relies on NaN propagation; build.py
+// says why the flag must not come back).
 __device__ __forceinline__ unsigned derived_nan_mask(const float* __restrict__ Wt) {
     return __builtin_bit_cast(unsigned, Wt[OFF_BL + 3]) == DIINN_PACKED_MAGIC ? 0u : 0x7fc00000u;
 }

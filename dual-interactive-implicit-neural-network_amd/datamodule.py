@@ -8,8 +8,6 @@ Behaviour follows /root/reference/src/datamodules/components/srdata.py and sr_da
                      resizing (srdata.py:163-236).  ``patch_size`` > 0: a random HR crop of
                      round(patch_size*scale) pixels resized to patch_size (training); 0: the whole
                      image, LR size round(H/scale) x round(W/scale) (validation / test, any real scale).
-  SRData             pre-computed ``LR_bicubic/X{scale}`` folders, integer scales (srdata.py:43-161),
-                     with the optional pickled-tensor cache (``bin=True``).
   SRDataModule       the train / val / test split and loaders of sr_datamodule.py:50-167 without the
                      Lightning base class (pytorch_lightning is not part of the target image): DIV2K
                      images 0-799 train (repeated), 800-899 validate / test, benchmark sets in full.
@@ -18,12 +16,14 @@ Images are decoded with PIL (torchvision.io, which the reference uses, is absent
 8-bit RGB PNG gives the same uint8 tensor either way.  Random choices use the ``random`` module in the
 reference's order (crop top, crop left, then hflip, vflip, transpose draws), so seeding reproduces
 the reference's patches.
+
+Not rebuilt on purpose: the reference's paired-folder dataset with its pickle cache (srdata.py:43-161, ``SRData``) and
+``Rotation90`` (sr_datamodule.py:12-20) -- nothing in the reference instantiates either.
 """
 from __future__ import annotations
 
 import glob
 import os
-import pickle
 import random
 from pathlib import Path
 from types import SimpleNamespace
@@ -121,78 +121,6 @@ class SRDataDownsample(_FolderDataset):
                 lr, hr = aug(lr), aug(hr)
             sample[scale] = (lr.float() / 255.0, hr.float() / 255.0, self._stem(path))
         return sample
-
-
-class SRData(_FolderDataset):
-    """HR + pre-computed ``X{scale}`` LR folders, integer scales (srdata.py:43-161)."""
-
-    def __init__(self, root: str = "./data/", name: str = "DIV2K", split: str = "train", file_ext: str = ".png",
-                 bin: bool = False, reset_bin: bool = False, scales: Sequence[int] = (2,), patch_size: int = 96,
-                 augment: bool = True):
-        super().__init__(root, name, split, file_ext, scales, patch_size, augment)
-        self.bin = bin
-        self.reset_bin = reset_bin
-        self.names_lr = {s: [str(self.lr_dir / f"X{s}" / f"{self._stem(f)}x{s}{file_ext}") for f in self.names_hr]
-                         for s in self.scales}
-        if bin:                                                   # pickled float tensors next to the images
-            layout = DATASET_DIR_STRUCTURE[name][split]
-            hr_bin = self.dataset_dir / "bin" / layout["hr_dir"]
-            lr_bin = self.dataset_dir / "bin" / layout["lr_dir"]
-            hr_bin.mkdir(parents=True, exist_ok=True)
-            self.names_hr_bin = [self._cache(f, hr_bin / (Path(f).name.replace(file_ext, ".pt"))) for f in self.names_hr]
-            self.names_lr_bin = {}
-            for s in self.scales:
-                (lr_bin / f"X{s}").mkdir(parents=True, exist_ok=True)
-                self.names_lr_bin[s] = [self._cache(f, lr_bin / f"X{s}" / (Path(f).name.replace(file_ext, ".pt")))
-                                        for f in self.names_lr[s]]
-
-    def _cache(self, image: str, target: Path) -> str:
-        if self.reset_bin or not target.exists():
-            with open(target, "wb") as fh:
-                pickle.dump(read_rgb(image) / 255.0, fh)
-        return str(target)
-
-    def _load(self, idx: int, scale: int):
-        if self.bin:
-            with open(self.names_hr_bin[idx], "rb") as fh:
-                hr = pickle.load(fh)
-            with open(self.names_lr_bin[scale][idx], "rb") as fh:
-                lr = pickle.load(fh)
-        else:
-            hr = read_rgb(self.names_hr[idx]) / 255.0
-            lr = read_rgb(self.names_lr[scale][idx]) / 255.0
-        return lr, hr, self._stem(self.names_hr[idx])
-
-    def get_patch(self, lr: torch.Tensor, hr: torch.Tensor, scale: int, patch_size: int):
-        lh, lw = lr.shape[-2:]
-        if patch_size == 0:                                       # whole image, HR cut to scale * LR
-            return lr, hr[:, :lh * scale, :lw * scale]
-        top = random.randrange(0, lh - patch_size + 1)
-        left = random.randrange(0, lw - patch_size + 1)
-        return (lr[:, top:top + patch_size, left:left + patch_size],
-                hr[:, top * scale:(top + patch_size) * scale, left * scale:(left + patch_size) * scale])
-
-    def __getitem__(self, idx: int):
-        sample = {}
-        for scale in self.scales:
-            lr, hr, name = self._load(idx, scale)
-            lr, hr = self.get_patch(lr, hr, scale, self.patch_size)
-            if self.augment:
-                aug = _draw_augmentation()
-                lr, hr = aug(lr), aug(hr)
-            sample[scale] = (lr.float(), hr.float(), name)
-        return sample
-
-
-class Rotation90:
-    """Transpose the two image axes (sr_datamodule.py:12-20)."""
-
-    def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        if x.dim() == 3:
-            return x.permute(0, 2, 1)
-        if x.dim() == 4:
-            return x.permute(0, 1, 3, 2)
-        raise ValueError("Rotation90 expects a [C,H,W] or [B,C,H,W] tensor")
 
 
 class SRDataModule:

@@ -52,24 +52,26 @@ def ssim(pred: torch.Tensor, target: torch.Tensor, data_range: float = 1.0, kern
     return m.reshape(b, -1).mean(-1).mean()
 
 
+# border shave per evaluation protocol: (pixels shaved beyond `scale`, luma-only)
+_SHAVE = {"benchmark": (0, True), "div2k": (6, False)}
+_LUMA = (65.738 / 256, 129.057 / 256, 25.064 / 256)
+
+
 def calc_psnr(sr: torch.Tensor, hr: torch.Tensor, dataset=None, scale=1, rgb_range=1) -> torch.Tensor:
-    """Reference sr_module.py:21-38: optional border shave (``scale`` px for 'benchmark' after
-    converting RGB differences to luma with (65.738, 129.057, 25.064)/256; ``scale+6`` for 'div2k')."""
-    diff = (sr - hr) / rgb_range
+    """The EDSR-lineage PSNR the reference's validation reports (behaviour of sr_module.py:21-38, pinned against that
+    function's own outputs in tests/test_metrics.py): the error image is normalised by ``rgb_range``; protocol
+    'benchmark' scores the luma of the error (BT.601 weights / 256) inside a border of ``scale`` pixels, 'div2k' all
+    channels inside a border of ``scale + 6``; ``dataset=None`` scores everything."""
+    err = (sr - hr) / rgb_range
     if dataset is not None:
-        if dataset == "benchmark":
-            shave = int(scale)
-            if diff.size(1) > 1:
-                coeffs = diff.new_tensor([65.738, 129.057, 25.064]).view(1, 3, 1, 1) / 256
-                diff = diff.mul(coeffs).sum(dim=1)
-        elif dataset == "div2k":
-            shave = int(scale) + 6
-        else:
-            raise NotImplementedError
-        valid = diff[..., shave:-shave, shave:-shave]
-    else:
-        valid = diff
-    return -10 * torch.log10(valid.pow(2).mean())
+        if dataset not in _SHAVE:
+            raise NotImplementedError(f"calc_psnr: unknown protocol {dataset!r}")
+        extra, luma = _SHAVE[dataset]
+        if luma and err.size(1) > 1:
+            err = torch.einsum("bchw,c->bhw", err, err.new_tensor(_LUMA))
+        m = int(scale) + extra
+        err = err[..., m:-m, m:-m]
+    return -10 * torch.log10(err.square().mean())
 
 
 def resize_fn(img: torch.Tensor, size) -> torch.Tensor:

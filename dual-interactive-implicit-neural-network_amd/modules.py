@@ -271,7 +271,8 @@ class _GraphReplay:
         return (tuple(x.shape), x.dtype, x.device, int(size[0]), int(size[1]),
                 tuple((p.data_ptr(), p._version) for p in self.parameters()),
                 getattr(dec, "sin_mode", None), getattr(dec, "compute", None), getattr(dec, "mode", None),
-                getattr(enc, "hip_trunk_max_pixels", None), getattr(enc, "hip_winograd", None))
+                getattr(enc, "hip_trunk_max_pixels", None), getattr(enc, "hip_winograd", None),
+                getattr(enc, "hip_split_bf16", None))
 
     def _forward_graphed(self, x, size, bsize):
         key = self._graph_key(x, size)
@@ -292,7 +293,7 @@ class _GraphReplay:
                 # private pool: workspaces, activations, the result) or kept alive by the entry below (packed
                 # weight images, which live in module caches that a later call may replace)
                 static_y = self._forward_eager(static_x, size, bsize)
-            keep = [getattr(m, a, None) for m in self.modules() for a in ("_packed", "_hip_pack")]
+            keep = [getattr(m, a, None) for m in self.modules() for a in ("_packed", "_hip_pack", "_hip_x3")]
             entry = (graph, static_x, static_y, keep)
             self._graph_cache[key] = entry
         graph, static_x, static_y = entry[:3]
@@ -346,7 +347,10 @@ class DIINN(nn.Module, _GraphReplay):
         b, _, h, w = x.shape
         shape = (int(b), 64, int(h), int(w))
         packed = self.decoder.packed_weights(x.device)
-        key = (shape, int(hu), int(wu), packed.data_ptr(), src, mode, id(group))
+        # the arithmetic and the sine mode are baked into a BandDecoder at construction: they are part of the key, so
+        # switching ``decoder.compute`` / ``sin_mode`` (or ``set_split_bf16``) between two calls rebuilds it
+        key = (shape, int(hu), int(wu), packed.data_ptr(), src, mode, id(group),
+               self.decoder.compute, self.decoder.sin_mode)
         if getattr(self, "_band_key", None) != key:           # band-sized buffers are allocated once per geometry
             self._band_dec = S.BandDecoder(shape, (int(hu), int(wu)), packed, group=group, src=src, mode=mode,
                                            sin_mode=self.decoder.sin_mode, compute=self.decoder.compute)
@@ -498,7 +502,10 @@ class SRLitModule(nn.Module):
         return self.net.forward_sharded(x, size, **kw)
 
     def step(self, batch: Any, eval_bsize=None):
-        """sr_module.py:113-125: ``batch`` maps scale -> (lr, hr, name); normalise, decode, L1, de-normalise."""
+        """Boundary restatement, not new design: this loop IS reference sr_module.py:113-125 (``batch`` maps scale ->
+        (lr, hr, name); normalise by sub/div, decode to the HR size, L1, de-normalise and clamp), kept statement for
+        statement because ``training_step`` / ``validation_step`` / ``test_step`` and any user subclass depend on its exact
+        return value ``(mean loss, {scale: prediction in [0, 1]})``."""
         loss = 0
         pred_hrs: Dict[Any, torch.Tensor] = {}
         for scale in batch:
@@ -526,7 +533,8 @@ class SRLitModule(nn.Module):
         return res
 
     def configure_optimizers(self):
-        """sr_module.py:185-194: Adam(lr) + StepLR(lr_step, lr_gamma), one scheduler step per epoch."""
+        """Boundary restatement of sr_module.py:185-194 (the return shape is Lightning's contract): Adam(lr) +
+        StepLR(lr_step, lr_gamma), one scheduler step per epoch."""
         optimizer = torch.optim.Adam(self.parameters(), lr=self.hparams.lr)
         scheduler = torch.optim.lr_scheduler.StepLR(optimizer=optimizer, step_size=self.hparams.lr_step,
                                                     gamma=self.hparams.lr_gamma)

@@ -140,6 +140,8 @@ class BandExchange:
         self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" and self.world > 1 else None
         self._pending = []                                   # src: sends of the running step
         self._staged = None                                  # src, host_staged: event behind the host copies
+        self._recv_done = None                               # host_staged receivers: event behind the last host -> device copy
+        self._gather_done = None                             # host_staged gather root: the same for the gather stages
         self.send_stage: List[Optional[torch.Tensor]] = [None] * self.world
         self.send_host: List[Optional[torch.Tensor]] = [None] * self.world
         self.feat_win: Optional[torch.Tensor] = None        # non-src ranks: what the hand-off fills
@@ -206,8 +208,14 @@ class BandExchange:
         if self.band.empty:
             return None, 0
         if self.host_staged:
+            # the previous step's asynchronous host -> device copy may still be reading the pinned message: it must
+            # have finished before the next message is received into the same buffer
+            if self._recv_done is not None:
+                self._recv_done.synchronize()
             _wait(_post([dist.P2POp(dist.irecv, self.recv_host, self.src, self.group)]))
             self.feat_win.copy_(self.recv_host, non_blocking=True)
+            self._recv_done = torch.cuda.Event()
+            self._recv_done.record()
         else:
             _wait(_post([dist.P2POp(dist.irecv, self.feat_win, self.src, self.group)]))
         return self.feat_win, self.band.a0
@@ -231,11 +239,15 @@ class BandExchange:
     def _broadcast(self, feat):
         buf = feat if self.rank == self.src else self.feat_win
         if self.host_staged:
+            if self._recv_done is not None:                  # the last step's copy out of the pinned message (see handoff)
+                self._recv_done.synchronize()
             if self.rank == self.src:
                 self.recv_host.copy_(feat)
             dist.broadcast(self.recv_host, src=self.src, group=self.group)
             if self.rank != self.src:
                 buf.copy_(self.recv_host, non_blocking=True)
+                self._recv_done = torch.cuda.Event()
+                self._recv_done.record()
         else:
             dist.broadcast(buf, src=self.src, group=self.group)
         return buf
@@ -257,6 +269,8 @@ class BandExchange:
             return out
         pin = self.host_staged
         if self.rank == dst:
+            if self._gather_done is not None:                # the previous gather's copies out of the pinned stages
+                self._gather_done.synchronize()
             ops, srcs = [], []
             for r, bd in enumerate(self.bands):
                 if r == dst or bd.empty:
@@ -269,6 +283,9 @@ class BandExchange:
             _wait(_post(ops))
             for r, bd in srcs:
                 out[:, :, bd.y0:bd.y1, :].copy_(self.gather_stage[r], non_blocking=True)
+            if pin:
+                self._gather_done = torch.cuda.Event()
+                self._gather_done.record()
         elif not self.band.empty:
             msg = out_band
             if pin:

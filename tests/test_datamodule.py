@@ -95,27 +95,6 @@ def test_downsample_dataset_whole_image_and_augment(data_root):
         assert float(((lr * 255) - ref.float()).abs().max()) <= 1.0
 
 
-def test_paired_dataset(data_root):
-    """Pre-computed LR folders (srdata.py:43-161): file naming, aligned crops, the pickled cache."""
-    root, imgs = data_root
-    ds = DM.SRData(root=root, name="benchmark", split="Set5", scales=[2, 4], patch_size=6, augment=False)
-    assert len(ds) == 2 and ds.names_lr[4][1].endswith(os.path.join("X4", "img1x4.png"))
-    random.seed(0)
-    sample = ds[0]
-    for s, (lr, hr, name) in sample.items():
-        assert lr.shape == (3, 6, 6) and hr.shape == (3, 6 * s, 6 * s) and name == "img0"
-    random.seed(0)
-    t = random.randrange(0, 24 - 6 + 1)
-    l = random.randrange(0, 20 - 6 + 1)
-    assert torch.equal((sample[2][1] * 255).round().to(torch.uint8), imgs["img0"][:, 2 * t:2 * t + 12, 2 * l:2 * l + 12])
-    whole = DM.SRData(root=root, name="benchmark", split="Set5", scales=[4], patch_size=0, augment=False)[1][4]
-    assert whole[0].shape == (3, 12, 10) and whole[1].shape == (3, 48, 40)
-    cached = DM.SRData(root=root, name="benchmark", split="Set5", scales=[2], patch_size=0, augment=False, bin=True)
-    assert os.path.exists(os.path.join(root, "benchmark", "bin", "Set5", "HR", "img0.pt"))
-    a, b = cached[0][2], DM.SRData(root=root, name="benchmark", split="Set5", scales=[2], patch_size=0, augment=False)[0][2]
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-
-
 def test_datamodule_batches_feed_the_module(data_root):
     """SRDataModule.setup + loaders produce the {scale: (lr, hr, name)} batches SRLitModule.step consumes."""
     root, _ = data_root
@@ -131,4 +110,3 @@ def test_datamodule_batches_feed_the_module(data_root):
     assert lr.shape == (2, 3, 8, 8) and hr.shape == (2, 3, 24, 24) and len(names) == 2
     tb = next(iter(dm.test_dataloader()[0]))
     assert tb[2.5][0].shape == (1, 3, round(48 / 2.5), round(40 / 2.5)) and tb[2.5][1].shape == (1, 3, 48, 40)
-    assert torch.equal(DM.Rotation90()(hr), hr.permute(0, 1, 3, 2))

@@ -227,6 +227,101 @@ def test_band_decoder_on_gpu_over_host_staged_gloo(world, mode):
     assert all(res)
 
 
+def _gpu_back_to_back_worker(rank, world, port, mode, geom, q):
+    """Several steps queued back to back with DIFFERENT features and no synchronisation between them (the
+    host-staged transport re-posted its receive into a pinned buffer an asynchronous copy could still be reading, and
+    every other test sent the same features each step or synchronised in between): the bands of every step, cloned
+    in stream order, must each equal the same rows of that step's unsharded decode."""
+    import diinn_amd.decoder as D
+    import diinn_amd.sharded as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        b, h, w, hu, wu = geom
+        packed = D.pack_state_dict(synth.decoder_state_dict(35)).to(dev)
+        dec = S.BandDecoder((b, 64, h, w), (hu, wu), packed, src=0, mode=mode)
+        steps = 6
+        feats = [torch.from_numpy(synth.encoder_features(100 + it, b, h, w)).to(dev) for it in range(steps)]
+        big = torch.randn(2048, 2048, device=dev)
+        torch.cuda.synchronize()
+        bands, imgs = [], []
+        for it in range(steps):
+            _ = big @ big                                          # keeps the stream busy: the copies queue up behind it
+            band = dec.step(feats[it] if rank == 0 else None)
+            bands.append(band.clone())                             # stream-ordered snapshot of the reused output band
+            if it % 2 == 1:                                        # and the gather's stages every other step
+                img = dec.gather(band, dst=0)
+                imgs.append((it, img.clone() if rank == 0 else None))
+        torch.cuda.synchronize()
+        bd = dec.band
+        ok = True
+        for it in range(steps):
+            full = D.decode_features(feats[it], packed, (hu, wu))
+            ok = ok and bool(torch.equal(bands[it], full[:, :, bd.y0:bd.y1]))
+        if rank == 0:
+            for it, img in imgs:
+                ok = ok and bool(torch.equal(img, D.decode_features(feats[it], packed, (hu, wu))))
+        q.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,mode", [(2, "halo"), (3, "bcast")])
+def test_host_staged_steps_back_to_back_with_changing_features(world, mode):
+    res = _run(world, mode, (1, 64, 96, 211, 317), target=_gpu_back_to_back_worker, timeout=600)
+    assert all(res)
+
+
+def _gpu_forward_sharded_toggle_worker(rank, world, port, mode, geom, q):
+    """``DIINN.forward_sharded`` caches its band-sized decoder per geometry; the arithmetic and the sine mode are baked
+    into it: switching ``decoder.compute`` between two calls must rebuild it, not keep decoding in
+    the old arithmetic."""
+    import diinn_amd.modules as M
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        b, h, w, hu, wu = geom
+        torch.manual_seed(7)
+        model = M.DIINN(mode=3, init_q=False).to(dev).eval()
+        x = torch.rand(b, 3, h, w, device=dev)
+        outs = {}
+        for compute in ("f32", "bf16_full", "f32", "bf16x3"):
+            model.decoder.compute = compute
+            img = model.forward_sharded(x, (hu, wu), src=0, gather_to=0)
+            torch.cuda.synchronize()
+            if rank == 0:
+                with torch.no_grad():
+                    whole = model(x, (hu, wu))
+                assert torch.equal(img, whole), f"{compute}: the sharded forward ran another arithmetic"
+                outs.setdefault(compute, []).append(img.clone())
+        if rank == 0:
+            ok = torch.equal(outs["f32"][0], outs["f32"][1]) and not torch.equal(outs["f32"][0], outs["bf16_full"][0])
+            model.set_split_bf16()                                   # both optional modes at once: the key sees it too
+        else:
+            ok = True
+            model.set_split_bf16()
+        img = model.forward_sharded(x, (hu, wu), src=0, gather_to=0)
+        if rank == 0:
+            with torch.no_grad():
+                ok = ok and bool(torch.equal(img, model(x, (hu, wu))))
+        q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_forward_sharded_follows_a_compute_toggle():
+    res = _run(2, "halo", (1, 40, 56, 132, 185), target=_gpu_forward_sharded_toggle_worker, timeout=900)
+    assert all(res)
+
+
 _RCCL_SELF = r'''
 import os, torch, torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
