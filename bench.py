@@ -79,11 +79,12 @@ def parse():
     ap.add_argument("--dist-mode", choices=["halo", "bcast"], default="halo")
     ap.add_argument("--gather", action="store_true", help="also time assembling the image on rank 0 (reported "
                                                            "as gather_ms, never part of value)")
-    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("DIINN_BENCH_BACKEND", "nccl"),
                     help="nccl = RCCL over xGMI (one rank per GPU).  gloo: messages staged through pinned host memory; "
                          "with DIINN_BENCH_ONE_DEVICE=1 all ranks share cuda:0, which is how every N>1 branch is "
                          "exercised on a one-GPU box (RCCL refuses two ranks on one device) -- a test transport, "
-                         "its timings mean nothing")
+                         "its timings mean nothing.  DIINN_BENCH_BACKEND sets the default, so that the driver's literal "
+                         "command line can be run on such a box")
     ap.add_argument("--no-strong", action="store_true", help="N>1: skip the strong-scaling legs")
     ap.add_argument("--strong-legs", default=None, help="N>1: comma-separated workloads of the strong-scaling legs "
                                                           "(default by N: tgt+c3 at 2/4, tgt+c4 at 8)")

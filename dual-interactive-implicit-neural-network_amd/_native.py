@@ -22,7 +22,7 @@ SIN_HW_REDUCED = 2
 # default: 2-term reduction in revolutions + v_sin_f32 (max abs error 2.5e-7 for |x| <= 1e4, measured in
 # tests/test_gpu_parity.py::test_device_sine_accuracy); SIN_ACCURATE (1e-7) costs ~4 % more time
 SIN_DEFAULT = SIN_HW_REDUCED
-ABI_VERSION = 6
+ABI_VERSION = 7
 PACKED_MAGIC = 0x44493036
 P_ALGO_DIRECT, P_ALGO_WINOGRAD, P_ALGO_DIRECT_BF16, P_ALGO_DIRECT_BF16X3 = 0, 1, 2, 3
 COMPUTE_F32 = 0
@@ -72,6 +72,9 @@ SIGNATURES = {
     "diinn_decode_win": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_void_p, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "diinn_decode_tile_win": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_longlong, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_cell_chain": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_decode_launch_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip]),
     "diinn_p_launch_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),

@@ -21,10 +21,10 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_kernel(const DecodeParams 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
-    const int x = blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
+    const int x = p.x0 + blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
     const int y = p.y0 + blockIdx.y * (TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
     const int b = blockIdx.z;
-    const bool valid = (x < p.Wu) && (y < p.y1);
+    const bool valid = (x < p.x1) && (y < p.y1);
     if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
     const int xc = x < p.Wu ? x : p.Wu - 1;
     const int yc = y < p.y1 ? y : p.y1 - 1;
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_kernel(const DecodeParams 
     o1 += __shfl_xor(o1, 32);
     o2 += __shfl_xor(o2, 32);
     if (valid && h == 0) {
-        const size_t plane = (size_t)p.Orows * p.Wu;
-        float* o = p.out + (size_t)b * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
+        const long long plane = p.o_ps;
+        float* o = out_px(p, b, y, x);
         const unsigned nanm = derived_nan_mask(Wt);
         o[0] = o0 + or_bits(Wt[OFF_BL + 0], nanm);
         o[plane] = o1 + or_bits(Wt[OFF_BL + 1], nanm);
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x2_kernel(const DecodeParam
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
-    const int x = blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
+    const int x = p.x0 + blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
     const int yb = p.y0 + blockIdx.y * (2 * TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
     const int b = blockIdx.z;
     int y[2];
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x2_kernel(const DecodeParam
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         y[t] = yb + t * (TILE_H * WG_TILES_Y);
-        valid[t] = (x < p.Wu) && (y[t] < p.y1);
+        valid[t] = (x < p.x1) && (y[t] < p.y1);
     }
     if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid[0] || valid[1]) == 0ull))) return;
     const int xc = x < p.Wu ? x : p.Wu - 1;
@@ -381,8 +381,8 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x2_kernel(const DecodeParam
         o1 += __shfl_xor(o1, 32);
         o2 += __shfl_xor(o2, 32);
         if (valid[t] && h == 0) {
-            const size_t plane = (size_t)p.Orows * p.Wu;
-            float* op = p.out + (size_t)b * 3 * plane + (size_t)(y[t] - p.Orow0) * p.Wu + x;
+            const long long plane = p.o_ps;
+            float* op = out_px(p, b, y[t], x);
             const unsigned nanm = derived_nan_mask(Wt);
             op[0] = o0 + or_bits(Wt[OFF_BL + 0], nanm);
             op[plane] = o1 + or_bits(Wt[OFF_BL + 1], nanm);
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_coop_kernel(const DecodePa
     CO_STAMP(0);
 
     // pixel of this lane in tile t: x = bx*16 + (t&1)*8 + (j&7), y = y0 + by*8 + (t>>1)*4 + (j>>3)
-    const int x0 = blockIdx.x * (2 * TILE_W) + (j & (TILE_W - 1));
+    const int x0 = p.x0 + blockIdx.x * (2 * TILE_W) + (j & (TILE_W - 1));
     const int yb = p.y0 + blockIdx.y * (2 * TILE_H) + (j / TILE_W);
     // LR index and relative coordinate of this lane's column / row in the two tile columns / rows of the block; lane 0
     // holds the block's first pixel, so its indices are the block's first LR cell (wave-uniform)
@@ -744,16 +744,16 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_coop_kernel(const DecodePa
     __syncthreads();
     if (threadIdx.x < TILES * 32) {
         const int t = threadIdx.x >> 5, jj = threadIdx.x & 31;    // one pixel per thread
-        const int x = blockIdx.x * (2 * TILE_W) + (t & 1) * TILE_W + (jj & (TILE_W - 1));
+        const int x = p.x0 + blockIdx.x * (2 * TILE_W) + (t & 1) * TILE_W + (jj & (TILE_W - 1));
         const int y = p.y0 + blockIdx.y * (2 * TILE_H) + (t >> 1) * TILE_H + (jj / TILE_W);
         float acc[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int w8 = 0; w8 < 8; ++w8)
 #pragma unroll
             for (int k = 0; k < 3; ++k) acc[k] += red[w8][threadIdx.x][k];
-        if (x < p.Wu && y < p.y1) {
-            const size_t plane = (size_t)p.Orows * p.Wu;
-            float* op = p.out + (size_t)b * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
+        if (x < p.x1 && y < p.y1) {
+            const long long plane = p.o_ps;
+            float* op = out_px(p, b, y, x);
             op[0] = acc[0] + bl0;
             op[plane] = acc[1] + bl1;
             op[2 * plane] = acc[2] + bl2;
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8_kernel(const DecodeP
 #endif
     CO_STAMP(0);
 
-    const int x0 = blk.x * (2 * TILE_W) + (j & (TILE_W - 1));
+    const int x0 = p.x0 + blk.x * (2 * TILE_W) + (j & (TILE_W - 1));
     const int yb = p.y0 + blk.y * (2 * TILE_H) + (j / TILE_W);
     int ixs[2], iys[2];
     float relws[2], relhs[2];
@@ -1047,16 +1047,16 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8_kernel(const DecodeP
     __syncthreads();
     if (threadIdx.x < TILES * 32) {
         const int t = threadIdx.x >> 5, jj = threadIdx.x & 31;
-        const int x = blk.x * (2 * TILE_W) + (t & 1) * TILE_W + (jj & (TILE_W - 1));
+        const int x = p.x0 + blk.x * (2 * TILE_W) + (t & 1) * TILE_W + (jj & (TILE_W - 1));
         const int y = p.y0 + blk.y * (2 * TILE_H) + (t >> 1) * TILE_H + (jj / TILE_W);
         float acc[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int w16 = 0; w16 < 16; ++w16)
 #pragma unroll
             for (int k = 0; k < 3; ++k) acc[k] += red[w16][threadIdx.x][k];
-        if (x < p.Wu && y < p.y1) {
-            const size_t plane = (size_t)p.Orows * p.Wu;
-            float* op = p.out + (size_t)b * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
+        if (x < p.x1 && y < p.y1) {
+            const long long plane = p.o_ps;
+            float* op = out_px(p, b, y, x);
             op[0] = acc[0] + bl0;
             op[plane] = acc[1] + bl1;
             op[2 * plane] = acc[2] + bl2;
@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
         int ln = lane;                                            // opaque: see stage_load
         asm volatile("" : "+v"(ln));
         const int j = ln & 31, h = ln >> 5;
-        const int x0 = bk.x * (2 * TILE_W) + (j & (TILE_W - 1));
+        const int x0 = p.x0 + bk.x * (2 * TILE_W) + (j & (TILE_W - 1));
         const int yb = p.y0 + bk.y * (2 * TILE_H) + (j / TILE_W);
 #pragma unroll
         for (int tx = 0; tx < 2; ++tx) {
@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
     };
     // first LR cell of a block (wave-uniform): the lane-0 pixel's indices
     auto first_cell = [&](const Blk& bk, int& cx0, int& cy0) {
-        const int x = bk.x * (2 * TILE_W), y = p.y0 + bk.y * (2 * TILE_H);
+        const int x = p.x0 + bk.x * (2 * TILE_W), y = p.y0 + bk.y * (2 * TILE_H);
         int a, b2;
         float rel;
         axis_eval(p.aw, x < p.Wu ? x : p.Wu - 1, a, rel);
@@ -1464,18 +1464,18 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
         asm volatile("" : "+v"(tid));
         if (tid < TILES * 32) {
             const int t = tid >> 5, jj = tid & 31;
-            const int x = blk.x * (2 * TILE_W) + (t & 1) * TILE_W + (jj & (TILE_W - 1));
+            const int x = p.x0 + blk.x * (2 * TILE_W) + (t & 1) * TILE_W + (jj & (TILE_W - 1));
             const int y = p.y0 + blk.y * (2 * TILE_H) + (t >> 1) * TILE_H + (jj / TILE_W);
             float acc[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int w8 = 0; w8 < 8; ++w8)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) acc[k] += red[w8][tid][k];
-            if (x < p.Wu && y < p.y1) {
+            if (x < p.x1 && y < p.y1) {
                 const unsigned nanm = derived_nan_mask(Wt);      // (read per block: three scalar loads instead of registers held across the loop)
                 const float bl0 = or_bits(Wt[OFF_BL + 0], nanm), bl1 = or_bits(Wt[OFF_BL + 1], nanm), bl2 = or_bits(Wt[OFF_BL + 2], nanm);
-                const size_t plane = (size_t)p.Orows * p.Wu;
-                float* op = p.out + (size_t)blk.z * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
+                const long long plane = p.o_ps;
+                float* op = out_px(p, blk.z, y, x);
                 op[0] = acc[0] + bl0;
                 op[plane] = acc[1] + bl1;
                 op[2 * plane] = acc[2] + bl2;
@@ -1487,31 +1487,30 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
     }
 }
 
-// cells of the LR footprint of the widest 16 x 8 pixel block: (columns, rows).  Rows: the maximum over EVERY start
-// row of the full image, not over the blocks of the band at hand (they are anchored at y0), so that the kernel choice
-// below is the same for a band and for the whole image.
-static void coop_footprint(const DecodeParams& p, int& ncx, int& ncy) {
-    ncx = ncy = 1;
-    int a, b2;
+// cells of the LR footprint of the widest 16 x 8 pixel block: (columns, rows).  The maximum over EVERY start column / row
+// of the FULL image, not over the blocks of the launch at hand (they are anchored at its x0 / y0), so that the kernel
+// choice below is the same for a row band, for a column tile and for the whole image.
+static int axis_footprint(const Axis& a, int n_out, int span) {
+    int m = 1, lo, hi;
     float rel;
-    for (int x = 0; x < p.Wu; x += 2 * TILE_W) {
-        const int xl = x + 2 * TILE_W - 1 < p.Wu ? x + 2 * TILE_W - 1 : p.Wu - 1;
-        axis_eval(p.aw, x, a, rel);
-        axis_eval(p.aw, xl, b2, rel);
-        ncx = b2 - a + 1 > ncx ? b2 - a + 1 : ncx;
+    for (int v = 0; v < n_out; ++v) {
+        const int vl = v + span - 1 < n_out ? v + span - 1 : n_out - 1;
+        axis_eval(a, v, lo, rel);
+        axis_eval(a, vl, hi, rel);
+        m = hi - lo + 1 > m ? hi - lo + 1 : m;
     }
-    static thread_local int key_h = -1, key_hu = -1, key_small = -1, cached = 1;
-    if (key_h != p.H || key_hu != p.Hu || key_small != p.ah.small_output) {
-        int m = 1;
-        for (int y = 0; y < p.Hu; ++y) {
-            const int yl = y + 2 * TILE_H - 1 < p.Hu ? y + 2 * TILE_H - 1 : p.Hu - 1;
-            axis_eval(p.ah, y, a, rel);
-            axis_eval(p.ah, yl, b2, rel);
-            m = b2 - a + 1 > m ? b2 - a + 1 : m;
-        }
-        key_h = p.H; key_hu = p.Hu; key_small = p.ah.small_output; cached = m;
-    }
-    ncy = cached;
+    return m;
+}
+
+static void coop_footprint(const DecodeParams& p, int& ncx, int& ncy) {
+    struct Key { int n_in, n_out, small, val; };
+    static thread_local Key kx = {-1, -1, -1, 1}, ky = {-1, -1, -1, 1};
+    if (kx.n_in != p.W || kx.n_out != p.Wu || kx.small != p.aw.small_output)
+        kx = Key{p.W, p.Wu, p.aw.small_output, axis_footprint(p.aw, p.Wu, 2 * TILE_W)};
+    if (ky.n_in != p.H || ky.n_out != p.Hu || ky.small != p.ah.small_output)
+        ky = Key{p.H, p.Hu, p.ah.small_output, axis_footprint(p.ah, p.Hu, 2 * TILE_H)};
+    ncx = kx.val;
+    ncy = ky.val;
 }
 
 int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int gz, int sin_mode) {
@@ -1526,7 +1525,8 @@ int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int 
         // bit-exactly into the same rows of an unsharded decode (sharded.py)
         const long long full_gy = (p.Hu + TILE_H * WG_TILES_Y - 1) / (TILE_H * WG_TILES_Y);
         const long long full_gy2 = (p.Hu + 2 * TILE_H * WG_TILES_Y - 1) / (2 * TILE_H * WG_TILES_Y);
-        const bool two_tiles = (long long)gx * full_gy2 * gz >= 512;
+        const long long full_gx = (p.Wu + TILE_W * WG_TILES_X - 1) / (TILE_W * WG_TILES_X);   // ... nor from a column tile [x0,x1)
+        const bool two_tiles = full_gx * full_gy2 * gz >= 512;
         // diagnostic override (tests / A-B timing): DIINN_BF16_KERNEL = 1 one tile per wave, 2 two tiles per wave,
         // 4 / 8 cooperative with 4 / 8 waves; unset = pick by launch size and scale
         const int force = (int)knob(diinn_knobs().bf16_kernel);
@@ -1539,7 +1539,7 @@ int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int 
         // a 16 x 8 block covers whole cells iff 16 / scale_x and 8 / scale_y are integers
         pc.xcd_runs = !((16LL * p.W) % p.Wu == 0 && (8LL * p.H) % p.Hu == 0);
         const bool coop_ok = ncx * ncy <= CO_SEED_CELLS;
-        const bool coop = coop_ok && (force ? (force == 4 || force == 8 || force == 9) : (long long)gx * full_gy * gz >= 1024);
+        const bool coop = coop_ok && (force ? (force == 4 || force == 8 || force == 9) : full_gx * full_gy * gz >= 1024);
         // (the polynomial sine needs a few registers more than the 256 a wave may have at two per SIMD once the block
         // loop's state is added: DIINN_SIN_ACCURATE stays on the one-block-per-workgroup form)
         if (coop && force != 4 && force != 8 && sin_mode != DIINN_SIN_ACCURATE) {   // 8 waves, persistent workgroups over super-tiles of 8 x 4 blocks

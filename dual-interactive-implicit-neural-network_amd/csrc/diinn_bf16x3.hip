@@ -79,10 +79,10 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x3_kernel(const DecodeParam
             }
         }
     }
-    const int x = blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
+    const int x = p.x0 + blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
     const int y = p.y0 + blockIdx.y * (TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
     const int b = blockIdx.z;
-    const bool valid = (x < p.Wu) && (y < p.y1);
+    const bool valid = (x < p.x1) && (y < p.y1);
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
     const int xc = x < p.Wu ? x : p.Wu - 1;
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x3_kernel(const DecodeParam
     o1 += __shfl_xor(o1, 32);
     o2 += __shfl_xor(o2, 32);
     if (valid && h == 0) {
-        const size_t plane = (size_t)p.Orows * p.Wu;
-        float* o = p.out + (size_t)b * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
+        const long long plane = p.o_ps;
+        float* o = out_px(p, b, y, x);
         o[0] = o0 + tab[6 * HID + 0];
         o[plane] = o1 + tab[6 * HID + 1];
         o[2 * plane] = o2 + tab[6 * HID + 2];
@@ -294,10 +294,10 @@ struct X3Pixel {
 __device__ __forceinline__ X3Pixel x3_locate(const DecodeParams& p, const int blk, const int wave, const int j, const int h) {
     const int bx = blk % p.pg[0], t = blk / p.pg[0], by = t % p.pg[1], bz = t / p.pg[1];
     X3Pixel r;
-    r.x = bx * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
+    r.x = p.x0 + bx * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
     r.y = p.y0 + by * (TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
     r.b = bz;
-    r.valid = (r.x < p.Wu) && (r.y < p.y1);
+    r.valid = (r.x < p.x1) && (r.y < p.y1);
     const int xc = r.x < p.Wu ? r.x : p.Wu - 1;
     const int yc = r.y < p.y1 ? r.y : p.y1 - 1;
     int iy, ix;
@@ -622,8 +622,8 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x3h_kernel(const DecodePara
         o1 += __shfl_xor(o1, 32);
         o2 += __shfl_xor(o2, 32);
         if (cur.valid && h == 0) {
-            const size_t plane = (size_t)p.Orows * p.Wu;
-            float* o = p.out + (size_t)cur.b * 3 * plane + (size_t)(cur.y - p.Orow0) * p.Wu + cur.x;
+            const long long plane = p.o_ps;
+            float* o = out_px(p, cur.b, cur.y, cur.x);
             o[0] = o0 + tab[6 * HID + 0];
             o[plane] = o1 + tab[6 * HID + 1];
             o[2 * plane] = o2 + tab[6 * HID + 2];
@@ -641,6 +641,7 @@ int launch_decode_bf16x3(void* stream, const DecodeParams& p, int gx, int gy, in
     // persistent workgroups with the shared hi stream from two blocks per CU up (below that there is no next block
     // whose layer 0 could be overlapped); DIINN_X3_KERNEL = 1 / 2 forces the one-block / the persistent form.
     // Bit-identical results.
+    // (the two forms are bit-identical, so the choice may depend on the launch -- band or tile -- at hand)
     const int force = (int)knob(diinn_knobs().x3_kernel);
     if (force ? force == 2 : nblk >= 2 * X3H_PGRID) {
         DecodeParams pc = p;

@@ -90,11 +90,11 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
         y = rem / p.Wu;
         x = pix < p.npix ? rem - y * p.Wu : p.Wu;                // ... and are marked invalid below
     } else {
-        x = blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
+        x = p.x0 + blockIdx.x * (TILE_W * WG_TILES_X) + (wave & 1) * TILE_W + (j & (TILE_W - 1));
         y = p.y0 + blockIdx.y * (TILE_H * WG_TILES_Y) + (wave >> 1) * TILE_H + (j / TILE_W);
         b = blockIdx.z;
     }
-    const bool valid = (x < p.Wu) && (y < p.y1);
+    const bool valid = (x < p.x1) && (y < p.y1);
     __syncthreads();                                             // the tables are in LDS
     // whole wave outside the band/image: nothing to do (wave-uniform; no barrier follows)
     if (__builtin_amdgcn_readfirstlane((int)(__ballot(valid) == 0ull))) return;
@@ -288,8 +288,8 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     o1 += __shfl_xor(o1, 32);
     o2 += __shfl_xor(o2, 32);
     if (valid && h == 0) {
-        const size_t plane = (size_t)p.Orows * p.Wu;
-        float* o = p.out + (size_t)b * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
+        const long long plane = p.o_ps;
+        float* o = out_px(p, b, y, x);
         o[0] = o0 + tab[6 * HID + 0];
         o[plane] = o1 + tab[6 * HID + 1];
         o[2 * plane] = o2 + tab[6 * HID + 2];
@@ -338,10 +338,10 @@ __global__ __launch_bounds__(256, 2) void decode_coop_kernel(const DecodeParams 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
     // one 8 x 4 pixel tile per workgroup
-    const int x = blockIdx.x * TILE_W + (j & (TILE_W - 1));
+    const int x = p.x0 + blockIdx.x * TILE_W + (j & (TILE_W - 1));
     const int y = p.y0 + blockIdx.y * TILE_H + (j / TILE_W);
     const int b = blockIdx.z;
-    const bool valid = (x < p.Wu) && (y < p.y1);
+    const bool valid = (x < p.x1) && (y < p.y1);
     const int xc = x < p.Wu ? x : p.Wu - 1;
     const int yc = y < p.y1 ? y : p.y1 - 1;
     int iy, ix;
@@ -475,8 +475,8 @@ __global__ __launch_bounds__(256, 2) void decode_coop_kernel(const DecodeParams 
         o1 += __shfl_xor(o1, 32);
         o2 += __shfl_xor(o2, 32);
         if (valid && h == 0) {
-            const size_t plane = (size_t)p.Orows * p.Wu;
-            float* op = p.out + (size_t)b * 3 * plane + (size_t)(y - p.Orow0) * p.Wu + x;
+            const long long plane = p.o_ps;
+            float* op = out_px(p, b, y, x);
             op[0] = o0 + tab[6 * HID + 0];
             op[plane] = o1 + tab[6 * HID + 1];
             op[2 * plane] = o2 + tab[6 * HID + 2];
@@ -582,15 +582,25 @@ static int cell_chain_impl(void* stream, float* P_dev, const float* packed_dev, 
     return hip_status(hipGetLastError());
 }
 
-static int decode_band_impl(void* stream, const float* P_dev, const float* packed_dev,
+// Where the pixels of a launch go: `out` points at pixel (b = 0, c = 0, y = row0, x = col0) of the caller's buffer, the
+// strides are in floats.  The row-band entry points describe a contiguous [B,3,rows,Wu] window this way (contig()).
+struct OutView { int row0, rows, col0; long long bs, ps, rs; };
+static inline OutView contig(RowWin ow, int Wu) {
+    return OutView{ow.row0, ow.rows, 0, 3LL * ow.rows * Wu, (long long)ow.rows * Wu, (long long)Wu};
+}
+
+// HR rows [y0,y1) x columns [x0,x1) of the image, every arithmetic mode.  Blocks are anchored at (x0, y0); no pixel's
+// arithmetic depends on its place in a block, and every kernel-variant choice that is not bit-neutral is made from the
+// FULL image, so a tile is bit-identical to the same pixels of a whole-image decode.
+static int decode_tile_impl(void* stream, const float* P_dev, const float* packed_dev,
                             float* out_dev, int B, int H, int W, int Hu, int Wu,
-                            int y0, int y1, int sin_mode, int compute, RowWin pw, RowWin ow) {
+                            int y0, int y1, int x0, int x1, int sin_mode, int compute, RowWin pw, OutView ov) {
     if (!compute_ok(compute))
         return DIINN_ERR_UNSUPPORTED;
     if (!P_dev || !packed_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
     if (st) return st;
-    if (Hu <= 0 || Wu <= 0 || y0 < 0 || y1 > Hu || y0 >= y1) return DIINN_ERR_INVALID_ARG;
+    if (Hu <= 0 || Wu <= 0 || y0 < 0 || y1 > Hu || y0 >= y1 || x0 < 0 || x1 > Wu || x0 >= x1) return DIINN_ERR_INVALID_ARG;
     if ((double)Hu * Wu >= 2.0e9) return DIINN_ERR_TOO_LARGE;
     {
         int r0, r1;
@@ -598,18 +608,24 @@ static int decode_band_impl(void* stream, const float* P_dev, const float* packe
         if (st) return st;
         st = check_window(pw.row0, pw.rows, H, r0, r1);
         if (st) return st;
-        st = check_window(ow.row0, ow.rows, Hu, y0, y1);
+        st = check_window(ov.row0, ov.rows, Hu, y0, y1);
         if (st) return st;
     }
+    // strides: a row holds the tile's columns, a plane its rows, a batch item its three planes (no overlap); < 2^40 floats
+    if (ov.col0 < 0 || ov.col0 > x0 || ov.rs < (long long)(x1 - ov.col0) || ov.ps < ov.rs * (y1 - ov.row0 - 1) + (x1 - ov.col0) ||
+        ov.bs < 2 * ov.ps + ov.rs * (y1 - ov.row0 - 1) + (x1 - ov.col0) || ov.bs > (1LL << 40))
+        return DIINN_ERR_INVALID_ARG;
     if (sin_mode < DIINN_SIN_ACCURATE || sin_mode > DIINN_SIN_HW_REDUCED) return DIINN_ERR_UNSUPPORTED;
-    int gx, gy, gz, blk;
-    diinn_decode_launch_info(B, Hu, Wu, y0, y1, &gx, &gy, &gz, &blk);
+    const int gx = (x1 - x0 + TILE_W * WG_TILES_X - 1) / (TILE_W * WG_TILES_X);
+    const int gy = (y1 - y0 + TILE_H * WG_TILES_Y - 1) / (TILE_H * WG_TILES_Y);
+    const int gz = B, blk = 256;
     if (gy > 65535 || gz > 65535) return DIINN_ERR_TOO_LARGE;   // HIP grid.y / grid.z limits
     DecodeParams p;
     p.P = P_dev; p.Wt = packed_dev; p.out = out_dev;
     p.B = B; p.H = H; p.W = W; p.Hu = Hu; p.Wu = Wu; p.y0 = y0; p.y1 = y1;
     p.ratio = (float)(((double)H * (double)W) / ((double)Hu * (double)Wu));
-    p.Prow0 = pw.row0; p.Prows = pw.rows; p.Orow0 = ow.row0; p.Orows = ow.rows;
+    p.Prow0 = pw.row0; p.Prows = pw.rows; p.Orow0 = ov.row0; p.Orows = ov.rows;
+    p.x0 = x0; p.x1 = x1; p.Ocol0 = ov.col0; p.o_bs = ov.bs; p.o_ps = ov.ps; p.o_rs = ov.rs;
     p.acts = nullptr; p.npix = 0; p.seed_cols = 0; p.xcd_runs = 0;
     for (int i = 0; i < 6; ++i) p.pg[i] = 0;
 #ifdef DIINN_STAMPS
@@ -635,7 +651,7 @@ static int decode_band_impl(void* stream, const float* P_dev, const float* packe
     // small launches: the latency variant (4 waves share a tile): fewer than ~3/4 of a round of 16 x 8 workgroups.
     // DIINN_F32_KERNEL = 1 / 2 forces the throughput / latency kernel (tests, A-B timing).
     const int force = (int)knob(diinn_knobs().f32_kernel);
-    const dim3 gridc((Wu + TILE_W - 1) / TILE_W, (y1 - y0 + TILE_H - 1) / TILE_H, B);
+    const dim3 gridc((x1 - x0 + TILE_W - 1) / TILE_W, (y1 - y0 + TILE_H - 1) / TILE_H, B);
     if (gridc.y <= 65535 && (force ? force == 2 : (long long)gx * gy * gz <= 192)) {
         if (sin_mode == DIINN_SIN_HW)
             hipLaunchKernelGGL(decode_coop_kernel<DIINN_SIN_HW>, gridc, dim3(256), 0, (hipStream_t)stream, p);
@@ -652,6 +668,14 @@ static int decode_band_impl(void* stream, const float* P_dev, const float* packe
     else
         hipLaunchKernelGGL(decode_kernel<DIINN_SIN_ACCURATE>, grid, dim3(blk), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
+}
+
+static int decode_band_impl(void* stream, const float* P_dev, const float* packed_dev,
+                            float* out_dev, int B, int H, int W, int Hu, int Wu,
+                            int y0, int y1, int sin_mode, int compute, RowWin pw, RowWin ow) {
+    if (Wu <= 0) return DIINN_ERR_INVALID_ARG;
+    return decode_tile_impl(stream, P_dev, packed_dev, out_dev, B, H, W, Hu, Wu, y0, y1, 0, Wu, sin_mode, compute, pw,
+                            contig(ow, Wu));
 }
 
 static int decode_impl(void* stream, const float* feat_dev, const float* packed_dev,
@@ -713,6 +737,16 @@ int diinn_decode_band_win(void* stream, const float* P_win_dev, int p_row0, int 
                             RowWin{p_row0, p_rows}, RowWin{out_row0, out_rows});
 }
 
+int diinn_decode_tile_win(void* stream, const float* P_win_dev, int p_row0, int p_rows, const float* packed_dev,
+                          float* out_tile_dev, long long out_row_stride, long long out_plane_stride,
+                          long long out_batch_stride, int B, int H, int W, int Hu, int Wu,
+                          int y0, int y1, int x0, int x1, int sin_mode, int compute) {
+    // the view starts at the tile's own first pixel: row0 = y0, col0 = x0, rows = what the tile covers
+    return decode_tile_impl(stream, P_win_dev, packed_dev, out_tile_dev, B, H, W, Hu, Wu, y0, y1, x0, x1, sin_mode, compute,
+                            RowWin{p_row0, p_rows},
+                            OutView{y0, y1 > y0 ? y1 - y0 : 1, x0, out_batch_stride, out_plane_stride, out_row_stride});
+}
+
 int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed_dev, float* out_dev,
                            float* acts_dev, int B, int H, int W, int Hu, int Wu, int sin_mode) {
     if (!P_dev || !packed_dev || !out_dev || !acts_dev) return DIINN_ERR_INVALID_ARG;
@@ -730,6 +764,7 @@ int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed
     p.B = B; p.H = H; p.W = W; p.Hu = Hu; p.Wu = Wu; p.y0 = 0; p.y1 = Hu;
     p.ratio = (float)(((double)H * (double)W) / ((double)Hu * (double)Wu));
     p.Prow0 = 0; p.Prows = H; p.Orow0 = 0; p.Orows = Hu;
+    p.x0 = 0; p.x1 = Wu; p.Ocol0 = 0; p.o_rs = Wu; p.o_ps = (long long)Hu * Wu; p.o_bs = 3 * p.o_ps;
     p.acts = acts_dev; p.npix = npix; p.seed_cols = 0; p.xcd_runs = 0;
     for (int i = 0; i < 6; ++i) p.pg[i] = 0;
 #ifdef DIINN_STAMPS

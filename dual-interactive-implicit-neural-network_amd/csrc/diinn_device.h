@@ -116,6 +116,12 @@ struct DecodeParams {
     // row windows (include/diinn_hip.h "row windows"): P holds LR rows [Prow0, Prow0+Prows), out holds HR rows
     // [Orow0, Orow0+Orows); the full-buffer entry points pass (0, H) and (0, Hu)
     int Prow0, Prows, Orow0, Orows;
+    // column range and output strides (include/diinn_hip.h "tiles"): the launch covers HR columns [x0, x1) -- blocks are
+    // anchored at x0, which changes no pixel's arithmetic -- and pixel (b, c, y, x) is written to
+    // out[b * o_bs + c * o_ps + (y - Orow0) * o_rs + (x - Ocol0)]; the row-band entry points pass (0, Wu), Ocol0 = 0 and
+    // the strides of a contiguous [B,3,Orows,Wu] tensor
+    int x0, x1, Ocol0;
+    long long o_bs, o_ps, o_rs;
     int seed_cols;         // decode_bf16_coop_kernel: LR columns of a block's footprint (row length of its LDS seed slab)
     int xcd_runs;          // decode_bf16_coop8_kernel: walk the blocks XCD by XCD (set when neighbouring blocks share P rows)
     int pg[6];             // decode_bf16_coop8p_kernel: block grid (x, y, z), super-tile grid (x, y), super-tiles per XCD
@@ -142,6 +148,11 @@ struct DecodeParams {
 #else
 #define STAMP(i) do {} while (0)
 #endif
+
+// colour plane 0 of HR pixel (b, y, x) in the caller's output; the other two planes are p.o_ps floats apart
+__device__ __forceinline__ float* out_px(const DecodeParams& p, int b, int y, int x) {
+    return p.out + (long long)b * p.o_bs + (long long)(y - p.Orow0) * p.o_rs + (x - p.Ocol0);
+}
 
 constexpr int TILE_W = 8, TILE_H = 4;           // one wave: 8x4 HR pixels
 // timing-ablation hooks (wrong results when defined; never in the shipped build)

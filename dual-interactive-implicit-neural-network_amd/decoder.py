@@ -220,6 +220,38 @@ def decode_window(feat_win: torch.Tensor, feat_row0: int, full_h: int, packed: t
     return out_win
 
 
+def decode_tile(p_win: torch.Tensor, p_row0: int, shape: Sequence[int], packed: torch.Tensor, size: Sequence[int],
+                rows: Tuple[int, int], cols: Tuple[int, int], out: torch.Tensor,
+                sin_mode: int = _native.SIN_DEFAULT, compute: str = "f32") -> torch.Tensor:
+    """Decode the HR tile rows x cols = [y0,y1) x [x0,x1) from a P window (``diinn_precompute_P_win``'s output: LR rows
+    [p_row0, p_row0 + p_rows) of the [B,H,W,1024] image, ``shape`` = (B, H, W) of the full map) INTO ``out``, any fp32
+    view of shape [B,3,y1-y0,x1-x0] with unit stride along x -- a tensor of its own or a window of a larger canvas;
+    nothing else of the canvas is written.  Bit-identical to the same pixels of ``decode_features``.  The reference's
+    analogue is ``batched_step``'s column strips (diinn.py:149-160).  C ABI: ``diinn_decode_tile_win``."""
+    lib = _native.load()
+    _require_cuda(p_win, "p_win")
+    _require_cuda(packed, "packed weights")
+    b, h, w = (int(v) for v in shape)
+    hu, wu = int(size[0]), int(size[1])
+    y0, y1 = int(rows[0]), int(rows[1])
+    x0, x1 = int(cols[0]), int(cols[1])
+    if out.dtype != torch.float32 or out.dim() != 4 or tuple(out.shape) != (b, 3, y1 - y0, x1 - x0) or out.device != p_win.device:
+        raise ValueError(f"out must be an fp32 [B,3,{y1 - y0},{x1 - x0}] view on the P window's device, got {out.dtype} {tuple(out.shape)}")
+    if out.stride(3) != 1 and x1 - x0 > 1:
+        raise ValueError("out must have unit stride along x")
+    if p_win.dtype != torch.float32 or not p_win.is_contiguous() or p_win.numel() % (b * w * P_CHANNELS):
+        raise ValueError("p_win must be a contiguous fp32 buffer of B * rows * W * 1024 floats")
+    p_rows = p_win.numel() // (b * w * P_CHANNELS)
+    with torch.cuda.device(p_win.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        st = lib.diinn_decode_tile_win(C.c_void_p(stream), C.c_void_p(p_win.data_ptr()), int(p_row0), p_rows,
+                                       C.c_void_p(packed.data_ptr()), C.c_void_p(out.data_ptr()),
+                                       out.stride(2), out.stride(1), out.stride(0), b, h, w, hu, wu, y0, y1, x0, x1,
+                                       int(sin_mode), _native.COMPUTE[compute])
+    _native.check(st, "diinn_decode_tile_win")
+    return out
+
+
 # ---------------------------------------------------------------------------
 # LIIF comparison decoder (reference liif.py; SURVEY.md §8 row f4)
 # ---------------------------------------------------------------------------

@@ -93,11 +93,18 @@ def decoder_param_shapes(mode: int = 3) -> "OrderedDict[str, tuple]":
     return shapes
 
 
-def decoder_state_dict(seed: int = 123, gain: float = 1.0, mode: int = 3) -> "OrderedDict[str, np.ndarray]":
+SIREN_Q_GAIN = (30.0, math.sqrt(6.0))
+
+
+def decoder_state_dict(seed: int = 123, gain: float = 1.0, mode: int = 3,
+                       q_gain=None) -> "OrderedDict[str, np.ndarray]":
     """Synthetic decoder weights in the reference's state_dict naming.
 
     ``gain`` scales every tensor (gain=3 is the SURVEY §8(d2) stress set:
-    larger sine arguments and output magnitude)."""
+    larger sine arguments and output magnitude).  ``q_gain = (first, hidden)`` additionally scales the
+    synthesis branch's WEIGHTS (``Q.0.0.weight`` by ``first``, ``Q.1..3.0.weight`` by ``hidden``; biases and
+    every other tensor untouched): ``SIREN_Q_GAIN`` = (30, sqrt 6) is the trained-SIREN range -- layer-0 sine
+    arguments of tens of radians on the raw coordinates (reference diinn.py:61-62,134) with |out| still O(1)."""
     sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
     shapes = decoder_param_shapes(mode)
     for name, shape in shapes.items():
@@ -106,6 +113,8 @@ def decoder_state_dict(seed: int = 123, gain: float = 1.0, mode: int = 3) -> "Or
         fan_in = wshape[1] * wshape[2] * wshape[3]
         bound = 1.0 / math.sqrt(fan_in)
         sd[name] = (uniform(seed, name, shape, bound) * np.float32(gain)).astype(np.float32)
+        if q_gain is not None and name.startswith("Q.") and name.endswith(".weight"):
+            sd[name] = (sd[name] * np.float32(q_gain[0] if name.startswith("Q.0.") else q_gain[1])).astype(np.float32)
     return sd
 
 

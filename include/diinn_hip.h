@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIINN_ABI_VERSION 6
+#define DIINN_ABI_VERSION 7
 /* History of the ABI number:
  *   1  diinn_pack_weights, axis tables, diinn_precompute_P / diinn_decode_band / diinn_decode (+ _ex: compute modes)
  *   2  training (diinn_decode_train_fwd, diinn_backward_*, diinn_plane_*), LIIF / MetaSR, the encoder trunk
@@ -43,7 +43,8 @@ extern "C" {
  *   6  the packed image carries a validity word for its derived sections (DIINN_PACKED_MAGIC, below);
  *      diinn_p_launch_info; diinn_debug_set / diinn_debug_get;
  *      bf16 kernel choice taken from the full image, not the band; DIINN_COMPUTE_BF16X3 and packed sections 14-15 (DIINN_P_ALGO_DIRECT_BF16X3);
- *      split-bf16 encoder layers (diinn_conv3x3_x3, diinn_rdn_forward_x3) */
+ *      split-bf16 encoder layers (diinn_conv3x3_x3, diinn_rdn_forward_x3)
+ *   7  tiles: diinn_decode_tile_win (HR column range + output strides; the row-band entry points are wrappers of it) */
 
 /* status codes */
 #define DIINN_OK                 0
@@ -220,6 +221,25 @@ int diinn_decode_win(void* stream, const float* feat_win_dev, int feat_row0, int
                      const float* packed_dev, float* P_win_dev, int p_row0, int p_rows,
                      float* out_win_dev, int out_row0, int out_rows,
                      int B, int H, int W, int Hu, int Wu, int y0, int y1, int sin_mode, int compute);
+
+/* ---- tiles: column range and output strides (SURVEY.md section 8 row b2's sketch `diinn_decode_tile(..., y0,y1,x0,x1, out,
+ * out_strides, ...)`; reference analogue: batched_step's column strips, diinn.py:149-160) -------------------------------
+ * diinn_decode_tile_win decodes HR rows [y0,y1) x columns [x0,x1) of the [B,3,Hu,Wu] image from the P window (as
+ * diinn_decode_band_win: P_win_dev holds LR rows [p_row0, p_row0+p_rows), full width) and writes them THROUGH STRIDES:
+ * pixel (b, c, y, x) goes to
+ *     out_tile_dev[b * out_batch_stride + c * out_plane_stride + (y - y0) * out_row_stride + (x - x0)]      (strides in floats)
+ * i.e. out_tile_dev points at the tile's first pixel inside whatever the caller owns -- a crop buffer of its own, or a
+ * view into a larger canvas (nothing outside the tile's pixels is written).  Requirements (else DIINN_ERR_INVALID_ARG):
+ * out_row_stride >= x1 - x0, out_plane_stride >= (y1 - y0 - 1) * out_row_stride + (x1 - x0), out_batch_stride >=
+ * 2 * out_plane_stride + that (rows, planes and batch items do not interleave), out_batch_stride <= 2^40.
+ * Every compute mode.  A tile is BIT-IDENTICAL to the same pixels of a whole-image decode: blocks are anchored at (x0, y0),
+ * no pixel's arithmetic depends on its place in a block, and kernel variants that differ in rounding are chosen from the
+ * full image's geometry (H, W, Hu, Wu), never from the tile.  diinn_decode_band_ex / _win are this function with
+ * x0 = 0, x1 = Wu and the strides of a contiguous [B,3,rows,Wu] window.  Enqueues one kernel; no allocation, no sync. */
+int diinn_decode_tile_win(void* stream, const float* P_win_dev, int p_row0, int p_rows, const float* packed_dev,
+                          float* out_tile_dev, long long out_row_stride, long long out_plane_stride,
+                          long long out_batch_stride, int B, int H, int W, int Hu, int Wu,
+                          int y0, int y1, int x0, int x1, int sin_mode, int compute);
 
 /* Modes 1 and 2 only: the modulation chain per LR cell, k_0 = relu(P_0), k_i = relu(K_i^k k_{i-1} + P_i)
  * (diinn.py:118-121,126-129), for LR rows [r0,r1); k_i overwrites the P_i slot (i = 1..3) of P_dev. */

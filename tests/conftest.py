@@ -32,6 +32,23 @@ def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "diinn_golden.npz"))
 
 
+@pytest.fixture(scope="session")
+def golden_r4():
+    """Round-4 additions (tests/golden/make_golden_r4.py): float64 reference outputs of every case (as a float32
+    difference to the fp32 output) and the SIREN-range cases."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "diinn_golden_r4.npz"))
+
+
+def siren_cases(g4):
+    """(name, b, h, w, hu, wu, gain, q_gain) of the SIREN-range fixtures."""
+    out = []
+    for k in g4.files:
+        if k.startswith("meta/siren"):
+            b, h, w, hu, wu, gain, bs, q0, qh = g4[k]
+            out.append((k[5:], int(b), int(h), int(w), int(hu), int(wu), float(gain), (float(q0), float(qh))))
+    return out
+
+
 def golden_cases(g):
     out = []
     for k in g.files:

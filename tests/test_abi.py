@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.diinn_abi_version() == 6
+    assert lib.diinn_abi_version() == 7
     assert lib.diinn_status_string(0) == b"ok"
     assert b"invalid" in lib.diinn_status_string(1)
 
@@ -275,3 +275,25 @@ def test_window_rows_and_window_validation(lib):
     assert lib.diinn_precompute_P_win(None, fake, 8, 8, fake, fake, 8, 8, 1, 64, 64, 8, 16, 0) == N.ERR_INVALID_ARG
     # window outside the map
     assert lib.diinn_precompute_P_win(None, fake, 60, 8, fake, fake, 61, 3, 1, 64, 64, 61, 64, 0) == N.ERR_INVALID_ARG
+
+
+def test_tile_entry_point_validates_ranges_and_strides(lib):
+    """diinn_decode_tile_win (ABI v7): bad column ranges and strides that would make rows / planes / batch items
+    interleave are refused before anything is launched (host-side checks only: no GPU needed for these calls)."""
+    import ctypes as C
+    dummy = C.c_void_p(16)                                       # never dereferenced: every call below fails validation
+
+    def tile(y0, y1, x0, x1, rs, ps, bs, p_row0=0, p_rows=64, compute=0, sin=2):
+        return lib.diinn_decode_tile_win(None, dummy, p_row0, p_rows, dummy, dummy, rs, ps, bs, 1, 64, 64, 256, 256,
+                                         y0, y1, x0, x1, sin, compute)
+    ok_strides = (40, 40 * 8, 3 * 40 * 8)
+    assert tile(0, 8, 10, 10, *ok_strides) == 1                 # empty column range
+    assert tile(0, 8, -1, 10, *ok_strides) == 1
+    assert tile(0, 8, 250, 257, *ok_strides) == 1               # past the image
+    assert tile(8, 8, 0, 16, *ok_strides) == 1                  # empty row range
+    assert tile(0, 8, 0, 41, *ok_strides) == 1                  # row stride shorter than the tile's width
+    assert tile(0, 8, 0, 40, 40, 40 * 7, 3 * 40 * 8) == 1       # planes would overlap
+    assert tile(0, 8, 0, 40, 40, 40 * 8, 2 * 40 * 8) == 1       # batch items would overlap
+    assert tile(0, 8, 0, 40, *ok_strides, p_row0=5, p_rows=4) == 1   # the P window does not hold the tile's LR rows
+    assert tile(0, 8, 0, 40, *ok_strides, compute=99) == 2      # unsupported arithmetic
+    assert tile(0, 8, 0, 40, *ok_strides, sin=7) == 2

@@ -46,6 +46,54 @@ def test_golden_fixtures(golden, dev, sin_mode):
         assert err <= _tol(ref), f"{name}: max err {err:.3e} > {_tol(ref):.3e} (sin_mode={sin_mode})"
 
 
+# Regression-level bounds (VERDICT r03 "what's weak" 1): the contract above is 1e-4, the fp32 kernels sit ~3,000x below
+# it at default-init weights, so a thousandfold loss of accuracy would stay green under it.  These hold the kernels
+# NEAR the noise floor instead: 5e-7 absolute at default init (observed 2e-8 .. 6e-8: one wrong sine mode, a dropped
+# term or a mis-rounded constant lands at 1e-6 or above), and on the x3 stress set 3x the reference's OWN fp32-vs-fp64
+# distance, measured against float64 truth (ref64 = ref32 + d64, tests/golden/make_golden_r4.py).
+REGRESSION_ABS = 5e-7
+
+
+@pytest.mark.parametrize("sin_mode", [0, 1, 2])
+def test_golden_fixtures_at_the_noise_floor(golden, golden_r4, dev, sin_mode):
+    for name, b, h, w, hu, wu, gain in golden_cases(golden):
+        sd = synth.decoder_state_dict(123, gain)
+        feat = synth.encoder_features(123, b, h, w)
+        got = _decode(sd, feat, (hu, wu), dev, sin_mode=sin_mode)
+        ref32 = golden[f"out/{name}"]
+        d64 = golden_r4[f"d64/{name}"].astype(np.float64)
+        ref64 = ref32.astype(np.float64) + d64
+        err32 = float(np.abs(got - ref32).max())
+        err64 = float(np.abs(got.astype(np.float64) - ref64).max())
+        if gain == 1.0:
+            assert err32 <= REGRESSION_ABS and err64 <= REGRESSION_ABS, f"{name} sin_mode={sin_mode}: {err32:.3e} / {err64:.3e}"
+        else:
+            noise = float(np.abs(d64).max())                      # the reference's own distance from float64
+            assert err64 <= 3.0 * noise, f"{name} sin_mode={sin_mode}: {err64:.3e} vs float64, reference itself {noise:.3e}"
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16x3"])
+@pytest.mark.parametrize("sin_mode", [0, 1, 2])
+def test_siren_range_fixtures(golden_r4, dev, sin_mode, compute):
+    """Reference outputs with trained-SIREN-range synthesis weights (Q.0 x 30, Q.1-3 x sqrt 6: layer-0 sine arguments of
+    ~33 rad, ~67 with every tensor doubled on top; diinn.py:61-62,134): the regime where the hardware sine on
+    revolutions and the pre-scaled weight image earn their keep.  fp32 and split bf16, all three sine modes, at the
+    north_star bound -- and near the noise floor for fp32 (10x the reference's own fp32-vs-fp64 distance)."""
+    from conftest import siren_cases
+    for name, b, h, w, hu, wu, gain, qg in siren_cases(golden_r4):
+        sd = synth.decoder_state_dict(123, gain, q_gain=qg)
+        feat = synth.encoder_features(123, b, h, w)
+        got = _decode(sd, feat, (hu, wu), dev, sin_mode=sin_mode, compute=compute)
+        ref32 = golden_r4[f"out/{name}"]
+        d64 = golden_r4[f"d64/{name}"].astype(np.float64)
+        err = float(np.abs(got - ref32).max())
+        assert err <= _tol(ref32), f"{name} {compute} sin_mode={sin_mode}: {err:.3e} > {_tol(ref32):.3e}"
+        if compute == "f32":
+            err64 = float(np.abs(got.astype(np.float64) - (ref32.astype(np.float64) + d64)).max())
+            noise = float(np.abs(d64).max())
+            assert err64 <= 10.0 * noise, f"{name} sin_mode={sin_mode}: {err64:.3e} vs float64, reference itself {noise:.3e}"
+
+
 def test_device_axis_tables_bit_exact(golden, dev):
     """The coordinate/index code the decode kernel runs, against the reference's own tables
     (_make_pos_encoding diinn.py:94-110 + ATen nearest-exact)."""
@@ -115,6 +163,32 @@ def test_full_size_config2_band_vs_oracle(dev):
         ref = orc.decode_reference_form(sd, feat_np, size, 30000, row_range=(y0, y1)).numpy()
         err = float(np.abs(full_np[:, :, y0:y1] - ref).max())
         assert err <= _tol(ref), f"rows {y0}:{y1} err {err:.3e}"
+        assert err <= REGRESSION_ABS, f"rows {y0}:{y1} err {err:.3e}: off the noise floor (observed 3e-8)"
+
+
+def test_full_size_config2_batch2_second_seed(dev):
+    """Config 2's geometry with B = 2 and another weight / feature seed (the full-size tests were one seed, B = 1):
+    random HR row bands of both images against the oracle at the noise floor, the two images decoded together bit-equal to
+    each decoded alone."""
+    import diinn_amd.decoder as D
+    import diinn_oracle as orc
+    sd = synth.decoder_state_dict(2024)
+    feat_np = synth.encoder_features(2024, 2, 256, 256)
+    feat = torch.from_numpy(feat_np).to(dev)
+    packed = D.pack_state_dict(sd).to(dev)
+    size = (1024, 1024)
+    full = D.decode_features(feat, packed, size)
+    single = [D.decode_features(feat[i:i + 1].contiguous(), packed, size) for i in range(2)]
+    torch.cuda.synchronize()
+    assert torch.equal(full, torch.cat(single, 0))
+    full_np = full.cpu().numpy()
+    rng = np.random.default_rng(11)
+    for _ in range(4):
+        y0 = int(rng.integers(0, 1020))
+        y1 = y0 + 4
+        ref = orc.decode_reference_form(sd, feat_np, size, 30000, row_range=(y0, y1)).numpy()
+        err = float(np.abs(full_np[:, :, y0:y1] - ref).max())
+        assert err <= REGRESSION_ABS, f"rows {y0}:{y1} err {err:.3e}"
 
 
 def test_module_interface_matches_reference_signature(dev):
@@ -361,6 +435,98 @@ def test_random_shapes_vs_oracle(dev):
         got = _decode(sd, feat, (hu, wu), dev)
         err = float(np.abs(got - ref).max())
         assert err <= _tol(ref), f"case {case}: B{b} {h}x{w} -> {hu}x{wu}: err {err:.3e}"
+
+
+def test_random_geometries_with_bands_vs_oracle(dev):
+    """Forty seeded random geometries for the DEFAULT fp32 path (what the optional split-bf16 mode already had): up- and
+    down-scaling, non-integer ratios, batches, launches on both sides of the latency / throughput kernel switch (192
+    workgroups); the whole image against the oracle at the noise floor, a random row band bit-equal to the same rows,
+    rows outside the band untouched."""
+    import diinn_amd.decoder as D
+    import diinn_oracle as orc
+    rng = np.random.default_rng(4040)
+    sd = synth.decoder_state_dict(43)
+    packed = D.pack_state_dict(sd).to(dev)
+    small = large = 0
+    for it in range(40):
+        b = int(rng.integers(1, 4))
+        h, w = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+        sy, sx = rng.uniform(0.6, 7.0), rng.uniform(0.6, 7.0)
+        hu, wu = max(1, int(h * sy)), max(1, int(w * sx))
+        if b * hu * wu > 120_000:                                 # the oracle decodes the whole image: keep it to seconds
+            hu, wu = min(hu, 200), min(wu, 200)
+        wgs = b * ((wu + 15) // 16) * ((hu + 7) // 8)
+        small += wgs <= 192
+        large += wgs > 192
+        feat_np = synth.encoder_features(300 + it, b, h, w)
+        feat = torch.from_numpy(feat_np).to(dev)
+        full = D.decode_features(feat, packed, (hu, wu))
+        y0 = int(rng.integers(0, hu))
+        y1 = int(rng.integers(y0 + 1, hu + 1))
+        band = torch.full_like(full, float("nan"))
+        D.decode_features(feat, packed, (hu, wu), out=band, rows=(y0, y1))
+        torch.cuda.synchronize()
+        ref = orc.decode_reference_form(sd, feat_np, (hu, wu), 30000).numpy()
+        err = float(np.abs(full.cpu().numpy() - ref).max())
+        assert err <= REGRESSION_ABS, f"case {it}: B{b} {h}x{w} -> {hu}x{wu}: err {err:.3e}"
+        assert torch.equal(band[:, :, y0:y1], full[:, :, y0:y1]), (b, h, w, hu, wu, y0, y1)
+        assert bool(torch.isnan(band[:, :, :y0]).all()) and bool(torch.isnan(band[:, :, y1:]).all())
+    assert small >= 5 and large >= 5, (small, large)
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16x3", "bf16", "bf16_full"])
+def test_tiles_with_column_ranges_and_strides(dev, knobs, compute):
+    """diinn_decode_tile_win (ABI v7; reference analogue: batched_step's column strips,
+    diinn.py:149-160): (i) a 3 x 3 tiling with ragged cuts, each tile written straight into its window of one
+    canvas through strides, stitches BIT-EXACTLY into the whole-image decode; (ii) a tile decoded into a strided view of
+    a larger canvas leaves every other element of the canvas untouched; (iii) the same into a compact crop buffer.
+    Every arithmetic mode; for the bf16 modes on a geometry large enough for the cooperative kernels, whose variant is
+    chosen from the full image, never the tile."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.decoder as D
+    lib = N.load()
+    big = compute in ("bf16", "bf16_full")
+    b, h, w, hu, wu = (1, 120, 150, 396, 495) if big else (2, 40, 56, 132, 185)     # x3.3 both ways
+    sd = synth.decoder_state_dict(19)
+    packed = D.pack_state_dict(sd).to(dev)
+    feat = torch.from_numpy(synth.encoder_features(19, b, h, w)).to(dev)
+    full = D.decode_features(feat, packed, (hu, wu), compute=compute)
+    pwin = torch.empty(b * h * w * 1024, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N.check(lib.diinn_precompute_P_win(stream, C.c_void_p(feat.data_ptr()), 0, h, C.c_void_p(packed.data_ptr()),
+                                       C.c_void_p(pwin.data_ptr()), 0, h, b, h, w, 0, h, N.COMPUTE[compute]), "P")
+    ycuts = [0, 37, 38 + 45, hu]
+    xcuts = [0, 61, 61 + 3, wu]                                   # a 3-pixel-wide strip in the middle
+    canvas = torch.full((b, 3, hu, wu), float("nan"), device=dev)
+    for ya, yb in zip(ycuts[:-1], ycuts[1:]):
+        for xa, xb in zip(xcuts[:-1], xcuts[1:]):
+            D.decode_tile(pwin, 0, (b, h, w), packed, (hu, wu), (ya, yb), (xa, xb), canvas[:, :, ya:yb, xa:xb], compute=compute)
+    torch.cuda.synchronize()
+    assert torch.equal(canvas, full), compute
+    # (ii) a larger canvas with a margin: only the tile's pixels change
+    ya, yb, xa, xb = 50, 101, 23, 160
+    wide = torch.full((b, 3, hu + 7, wu + 11), -7.0, device=dev)
+    D.decode_tile(pwin, 0, (b, h, w), packed, (hu, wu), (ya, yb), (xa, xb), wide[:, :, 3 + ya:3 + yb, 5 + xa:5 + xb], compute=compute)
+    torch.cuda.synchronize()
+    assert torch.equal(wide[:, :, 3 + ya:3 + yb, 5 + xa:5 + xb], full[:, :, ya:yb, xa:xb])
+    mask = torch.ones_like(wide, dtype=torch.bool)
+    mask[:, :, 3 + ya:3 + yb, 5 + xa:5 + xb] = False
+    assert bool((wide[mask] == -7.0).all())
+    # (iii) a compact crop, and the band-sized P window of just the rows the tile reads
+    (_, _), (r0, rn) = D.window_rows(h, hu, wu, ya, yb)
+    pband = pwin.view(b, h, w, 1024)[:, r0:r0 + rn].contiguous().view(-1)
+    crop = torch.empty((b, 3, yb - ya, xb - xa), device=dev)
+    D.decode_tile(pband, r0, (b, h, w), packed, (hu, wu), (ya, yb), (xa, xb), crop, compute=compute)
+    torch.cuda.synchronize()
+    assert torch.equal(crop, full[:, :, ya:yb, xa:xb])
+    if compute == "f32":                                          # the latency kernel takes small tiles: forced both ways
+        for force in (1, 2):
+            knobs("DIINN_F32_KERNEL", force)
+            crop.fill_(0)
+            D.decode_tile(pband, r0, (b, h, w), packed, (hu, wu), (ya, yb), (xa, xb), crop)
+            torch.cuda.synchronize()
+            assert torch.equal(crop, full[:, :, ya:yb, xa:xb]), force
 
 
 def test_invalid_sizes_raise(dev):

@@ -48,6 +48,30 @@ def test_reference_form_matches_reference_outputs(golden):
             assert float(np.abs(got - ref).max()) <= 1e-6 * max(1.0, float(np.abs(ref).max())), (name, bsize)
 
 
+def test_reference_form_matches_siren_range_outputs(golden_r4):
+    """The same on the SIREN-range fixtures (Q.0 x 30, Q.1-3 x sqrt 6: layer-0 sine arguments of ~33-67 rad), and the
+    hoisted form the kernels use stays at rounding noise there too."""
+    from conftest import siren_cases
+    for name, b, h, w, hu, wu, gain, qg in siren_cases(golden_r4):
+        sd = synth.decoder_state_dict(123, gain, q_gain=qg)
+        feat = synth.encoder_features(123, b, h, w)
+        ref = golden_r4[f"out/{name}"]
+        scale = max(1.0, float(np.abs(ref).max()))
+        got = orc.decode_reference_form(sd, feat, (hu, wu), 30000).numpy()
+        assert float(np.abs(got - ref).max()) <= 1e-6 * scale, name
+        hoisted = orc.decode_hoisted_form(sd, feat, (hu, wu)).numpy()
+        assert float(np.abs(hoisted - ref).max()) <= 2e-5 * scale, name
+
+
+def test_float64_differences_are_reference_rounding_noise(golden, golden_r4):
+    """d64 = ref64 - ref32 of every fixture: ~2e-8 .. 9e-8 at default init, 8e-6 on the x3 stress set."""
+    from conftest import golden_cases
+    for name, *_rest, gain in golden_cases(golden):
+        d = float(np.abs(golden_r4[f"d64/{name}"]).max())
+        assert d <= (1e-7 if gain == 1.0 else 2e-5), (name, d)
+        assert golden_r4[f"d64/{name}"].shape == golden[f"out/{name}"].shape
+
+
 def test_hoisted_form_is_within_rounding(golden):
     """The per-cell hoist the kernels use equals the reference to rounding noise."""
     for name, b, h, w, hu, wu, gain in golden_cases(golden):

@@ -145,6 +145,42 @@ def test_more_ranks_than_rows():
     assert max(r[1] for r in res) <= 1e-6
 
 
+def test_eight_ranks_c4_and_c5_proportions():
+    """world_size 8 -- the target machine -- over gloo: x8 with even bands (c4's proportions: 256 HR rows / 8) and x3.3
+    with 297 = 2376 / 8 HR rows (c5's proportions: bands of 38,37,... rows whose LR windows overlap by the halo)."""
+    for geom in [(1, 32, 24, 256, 192), (1, 90, 20, 297, 66)]:
+        res = _run(8, "halo", geom, timeout=600)
+        assert len(res) == 8 and all(r[0] for r in res)
+        assert max(r[1] for r in res) <= 1e-6
+
+
+def test_eight_ranks_bcast_and_more_ranks_than_rows():
+    res = _run(8, "bcast", (1, 12, 10, 40, 33), timeout=600)
+    assert all(r[0] for r in res) and max(r[1] for r in res) <= 1e-6
+    res = _run(8, "halo", (1, 5, 6, 5, 9), timeout=600)           # 5 HR rows on 8 ranks: three empty bands
+    assert all(r[0] for r in res) and max(r[1] for r in res) <= 1e-6
+
+
+def test_plan_bands_at_the_baseline_sizes_for_eight_ranks():
+    """plan_bands at the real c3 / target / c4 / c5 sizes for 2, 4 and 8 ranks (index math only): the bands tile the HR
+    grid, pixel counts differ by < 1 %, the P rows of neighbouring bands overlap by at most one LR row (a cell whose
+    HR rows straddle the cut) and together cover the map, every feature window is the P rows + the clipped halo."""
+    import diinn_amd.sharded as S
+    for (h, w, hu, wu) in [(512, 512, 2048, 2048), (1024, 1024, 4096, 4096), (1024, 1024, 8192, 8192),
+                           (720, 1280, 2376, 4224)]:
+        for world in (2, 4, 8):
+            bands = S.plan_bands(h, hu, wu, world)
+            assert bands[0].y0 == 0 and bands[-1].y1 == hu and bands[0].r0 == 0 and bands[-1].r1 == h
+            px = [(b.y1 - b.y0) * wu for b in bands]
+            assert (max(px) - min(px)) / max(px) < 0.01, (h, hu, world, px)
+            for a, b in zip(bands, bands[1:]):
+                assert a.y1 == b.y0 and 0 <= a.r1 - b.r0 <= 1, (a, b)
+            for b in bands:
+                assert (b.a0, b.a1) == (max(b.r0 - 1, 0), min(b.r1 + 1, h))
+            # a rank's share of the feature map: 1/world of the rows + at most 3 (halo on both sides + a shared cell row)
+            assert max(b.a1 - b.a0 for b in bands) <= -(-h // world) + 3
+
+
 def _gpu_worker(rank, world, port, mode, geom, q):
     """Two ranks sharing cuda:0 (the test box has one GPU, and RCCL refuses two ranks on one device): the
     hand-off and the gather travel over gloo on CPU buffers, each rank's band is decoded by the HIP
