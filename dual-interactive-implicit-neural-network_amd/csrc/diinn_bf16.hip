@@ -1327,16 +1327,24 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
                 const bf16x8 bv = bq[ks % CO_BRING];
                 ak = MFMA_BF16(__builtin_bit_cast(bf16x8, Ak[ks]), bv, ak);
                 as = MFMA_BF16(__builtin_bit_cast(bf16x8, As[ks]), bv, as);
+#ifndef ABL_P_NOLDS
                 if (ks + CO_BRING < 16) bq[ks % CO_BRING] = qin[qoff[ti] + (ks + CO_BRING) * 64];
                 else if (ti + 1 < TILES) bq[ks % CO_BRING] = qin[qoff[ti + 1] + (ks + CO_BRING - 16) * 64];
+#endif
                 if (ti == TILES - 1) {                            // last use of this fragment: fetch the next layer's --
                     const int nwp = LAST ? wp0 : wp + (int)(WLB_LAYER * sizeof(float));   // or the next block's first layer
+#ifndef ABL_P_NOREFILL
                     if (!LAST || has_next) {
                         Ak[ks] = ld_w(nwp, 2 * ks + 0);
                         As[ks] = ld_w(nwp, 2 * ks + 1);
                     }
+#else
+                    (void)nwp;
+#endif
                 }
+#ifndef ABL_P_NOSEED
                 if (!LAST && ti == 1 && ks == 8) stage_load(layer + 2, ix0, iy0, blk.z);   // next layer's seed column, into registers
+#endif
                 if (LAST && ks == 0 && has_next) {
                     if (ti == 0) {
                         na = *(const f32x4*)nrow(0);
@@ -1359,7 +1367,11 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
                 f32x2 v;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
+#ifdef ABL_P_NOEPI
+                    v[i] = ak[r + i] + as[r + i];
+#else
                     v[i] = relu0(ak[r + i]) * co_sin_fin<SIN_MODE>(co_sin_prep<SIN_MODE>(as[r + i]));
+#endif
                 if (LAST) {                                       // head rows of this element's channel, from the LDS table
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
@@ -1397,7 +1409,9 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
                 }
             }
         }
+#ifndef ABL_P_NOBAR
         __syncthreads();                                          // layer output complete, its input image is free
+#endif
     };
 
     for (;;) {
@@ -1424,8 +1438,13 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
             };
             fetch(0, cpv, cwh, cww, ctq);
             u32x4 fragw;
+#ifdef ABL_P_NOL0
+#pragma unroll 1
+            for (int i = 0; i < 0; ++i) {
+#else
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
+#endif
                 if (i + 1 < 16) fetch(i + 1, npv, nwh, nww, ntq2);
                 f32x4 v;
 #pragma unroll

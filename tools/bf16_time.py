@@ -18,7 +18,7 @@ def runP():
     N.check(lib.diinn_precompute_P_ex(C.c_void_p(st), C.c_void_p(feat.data_ptr()), C.c_void_p(packed.data_ptr()), C.c_void_p(ws.data_ptr()), 1, h, w, 0, h, comp), "P")
 def runD():
     N.check(lib.diinn_decode_band_ex(C.c_void_p(st), C.c_void_p(ws.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                     C.c_void_p(out.data_ptr()), 1, h, w, hu, wu, 0, hu, 2, comp), "D")
+                                     C.c_void_p(out.data_ptr()), 1, h, w, hu, wu, 0, hu, int(os.environ.get("SIN", "2")), comp), "D")
 res = {}
 for name, fn in (("P", runP), ("decode", runD)):
     for _ in range(3): fn()
