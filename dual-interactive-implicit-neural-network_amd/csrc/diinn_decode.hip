@@ -485,6 +485,214 @@ __global__ __launch_bounds__(256, 2) void decode_coop_kernel(const DecodeParams 
 }
 
 // ---------------------------------------------------------------------------------
+// decode_coop16_kernel: the fp32 latency form for the SMALLEST launches (BASELINE config 1: 96 x 96).  decode_coop_kernel
+// gives a workgroup a 32-pixel tile and each wave a chain of 3 x 512 dependent-paced MFMAs of 64 clocks (41 us); an
+// image of 288 such tiles puts two workgroups on 32 of the 256 CUs and takes ~2 x 41 us.  Here a workgroup owns a
+// 4 x 4 = 16-pixel tile on v_mfma_f32_16x16x4_f32 (32 clocks): wave w owns output channels 64 w .. 64 w + 63 of both
+// branches as four 16-row M-tiles each (8 accumulators of 4 registers, 512 MFMAs per layer, 20 us per tile), twice
+// the workgroups at half the chain, four workgroups per CU (38 KiB of LDS, < 128 registers).  Measured at c1 (r04,
+// profiles/r04_c1_latency.txt): decode 0.099 -> 0.076-0.079 ms, step 0.122 -> 0.100-0.102 ms.  What bounds it now is the
+// makespan of 576 tiles on 256 CUs (three per busiest CU x ~23 us); capping the workgroups per CU at 3 or 2, weights kept
+// L1-resident, or no weight requests at all (timing ablations) move it by < 4 %.
+//   * A operands: packed section 16 (WL16), [i][half][lane][T]: a k-step's two 1 KiB pieces feed its 8 MFMAs;
+//   * B operand: the activation in LDS in POSITION order -- position p = the p-th term of decode_kernel's accumulation
+//     chain, channel chan_of(p >> 1, p & 1) -- as [p >> 4][16 (p & 3) + pixel][(p >> 2) & 3]: lane (g, n) reads the
+//     four k-steps 4 ib .. 4 ib + 3 of its k = g with one ds_read_b128;
+//   * per output channel the arithmetic is decode_kernel's: same seed, the same k-ordered chain (the 16x16x4 MFMA adds
+//     its four products in k order like the 32x32x2 one adds its two: tests hold the two kernels bit-equal), same
+//     epilogue, and wave 0 runs decode_kernel's head order on the last activation.
+// ---------------------------------------------------------------------------------
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+constexpr int T16_W = 4, T16_H = 4;
+
+template <int SIN_MODE>
+__global__ __launch_bounds__(256, 4) void decode_coop16_kernel(const DecodeParams p) {
+    __shared__ __attribute__((aligned(16))) f32x4 qs[2][16][64];           // 2 x 16 KiB: activation in position order
+    __shared__ __attribute__((aligned(16))) float tab[6 * HID + 4];        // Q0h, Q0w, fma(Q0r, ratio, bQ0), L0..L2, bL
+    {
+        const int i = threadIdx.x & 63, part = threadIdx.x >> 6;
+        const float* __restrict__ Q0s = p.Wt + OFF_Q0R + 4 * i;
+        if (part == 0) {
+            *(f32x4*)(tab + 0 * HID + 4 * i) = *(const f32x4*)(Q0s + 0 * HID);
+            *(f32x4*)(tab + 1 * HID + 4 * i) = *(const f32x4*)(Q0s + 1 * HID);
+        } else if (part == 1) {
+            const f32x4 wr = *(const f32x4*)(Q0s + 2 * HID), bq = *(const f32x4*)(Q0s + 3 * HID);
+            f32x4 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = __builtin_fmaf(wr[e], p.ratio, bq[e]);
+            *(f32x4*)(tab + 2 * HID + 4 * i) = t;
+        } else if (part == 2) {
+            *(f32x4*)(tab + 3 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 0 * HID + 4 * i);
+            *(f32x4*)(tab + 4 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 1 * HID + 4 * i);
+        } else {
+            *(f32x4*)(tab + 5 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 2 * HID + 4 * i);
+            if (i == 0) *(f32x4*)(tab + 6 * HID) = or_bits(*(const f32x4*)(p.Wt + OFF_BL), derived_nan_mask(p.Wt));
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, n = lane & 15;
+    const int x = p.x0 + blockIdx.x * T16_W + (n & (T16_W - 1));
+    const int y = p.y0 + blockIdx.y * T16_H + (n / T16_W);
+    const int b = blockIdx.z;
+    const bool valid = (x < p.x1) && (y < p.y1);
+    const int xc = x < p.Wu ? x : p.Wu - 1;
+    const int yc = y < p.y1 ? y : p.y1 - 1;
+    int iy, ix;
+    float relh, relw;
+    axis_eval(p.ah, yc, iy, relh);
+    axis_eval(p.aw, xc, ix, relw);
+    const float* __restrict__ Wt = p.Wt;
+    // this lane's channels: 64 wave + 16 T + 4 g + j (T, j = 0..3) = accumulator register j of M-tile T
+    const float* __restrict__ Pc = p.P + (((size_t)b * p.Prows + (iy - p.Prow0)) * p.W + ix) * PCH + 64 * wave + 4 * g;
+    // where channel 64 wave + 16 T + 4 g + j goes in a position-ordered image (floats): base + 256 T + {0, 128, 1, 129}[j]
+    // (position 32 m + 8 a + 2 j + h with m = 2 wave + (T >> 1), a = 2 (T & 1) + (g >> 1), h = g & 1)
+    float* const qf = reinterpret_cast<float*>(&qs[0][0][0]);
+    const int wbase = (4 * wave * 64 + 16 * (g & 1) + n) * 4 + 2 * (g >> 1);
+    auto put = [&](const int img, const int T, const f32x4 v) {
+        float* d = qf + img * (16 * 64 * 4) + wbase + 256 * T;
+        d[0] = v[0]; d[128] = v[1]; d[1] = v[2]; d[129] = v[3];
+    };
+    __syncthreads();
+
+    // ---- layer 0 (diinn.py:133-134), decode_kernel's operation order
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        const int c0 = 64 * wave + 16 * T + 4 * g;
+        const f32x4 pv = *(const f32x4*)(Pc + 16 * T);
+        const f32x4 wh = *(const f32x4*)(tab + 0 * HID + c0);
+        const f32x4 ww = *(const f32x4*)(tab + 1 * HID + c0);
+        const f32x4 tq = *(const f32x4*)(tab + 2 * HID + c0);
+        f32x4 q0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = tq[e];
+            a = __builtin_fmaf(ww[e], relw, a);
+            a = __builtin_fmaf(wh[e], relh, a);
+            q0[e] = relu0(pv[e]) * dsin_rev<SIN_MODE>(a);
+        }
+        put(0, T, q0);
+    }
+
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);
+    const int lane_off = lane * 16;
+    int wp = (int)(OFF_WL16 * sizeof(float)) + wave * (int)(WL16_WAVE * sizeof(float));
+    auto ld_w = [&](const int i, const int half) {
+#if defined(ABL_C16_NOLOAD)
+        return f32x4{0.5f, 0.25f, 0.125f, (float)(i + half + wp)};                  // timing ablation: no weight requests at all
+#elif defined(ABL_C16_SAMEW)
+        return ld_piece(wrs, lane_off, wp + (2 * (i & 3) + half) * PIECE_BYTES);    // timing ablation: 8 KiB of weights, L1-resident
+#else
+        return ld_piece(wrs, lane_off, wp + (2 * i + half) * PIECE_BYTES);
+#endif
+    };
+    __syncthreads();
+
+    // The weight ring (RING - 1 k-steps of two pieces in flight; 8 MFMAs = 256 clocks per k-step) and the accumulator seeds
+    // run on ACROSS the layers: the last steps of a layer request the next layer's first pieces, and its seeds (P_{i+1} of
+    // the pixel's cell, bQ) are requested in the middle of the layer before -- nothing a layer needs is fetched at its start.
+    constexpr int RING = 4;
+    f32x4 rw[RING][2];
+#pragma unroll
+    for (int d = 0; d < RING - 1; ++d) {
+        rw[d][0] = ld_w(d, 0);
+        rw[d][1] = ld_w(d, 1);
+    }
+    f32x4 seed[8];
+    auto ld_seeds = [&](const int layer) {
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            seed[T] = *(const f32x4*)(Pc + (layer + 1) * HID + 16 * T);
+            seed[4 + T] = *(const f32x4*)(Wt + OFF_BQR + layer * HID + 64 * wave + 16 * T + 4 * g);
+        }
+    };
+    ld_seeds(0);
+    auto layer_body = [&](auto cur_tag, auto last_tag, const int layer) {
+        constexpr int CUR = decltype(cur_tag)::value ? 1 : 0;
+        constexpr bool LAST = decltype(last_tag)::value;
+        f32x4 acc[8];                                            // [T]: modulation, [4 + T]: synthesis
+#pragma unroll
+        for (int T = 0; T < 8; ++T) acc[T] = seed[T];
+        f32x4 bq = qs[CUR][0][lane];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const float bv = bq[i & 3];
+            if ((i & 3) == 3 && i + 1 < 64) bq = qs[CUR][(i + 1) >> 2][lane];
+            if (i + RING - 1 < 64) {
+                rw[(i + RING - 1) % RING][0] = ld_w(i + RING - 1, 0);
+                rw[(i + RING - 1) % RING][1] = ld_w(i + RING - 1, 1);
+            } else if (!LAST) {                                  // the next layer's first k-steps (64 % RING == 0: same slots)
+                rw[(i + RING - 1) % RING][0] = ld_w(i + RING - 1 + (int)(WL16_LAYER / WL16_KSTEP) - 64, 0);
+                rw[(i + RING - 1) % RING][1] = ld_w(i + RING - 1 + (int)(WL16_LAYER / WL16_KSTEP) - 64, 1);
+            }
+            if (i == 32 && !LAST) ld_seeds(layer + 1);
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                acc[T] = MFMA16(rw[i % RING][0][T], bv, acc[T]);
+                acc[4 + T] = MFMA16(rw[i % RING][1][T], bv, acc[4 + T]);
+            }
+            // a k-step's two requests stay RING - 1 steps (768 clocks of MFMAs) ahead of their use: left alone, hipcc sinks
+            // every load to 4 MFMAs in front of its first use and the wave waits for the L2 at each step
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue: q = relu(k) * sin(s) for this wave's 64 channels -> the other image
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            f32x4 qn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qn[e] = relu0(acc[T][e]) * dsin_rev<SIN_MODE>(acc[4 + T][e]);
+            put(1 - CUR, T, qn);
+        }
+        __syncthreads();
+    };
+    static_assert(64 % RING == 0 && WL16_LAYER == 4 * WL16_WAVE && WL16_WAVE == 64 * WL16_KSTEP, "ring runs on across layers");
+    layer_body(TagCoopF{}, TagCoopF{}, 0);                       // image 0 -> 1
+    wp += (int)(WL16_LAYER * sizeof(float));
+    layer_body(TagCoopT{}, TagCoopF{}, 1);                       // 1 -> 0
+    wp += (int)(WL16_LAYER * sizeof(float));
+    layer_body(TagCoopF{}, TagCoopT{}, 2);                       // 0 -> 1
+
+    // ---- head (diinn.py:138): decode_kernel's order -- per lane half h the channels 32 m + 8 gq + 4 h + e in (m, gq, e)
+    // order, then the two halves added -- on the last activation (image 1), by lanes (h, n) of wave 0
+    if (wave == 0 && lane < 32) {
+        const int h = lane >> 4;
+        float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+        const float* __restrict__ L = tab + 3 * HID + 4 * h;
+        const float* __restrict__ q1 = qf + 16 * 64 * 4 + (16 * h + n) * 4;     // position 32 m + 8 gq + 2 e + h
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int c0 = 32 * m + 8 * gq;
+                const f32x4 l0 = *(const f32x4*)(L + 0 * HID + c0);
+                const f32x4 l1 = *(const f32x4*)(L + 1 * HID + c0);
+                const f32x4 l2 = *(const f32x4*)(L + 2 * HID + c0);
+                // positions 32 m + 8 gq + 2 e + h: image row 2 m + (gq >> 1), lane group 2 (e & 1) + h, element 2 (gq & 1) + (e >> 1)
+                const float* __restrict__ r = q1 + (2 * m + (gq >> 1)) * 256 + 2 * (gq & 1);
+                const float v[4] = {r[0], r[128], r[1], r[129]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0 = __builtin_fmaf(l0[e], v[e], o0);
+                    o1 = __builtin_fmaf(l1[e], v[e], o1);
+                    o2 = __builtin_fmaf(l2[e], v[e], o2);
+                }
+            }
+        }
+        o0 += __shfl_xor(o0, 16);
+        o1 += __shfl_xor(o1, 16);
+        o2 += __shfl_xor(o2, 16);
+        if (valid && h == 0) {
+            const long long plane = p.o_ps;
+            float* op = out_px(p, b, y, x);
+            op[0] = o0 + tab[6 * HID + 0];
+            op[plane] = o1 + tab[6 * HID + 1];
+            op[2 * plane] = o2 + tab[6 * HID + 2];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // cell_chain_kernel (decoder modes 1 and 2, diinn.py:116-131): the modulation chain depends on the
 // LR cell only: k_0 = relu(P_0), k_i = relu(K_i^k k_{i-1} + P_i), i = 1..3.  Same register-resident
 // scheme as decode_kernel with LR cells in place of HR pixels and the modulation half of the
@@ -649,8 +857,27 @@ static int decode_tile_impl(void* stream, const float* P_dev, const float* packe
         return hip_status(hipGetLastError());
     }
     // small launches: the latency variant (4 waves share a tile): fewer than ~3/4 of a round of 16 x 8 workgroups.
-    // DIINN_F32_KERNEL = 1 / 2 forces the throughput / latency kernel (tests, A-B timing).
+    // DIINN_F32_KERNEL = 1 / 2 / 3 forces the throughput / 32-pixel latency / 16-pixel latency kernel (tests, A-B timing).
     const int force = (int)knob(diinn_knobs().f32_kernel);
+    // The smallest IMAGES take the 16-pixel latency kernel: rounds of tiles on the 256 CUs, a 32-pixel tile's chain being
+    // twice a 16-pixel tile's.  Chosen from the full image (B, Hu, Wu), so that a band or a tile of an image takes the
+    // kernel the whole image takes (the three fp32 kernels are bit-equal; this keeps that from being load-bearing).
+    {
+        const long long t32 = (long long)((Wu + TILE_W - 1) / TILE_W) * ((Hu + TILE_H - 1) / TILE_H) * B;
+        const long long t16 = (long long)((Wu + T16_W - 1) / T16_W) * ((Hu + T16_H - 1) / T16_H) * B;
+        const long long full_wgs = (long long)((Wu + 15) / 16) * ((Hu + 7) / 8) * B;
+        const bool small16 = full_wgs <= 192 && (t16 + 255) / 256 < 2 * ((t32 + 255) / 256);
+        const dim3 grid16((x1 - x0 + T16_W - 1) / T16_W, (y1 - y0 + T16_H - 1) / T16_H, B);
+        if (grid16.y <= 65535 && (force ? force == 3 : small16)) {
+            if (sin_mode == DIINN_SIN_HW)
+                hipLaunchKernelGGL(decode_coop16_kernel<DIINN_SIN_HW>, grid16, dim3(256), 0, (hipStream_t)stream, p);
+            else if (sin_mode == DIINN_SIN_HW_REDUCED)
+                hipLaunchKernelGGL(decode_coop16_kernel<DIINN_SIN_HW_REDUCED>, grid16, dim3(256), 0, (hipStream_t)stream, p);
+            else
+                hipLaunchKernelGGL(decode_coop16_kernel<DIINN_SIN_ACCURATE>, grid16, dim3(256), 0, (hipStream_t)stream, p);
+            return hip_status(hipGetLastError());
+        }
+    }
     const dim3 gridc((x1 - x0 + TILE_W - 1) / TILE_W, (y1 - y0 + TILE_H - 1) / TILE_H, B);
     if (gridc.y <= 65535 && (force ? force == 2 : (long long)gx * gy * gz <= 192)) {
         if (sin_mode == DIINN_SIN_HW)

@@ -146,11 +146,11 @@ size_t diinn_metasr_workspace_bytes(int B, int H, int W) {
 }
 
 int diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats) {
-    static const size_t off[16] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT, OFF_WPB, OFF_BQR,
-                                   OFF_Q0R, OFF_WLR, OFF_WPU, OFF_WLX, OFF_WPX};
-    static const size_t sz[16]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT, SZ_WPB, 3 * HID,
-                                   4 * HID, SZ_WL, SZ_WPU, SZ_WLX, SZ_WPX};
-    if (section < 0 || section > 15 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
+    static const size_t off[17] = {OFF_WL, OFF_WP, OFF_BK, OFF_Q0, OFF_BQ, OFF_L, OFF_BL, OFF_WLB, OFF_WLT, OFF_WPB, OFF_BQR,
+                                   OFF_Q0R, OFF_WLR, OFF_WPU, OFF_WLX, OFF_WPX, OFF_WL16};
+    static const size_t sz[17]  = {SZ_WL, SZ_WP, 4 * HID, 4 * HID, 3 * HID, 3 * HID, 4, SZ_WLB, SZ_WLT, SZ_WPB, 3 * HID,
+                                   4 * HID, SZ_WL, SZ_WPU, SZ_WLX, SZ_WPX, SZ_WL16};
+    if (section < 0 || section > 16 || !offset_floats || !size_floats) return DIINN_ERR_INVALID_ARG;
     *offset_floats = off[section];
     *size_floats = sz[section];
     return DIINN_OK;
@@ -197,6 +197,23 @@ int diinn_pack_weights(const float* K0w, const float* K0b,
         const bool synth = (pc & 1) != 0;                       // [..][part 2][lane][e]: odd pieces are part 1
         for (size_t i = 0; i < WL_PIECE; ++i) dst[i] = synth ? src[i] * INV_2PI : src[i];
     }
+    // WL16: A operands of v_mfma_f32_16x16x4_f32, [layer][wave][i][half][lane][T]; synthesis rows in revolutions
+    for (int il = 0; il < 3; ++il)
+        for (int w = 0; w < 4; ++w)
+            for (int i = 0; i < 64; ++i)
+                for (int half = 0; half < 2; ++half) {
+                    float* dst = packed + OFF_WL16 + (size_t)il * WL16_LAYER + (size_t)w * WL16_WAVE + (size_t)i * WL16_KSTEP +
+                                 (size_t)half * WL_PIECE;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int pos = 4 * i + (lane >> 4);
+                        const int in = chan_of(pos >> 1, pos & 1);
+                        for (int T = 0; T < 4; ++T) {
+                            const int out = 64 * w + 16 * T + (lane & 15);
+                            dst[lane * 4 + T] = half == 0 ? Kw[il][(size_t)out * (HID + UNF) + in]
+                                                          : Qw[il][(size_t)out * HID + in] * INV_2PI;
+                        }
+                    }
+                }
     // WLT: WL with the two channel indices swapped (backward pass)
     for (int i = 0; i < 3; ++i) {
         const float* wk = Kw[i];

@@ -100,7 +100,18 @@ constexpr size_t SZ_WLX     = 3 * WLX_LAYER;               // 393,216 floats = 1
 //     hi = bf16(w), lo = bf16(w - hi).  Derived, inference only.
 constexpr size_t OFF_WPX    = OFF_WLX + SZ_WLX;
 constexpr size_t SZ_WPX     = (size_t)16 * 4 * 9 * 2 * 2 * WLB_PIECE;   // 589,824 floats = 2.25 MiB
-constexpr size_t PACKED_FLOATS = OFF_WPX + SZ_WPX;         // 4,297,988
+// WL16: the per-pixel layers as A operands of v_mfma_f32_16x16x4_f32 (decode_coop16_kernel: the fp32 latency form for the
+//     smallest launches, a 16-pixel tile per workgroup).  [layer 3][wave 4][i 64][half 2][lane 64][T 4]: wave w owns output
+//     channels 64 w .. 64 w + 63 of both branches as four 16-row M-tiles T; half 0 = modulation rows (K.i[:, :256]), half 1
+//     = synthesis rows (Q.i, in revolutions like WLR); k-step i covers the four activations at POSITIONS 4 i + g, g = lane >> 4,
+//     where position p is the p-th term of decode_kernel's accumulation order: channel chan_of(p >> 1, p & 1);
+//     value = W_half[ out = 64 w + 16 T + (lane & 15) ][ in = chan_of((4 i + g) >> 1, g & 1) ].  Derived, inference only.
+constexpr size_t WL16_KSTEP = 2 * WL_PIECE;                // floats per (wave, k-step): the two 1 KiB pieces
+constexpr size_t WL16_WAVE  = 64 * WL16_KSTEP;
+constexpr size_t WL16_LAYER = 4 * WL16_WAVE;
+constexpr size_t OFF_WL16   = OFF_WPX + SZ_WPX;
+constexpr size_t SZ_WL16    = 3 * WL16_LAYER;              // 393,216 floats = 1.5 MiB
+constexpr size_t PACKED_FLOATS = OFF_WL16 + SZ_WL16;       // 4,691,204
 
 // channel held by activation register (m, r) of lane-half h
 DIINN_HD int chan_of(int kk /* = 16*m + r */, int h) {

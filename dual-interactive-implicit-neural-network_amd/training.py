@@ -79,7 +79,7 @@ def pack_gather_index() -> torch.Tensor:
     packed = pack_state_dict(sd, mode=3).numpy()
     idx = np.rint(packed).astype(np.int64) - 1
     off, size = C.c_size_t(), C.c_size_t()
-    for section in (7, 9, 10, 11, 12, 13, 14, 15):          # inference-only sections: derived values, not a permutation
+    for section in (7, 9, 10, 11, 12, 13, 14, 15, 16):          # inference-only sections: derived values, not a permutation
         _native.check(lib.diinn_packed_section(section, C.byref(off), C.byref(size)), "diinn_packed_section")
         idx[off.value:off.value + size.value] = -1
     # the validity word behind bL (DIINN_PACKED_MAGIC) reads as zero in a gathered image: the inference entry points,

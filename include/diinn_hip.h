@@ -44,7 +44,8 @@ extern "C" {
  *      diinn_p_launch_info; diinn_debug_set / diinn_debug_get;
  *      bf16 kernel choice taken from the full image, not the band; DIINN_COMPUTE_BF16X3 and packed sections 14-15 (DIINN_P_ALGO_DIRECT_BF16X3);
  *      split-bf16 encoder layers (diinn_conv3x3_x3, diinn_rdn_forward_x3)
- *   7  tiles: diinn_decode_tile_win (HR column range + output strides; the row-band entry points are wrappers of it) */
+ *   7  tiles: diinn_decode_tile_win (HR column range + output strides; the row-band entry points are wrappers of it);
+ *      packed section 16 (WL16) and the 16-pixel fp32 latency kernel for the smallest launches (DIINN_F32_KERNEL = 3) */
 
 /* status codes */
 #define DIINN_OK                 0
@@ -119,9 +120,10 @@ size_t diinn_packed_weight_floats(void);
  * sine on revolutions as well), 13 WPU (section 1 in Winograd F(2x2,3x3) form, U = G Wx G^T: what the fp32 inference
  * entry points -- everything but diinn_precompute_P -- read, at every map size), 14 WLX (the per-pixel
  * layers as hi + lo bf16 parts, hi = bf16(w), lo = bf16(w - hi), for DIINN_COMPUTE_BF16X3), 15 WPX (the hoisted 3x3 conv
- * in the same form).  Every section but 7 and
- * 9..15 is a pure permutation (plus zero padding) of the reference tensors, so a training loop can re-pack on the
- * device with one gather; sections 7 and 9..15 hold derived values, read by the inference kernels only (the
+ * in the same form), 16 WL16 (the per-pixel layers as A operands of v_mfma_f32_16x16x4_f32 for the 16-pixel latency kernel,
+ * synthesis rows in revolutions).  Every section but 7 and
+ * 9..16 is a pure permutation (plus zero padding) of the reference tensors, so a training loop can re-pack on the
+ * device with one gather; sections 7 and 9..16 hold derived values, read by the inference kernels only (the
  * training forward and LIIF read sections 0, 1 and 4; diinn_precompute_P reads section 1 whatever the map size).
  *
  * VALIDITY WORD.  The pad word behind bL (float index 3 of section 6) holds the bit pattern DIINN_PACKED_MAGIC in an

@@ -115,7 +115,7 @@ def test_packed_image_layout(lib):
     import diinn_amd.decoder as D
     sd = synth.decoder_state_dict(11)
     packed = D.pack_state_dict(sd).numpy()
-    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608 + 393_216 + 294_912 + 768 + 1024 + 393_216 + 1_048_576 + 393_216 + 589_824
+    assert packed.size == lib.diinn_packed_weight_floats() == 986_628 + 196_608 + 393_216 + 294_912 + 768 + 1024 + 393_216 + 1_048_576 + 393_216 + 589_824 + 393_216
     lane = np.arange(64)
     out_l, h_l = lane & 31, lane >> 5
     # WL section
@@ -223,7 +223,7 @@ def test_packed_image_layout(lib):
         assert abs(float(hi) + float(bf16_val(lo_bits)) - float(w)) <= 2.0 ** -16 * abs(float(w))
     # WPX (split-bf16 hoisted conv): [og 16][group 4][tap 9][mt 2][hi, lo][lane][j]: output channel 64 og + 32 mt + (lane & 31) of
     # the 1024 (layer og >> 2), input channel 16 group + 8 (lane >> 5) + j
-    WPX = tail[1792 + 393_216 + 1_048_576 + 393_216:].view(np.uint16).reshape(16, 4, 9, 2, 2, 64, 8)
+    WPX = tail[1792 + 393_216 + 1_048_576 + 393_216:1792 + 393_216 + 1_048_576 + 393_216 + 589_824].view(np.uint16).reshape(16, 4, 9, 2, 2, 64, 8)
     for _ in range(300):
         og, g, tap, mt, l, jj = (int(rng.integers(n)) for n in (16, 4, 9, 2, 64, 8))
         i, ch = og >> 2, 64 * (og & 3) + 32 * mt + (l & 31)
@@ -233,6 +233,15 @@ def test_packed_image_layout(lib):
         hi_bits = bf16_bits(w)
         assert int(WPX[og, g, tap, mt, 0, l, jj]) == hi_bits
         assert int(WPX[og, g, tap, mt, 1, l, jj]) == bf16_bits(w - bf16_val(hi_bits))
+    # WL16 (16-pixel fp32 latency kernel, v_mfma_f32_16x16x4_f32 A operands): [layer][wave][i][half][lane][T]: output channel
+    # 64 wave + 16 T + (lane & 15), input = the channel at POSITION 4 i + (lane >> 4) of decode_kernel's accumulation order
+    WL16 = tail[1792 + 393_216 + 1_048_576 + 393_216 + 589_824:].reshape(3, 4, 64, 2, 64, 4)
+    for _ in range(300):
+        i, wv, ks, half, l, T = (int(rng.integers(n)) for n in (3, 4, 64, 2, 64, 4))
+        pos = 4 * ks + (l >> 4)
+        o, cin = 64 * wv + 16 * T + (l & 15), _chan_of(pos >> 1, pos & 1)
+        w = sd[f"K.{i + 1}.0.weight"][o, cin, 0, 0] if half == 0 else np.float32(sd[f"Q.{i + 1}.0.weight"][o, cin, 0, 0] * inv2pi)
+        assert WL16[i, wv, ks, half, l, T] == w
     # every channel appears exactly once per lane-half in the activation register order
     seen = sorted(_chan_of(kk, h) for kk in range(128) for h in range(2))
     assert seen == list(range(256))

@@ -585,10 +585,11 @@ def test_latency_kernel_is_bit_identical_to_throughput_kernel(golden, dev, knobs
         sd = synth.decoder_state_dict(123, gain)
         feat = synth.encoder_features(123, b, h, w)
         outs = {}
-        for k in ("1", "2"):
-            knobs("DIINN_F32_KERNEL", int(k))
+        for k in ("1", "2", "3"):                  # throughput, 32-pixel latency (4 waves share a tile), 16-pixel latency
+            knobs("DIINN_F32_KERNEL", int(k))      # (v_mfma_f32_16x16x4_f32: four products per instruction, added in k order)
             outs[k] = _decode(sd, feat, (hu, wu), dev)
         assert np.array_equal(outs["1"], outs["2"]), name
+        assert np.array_equal(outs["1"], outs["3"]), name
         ref = golden[f"out/{name}"]
         assert float(np.abs(outs["2"] - ref).max()) <= _tol(ref), name
     knobs("DIINN_F32_KERNEL", 2)
@@ -596,11 +597,13 @@ def test_latency_kernel_is_bit_identical_to_throughput_kernel(golden, dev, knobs
     feat = torch.from_numpy(synth.encoder_features(5, 2, 19, 23)).to(dev)
     packed = D.pack_state_dict(sd).to(dev)
     full = D.decode_features(feat, packed, (61, 70))
-    out = torch.zeros_like(full)
-    for y0, y1 in [(0, 17), (17, 18), (18, 61)]:
-        D.decode_features(feat, packed, (61, 70), out=out, rows=(y0, y1))
-    torch.cuda.synchronize()
-    assert torch.equal(full, out)
+    for force in (2, 3):
+        knobs("DIINN_F32_KERNEL", force)
+        out = torch.zeros_like(full)
+        for y0, y1 in [(0, 17), (17, 18), (18, 61)]:
+            D.decode_features(feat, packed, (61, 70), out=out, rows=(y0, y1))
+        torch.cuda.synchronize()
+        assert torch.equal(full, out), force
 
 
 def test_bf16_kernel_variants_agree(golden, dev, knobs):

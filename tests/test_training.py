@@ -74,7 +74,7 @@ def test_pack_gather_index_is_the_host_packer():
     ref = D.pack_state_dict(sd).numpy()
     off, size = C.c_size_t(), C.c_size_t()
     keep = np.ones(ref.size, bool)
-    for section in (7, 9, 10, 11, 12, 13, 14, 15):     # inference-only sections: derived values, left zero by the gather
+    for section in (7, 9, 10, 11, 12, 13, 14, 15, 16):     # inference-only sections: derived values, left zero by the gather
         assert lib.diinn_packed_section(section, C.byref(off), C.byref(size)) == 0
         keep[off.value:off.value + size.value] = False
     assert lib.diinn_packed_section(6, C.byref(off), C.byref(size)) == 0
@@ -83,13 +83,13 @@ def test_pack_gather_index_is_the_host_packer():
     keep[word] = False
     assert np.array_equal(got[keep], ref[keep]) and not got[~keep].any()
     total = 0
-    for s in range(16):
+    for s in range(17):
         o, z = C.c_size_t(), C.c_size_t()
         assert lib.diinn_packed_section(s, C.byref(o), C.byref(z)) == 0
         assert o.value == total                    # sections are contiguous
         total = o.value + z.value
     assert total == ref.size == lib.diinn_packed_weight_floats()
-    assert lib.diinn_packed_section(16, C.byref(off), C.byref(size)) != 0
+    assert lib.diinn_packed_section(17, C.byref(off), C.byref(size)) != 0
 
 
 def test_backward_formulas_on_cpu(gold):
