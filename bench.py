@@ -91,6 +91,8 @@ def parse():
     ap.add_argument("--strong-steps", type=int, default=3)
     ap.add_argument("--no-target", action="store_true", help="N=1: skip the two extra steps at the target shape")
     ap.add_argument("--no-side-legs", action="store_true", help="N=1: skip the c5 fp32 / c5 bf16_full / c1 side legs")
+    ap.add_argument("--no-traffic", action="store_true", help="N=1 c2 fp32: skip the two rocprofv3 --pmc child runs that measure "
+                                                              "roofline.traffic (the committed measurement is reported, labelled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args()
@@ -200,6 +202,57 @@ def load_traffic():
             return json.load(f).get("hbm_bytes_per_launch")
     except Exception:
         return None
+
+
+def measure_traffic(args, kernel_prefix="void decode_kernel<", timeout_s=240):
+    """HBM bytes per launch of the dominant kernel, MEASURED by this run: two `rocprofv3 --pmc` passes of this very script
+    (FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md, HBM / rocprofv3 sections) in child processes --
+    `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --steps 3 --warmup 1` with every extra leg off --
+    averaged over that kernel's dispatches and corrected as the guide prescribes for gfx950: FETCH_SIZE tallies a wide
+    streaming read at half its bytes, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (the counters are in KB).
+    Returns (bytes or None, description).  Never raises: a box without a working profiler yields (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="diinn_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                   "--workload", args.workload, "--compute", args.compute, "--no-cpu-baseline",
+                   "--no-check", "--no-target", "--no-split", "--no-side-legs", "--no-traffic"]
+            if args.sin != "default":
+                cmd += ["--sin", args.sin]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+            env["TMPDIR"] = "/tmp"
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited {r.returncode}: {r.stderr[-300:]}"
+            got = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Kernel_Name"].startswith(kernel_prefix) and row["Counter_Name"] == counter:
+                        got.append(float(row["Counter_Value"]))
+            if not got:
+                return None, f"rocprofv3 --pmc {counter}: no rows for {kernel_prefix!r}"
+            vals[counter] = (sum(got) / len(got), len(got))
+    except Exception as e:                                        # timeout, unreadable csv, ...
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, nf = vals["FETCH_SIZE"]
+    write, nw = vals["WRITE_SIZE"]
+    return int((2.0 * fetch + write) * 1024), (
+        f"measured by this run: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3 --warmup 1` "
+        f"in child processes, mean over {nf} / {nw} dispatches of {kernel_prefix}...>: FETCH_SIZE {fetch:.0f} KB, "
+        f"WRITE_SIZE {write:.0f} KB; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 counts wide reads at 1/2)")
 
 
 def check_band_rows(sd, feat_win_cpu, feat_row0, full_h, size, out_band_cpu, band_y0, rows_list, compute):
@@ -585,9 +638,18 @@ def main():
             wl = (f"{wl_label} per GPU, {HU}x{WU} HR total ({world} row band(s) of {hu1}x{WU}), B=1, mode=3")
         else:
             wl = (f"{wl_label}, split into {world} HR row band(s) of ~{HU // world}x{WU}, B=1, mode=3")
-        traffic, traffic_source = (load_traffic(), "profiles/decode_kernel_traffic.json: separate rocprofv3 --pmc "
-                                   "passes of this command, committed; not measured in this run") \
-            if (not bf and args.workload == "c2" and world == 1) else (None, None)
+        traffic, traffic_source = None, None
+        if not bf and args.workload == "c2" and world == 1:
+            why = "--no-traffic"
+            if "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+                why = "this run is itself being profiled"
+            elif not args.no_traffic:
+                traffic, traffic_source = measure_traffic(args)
+                why = traffic_source
+            if traffic is None:                                  # no profiler on this box: the committed measurement, labelled
+                traffic = load_traffic()
+                traffic_source = ("profiles/decode_kernel_traffic.json: separate rocprofv3 --pmc passes of this command, "
+                                  f"committed; NOT measured in this run ({why})")
         res = {
             "metric": METRIC[args.workload],
             "value": round(total_px * args.steps / elapsed / 1e6, 3),

@@ -5,7 +5,7 @@ TAG=$1; KG=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/r03pmc_$TAG; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py $* --steps 5 --warmup 2 --no-cpu-baseline --no-check --no-target --no-strong"
+B="python3 $R/bench.py $* --steps 5 --warmup 2 --no-cpu-baseline --no-check --no-target --no-strong --no-traffic --no-side-legs --no-split"
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
 SQ2="SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 timeout 300 rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $O/sq1 -- $B > $O/sq1.log 2>&1
