@@ -57,7 +57,7 @@ FLOP_DECODE_PER_PX = 789_504.0        # 3 stacked 512x256 lay
 FLOP_P_PER_CELL = 1_179_648.0         # hoisted 3x3 conv 64 -> 1024, 2*MAC
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (only for --compute bf16*)
-# parity bound of the post-run check: f32 = north_star's 1e-4; bf16 restated (SURVEY §8 d4 / DESIGN §4.3)
+# parity bound of the post-run check: f32 = north_star's 1e-4; bf16 restated (SURVEY §8 d4 / DESIGN §3.4)
 CHECK_TOL = {"f32": (1e-4, True), "bf16": (2e-3, False), "bf16_full": (3e-3, False), "bf16x3": (1e-4, True)}
 
 
@@ -707,7 +707,7 @@ def main():
             res["roofline"]["note"] = ("achieved counts the algorithm's 789,504 FLOP per pixel once; the kernel issues "
                                        "3 bf16 MFMAs per product (hi*hi + hi*lo + lo*hi): issued_* is the matrix-core load")
         if bf and args.compute != "bf16x3":
-            # second roof for the bf16 path (DESIGN.md section 4.3): the vector L1 (64 B/clk/CU).  The cooperative kernel
+            # second roof for the bf16 path (DESIGN.md section 3.4): the vector L1 (64 B/clk/CU).  The cooperative kernel
             # moves, per 128-pixel block, 768 KiB of weights (each wave its own slice, no reuse between waves), 4 slices
             # of up to 24 staged P rows of 1 KiB, and ~8 KiB of tables through it; VALU / LDS / wait shares from the PMC
             # passes are in profiles/r02_pmc_summary.txt.

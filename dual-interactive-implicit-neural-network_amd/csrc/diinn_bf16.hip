@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x2_kernel(const DecodeParam
 //   * the RGB head is accumulated in the last layer's epilogue (fp32, unrounded activation) and the four
 //     waves' partial sums meet in LDS.
 // At one wave per SIMD a wave can issue about 8 instructions per 32-cycle bf16 MFMA, the MFMA included
-// (tools + PMC: DESIGN.md section 4.3), so the instruction stream between two MFMAs is placed by hand
+// (tools + PMC: DESIGN.md section 3.4), so the instruction stream between two MFMAs is placed by hand
 // (sched_barrier): LDS read | MFMA | half an epilogue element | MFMA | the other half + refill loads.
 // Same products and the same k-order of accumulation as decode_bf16_kernel.
 // ---------------------------------------------------------------------------------

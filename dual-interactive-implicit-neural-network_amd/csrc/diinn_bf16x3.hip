@@ -20,7 +20,7 @@
 //   * layer 0 as in decode_kernel: the Q0 rows in revolutions with t = fma(Q0r, ratio, bQ0) folded once per
 //     workgroup, and the head rows, in an LDS table; P, seeds, biases, sine and the RGB head in fp32; the head is
 //     accumulated in the last layer's epilogue on the unsplit activation.
-// What bounds it (DESIGN.md section 4.3b): at one wave per SIMD the instruction stream of a wave is serial -- the
+// What bounds it (DESIGN.md section 3.5): at one wave per SIMD the instruction stream of a wave is serial -- the
 // four 1 KiB weight loads of a k-step and layer 0's VALU work add to the six MFMAs' 192 clocks instead of hiding
 // behind them (ablations: no weight loads -0.47 ms, no layer 0 -0.27 ms of 2.06 at c2), and a second wave per SIMD
 // does not fit (the activation alone is 128 registers).  Moving the weight stream into LDS (shared by the four

@@ -4,7 +4,7 @@
 // Reference: src/models/components/rdn.py:9-35,90-105 -- the same 130 layers diinn_winograd.hip runs as fp32 Winograd
 // (3x3, stride 1, zero padding 1, 64 outputs, 64..512 inputs).  Here the DIRECT sum is evaluated on
 // v_mfma_f32_32x32x16_bf16 with every operand carried as hi + lo bf16 parts (hi = bf16(v), lo = bf16(v - hi)) and a
-// product as  w_lo.x_hi + w_hi.x_lo + w_hi.x_hi  with fp32 accumulation (DESIGN.md section 4.3b / 4.8): 2.25x the
+// product as  w_lo.x_hi + w_hi.x_lo + w_hi.x_hi  with fp32 accumulation (DESIGN.md section 3.5 / 3.9): 2.25x the
 // multiplies of F(2x2, 3x3), three MFMAs per product, at 16x the fp32 MFMA rate = 0.42 of the matrix-core time.
 // Per layer the error against float64 is ~4e-6 of max|out| (fp32 Winograd: ~5e-7); through the whole trunk it does
 // not pile up (7e-6 of max|feat|, 1e-7 in the decoded image against the 1e-4 bound: tools/enc_x3_error.py).

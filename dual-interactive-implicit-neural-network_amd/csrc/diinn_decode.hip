@@ -33,7 +33,7 @@ struct TagCoopT { static constexpr bool value = true; };
 template <int SIN_MODE, bool KPART = true, bool SAVE = false>
 __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     // The small tables of layer 0 and of the head go through LDS: a vector-memory instruction blocks its wave for
-    // ~60 cycles (stamps, DESIGN.md section 4.3), and a wave reading them straight from the packed image issued 128 + 96
+    // ~60 cycles (stamps, DESIGN.md section 3.4), and a wave reading them straight from the packed image issued 128 + 96
     // of those per tile.  Rows: Q0h, Q0w, t = fma(Q0r, ratio, bQ0) (the pixel-independent part of the sine
     // argument, the same first fma the per-pixel chain used to start with: results are bit-identical), L0, L1, L2.
     __shared__ __attribute__((aligned(16))) float tab[6 * HID + 4];      // + the head bias bL

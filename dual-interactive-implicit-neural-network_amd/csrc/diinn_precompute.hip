@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_wide_kernel(const PP
     // Round 2 read one 1 KiB fragment from LDS per MFMA (8 waves per CU x 1 KiB per 32-cycle MFMA = twice the 128 B/clk
     // of the LDS) into ONE dependent accumulation chain; now 120 LDS reads per 288 MFMAs and three independent chains.
     // Per output value the products are added in the same order as before (ky, kx, channel group = ascending k-step):
-    // bit-identical results.  Measured effect on the kernel's time: none (DESIGN.md section 4.3 has the ablations: the
+    // bit-identical results.  Measured effect on the kernel's time: none (DESIGN.md section 3.4 has the ablations: the
     // loop alone 0.66-0.83 ms, staging +0.1-0.2, stores +0.1-0.25 at c5, and they add instead of overlapping) -- kept for
     // the LDS traffic it removes.  The HBM write stream is NOT the bound it was taken for in round 2: a plain fill of the
     // same 3.7 GB runs at 6.8 TB/s on the same box (tools/hbm_write_roof.py), this kernel writes at ~3.

@@ -117,7 +117,7 @@ def pack_conv_x3(weight: torch.Tensor) -> torch.Tensor:
 
 class RDN(nn.Module):
     _CONFIGS = {"A": (20, 6, 32), "B": (16, 8, 64)}
-    # Inference (no autograd, fp32, config 'B') runs the whole encoder on the library's kernels (DESIGN.md section 4.8):
+    # Inference (no autograd, fp32, config 'B') runs the whole encoder on the library's kernels (DESIGN.md section 3.9):
     # SFENet1 on diinn_sfe1_forward, the 147 convolutions after it through diinn_rdn_forward[_wino] -- the split-K
     # kernel on small maps, Winograd 3x3 + streaming 1x1 kernels from 8192 pixels on.  Measured (tools/enc_trunk_time.py,
     # HIP vs MIOpen eager): 1.95 vs 7.6 ms at 48x48, 3.6 vs 7.6 at 96x96, 3.9 vs 8.1 at 128x128, 9.3 vs 20.2 at 192x192,
@@ -130,7 +130,7 @@ class RDN(nn.Module):
     # optional: the 3x3 layers in split-bf16 arithmetic on the bf16 MFMA (csrc/diinn_conv_x3.hip) on maps of >= 32,768
     # pixels: hi + lo bf16 operands, three products per term, fp32 accumulation; inside a dense block the activations are
     # exchanged already split.  Per layer ~4e-6 of max|out| against float64; the whole trunk differs from the fp32 one by
-    # ~3e-6 of max|feat| and the decoded image by ~3e-8 (DESIGN.md 4.8).  Measured per trunk: 192x192 9.4 -> 6.7 ms,
+    # ~3e-6 of max|feat| and the decoded image by ~3e-8 (DESIGN.md 3.9).  Measured per trunk: 192x192 9.4 -> 6.7 ms,
     # 256x256 11.85 -> 7.9 ms, 384x384 28.1 -> 20.1 ms, 512x512 46.6 -> 31.4 ms; below ~180x180 the Winograd kernels stay faster and are used.
     hip_split_bf16: bool = False
 
@@ -316,7 +316,7 @@ class DIINN(nn.Module, _GraphReplay):
         return self.decoder(self.encoder(x), size, bsize)
 
     def set_split_bf16(self, enabled: bool = True) -> "DIINN":
-        """Switch both optional split-bf16 modes (not in the reference; DESIGN.md sections 4.3b and 4.8): the decoder's
+        """Switch both optional split-bf16 modes (not in the reference; DESIGN.md sections 3.5 and 3.9): the decoder's
         per-pixel layers (``decoder.compute = "bf16x3"``) and the encoder's 3x3 layers (``encoder.hip_split_bf16``).  The
         output stays within the reference tolerance (1e-4 x max(1, |ref|)); 256x256 x4: 17.9 -> 10.1 ms per forward."""
         self.decoder.compute = "bf16x3" if enabled else "f32"
@@ -331,7 +331,7 @@ class DIINN(nn.Module, _GraphReplay):
     @torch.no_grad()
     def forward_sharded(self, x, size, src: int = 0, gather_to: Optional[int] = 0, group=None, mode: str = "halo"):
         """The same forward with the HR grid cut into row bands, one per rank of the process group (one process per
-        GPU under ``torch.distributed``; DESIGN.md section 7): rank ``src`` runs the encoder, every rank receives the
+        GPU under ``torch.distributed``; DESIGN.md section 6): rank ``src`` runs the encoder, every rank receives the
         LR feature rows its band reads (+ a one-row halo) and decodes its band, and the image is assembled on
         ``gather_to`` (returned there, ``None`` elsewhere) -- or, with ``gather_to=None``, every rank gets
         ``(band, (y0, y1))``.  Every rank passes ``x`` (only its shape is used away from ``src``).  Inference, mode 3.

@@ -382,7 +382,7 @@ int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* 
 /* Split-bf16 arithmetic for the trunk's 3x3 convolutions (csrc/diinn_conv_x3.hip; optional, large maps): the direct sum
  * on v_mfma_f32_32x32x16_bf16 with every operand as hi + lo bf16 parts (hi = bf16(v), lo = bf16(v - hi)), a product as
  * w_lo.x_hi + w_hi.x_lo + w_hi.x_hi, fp32 accumulation.  Per layer ~4e-6 of max|out| against float64 (fp32 Winograd:
- * ~5e-7); through the whole trunk 7e-6 of max|feat| and 1e-7 in the decoded image (DESIGN.md 4.8).
+ * ~5e-7); through the whole trunk 7e-6 of max|feat| and 1e-7 in the decoded image (DESIGN.md 3.9).
  * diinn_conv3x3_x3: one 3x3 zero-padded 64-output convolution over Cin % 16 == 0 input planes (addressing and epilogue as
  *   diinn_conv_wino).  packed_x3_dev: [group Cin/16][tap 9][M-tile 2][hi, lo][lane 64][8 bf16] with
  *   value = part(W[32 mt + (lane&31)][16 group + 8 (lane>>5) + j][tap / 3][tap % 3])   (9 * 64 * Cin floats).

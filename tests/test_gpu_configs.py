@@ -7,7 +7,7 @@ each test decodes the full image on the GPU and checks
     the full decode, every value finite;
   * the ABI's size limits just past the largest config.
 Tolerances: fp32 1e-4 * max(1, max|ref|) (north_star); bf16 2e-3 * max|ref|, bf16_full 3e-3 * max|ref|
-(restated, SURVEY §8 d4 / DESIGN §4.3)."""
+(restated, SURVEY §8 d4 / DESIGN §3.4)."""
 import ctypes as C
 
 import numpy as np

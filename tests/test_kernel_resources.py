@@ -1,7 +1,7 @@
 """CPU gate on the SHIPPED code objects: no kernel of libdiinn_hip.so may use scratch memory (a register spill to
 scratch is a silent several-fold slowdown: round 2 shipped liif_kernel with 954 spilled registers and
 decode_bf16x2_kernel with 360 while the docs said "no kernel uses scratch"), and every kernel must keep the occupancy its
-design counts on (DESIGN.md section 4: one wave per SIMD for the register-resident kernels, two where two workgroups or
+design counts on (DESIGN.md section 3: one wave per SIMD for the register-resident kernels, two where two workgroups or
 two waves are meant to cover each other).
 
 Reads the AMDGPU metadata notes of the gfx950 code objects embedded in the library (clang offload bundles in
@@ -21,7 +21,7 @@ REGS_PER_SIMD = 512
 
 # kernel name (as in the mangled symbol) -> waves per SIMD the design needs.  Anything not listed needs >= 1.
 DESIGN_OCCUPANCY = {
-    "decode_bf16_coop8_kernel": 2,       # two waves per SIMD cover each other's vector-memory stalls (DESIGN 4.3)
+    "decode_bf16_coop8_kernel": 2,       # two waves per SIMD cover each other's vector-memory stalls (DESIGN 3.4)
     "decode_coop_kernel": 2,             # two workgroups per CU where the grid over-subscribes it (4.4a)
     "precompute_P_kernel": 2,            # two workgroups per CU hide each other's waits (4.2)
     "precompute_P_bf16_wide_kernel": 2,

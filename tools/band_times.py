@@ -2,7 +2,7 @@
 """Per-rank compute time of the row-band sharding on ONE GPU: for each BASELINE multi-GPU config the time of the
 slowest band (precompute_P on the band's LR rows + decode of the band), i.e. what every rank would spend per
 decode if it held its feature rows.  With the measured whole-image time it gives the compute-side speed-up the
-band partition allows (the feature hand-off is extra; DESIGN.md section 7)."""
+band partition allows (the feature hand-off is extra; DESIGN.md section 6)."""
 import os
 import sys
 

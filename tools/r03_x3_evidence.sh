@@ -1,5 +1,5 @@
 #!/bin/bash
-# evidence for DESIGN 4.3b: PMC passes + kernel stats of the split-bf16 c2 step for both decode forms, the issue
+# evidence for DESIGN 3.5: PMC passes + kernel stats of the split-bf16 c2 step for both decode forms, the issue
 # microbenchmark, and the default bench line (fp32 headline + split_bf16 side leg).  Output: gpurun_out/r03x3/
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/r03x3; rm -rf $O; mkdir -p $O
