@@ -204,7 +204,7 @@ def load_traffic():
         return None
 
 
-def measure_traffic(args, kernel_prefix="void decode_kernel<", timeout_s=240):
+def measure_traffic(args, kernel_prefix="void decode_kernel<", timeout_s=90):
     """HBM bytes per launch of the dominant kernel, MEASURED by this run: two `rocprofv3 --pmc` passes of this very script
     (FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md, HBM / rocprofv3 sections) in child processes --
     `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --steps 3 --warmup 1` with every extra leg off --
