@@ -390,7 +390,7 @@ def run_workload(job, name, scaling, steps, warmup, solo=False, check=True, gath
     # record costs ~4 us of stream time (tools/event_overhead.py: 4 per step add 15 us to the 117 us c1 step and 18 us to
     # the 6.12 ms c2 step), so sampling keeps the instrument out of the number it sits in; with one rank the hand-off
     # is empty and its two stamps are one.
-    ev_every = max(1, min(4, steps // 3))
+    ev_every = max(1, min(4, steps // 3)) if steps < 32 else steps // 8      # long runs (c1: 200 steps): 8 sampled steps
     ev = {i: (mk(), mk(), mk(), mk()) for i in range(0, steps, ev_every)}
     res["event_steps"] = len(ev)
     packed = job.packed
@@ -530,7 +530,7 @@ def strong_legs(job):
 
 # Driver-timed side legs of the default N = 1 run: the other single-GPU BASELINE configs, a few
 # steps each, so that their numbers are measured by the same run that produces the headline -- never part of `value`.
-SIDE_LEGS = [("c5", "f32", 2, 1), ("c5", "bf16_full", 5, 2), ("c1", "f32", 40, 10)]
+SIDE_LEGS = [("c5", "f32", 2, 1), ("c5", "bf16_full", 5, 2), ("c1", "f32", 200, 20)]
 
 
 def side_leg(job, name, compute, steps, warmup, check=True):
