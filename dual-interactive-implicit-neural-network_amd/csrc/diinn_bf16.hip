@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256, 1) void decode_bf16_coop_kernel(const DecodePa
             for (int e = 0; e < 4; ++e) {
                 float a = __builtin_fmaf(cww[e], relw, ctq[e]);
                 a = __builtin_fmaf(cwh[e], relh, a);
-                v[e] = relu0(cpv[e]) * dsin_rev<SIN_MODE>(a);
+                v[e] = relu0(cpv[e]) * co_sin_fin<SIN_MODE>(co_sin_prep<SIN_MODE>(a));   // as the epilogues: v_fract + v_sin on revolutions
             }
             const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
             fragw[2 * (i & 1) + 0] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8_kernel(const DecodeP
             for (int e = 0; e < 4; ++e) {
                 float a = __builtin_fmaf(cww[e], relw, ctq[e]);
                 a = __builtin_fmaf(cwh[e], relh, a);
-                v[e] = relu0(cpv[e]) * dsin_rev<SIN_MODE>(a);
+                v[e] = relu0(cpv[e]) * co_sin_fin<SIN_MODE>(co_sin_prep<SIN_MODE>(a));   // as the epilogues: v_fract + v_sin on revolutions
             }
             const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
             fragw[2 * (i & 1) + 0] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
@@ -1468,7 +1468,7 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
                 for (int e = 0; e < 4; ++e) {
                     float a = __builtin_fmaf(cww[e], relw, ctq[e]);
                     a = __builtin_fmaf(cwh[e], relh, a);
-                    v[e] = relu0(cpv[e]) * dsin_rev<SIN_MODE>(a);
+                    v[e] = relu0(cpv[e]) * co_sin_fin<SIN_MODE>(co_sin_prep<SIN_MODE>(a));   // as the epilogues: v_fract + v_sin on revolutions
                 }
                 const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
                 fragw[2 * (i & 1) + 0] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
