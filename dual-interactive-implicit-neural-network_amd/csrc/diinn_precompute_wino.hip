@@ -232,15 +232,23 @@ __device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, flo
         kgroup(IC<6>{});
         kgroup(IC<7>{});
     };
-    // this workgroup's M-tiles [mt0, mt0 + mtn): mt0 and mtn are even, so an M-tile's parity is its accumulator set
+    // this workgroup's M-tiles [mt0, mt0 + mtn), any count >= 1 (r04: small maps split the 32 M-tiles over any number of
+    // workgroups up to 16, not only powers of two): the accumulator sets alternate from set 0 at mt0
+    int mt = mt0;
 #pragma unroll 1
-    for (int mt = mt0; mt < mt0 + mtn; mt += 2) {
+    for (; mt + 1 < mt0 + mtn; mt += 2) {
         mtile(IC<0>{}, mt, mt > mt0);
         mtile(IC<1>{}, mt + 1, true);
     }
+    const bool odd = mt < mt0 + mtn;                             // workgroup-uniform
+    if (odd) mtile(IC<0>{}, mt, mt > mt0);
     const int mtl = mt0 + mtn - 1;
-    // the last M-tile (parity 1)
-    col_transform(IC<1>{}, IC<0>{}); col_transform(IC<1>{}, IC<1>{}); col_transform(IC<1>{}, IC<2>{}); col_transform(IC<1>{}, IC<3>{});
+    // the last M-tile (set 1, or set 0 after an odd count)
+    if (odd) {
+        col_transform(IC<0>{}, IC<0>{}); col_transform(IC<0>{}, IC<1>{}); col_transform(IC<0>{}, IC<2>{}); col_transform(IC<0>{}, IC<3>{});
+    } else {
+        col_transform(IC<1>{}, IC<0>{}); col_transform(IC<1>{}, IC<1>{}); col_transform(IC<1>{}, IC<2>{}); col_transform(IC<1>{}, IC<3>{});
+    }
     exchange_write(mtl & 1);
     bias4 = or_bits(*reinterpret_cast<const f32x4*>(bk + 32 * mtl), nanm);
     __syncthreads();
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void precompute_P_wino_kernel(const PWinoPa
 #endif
     const int part = __builtin_amdgcn_readfirstlane(t % p.msplit);   // the parts of a block are neighbours: they share its patch rows
     t /= p.msplit;
-    const int mtn = 32 / p.msplit, mt0 = part * mtn;
+    const int mt0 = part * 32 / p.msplit, mtn = (part + 1) * 32 / p.msplit - mt0;   // parts of floor or ceil(32 / msplit) M-tiles
     const int b = __builtin_amdgcn_readfirstlane(t / per_b);
     t -= b * per_b;
     const int by = __builtin_amdgcn_readfirstlane(t / p.bx_n), bx = t - by * p.bx_n;
@@ -311,9 +319,9 @@ int launch_P_wino(void* stream, const float* feat_dev, const float* packed_dev, 
         const double prologue_us = 4.0, mtile_us = 3.4;          // measured: V + pipeline fill; 128 MFMAs
         double best = 1e30;
         p.msplit = 1;
-        for (int ms = 1; ms <= 16; ms *= 2) {
-            const double rounds = (double)((blocks * ms + 255) / 256);
-            const double cost = rounds * (prologue_us + (32 / ms) * mtile_us);
+        for (int ms = 1; ms <= 16; ++ms) {                       // (r04: any split -- c1's 18 blocks take 11 parts of <= 3 M-tiles
+            const double rounds = (double)((blocks * ms + 255) / 256);   //  in one round where powers of two offered 8 parts of 4)
+            const double cost = rounds * (prologue_us + ((32 + ms - 1) / ms) * mtile_us);
             if (cost < best * 0.97) { best = cost; p.msplit = ms; }   // prefer the coarser split unless clearly worse
         }
     }
