@@ -856,19 +856,19 @@ static int decode_tile_impl(void* stream, const float* P_dev, const float* packe
             hipLaunchKernelGGL((decode_kernel<DIINN_SIN_ACCURATE, false>), grid, dim3(blk), 0, (hipStream_t)stream, p);
         return hip_status(hipGetLastError());
     }
-    // small launches: the latency variant (4 waves share a tile): fewer than ~3/4 of a round of 16 x 8 workgroups.
+    // Which of the three fp32 kernels (bit-equal: tests/test_gpu_parity.py::test_latency_kernel_is_bit_identical_...)?
+    // decode_kernel runs whole ROUNDS of 256 workgroups of 16 x 8 pixels, 181 us each whatever the fill; the 16-pixel
+    // latency kernel is work-conserving (four workgroups per CU) at 0.0896 us per tile + ~25 us -- 1.3 % behind on exact
+    // rounds (c2: 5.87 vs 5.79 ms), far ahead on a partly filled last round (48 -> 192: 0.234 vs 0.363 ms; r04,
+    // tools/f32_kernel_choice.py, profiles/r04_f32_kernel_choice.txt).  The launch takes the cheaper by that model; the 32-pixel
+    // latency kernel (r02) never wins any more and runs only when forced.
     // DIINN_F32_KERNEL = 1 / 2 / 3 forces the throughput / 32-pixel latency / 16-pixel latency kernel (tests, A-B timing).
     const int force = (int)knob(diinn_knobs().f32_kernel);
-    // The smallest IMAGES take the 16-pixel latency kernel: rounds of tiles on the 256 CUs, a 32-pixel tile's chain being
-    // twice a 16-pixel tile's.  Chosen from the full image (B, Hu, Wu), so that a band or a tile of an image takes the
-    // kernel the whole image takes (the three fp32 kernels are bit-equal; this keeps that from being load-bearing).
     {
-        const long long t32 = (long long)((Wu + TILE_W - 1) / TILE_W) * ((Hu + TILE_H - 1) / TILE_H) * B;
-        const long long t16 = (long long)((Wu + T16_W - 1) / T16_W) * ((Hu + T16_H - 1) / T16_H) * B;
-        const long long full_wgs = (long long)((Wu + 15) / 16) * ((Hu + 7) / 8) * B;
-        const bool small16 = full_wgs <= 192 && (t16 + 255) / 256 < 2 * ((t32 + 255) / 256);
         const dim3 grid16((x1 - x0 + T16_W - 1) / T16_W, (y1 - y0 + T16_H - 1) / T16_H, B);
-        if (grid16.y <= 65535 && (force ? force == 3 : small16)) {
+        const double t16 = (double)grid16.x * grid16.y * grid16.z, rounds = (double)(((long long)gx * gy * gz + 255) / 256);
+        const bool cheaper16 = 0.0896 * t16 + 25.0 < 181.1 * rounds + 3.0;
+        if (grid16.y <= 65535 && (force ? force == 3 : cheaper16)) {
             if (sin_mode == DIINN_SIN_HW)
                 hipLaunchKernelGGL(decode_coop16_kernel<DIINN_SIN_HW>, grid16, dim3(256), 0, (hipStream_t)stream, p);
             else if (sin_mode == DIINN_SIN_HW_REDUCED)
@@ -879,7 +879,7 @@ static int decode_tile_impl(void* stream, const float* P_dev, const float* packe
         }
     }
     const dim3 gridc((x1 - x0 + TILE_W - 1) / TILE_W, (y1 - y0 + TILE_H - 1) / TILE_H, B);
-    if (gridc.y <= 65535 && (force ? force == 2 : (long long)gx * gy * gz <= 192)) {
+    if (gridc.y <= 65535 && force == 2) {
         if (sin_mode == DIINN_SIN_HW)
             hipLaunchKernelGGL(decode_coop_kernel<DIINN_SIN_HW>, gridc, dim3(256), 0, (hipStream_t)stream, p);
         else if (sin_mode == DIINN_SIN_HW_REDUCED)
