@@ -621,6 +621,11 @@ size_t diinn_rdn_wino_packed_floats(void) {
     return n;
 }
 
+size_t diinn_rdn_wino4_packed_floats(void) {
+    // the 3x3 layers only, 36 floats per (output, input) pair (F(4x4, 3x3): csrc/diinn_winograd4.hip)
+    return diinn_rdn_wino_packed_floats() / 16 * 36;
+}
+
 size_t diinn_rdn_x3_workspace_floats(int B, int H, int W) {
     // diinn_rdn_workspace_floats + the split-format copy of one dense buffer ([B][72 groups][hi, lo][H][W] x 16 bytes)
     if (B <= 0 || H <= 0 || W <= 0) return 0;
@@ -636,7 +641,7 @@ size_t diinn_rdn_x3_packed_floats(void) {
 }
 
 static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
-                            const float* packed_x3_dev,
+                            const float* packed_wino4_dev, const float* packed_x3_dev,
                             const float* biases_dev, float* workspace_dev, float* out_dev, int B, int H, int W) {
     if (!sfe1_dev || !packed_dev || !biases_dev || !workspace_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
@@ -646,6 +651,9 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     // about 90 x 90 pixels up (tools/r02_ab_env.sh: 96x96 3.6 vs 4.5 ms, 64x64 3.4 vs 2.1 ms per trunk)
     const long long wino_min = knob(diinn_knobs().enc_wino_min);
     const bool wino = packed_wino_dev && (long long)B * hw >= wino_min;
+    // F(4x4, 3x3) (csrc/diinn_winograd4.hip): 1.78x fewer MFMAs again, blocks of 32 x 16 pixels x one output half: from the
+    // map size on where those fill the chip better than F(2x2)'s (DIINN_ENC_WINO4_MIN pixels)
+    const bool wino4 = packed_wino4_dev && (long long)B * hw >= knob(diinn_knobs().enc_wino4_min);
     float* buf[2] = {workspace_dev, workspace_dev + (size_t)B * 576 * hw};     // dense buffers [B,576,H,W]
     float* gff_in = workspace_dev + (size_t)2 * B * 576 * hw;                    // [B,1024,H,W]
     float* tmp = gff_in + (size_t)B * 1024 * hw;                                 // [B,64,H,W]
@@ -655,17 +663,21 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     const bool x3 = packed_x3_dev && (long long)B * hw >= knob(diinn_knobs().enc_x3_min);
     const float* w = packed_dev;
     const float* wu = packed_wino_dev;
+    const float* wu4 = packed_wino4_dev;
     const float* wx = packed_x3_dev;
     const float* bias = biases_dev;
     auto conv = [&](const float* in, long long in_bs, int cin, int taps, const float* res, long long res_bs,
                     float* o0, long long o0_bs, float* o1, long long o1_bs, int relu) {
         const int s = (x3 && taps == 9 && !o1)
             ? diinn_conv3x3_x3(stream, in, in_bs, cin, wx, bias, res, res_bs, o0, o0_bs, relu, B, H, W)
+            : (wino4 && taps == 9 && !o1)
+            ? diinn_conv_wino4(stream, in, in_bs, cin, wu4, bias, res, res_bs, o0, o0_bs, relu, B, H, W)
             : (wino && taps == 9 && !o1)
             ? diinn_conv_wino(stream, in, in_bs, cin, wu, bias, res, res_bs, o0, o0_bs, relu, B, H, W)
             : diinn_conv_ksplit(stream, in, in_bs, cin, taps, w, bias, res, res_bs, o0, o0_bs, o1, o1_bs, relu, B, H, W);
         w += (size_t)64 * cin * taps;
         if (taps == 9 && wu) wu += (size_t)64 * cin * 16;
+        if (taps == 9 && wu4) wu4 += (size_t)64 * cin * 36;
         if (taps == 9 && wx) wx += (size_t)64 * cin * 9;
         bias += 64;
         return s;
@@ -679,6 +691,7 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     if (x3) {
         st = diinn_conv3x3_x3_split(stream, sfe1_dev, 64 * hw, xs, xs_bs16, 0, 64, wx, bias, buf[0], 576 * hw, 0, B, H, W);
         w += (size_t)64 * 64 * 9; wu += (size_t)64 * 64 * 16; wx += (size_t)64 * 64 * 9; bias += 64;
+        if (wu4) wu4 += (size_t)64 * 64 * 36;
     } else {
         st = conv(sfe1_dev, 64 * hw, 64, 9, nullptr, 0, buf[0], 576 * hw, nullptr, 0, 0);
     }
@@ -699,6 +712,7 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
                 if (st) return st;
                 w += (size_t)64 * 64 * (c + 1) * 9;
                 wu += (size_t)64 * 64 * (c + 1) * 16;
+                if (wu4) wu4 += (size_t)64 * 64 * (c + 1) * 36;
                 wx += (size_t)64 * 64 * (c + 1) * 9;
                 bias += 64;
             }
@@ -725,20 +739,28 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
 
 int diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packed_dev, const float* biases_dev,
                       float* workspace_dev, float* out_dev, int B, int H, int W) {
-    return rdn_forward_impl(stream, sfe1_dev, packed_dev, nullptr, nullptr, biases_dev, workspace_dev, out_dev, B, H, W);
+    return rdn_forward_impl(stream, sfe1_dev, packed_dev, nullptr, nullptr, nullptr, biases_dev, workspace_dev, out_dev, B, H, W);
 }
 
 int diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
                            const float* biases_dev, float* workspace_dev, float* out_dev, int B, int H, int W) {
     if (!packed_wino_dev) return DIINN_ERR_INVALID_ARG;
-    return rdn_forward_impl(stream, sfe1_dev, packed_dev, packed_wino_dev, nullptr, biases_dev, workspace_dev, out_dev, B, H, W);
+    return rdn_forward_impl(stream, sfe1_dev, packed_dev, packed_wino_dev, nullptr, nullptr, biases_dev, workspace_dev, out_dev, B, H, W);
+}
+
+int diinn_rdn_forward_wino4(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
+                            const float* packed_wino4_dev, const float* biases_dev, float* workspace_dev, float* out_dev,
+                            int B, int H, int W) {
+    if (!packed_wino_dev || !packed_wino4_dev) return DIINN_ERR_INVALID_ARG;
+    return rdn_forward_impl(stream, sfe1_dev, packed_dev, packed_wino_dev, packed_wino4_dev, nullptr, biases_dev, workspace_dev, out_dev,
+                            B, H, W);
 }
 
 int diinn_rdn_forward_x3(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
                          const float* packed_x3_dev, const float* biases_dev, float* workspace_dev, float* out_dev,
                          int B, int H, int W) {
     if (!packed_wino_dev || !packed_x3_dev) return DIINN_ERR_INVALID_ARG;
-    return rdn_forward_impl(stream, sfe1_dev, packed_dev, packed_wino_dev, packed_x3_dev, biases_dev, workspace_dev, out_dev, B, H, W);
+    return rdn_forward_impl(stream, sfe1_dev, packed_dev, packed_wino_dev, nullptr, packed_x3_dev, biases_dev, workspace_dev, out_dev, B, H, W);
 }
 
 }  // extern "C"

@@ -1,0 +1,329 @@
+// diinn_winograd4.hip -- the 3x3 convolutions of the RDN trunk as Winograd F(4x4, 3x3) on the fp32 MFMA (gfx950).
+// (part of libdiinn_hip.so; shared definitions in diinn_device.h)
+//
+// Reference: src/models/components/rdn.py:9-35,90-105 (130 of the trunk's 147 convolutions: 3x3, stride 1, zero
+// padding 1, 64 outputs, 64..512 inputs).  F(4x4, 3x3) computes a 4x4 output block from a 6x6 input patch with 36
+// multiplies per (input, output) channel pair instead of 144:
+//     Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A            (Lavin & Gray's matrices, interpolation points 0, +-1, +-2, inf)
+// i.e. 36 independent GEMMs (one per position of the transformed 6x6 tile) with 2.25 multiplies per output against
+// 4 in F(2x2, 3x3) (diinn_winograd.hip): 1.78x fewer MFMAs.  fp32 throughout; G g G^T is computed in float64 on the host
+// and rounded once.  The price is accuracy: B^T holds 4 and 5, A^T up to 8, so the sums cancel more -- measured over the
+// whole trunk (tools/enc_wino43_error.py, against float64): max error 2.9e-6 of max|feat| 1.6 against 3e-7 for
+// F(2x2, 3x3) and 3.6e-7 for the direct sum; the trunk's parity bound is 2e-5 x max|ref| (tests/test_encoder_hip.py).
+//
+// Work split: a workgroup owns a block of 8 x 4 Winograd tiles (32 x 16 output pixels) = one 32-wide MFMA N-tile, and
+// ONE half of the 64 outputs (a 256 x 256 map is 128 blocks x 2 halves = one workgroup per CU).  It has 12 waves, three
+// per SIMD; wave w owns positions 3 w .. 3 w + 2 of the 36: three accumulators.  Unlike the F(2x2) kernel the data
+// transform is shared: per chunk of 8 input channels the 256 (tile, channel) patches are transformed ONCE, by the four
+// waves of one of three wave groups in rotation (one thread per patch: 18 loads, ~110 VALU instructions, 36 LDS
+// stores), and every wave reads the B operands of its positions from LDS (one 16-byte read per position and chunk).
+// Chunk k is transformed by group k % 3 during iteration k - 2 into a ring of three LDS buffers, so one barrier per
+// iteration orders everything and nobody waits for LDS data behind it; each SIMD always holds one transforming wave and
+// two that keep its matrix core busy.  Weights: 1 KiB per position and chunk, straight from L2 into registers, requested
+// one chunk ahead behind the last MFMA that used the register.
+// (W4_ABL_* are timing-ablation hooks for tools/ubench/wino4_bench.hip: wrong results when defined, never in the library.)
+// Epilogue: the 36 positions meet through LDS (144 KiB, over the ring), one thread per (tile, output channel):
+// A^T (.) A, bias, ReLU / residual, 16-byte stores.
+#include "diinn_device.h"
+
+constexpr int W4_TX = 8, W4_TY = 4;                  // Winograd tiles per block (x, y): 32 = one MFMA N-tile
+constexpr int W4_THREADS = 768;
+constexpr int W4_VBUF = 36 * 256;                    // floats of one chunk's transformed data: [pos 36][h 2][tile 32][e 4]
+constexpr int W4_LDS_FLOATS = 36 * 1024;             // epilogue exchange [pos 36][reg pair 8][lane 64][2]; the ring uses 3 * W4_VBUF of it
+constexpr int W4_PIECE_BYTES = 1024;                 // one A piece: 64 lanes x 4 k-steps
+static_assert(3 * W4_VBUF <= W4_LDS_FLOATS, "ring inside the exchange buffer");
+
+#define W4_SB() __builtin_amdgcn_sched_barrier(0)
+
+struct ConvWino4Params {
+    const float* in;         // input channel planes: in + b*in_bs + c*H*W
+    const float* wu;         // packed transformed weight: [wave 12][half 2][chunk Cin/8][q 3][lane 64][4]
+    const float* bias;       // [64]
+    const float* res;        // optional residual [B,64,H,W] (batch stride res_bs), added after bias (no ReLU with it)
+    float* out;              // out + b*out_bs + co*H*W
+    long long in_bs, out_bs, res_bs;
+    int Cin, B, H, W, relu;
+};
+
+// one dimension of B^T (6 -> 6) and of A^T (6 -> 4); T = float or f32x2 (two columns at a time: v_pk_* instructions)
+template <typename T>
+__device__ __forceinline__ void w4_bt(const T d0, const T d1, const T d2, const T d3, const T d4, const T d5,
+                                      T& r0, T& r1, T& r2, T& r3, T& r4, T& r5) {
+    const T a = __builtin_elementwise_fma(T(-4.0f), d2, d4), b = __builtin_elementwise_fma(T(-4.0f), d1, d3);
+    const T c = d4 - d2, e = d3 - d1;
+    r0 = __builtin_elementwise_fma(T(4.0f), d0, __builtin_elementwise_fma(T(-5.0f), d2, d4));
+    r1 = a + b;
+    r2 = a - b;
+    r3 = __builtin_elementwise_fma(T(2.0f), e, c);
+    r4 = __builtin_elementwise_fma(T(-2.0f), e, c);
+    r5 = __builtin_elementwise_fma(T(4.0f), d1, __builtin_elementwise_fma(T(-5.0f), d3, d5));
+}
+template <typename T>
+__device__ __forceinline__ void w4_at(const T m0, const T m1, const T m2, const T m3, const T m4, const T m5,
+                                      T& y0, T& y1, T& y2, T& y3) {
+    const T s = m1 + m2, d = m1 - m2, u = m3 + m4, v = m3 - m4;
+    y0 = (m0 + s) + u;
+    y1 = __builtin_elementwise_fma(T(2.0f), v, d);
+    y2 = __builtin_elementwise_fma(T(4.0f), u, s);
+    y3 = __builtin_elementwise_fma(T(8.0f), v, d) + m5;
+}
+
+__device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float* __restrict__ lds, int b, int tx0, int ty0, int hh0) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..11: positions 3 wave .. 3 wave + 2
+    const int grp = wave >> 2;                                   // transform duty: chunks k with k % 3 == grp
+    const size_t plane = (size_t)p.H * p.W;
+    const unsigned plane_b = (unsigned)(plane * sizeof(float));
+    const float* __restrict__ in_b = p.in + (size_t)b * p.in_bs;
+    const int n = p.Cin / 8;                                     // chunks of 8 input channels
+    constexpr unsigned OUTSIDE = 0x80000000u;
+
+    // ---- transform role: one (tile, channel of the chunk) patch per thread.  Lanes = 16 tiles x 4 k-steps e of one
+    // channel parity th, so that a wave's 36 LDS stores are each 256 contiguous bytes.
+    const int wt = wave & 3;
+    const int th = wt & 1, tm = 16 * (wt >> 1) + (lane >> 2), te = lane & 3;
+    const int ptx = tx0 + (tm & (W4_TX - 1)), pty = ty0 + tm / W4_TX;
+    // patch rows 4 ty - 1 .. 4 ty + 4, columns 4 tx - 1 .. 4 tx + 4: per row one aligned 16-byte load of the middle
+    // columns and a 4-byte load either side.  Rows outside the map get an offset the descriptor's range check answers
+    // with zeros; columns outside it are zeroed by selects (the loads stay inside the chunk's planes or out of range).
+    unsigned voff[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int y = 4 * pty - 1 + k;
+        voff[k] = (y >= 0 && y < p.H) ? (unsigned)(2 * te + th) * plane_b + (unsigned)(y * p.W + 4 * ptx) * 4u : OUTSIDE;
+    }
+    const bool okl = ptx > 0;
+    const bool ok1 = 4 * ptx + 1 < p.W, ok2 = 4 * ptx + 2 < p.W, ok3 = 4 * ptx + 3 < p.W, okr = 4 * ptx + 4 < p.W;
+    const bool ragged = (p.W & 3) != 0;                          // uniform: only then can the 16-byte load cross the row's end
+    float PL[6], PR[6];
+    f32x4 PC[6];
+    auto load_patch = [&](int c) {
+        const __amdgpu_buffer_rsrc_t irs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(in_b + (size_t)8 * c * plane), 0, (int)(8u * plane_b), 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+#ifdef W4_ABL_LINEAR
+            PC[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, (int)((threadIdx.x & 255) * 16 + k * 4096), 0, 0));
+            PL[k] = PR[k] = 0.0f;
+#else
+            PC[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, (int)voff[k], 0, 0));
+#ifndef W4_ABL_NOSIDE
+            PL[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, (int)(voff[k] - 4u), 0, 0));
+            PR[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, (int)(voff[k] + 16u), 0, 0));
+#else
+            PL[k] = PR[k] = 0.0f;
+#endif
+#endif
+        }
+    };
+    auto transform = [&](float* __restrict__ vb) {
+        // B^T d down the columns, two columns at a time, then (.) B along each row
+        f32x2 d[6][3], t[6][3];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            float c0 = PC[k][0], c1 = PC[k][1], c2 = PC[k][2], c3 = PC[k][3];
+            if (ragged) {
+                c1 = ok1 ? c1 : 0.0f;
+                c2 = ok2 ? c2 : 0.0f;
+                c3 = ok3 ? c3 : 0.0f;
+            }
+            d[k][0] = f32x2{okl ? PL[k] : 0.0f, c0};
+            d[k][1] = f32x2{c1, c2};
+            d[k][2] = f32x2{c3, okr ? PR[k] : 0.0f};
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            w4_bt<f32x2>(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], t[0][j], t[1][j], t[2][j], t[3][j], t[4][j], t[5][j]);
+        float* __restrict__ dst = vb + th * 128 + tm * 4 + te;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float v0, v1, v2, v3, v4, v5;
+            w4_bt<float>(t[i][0][0], t[i][0][1], t[i][1][0], t[i][1][1], t[i][2][0], t[i][2][1], v0, v1, v2, v3, v4, v5);
+            dst[(6 * i + 0) * 256] = v0;
+            dst[(6 * i + 1) * 256] = v1;
+            dst[(6 * i + 2) * 256] = v2;
+            dst[(6 * i + 3) * 256] = v3;
+            dst[(6 * i + 4) * 256] = v4;
+            dst[(6 * i + 5) * 256] = v5;
+        }
+    };
+
+    // ---- MFMA role: A = weights (32 outputs of half hh0 x 2 channels), B = transformed data (2 channels x 32 tiles)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.wu + (size_t)(wave * 2 + hh0) * n * (3 * W4_PIECE_BYTES / 4)), 0, n * 3 * W4_PIECE_BYTES, 0x00020000);
+    const int lane_off = lane * 16;
+    const float* __restrict__ bsrc = lds + 3 * wave * 256 + lane * 4;
+    f32x16 acc[3];
+    f32x4 A[2][3], Bf[3];    // weights of chunks c, c + 1 (ring of two: a request has a whole iteration to arrive); B operands of chunk c
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+
+    // prologue: chunks 0 and 1 into ring slots 0 and 1; every group leaves with its next patch requested
+    if (grp < 2) {
+        load_patch(grp < n ? grp : n - 1);
+        transform(lds + grp * W4_VBUF);
+        load_patch(grp + 3 < n ? grp + 3 : n - 1);
+    } else {
+        load_patch(2 < n ? 2 : n - 1);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        A[0][q] = ld_piece(wrs, lane_off, q * W4_PIECE_BYTES);
+        A[1][q] = ld_piece(wrs, lane_off, ((n > 1 ? 3 : 0) + q) * W4_PIECE_BYTES);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) Bf[q] = *reinterpret_cast<const f32x4*>(bsrc + q * 256);
+
+    int slot = 0;                                                // c % 3: the ring slot of chunk c
+    // One iteration = one chunk: [this group's turn: transform chunk c + 2 into its slot, request the patch of chunk
+    // c + 5], then per position its four MFMAs, behind them the request of the position's weights of chunk c + 2 into
+    // the registers just used and the read of its B operands of chunk c + 1; one barrier.  The barrier waits for all
+    // but the newest LDS operation (a read of slot c + 1, which nobody writes before the NEXT barrier): the transform's
+    // stores are complete, and no wave sits behind an LDS round trip with the matrix core idle.
+    auto iter = [&](auto PAR_, int c) {
+        constexpr int PAR = decltype(PAR_)::value;
+        const int slot1 = slot == 2 ? 0 : slot + 1;              // slot of chunk c + 1
+        const int slot2 = slot == 0 ? 2 : slot - 1;              // slot of chunk c + 2
+        if (slot2 == grp && c + 2 < n) {                         // (c + 2) % 3 == grp
+#ifndef W4_ABL_NOTRANSFORM
+            transform(lds + slot2 * W4_VBUF);
+#endif
+#ifndef W4_ABL_NOPATCH
+            load_patch(c + 5 < n ? c + 5 : n - 1);
+#endif
+        }
+        W4_SB();
+        const int c2 = c + 2 < n ? c + 2 : n - 1;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#ifndef W4_ABL_NOMFMA
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[q] = MFMA32(A[PAR][q][e], Bf[q][e], acc[q]);
+#else
+            acc[q][0] += A[PAR][q][0] * Bf[q][0] + A[PAR][q][3] * Bf[q][3];
+#endif
+            W4_SB();
+#ifndef W4_ABL_NOW
+            A[PAR][q] = ld_piece(wrs, lane_off, (c2 * 3 + q) * W4_PIECE_BYTES);
+#endif
+#ifndef W4_ABL_NOBREAD
+            Bf[q] = *reinterpret_cast<const f32x4*>(bsrc + slot1 * W4_VBUF + q * 256);
+#endif
+            W4_SB();
+        }
+#ifndef W4_ABL_NOBAR
+        asm volatile("s_waitcnt lgkmcnt(1)\n\ts_barrier" ::: "memory");
+#endif
+        slot = slot1;
+    };
+    int c = 0;
+    for (; c + 1 < n; c += 2) {
+        iter(IC<0>{}, c);
+        iter(IC<1>{}, c + 1);
+    }
+    if (c < n) iter(IC<0>{}, c);
+    __syncthreads();
+
+    // ---- A^T (.) A through LDS: [pos][register pair rp][lane][2]
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp)
+            *reinterpret_cast<f32x2*>(lds + ((3 * wave + q) * 8 + rp) * 128 + lane * 2) = f32x2{acc[q][2 * rp], acc[q][2 * rp + 1]};
+    __syncthreads();
+    if (wave < 8) {
+        // wave: accumulator registers 2 wave, 2 wave + 1; lane (h, m): tile m, output channels 32 hh0 + 8 (r >> 2) + 4 h + (r & 3)
+        const int h = lane >> 5, m = lane & 31;
+        const int tx = tx0 + (m & (W4_TX - 1)), ty = ty0 + m / W4_TX;
+        const float* __restrict__ src = lds + wave * 128 + lane * 2;
+        f32x2 z[6][4], y[4][4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            f32x2 mm[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) mm[j] = *reinterpret_cast<const f32x2*>(src + (6 * i + j) * 1024);
+            w4_at<f32x2>(mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], z[i][0], z[i][1], z[i][2], z[i][3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            w4_at<f32x2>(z[0][j], z[1][j], z[2][j], z[3][j], z[4][j], z[5][j], y[0][j], y[1][j], y[2][j], y[3][j]);
+        const int ox = 4 * tx, oy0 = 4 * ty;
+        const bool vec = !ragged && (p.out_bs & 3) == 0 && (((size_t)p.out) & 15) == 0 &&
+                         (!p.res || ((p.res_bs & 3) == 0 && (((size_t)p.res) & 15) == 0));
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int r = 2 * wave + s;
+            const int co = 32 * hh0 + 8 * (r >> 2) + 4 * h + (r & 3);
+            const float bias = p.bias[co];
+            float* __restrict__ op = p.out + (size_t)b * p.out_bs + (size_t)co * plane;
+            const float* __restrict__ rp = p.res ? p.res + (size_t)b * p.res_bs + (size_t)co * plane : nullptr;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int oy = oy0 + a;
+                if (oy >= p.H || ox >= p.W) continue;
+                f32x4 v = {y[a][0][s] + bias, y[a][1][s] + bias, y[a][2][s] + bias, y[a][3][s] + bias};
+                if (p.relu) v = f32x4{relu0(v[0]), relu0(v[1]), relu0(v[2]), relu0(v[3])};
+                const size_t o = (size_t)oy * p.W + ox;
+                if (vec) {
+                    if (rp) v += *reinterpret_cast<const f32x4*>(rp + o);
+                    *reinterpret_cast<f32x4*>(op + o) = v;
+                } else {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        if (ox + x < p.W) op[o + x] = rp ? v[x] + rp[o + x] : v[x];
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvWino4Params p) {
+    __shared__ __attribute__((aligned(16))) float lds[W4_LDS_FLOATS];
+    const int tiles_x = (p.W + 3) / 4, tiles_y = (p.H + 3) / 4;
+    const int bx_n = (tiles_x + W4_TX - 1) / W4_TX, by_n = (tiles_y + W4_TY - 1) / W4_TY;
+    const int total = p.B * bx_n * by_n * 2;
+    // every XCD takes a contiguous run of work items (as conv_wino_entry): neighbours share patch rows in one L2, and
+    // the two halves of a block sit next to each other
+    const int wg_per_xcd = gridDim.x >> 3;
+    const int per_xcd = (total + 7) >> 3;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    for (int k = idx; k < per_xcd; k += wg_per_xcd) {
+        int t = xcd * per_xcd + k;
+        if (t >= total) break;
+        const int hh0 = t & 1;
+        t >>= 1;
+        const int b = __builtin_amdgcn_readfirstlane(t / (bx_n * by_n));
+        t -= b * bx_n * by_n;
+        const int by = __builtin_amdgcn_readfirstlane(t / bx_n), bx = t - by * bx_n;
+        conv_wino4_body(p, lds, b, bx * W4_TX, by * W4_TY, hh0);
+        __syncthreads();                                         // the exchange buffer is free again
+    }
+}
+
+extern "C" {
+
+int diinn_conv_wino4(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
+                     const float* packed_u_dev, const float* bias_dev, const float* res_dev, long long res_batch_stride,
+                     float* out_dev, long long out_batch_stride, int relu, int B, int H, int W) {
+    if (!in_dev || !packed_u_dev || !bias_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (Cin <= 0 || Cin % 8) return DIINN_ERR_UNSUPPORTED;
+    if ((((size_t)in_dev) & 3) || (((size_t)packed_u_dev) & 15) || (((size_t)bias_dev) & 3))
+        return DIINN_ERR_INVALID_ARG;
+    const long long blocks = (long long)(((W + 3) / 4 + W4_TX - 1) / W4_TX) * (((H + 3) / 4 + W4_TY - 1) / W4_TY) * B;
+    if (2 * blocks > 2147483000LL) return DIINN_ERR_TOO_LARGE;
+    if ((long long)H * W * 4 * 64 > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;     // planes are addressed with 32-bit byte offsets
+    if ((long long)Cin / 8 * 3 * W4_PIECE_BYTES > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;
+    ConvWino4Params p;
+    p.in = in_dev; p.wu = packed_u_dev; p.bias = bias_dev; p.res = res_dev; p.out = out_dev;
+    p.in_bs = in_batch_stride; p.out_bs = out_batch_stride; p.res_bs = res_batch_stride;
+    p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0;
+    hipLaunchKernelGGL(conv_wino4_kernel, dim3((unsigned)((2 * blocks + 7) / 8 * 8)), dim3(W4_THREADS), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+}  // extern "C"

@@ -98,6 +98,23 @@ def pack_conv_wino(weight: torch.Tensor) -> torch.Tensor:
     return u.permute(5, 2, 6, 0, 4, 1, 3).reshape(-1)           # [i, chunk, j, half, h, m, e]
 
 
+_WINO4_G = ((1 / 4, 0, 0), (-1 / 6, -1 / 6, -1 / 6), (-1 / 6, 1 / 6, -1 / 6), (1 / 24, 1 / 12, 1 / 6), (1 / 24, -1 / 12, 1 / 6), (0, 0, 1))
+
+
+def pack_conv_wino4(weight: torch.Tensor) -> torch.Tensor:
+    """3x3 conv weight [64, Cin, 3, 3] (Cin % 8 == 0) -> the Winograd F(4x4, 3x3) image ``diinn_conv_wino4`` reads
+    (include/diinn_hip.h): U = G W G^T (6x6 per (output, input) pair), computed in float64 and rounded once, laid out
+    [wave 12][half 2][chunk Cin/8][q 3][lane 64][4] with position 6 i + j = 3 wave + q, cout = 32 half + (lane & 31)
+    and input channel = 8 chunk + 2 e + (lane >> 5)."""
+    co, cin, kh, kw = weight.shape
+    if co != 64 or cin % 8 or (kh, kw) != (3, 3):
+        raise ValueError(f"unsupported convolution shape {tuple(weight.shape)}")
+    g = torch.tensor(_WINO4_G, dtype=torch.float64, device=weight.device)
+    u = torch.einsum("ia,ocab,jb->ocij", g, weight.detach().to(torch.float64), g).to(torch.float32)
+    u = u.reshape(2, 32, cin // 8, 4, 2, 12, 3)                 # [half, m, chunk, e, h, wave, q]
+    return u.permute(5, 0, 2, 6, 4, 1, 3).reshape(-1)           # [wave, half, chunk, q, h, m, e]
+
+
 def pack_conv_x3(weight: torch.Tensor) -> torch.Tensor:
     """Conv weight [64, Cin, k, k] (k = 3 or 1, Cin % 16 == 0) -> the split-bf16 image ``diinn_conv3x3_x3`` and the trunk's
     split-bf16 fusion layer read (include/diinn_hip.h): every weight as hi = bf16(w), lo = bf16(w - hi), laid out
@@ -127,12 +144,17 @@ class RDN(nn.Module):
     # 3x3 layers as Winograd F(2x2, 3x3) (csrc/diinn_winograd.hip) on maps of >= 8192 pixels: 2.25x fewer MFMAs, fp32,
     # equal to the direct sum up to reassociation (~1e-6 relative).  False keeps every layer on the direct kernel.
     hip_winograd: bool = True
+    # ... and as Winograd F(4x4, 3x3) (csrc/diinn_winograd4.hip) on maps of >= 36,864 pixels: 1.78x fewer MFMAs again;
+    # through the whole trunk 3e-6 of max|feat| against float64 (F(2x2): 3e-7; the parity bound is 2e-5).  False keeps
+    # F(2x2, 3x3) on every map size.
+    hip_winograd4: bool = True
     # optional: the 3x3 layers in split-bf16 arithmetic on the bf16 MFMA (csrc/diinn_conv_x3.hip) on maps of >= 32,768
     # pixels: hi + lo bf16 operands, three products per term, fp32 accumulation; inside a dense block the activations are
     # exchanged already split.  Per layer ~4e-6 of max|out| against float64; the whole trunk differs from the fp32 one by
     # ~3e-6 of max|feat| and the decoded image by ~3e-8.  Measured per trunk: 192x192 9.4 -> 6.7 ms,
     # 256x256 11.85 -> 7.9 ms, 384x384 28.1 -> 20.1 ms, 512x512 46.6 -> 31.4 ms; below ~180x180 the Winograd kernels stay faster and are used.
     hip_split_bf16: bool = False
+    _WINO4_MIN_PIXELS = 8192                                    # below that the library never takes the F(4x4) kernels: no image is built
 
     def __init__(self, G0: int = 64, RDNkSize: int = 3, RDNconfig: str = "B", n_colors: int = 3):
         super().__init__()
@@ -163,8 +185,16 @@ class RDN(nn.Module):
             w = torch.cat([pack_conv_ksplit(l.weight) for l in layers]).to(device)
             b = torch.cat([l.bias.detach().to(torch.float32) for l in layers]).to(device)
             wu = torch.cat([pack_conv_wino(l.weight) for l in layers if l.kernel_size == (3, 3)]).to(device)
-            self._hip_pack, self._hip_key, self._hip_x3 = (w, b, wu), key, None
+            self._hip_pack, self._hip_key, self._hip_x3, self._hip_wu4 = (w, b, wu), key, None, None
         return self._hip_pack
+
+    def _hip_packed_wino4(self, device):
+        """The F(4x4, 3x3) image of the 130 3x3 weights, built on first use (and again when a weight changes)."""
+        self._hip_packed(device)
+        if getattr(self, "_hip_wu4", None) is None:
+            self._hip_wu4 = torch.cat([pack_conv_wino4(l.weight.to(device)) for l in self._trunk_layers()
+                                       if l.kernel_size == (3, 3)]).to(device)
+        return self._hip_wu4
 
     def _hip_packed_x3(self, device):
         """The split-bf16 image of the 130 3x3 weights, built on first use (and again when a weight changes)."""
@@ -195,6 +225,12 @@ class RDN(nn.Module):
                                                        C.c_void_p(packed_wino.data_ptr()), C.c_void_p(px3.data_ptr()),
                                                        C.c_void_p(biases.data_ptr()), C.c_void_p(ws.data_ptr()),
                                                        C.c_void_p(out.data_ptr()), b, h, w), "diinn_rdn_forward_x3")
+            elif self.hip_winograd and self.hip_winograd4 and b * h * w >= self._WINO4_MIN_PIXELS:
+                pw4 = self._hip_packed_wino4(shallow.device)
+                _native.check(lib.diinn_rdn_forward_wino4(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                                          C.c_void_p(packed_wino.data_ptr()), C.c_void_p(pw4.data_ptr()),
+                                                          C.c_void_p(biases.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                                          C.c_void_p(out.data_ptr()), b, h, w), "diinn_rdn_forward_wino4")
             elif self.hip_winograd:
                 _native.check(lib.diinn_rdn_forward_wino(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
                                                          C.c_void_p(packed_wino.data_ptr()), C.c_void_p(biases.data_ptr()),
@@ -272,7 +308,7 @@ class _GraphReplay:
                 tuple((p.data_ptr(), p._version) for p in self.parameters()),
                 getattr(dec, "sin_mode", None), getattr(dec, "compute", None), getattr(dec, "mode", None),
                 getattr(enc, "hip_trunk_max_pixels", None), getattr(enc, "hip_winograd", None),
-                getattr(enc, "hip_split_bf16", None))
+                getattr(enc, "hip_split_bf16", None), getattr(enc, "hip_winograd4", None))
 
     def _forward_graphed(self, x, size, bsize):
         key = self._graph_key(x, size)
@@ -293,7 +329,7 @@ class _GraphReplay:
                 # private pool: workspaces, activations, the result) or kept alive by the entry below (packed
                 # weight images, which live in module caches that a later call may replace)
                 static_y = self._forward_eager(static_x, size, bsize)
-            keep = [getattr(m, a, None) for m in self.modules() for a in ("_packed", "_hip_pack", "_hip_x3")]
+            keep = [getattr(m, a, None) for m in self.modules() for a in ("_packed", "_hip_pack", "_hip_x3", "_hip_wu4")]
             entry = (graph, static_x, static_y, keep)
             self._graph_cache[key] = entry
         graph, static_x, static_y = entry[:3]

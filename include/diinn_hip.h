@@ -45,7 +45,8 @@ extern "C" {
  *      bf16 kernel choice taken from the full image, not the band; DIINN_COMPUTE_BF16X3 and packed sections 14-15 (DIINN_P_ALGO_DIRECT_BF16X3);
  *      split-bf16 encoder layers (diinn_conv3x3_x3, diinn_rdn_forward_x3)
  *   7  tiles: diinn_decode_tile_win (HR column range + output strides; the row-band entry points are wrappers of it);
- *      packed section 16 (WL16) and the 16-pixel fp32 latency kernel for the smallest launches (DIINN_F32_KERNEL = 3) */
+ *      packed section 16 (WL16) and the 16-pixel fp32 latency kernel for the smallest launches (DIINN_F32_KERNEL = 3);
+ *      Winograd F(4x4,3x3) encoder layers (diinn_conv_wino4, diinn_rdn_forward_wino4) */
 
 /* status codes */
 #define DIINN_OK                 0
@@ -378,6 +379,25 @@ int    diinn_conv_wino(void* stream, const float* in_dev, long long in_batch_str
 size_t diinn_rdn_wino_packed_floats(void);
 int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
                               const float* biases_dev, float* workspace_dev, float* out_dev, int B, int H, int W);
+
+/* Winograd F(4x4, 3x3) for the same layers on larger maps (csrc/diinn_winograd4.hip): 36 multiplies per (input, output)
+ * pair and 4x4 output block, 1.78x fewer MFMAs than F(2x2, 3x3); fp32, transformed weights computed in float64 and
+ * rounded once.  Accuracy: ~1e-6 of max|out| per layer and 3e-6 of max|feat| through the whole trunk against float64
+ * (F(2x2): 3e-7; the direct fp32 sum: 4e-7; tools/enc_wino43_error.py).
+ * diinn_conv_wino4: as diinn_conv_wino.  packed_u_dev holds U = G W G^T (6x6 per pair, G of F(4x4,3x3): Lavin & Gray,
+ *   points 0, +-1, +-2, inf) as [wave 12][half 2][chunk Cin/8][q 3][lane 64][4]:
+ *   value = U[32 half + (lane&31)][8 chunk + 2 e + (lane>>5)][i][j] with 6 i + j = 3 wave + q     (36 * 64 * Cin floats).
+ * diinn_rdn_wino4_packed_floats: floats of the 130 such weights of the trunk, in execution order.
+ * diinn_rdn_forward_wino4: diinn_rdn_forward_wino with the 3x3 layers on diinn_conv_wino4 from B*H*W >= 36864 pixels on
+ *   (DIINN_ENC_WINO4_MIN); smaller maps run exactly as diinn_rdn_forward_wino. */
+int    diinn_conv_wino4(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
+                        const float* packed_u_dev, const float* bias_dev,
+                        const float* res_dev, long long res_batch_stride,
+                        float* out_dev, long long out_batch_stride, int relu, int B, int H, int W);
+size_t diinn_rdn_wino4_packed_floats(void);
+int    diinn_rdn_forward_wino4(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
+                               const float* packed_wino4_dev, const float* biases_dev, float* workspace_dev, float* out_dev,
+                               int B, int H, int W);
 
 /* Split-bf16 arithmetic for the trunk's 3x3 convolutions (csrc/diinn_conv_x3.hip; optional, large maps): the direct sum
  * on v_mfma_f32_32x32x16_bf16 with every operand as hi + lo bf16 parts (hi = bf16(v), lo = bf16(v - hi)), a product as

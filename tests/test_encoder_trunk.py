@@ -43,6 +43,112 @@ def test_pack_conv_wino_layout():
         M.pack_conv_wino(torch.zeros(64, 64, 1, 1))
 
 
+def test_pack_conv_wino4_layout():
+    """The packed F(4x4, 3x3) image holds U = G W G^T (float64 reference, 6x6 per pair) at the documented positions."""
+    import diinn_amd.modules as M
+    rng = np.random.default_rng(2)
+    g = np.array(M._WINO4_G, dtype=np.float64)
+    for cin in (8, 64, 192):
+        w = rng.standard_normal((64, cin, 3, 3)).astype(np.float32)
+        packed = M.pack_conv_wino4(torch.from_numpy(w)).numpy()
+        assert packed.size == 36 * 64 * cin
+        pk = packed.reshape(12, 2, cin // 8, 3, 64, 4)
+        u = np.einsum("ia,ocab,jb->ocij", g, w.astype(np.float64), g).astype(np.float32)
+        for _ in range(300):
+            wave, half, chunk, q, lane, e = (int(rng.integers(n)) for n in (12, 2, cin // 8, 3, 64, 4))
+            pos = 3 * wave + q
+            want = u[32 * half + (lane & 31), 8 * chunk + 2 * e + (lane >> 5), pos // 6, pos % 6]
+            assert abs(pk[wave, half, chunk, q, lane, e] - want) <= 2.4e-7 * abs(want)      # float64 sums in another order: one ulp
+    # the transform is exact on a constant filter: F(4x4, 3x3) of an all-ones 3x3 filter sums the patch
+    ones = M.pack_conv_wino4(torch.ones(64, 8, 3, 3)).reshape(12, 2, 1, 3, 64, 4)
+    gg = g.sum(1)
+    assert np.allclose(ones[0, 0, 0, 0, 0, 0].item(), gg[0] * gg[0])
+    with pytest.raises(ValueError):
+        M.pack_conv_wino4(torch.zeros(64, 64, 1, 1))
+
+
+WINO_SHAPES = [(1, 64, 48, 48, 1, 0), (2, 320, 13, 21, 1, 0), (1, 512, 5, 3, 0, 1),
+               (1, 8, 1, 1, 0, 0), (1, 72, 1, 37, 1, 0), (1, 64, 33, 1, 0, 1),
+               (1, 192, 128, 136, 1, 0), (2, 128, 70, 61, 0, 1), (1, 64, 64, 80, 1, 1),
+               (1, 576, 31, 50, 1, 0), (1, 64, 256, 240, 1, 1), (1, 128, 250, 255, 0, 0)]
+
+
+@pytest.mark.gpu
+def test_conv_wino4_kernel_matches_fp64_conv():
+    """diinn_conv_wino4 (Winograd F(4x4,3x3)): ReLU, residual, strided channel-plane views, odd / ragged maps (partial
+    tiles, partial blocks, one-pixel maps, widths that are not multiples of 4: the scalar store path), batch > 1, 8 ..
+    576 input channels (1 .. 72 chunks: every phase of the three-slot ring), and more work items than workgroups.
+    Bound 2e-5 of max|out| (measured ~1e-6: the F(4x4) transforms cost about a digit against F(2x2))."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    gen = torch.Generator(device=dev).manual_seed(6)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
+    worst = 0.0
+    for (b, cin, h, w, relu, use_res) in WINO_SHAPES + [(1, 16, 40, 44, 0, 0), (1, 24, 17, 36, 1, 1), (1, 32, 16, 32, 0, 0),
+                                                         (1, 40, 100, 8, 1, 0), (3, 64, 36, 68, 0, 1)]:
+        total = cin + 64
+        buf = torch.randn((b, total, h, w), device=dev, generator=gen)          # input = first cin planes of a larger buffer
+        wt = torch.randn((64, cin, 3, 3), device=dev, generator=gen) / (cin * 9) ** 0.5
+        bias = torch.randn(64, device=dev, generator=gen)
+        res = torch.randn((b, 64, h, w), device=dev, generator=gen) if use_res else None
+        out = torch.full((b, 96, h, w), float("nan"), device=dev)
+        packed = M.pack_conv_wino4(wt).to(dev)
+        st = lib.diinn_conv_wino4(stream, ptr(buf), total * h * w, cin, ptr(packed), ptr(bias),
+                                  ptr(res) if use_res else None, 64 * h * w, ptr(out[:, 32:]), 96 * h * w, relu, b, h, w)
+        assert st == 0
+        torch.cuda.synchronize()
+        ref = F.conv2d(buf[:, :cin].double(), wt.double(), bias.double(), padding=1)
+        if relu:
+            ref = torch.relu(ref)
+        if use_res:
+            ref = ref + res.double()
+        err = float((out[:, 32:].double() - ref).abs().max())
+        scale = max(1.0, float(ref.abs().max()))
+        assert err <= 2e-5 * scale, (cin, h, w, err)
+        worst = max(worst, err / scale)
+        assert torch.isnan(out[:, :32]).all()
+    print(f"diinn_conv_wino4: worst error {worst:.2e} of max|out|")
+    assert lib.diinn_conv_wino4(stream, ptr(buf), 1, 12, ptr(packed), ptr(bias), None, 0, ptr(out), 1, 0, 1, 4, 4) == N.ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+def test_conv_wino4_kernel_fuzz():
+    """Seeded random shapes (batch 1..3, 8..136 input channels, maps from 1x1 to 70x90, ReLU / residual at random)
+    through diinn_conv_wino4 against a float64 convolution."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    rng = np.random.default_rng(12)
+    gen = torch.Generator(device=dev).manual_seed(12)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
+    for _ in range(40):
+        b, cin = int(rng.integers(1, 4)), 8 * int(rng.integers(1, 18))
+        h, w = int(rng.integers(1, 71)), int(rng.integers(1, 91))
+        relu, use_res = int(rng.integers(2)), int(rng.integers(2))
+        x = torch.randn((b, cin, h, w), device=dev, generator=gen)
+        wt = torch.randn((64, cin, 3, 3), device=dev, generator=gen) / (cin * 9) ** 0.5
+        bias = torch.randn(64, device=dev, generator=gen)
+        res = torch.randn((b, 64, h, w), device=dev, generator=gen) if use_res else None
+        out = torch.full((b, 64, h, w), float("nan"), device=dev)
+        packed = M.pack_conv_wino4(wt).to(dev)
+        assert lib.diinn_conv_wino4(stream, ptr(x), cin * h * w, cin, ptr(packed), ptr(bias), ptr(res) if use_res else None,
+                                    64 * h * w, ptr(out), 64 * h * w, relu, b, h, w) == 0
+        ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+        if relu:
+            ref = torch.relu(ref)
+        if use_res:
+            ref = ref + res.double()
+        err = float((out.double() - ref).abs().max())
+        assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (b, cin, h, w, relu, use_res, err)
+
+
 @pytest.mark.gpu
 def test_conv_wino_kernel_matches_fp64_conv():
     """diinn_conv_wino (Winograd F(2x2,3x3)): ReLU, residual, strided channel-plane views, odd / ragged maps (partial
@@ -55,12 +161,7 @@ def test_conv_wino_kernel_matches_fp64_conv():
     gen = torch.Generator(device=dev).manual_seed(5)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
-    for (b, cin, h, w, relu, use_res) in [(1, 64, 48, 48, 1, 0), (2, 320, 13, 21, 1, 0), (1, 512, 5, 3, 0, 1),
-                                          (1, 8, 1, 1, 0, 0), (1, 72, 1, 37, 1, 0), (1, 64, 33, 1, 0, 1),
-                                          (1, 192, 128, 136, 1, 0), (2, 128, 70, 61, 0, 1), (1, 64, 64, 80, 1, 1),
-                                          (1, 576, 31, 50, 1, 0),
-                                          # >= 448 blocks: both halves per workgroup (smaller maps: one half each)
-                                          (1, 64, 256, 240, 1, 1), (1, 128, 250, 255, 0, 0)]:
+    for (b, cin, h, w, relu, use_res) in WINO_SHAPES:           # (the last two: >= 448 blocks, both halves per workgroup)
         total = cin + 64
         buf = torch.randn((b, total, h, w), device=dev, generator=gen)          # input = first cin planes of a larger buffer
         wt = torch.randn((64, cin, 3, 3), device=dev, generator=gen) / (cin * 9) ** 0.5

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer timing of diinn_conv_ksplit on one MI355X: every (Cin, taps) shape of the RDN trunk at a given map size,
 each launched alone in a loop -- shows which layers of the encoder sit furthest below the fp32 MFMA roof.
-usage: enc_layer_time.py [SIZE=256]"""
+usage: enc_layer_time.py [SIZE=256] [--wino | --wino4] [--relu]"""
 import ctypes as C
 import os
 import sys
@@ -18,7 +18,8 @@ PEAK = 157.3e12
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     lr = int(args[0]) if args else 256
-    wino = "--wino" in sys.argv                                # 3x3 layers on diinn_conv_wino (% of peak = direct-conv flops / time)
+    wino4 = "--wino4" in sys.argv                              # 3x3 layers on diinn_conv_wino4 (F(4x4,3x3))
+    wino = "--wino" in sys.argv or wino4                                # 3x3 layers on diinn_conv_wino (% of peak = direct-conv flops / time)
     dev = torch.device("cuda:0")
     lib = _native.load()
     hw = lr * lr
@@ -32,12 +33,12 @@ def main():
     for cin, taps, count in shapes:
         k = 3 if taps == 9 else 1
         wt = torch.randn(64, cin, k, k) * 0.01
-        w = (M.pack_conv_wino(wt) if wino and taps == 9 else M.pack_conv_ksplit(wt)).to(dev)
+        w = ((M.pack_conv_wino4(wt) if wino4 else M.pack_conv_wino(wt)) if wino and taps == 9 else M.pack_conv_ksplit(wt)).to(dev)
         out = buf[:, 1024:]
 
         def run():
             if wino and taps == 9:
-                _native.check(lib.diinn_conv_wino(stream, C.c_void_p(buf.data_ptr()), (1024 + 64) * hw, cin,
+                _native.check((lib.diinn_conv_wino4 if wino4 else lib.diinn_conv_wino)(stream, C.c_void_p(buf.data_ptr()), (1024 + 64) * hw, cin,
                                                   C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), None, 0,
                                                   C.c_void_p(out.data_ptr()), (1024 + 64) * hw, 1, 1, lr, lr), "conv")
                 return
