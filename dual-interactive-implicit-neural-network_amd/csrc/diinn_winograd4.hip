@@ -26,14 +26,24 @@
 // A^T (.) A, bias, ReLU / residual, 16-byte stores.
 #include "diinn_device.h"
 
-constexpr int W4_TX = 8, W4_TY = 4;                  // Winograd tiles per block (x, y): 32 = one MFMA N-tile
-constexpr int W4_THREADS = 768;
-constexpr int W4_VBUF = 36 * 256;                    // floats of one chunk's transformed data: [pos 36][h 2][tile 32][e 4]
-constexpr int W4_LDS_FLOATS = 36 * 1024;             // epilogue exchange [pos 36][reg pair 8][lane 64][2]; the ring uses 3 * W4_VBUF of it
+constexpr int W4_TX = 32, W4_TY = 1;                 // Winograd tiles per block (x, y): 32 = one MFMA N-tile, one tile row (128 x 4 output pixels)
+constexpr int W4_MFMA_WAVES = 12, W4_THREADS = 1024;  // + 4 transform waves
+constexpr int W4_VBUF = 36 * 256;                    // floats of one chunk's transformed data: [pos 36][e 4][h 2][tile 32]
+constexpr int W4_RAW0 = 3 * W4_VBUF;                     // raw input slots behind the ring: [slot 2][transform wave 4][6 rows x 256 + 64 edge values]
+constexpr int W4_RAW_WAVE = 6 * 256 + 64;
+constexpr int W4_LDS_FLOATS = W4_RAW0 + 2 * 4 * W4_RAW_WAVE;   // 161,792 bytes; the epilogue exchange (36 * 1024 floats) lies over ring and raw slots
+static_assert(W4_LDS_FLOATS >= 36 * 1024 && W4_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");             // epilogue exchange [pos 36][accumulator register 16][lane 64]; the ring uses 3 * W4_VBUF of it
 constexpr int W4_PIECE_BYTES = 1024;                 // one A piece: 64 lanes x 4 k-steps
 static_assert(3 * W4_VBUF <= W4_LDS_FLOATS, "ring inside the exchange buffer");
 
+#pragma clang diagnostic ignored "-Winline-asm"          // the LDS-DMA requests below set M0 (a reserved register) in inline asm
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// a raw buffer descriptor as four plain SGPRs (for inline asm operands): base, stride 0, bytes, the flags diinn_device.h uses
+__device__ __forceinline__ i32x4 w4_rsrc(const void* ptr, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)ptr;
+    return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
 
 struct ConvWino4Params {
     const float* in;         // input channel planes: in + b*in_bs + c*H*W
@@ -70,211 +80,236 @@ __device__ __forceinline__ void w4_at(const T m0, const T m1, const T m2, const 
 
 __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float* __restrict__ lds, int b, int tx0, int ty0, int hh0) {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..11: positions 3 wave .. 3 wave + 2
-    const int grp = wave >> 2;                                   // transform duty: chunks k with k % 3 == grp
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..11: MFMA waves; 12..15: transform waves
     const size_t plane = (size_t)p.H * p.W;
     const unsigned plane_b = (unsigned)(plane * sizeof(float));
-    const float* __restrict__ in_b = p.in + (size_t)b * p.in_bs;
     const int n = p.Cin / 8;                                     // chunks of 8 input channels
     constexpr unsigned OUTSIDE = 0x80000000u;
+    const bool ragged = (p.W & 3) != 0;                          // uniform: only then can a 16-byte access cross a row's end
 
-    // ---- transform role: one (tile, channel of the chunk) patch per thread.  Lanes = 16 tiles x 4 k-steps e of one
-    // channel parity th, so that a wave's 36 LDS stores are each 256 contiguous bytes.
-    const int wt = wave & 3;
-    const int th = wt & 1, tm = 16 * (wt >> 1) + (lane >> 2), te = lane & 3;
-    const int ptx = tx0 + (tm & (W4_TX - 1)), pty = ty0 + tm / W4_TX;
-    // patch rows 4 ty - 1 .. 4 ty + 4, columns 4 tx - 1 .. 4 tx + 4: per row one aligned 16-byte load of the middle
-    // columns and a 4-byte load either side.  Rows outside the map get an offset the descriptor's range check answers
-    // with zeros; columns outside it are zeroed by selects (the loads stay inside the chunk's planes or out of range).
-    unsigned voff[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int y = 4 * pty - 1 + k;
-        voff[k] = (y >= 0 && y < p.H) ? (unsigned)(2 * te + th) * plane_b + (unsigned)(y * p.W + 4 * ptx) * 4u : OUTSIDE;
-    }
-    const bool okl = ptx > 0;
-    const bool ok1 = 4 * ptx + 1 < p.W, ok2 = 4 * ptx + 2 < p.W, ok3 = 4 * ptx + 3 < p.W, okr = 4 * ptx + 4 < p.W;
-    const bool ragged = (p.W & 3) != 0;                          // uniform: only then can the 16-byte load cross the row's end
-    float PL[6], PR[6];
-    f32x4 PC[6];
-    auto load_patch = [&](int c) {
-        const __amdgpu_buffer_rsrc_t irs =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(in_b + (size_t)8 * c * plane), 0, (int)(8u * plane_b), 0x00020000);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-#ifdef W4_ABL_LINEAR
-            PC[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, (int)((threadIdx.x & 255) * 16 + k * 4096), 0, 0));
-            PL[k] = PR[k] = 0.0f;
-#else
-            PC[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, (int)voff[k], 0, 0));
-#ifndef W4_ABL_NOSIDE
-            PL[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, (int)(voff[k] - 4u), 0, 0));
-            PR[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, (int)(voff[k] + 16u), 0, 0));
-#else
-            PL[k] = PR[k] = 0.0f;
+    if (wave >= W4_MFMA_WAVES) {
+        // ---- transform waves: one (tile, channel of the chunk) patch per thread: wave wt takes the chunk's channels
+        // 2 wt and 2 wt + 1 (= k-step wt of the MFMAs), a lane one of the block's 32 tiles.  Its input is in LDS already
+        // (raw slots, filled by the MFMA waves' LDS-DMA requests): per chunk and wave six 1-KiB rows [row k][channel 2]
+        // [128 columns] + the 24 values left and right of the block (6 rows x 2 channels x 2 sides).  These waves issue no
+        // vector-memory instruction at all: a chunk's transform is one serial instruction stream per SIMD and sets the
+        // iteration time, so nothing that can stall goes into it.
+        const int wt = wave - W4_MFMA_WAVES;
+#ifndef W4_ABL_NOPRIO
+        __builtin_amdgcn_s_setprio(3);                           // the chunk's critical path: ahead of the MFMA waves' issue
 #endif
-#endif
-        }
-    };
-    auto transform = [&](float* __restrict__ vb) {
-        // B^T d down the columns, two columns at a time, then (.) B along each row
-        f32x2 d[6][3], t[6][3];
+        const int th = lane >> 5, tm = lane & 31;
+        const int ptx = tx0 + tm;
+        const bool first = tm == 0, last = tm == W4_TX - 1;
+        const bool ok1 = 4 * ptx + 1 < p.W, ok2 = 4 * ptx + 2 < p.W, ok3 = 4 * ptx + 3 < p.W;
+        const float* __restrict__ raw = lds + W4_RAW0 + wt * W4_RAW_WAVE;     // + slot * 4 * W4_RAW_WAVE
+        // the outer columns: the neighbouring tiles' values in the row, for the block's first / last tile the edge values
+        const int la = first ? 1536 + 12 * th : th * 128 + tm * 4 - 1, lstep = first ? 1 : 256;
+        const int ra = last ? 1536 + 12 * th + 6 : th * 128 + tm * 4 + 4, rstep = last ? 1 : 256;
+        auto transform = [&](int slot, float* __restrict__ vb) {
+            const float* __restrict__ src = raw + slot * 4 * W4_RAW_WAVE;
+            // B^T d down the columns, two columns at a time, then (.) B along each row
+            f32x2 d[6][3], t[6][3];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            float c0 = PC[k][0], c1 = PC[k][1], c2 = PC[k][2], c3 = PC[k][3];
-            if (ragged) {
-                c1 = ok1 ? c1 : 0.0f;
-                c2 = ok2 ? c2 : 0.0f;
-                c3 = ok3 ? c3 : 0.0f;
+            for (int k = 0; k < 6; ++k) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(src + k * 256 + th * 128 + tm * 4);
+                float c1 = c4[1], c2 = c4[2], c3 = c4[3];
+                if (ragged) {                                    // the 16-byte load ran past the row's end
+                    c1 = ok1 ? c1 : 0.0f;
+                    c2 = ok2 ? c2 : 0.0f;
+                    c3 = ok3 ? c3 : 0.0f;
+                }
+                d[k][0] = f32x2{src[la + k * lstep], c4[0]};
+                d[k][1] = f32x2{c1, c2};
+                d[k][2] = f32x2{c3, src[ra + k * rstep]};
             }
-            d[k][0] = f32x2{okl ? PL[k] : 0.0f, c0};
-            d[k][1] = f32x2{c1, c2};
-            d[k][2] = f32x2{c3, okr ? PR[k] : 0.0f};
-        }
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-            w4_bt<f32x2>(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], t[0][j], t[1][j], t[2][j], t[3][j], t[4][j], t[5][j]);
-        float* __restrict__ dst = vb + th * 128 + tm * 4 + te;
+            for (int j = 0; j < 3; ++j)
+                w4_bt<f32x2>(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], t[0][j], t[1][j], t[2][j], t[3][j], t[4][j], t[5][j]);
+            float* __restrict__ dst = vb + (2 * wt + th) * 32 + tm;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            float v0, v1, v2, v3, v4, v5;
-            w4_bt<float>(t[i][0][0], t[i][0][1], t[i][1][0], t[i][1][1], t[i][2][0], t[i][2][1], v0, v1, v2, v3, v4, v5);
-            dst[(6 * i + 0) * 256] = v0;
-            dst[(6 * i + 1) * 256] = v1;
-            dst[(6 * i + 2) * 256] = v2;
-            dst[(6 * i + 3) * 256] = v3;
-            dst[(6 * i + 4) * 256] = v4;
-            dst[(6 * i + 5) * 256] = v5;
-        }
-    };
-
-    // ---- MFMA role: A = weights (32 outputs of half hh0 x 2 channels), B = transformed data (2 channels x 32 tiles)
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.wu + (size_t)(wave * 2 + hh0) * n * (3 * W4_PIECE_BYTES / 4)), 0, n * 3 * W4_PIECE_BYTES, 0x00020000);
-    const int lane_off = lane * 16;
-    const float* __restrict__ bsrc = lds + 3 * wave * 256 + lane * 4;
-    f32x16 acc[3];
-    f32x4 A[2][3], Bf[3];    // weights of chunks c, c + 1 (ring of two: a request has a whole iteration to arrive); B operands of chunk c
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
-
-    // prologue: chunks 0 and 1 into ring slots 0 and 1; every group leaves with its next patch requested
-    if (grp < 2) {
-        load_patch(grp < n ? grp : n - 1);
-        transform(lds + grp * W4_VBUF);
-        load_patch(grp + 3 < n ? grp + 3 : n - 1);
-    } else {
-        load_patch(2 < n ? 2 : n - 1);
-    }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        A[0][q] = ld_piece(wrs, lane_off, q * W4_PIECE_BYTES);
-        A[1][q] = ld_piece(wrs, lane_off, ((n > 1 ? 3 : 0) + q) * W4_PIECE_BYTES);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 3; ++q) Bf[q] = *reinterpret_cast<const f32x4*>(bsrc + q * 256);
-
-    int slot = 0;                                                // c % 3: the ring slot of chunk c
-    // One iteration = one chunk: [this group's turn: transform chunk c + 2 into its slot, request the patch of chunk
-    // c + 5], then per position its four MFMAs, behind them the request of the position's weights of chunk c + 2 into
-    // the registers just used and the read of its B operands of chunk c + 1; one barrier.  The barrier waits for all
-    // but the newest LDS operation (a read of slot c + 1, which nobody writes before the NEXT barrier): the transform's
-    // stores are complete, and no wave sits behind an LDS round trip with the matrix core idle.
-    auto iter = [&](auto PAR_, int c) {
-        constexpr int PAR = decltype(PAR_)::value;
-        const int slot1 = slot == 2 ? 0 : slot + 1;              // slot of chunk c + 1
-        const int slot2 = slot == 0 ? 2 : slot - 1;              // slot of chunk c + 2
-        if (slot2 == grp && c + 2 < n) {                         // (c + 2) % 3 == grp
+            for (int i = 0; i < 6; ++i) {
+                float v0, v1, v2, v3, v4, v5;
+                w4_bt<float>(t[i][0][0], t[i][0][1], t[i][1][0], t[i][1][1], t[i][2][0], t[i][2][1], v0, v1, v2, v3, v4, v5);
+                dst[(6 * i + 0) * 256] = v0;
+                dst[(6 * i + 1) * 256] = v1;
+                dst[(6 * i + 2) * 256] = v2;
+                dst[(6 * i + 3) * 256] = v3;
+                dst[(6 * i + 4) * 256] = v4;
+                dst[(6 * i + 5) * 256] = v5;
+            }
+        };
+        // chunk k arrives in raw slot k & 1 (requested by the MFMA waves one iteration ahead) and is transformed into ring
+        // slot k % 3; iteration c (the MFMA waves compute chunk c) transforms chunk c + 2
+        __builtin_amdgcn_s_barrier();                            // P1: chunks 0 and 1 have landed
+        transform(0, lds);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // P2: raw slot 0 is free again
+        transform(1, lds + W4_VBUF);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // P3: chunks 0 and 1 transformed, chunk 2 landed
+        int slot2 = 2;
+        for (int c = 0; c < n; ++c) {
 #ifndef W4_ABL_NOTRANSFORM
-            transform(lds + slot2 * W4_VBUF);
+            if (c + 2 < n) transform(c & 1, lds + slot2 * W4_VBUF);
 #endif
-#ifndef W4_ABL_NOPATCH
-            load_patch(c + 5 < n ? c + 5 : n - 1);
+            slot2 = slot2 == 2 ? 0 : slot2 + 1;
+#ifndef W4_ABL_NOBAR
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the raw slot is read, the transformed data stored
 #endif
         }
-        W4_SB();
-        const int c2 = c + 2 < n ? c + 2 : n - 1;
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    } else {
+        // ---- MFMA waves: positions 3 wave .. 3 wave + 2; A = weights (32 outputs of half hh0 x 2 channels), B =
+        // transformed data (2 channels x 32 tiles)
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.wu + (size_t)(wave * 2 + hh0) * n * (3 * W4_PIECE_BYTES / 4)), 0, n * 3 * W4_PIECE_BYTES, 0x00020000);
+        const int lane_off = lane * 16;
+        // The raw input of chunk c + 3 is requested here, one iteration ahead, by LDS-DMA (buffer_load ... lds: no
+        // registers; range-checked -- an out-of-range lane deposits zero, which is the zero padding): wave w takes rows
+        // 2 w and 2 w + 1 of the chunk's 24 (channel pair cp, patch row k) rows -- one 16-byte load per tile: 2 channels
+        // x 512 contiguous bytes per request -- and waves 0..3 the edge values of channel pair w (one 4-byte load whose
+        // lanes 0..23 fetch the columns left and right of the block for 6 rows x 2 channels).  Inline asm: with the
+        // builtin the compiler drains every outstanding load (vmcnt(0)) at the next use of a weight register.
+        const float* __restrict__ in_b = p.in + (size_t)b * p.in_bs;
+        unsigned dvoff[2], dvoffe = OUTSIDE;
+        unsigned dlds[2], dldse;
+        {
+            const int th = lane >> 5, ptx = tx0 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = 2 * wave + i, cp = idx / 6, k = idx - 6 * cp;
+                const int y = 4 * ty0 - 1 + k;
+                dvoff[i] = (y >= 0 && y < p.H && 4 * ptx < p.W) ? (unsigned)(2 * cp + th) * plane_b + (unsigned)(y * p.W + 4 * ptx) * 4u : OUTSIDE;
+                dlds[i] = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + W4_RAW0 + cp * W4_RAW_WAVE + k * 256);
+            }
+            const int ek = lane % 6, ew = lane / 6;              // the edge load: lane < 24 -> row ek, (channel, side) ew
+            const int ex = (ew & 1) ? 4 * (tx0 + W4_TX) : 4 * tx0 - 1;
+            const int ey = 4 * ty0 - 1 + ek;
+            if (wave < 4 && lane < 24 && ey >= 0 && ey < p.H && ex >= 0 && ex < p.W)
+                dvoffe = (unsigned)(2 * wave + (ew >> 1)) * plane_b + (unsigned)(ey * p.W + ex) * 4u;
+            dldse = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + W4_RAW0 + (wave & 3) * W4_RAW_WAVE + 1536);
+        }
+        auto fetch = [&](int slot, int c) {
+#ifndef W4_ABL_NOPATCH
+            const i32x4 irs = w4_rsrc(in_b + (size_t)8 * c * plane, 8u * plane_b);
+            const unsigned so = (unsigned)slot * (4 * W4_RAW_WAVE * 4);
+            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(dlds[0] + so), "v"(dvoff[0]), "s"(irs) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(dlds[1] + so), "v"(dvoff[1]), "s"(irs) : "memory", "m0");
+            if (wave < 4)
+                asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" :: "s"(dldse + so), "v"(dvoffe), "s"(irs) : "memory", "m0");
+#endif
+        };
+        auto chunk_of = [&](int k) { return k < n ? k : n - 1; };
+        const float* __restrict__ bsrc = lds + 3 * wave * 256 + lane;      // + 64 e: [pos][e][h][tile]
+        f32x16 acc[3];
+        f32x4 A[2][3], Bf[3];    // weights of chunks c, c + 1 (ring of two: a request has a whole iteration to arrive); B operands of chunk c
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+        fetch(0, 0);
+        fetch(1, chunk_of(1));
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // P1: chunks 0 and 1 have landed
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
+            A[0][q] = ld_piece(wrs, lane_off, q * W4_PIECE_BYTES);
+            A[1][q] = ld_piece(wrs, lane_off, ((n > 1 ? 3 : 0) + q) * W4_PIECE_BYTES);
+        }
+        __builtin_amdgcn_s_barrier();                            // P2: raw slot 0 is free again
+        fetch(0, chunk_of(2));
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // P3: chunks 0 and 1 transformed, chunk 2 landed
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Bf[q] = f32x4{bsrc[q * 256], bsrc[q * 256 + 64], bsrc[q * 256 + 128], bsrc[q * 256 + 192]};
+
+        int slot1 = 1;                                           // ring slot of chunk c + 1
+        // One iteration = one chunk: per position its four MFMAs, behind them the request of the position's weights of
+        // chunk c + 2 into the registers just used and the read of its B operands of chunk c + 1; one barrier.  The
+        // barrier waits for all but the two newest LDS operations (the last position's reads of slot c + 1, which
+        // nobody writes before the NEXT barrier): no wave sits behind an LDS round trip with the matrix core idle.
+        auto iter = [&](auto PAR_, int c) {
+            constexpr int PAR = decltype(PAR_)::value;
+            const int c2 = c + 2 < n ? c + 2 : n - 1;
+            fetch((c + 1) & 1, chunk_of(c + 3));                 // always issued (past the end: the last chunk again): the count below relies on it
+            W4_SB();
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
 #ifndef W4_ABL_NOMFMA
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[q] = MFMA32(A[PAR][q][e], Bf[q][e], acc[q]);
+                for (int e = 0; e < 4; ++e) acc[q] = MFMA32(A[PAR][q][e], Bf[q][e], acc[q]);
 #else
-            acc[q][0] += A[PAR][q][0] * Bf[q][0] + A[PAR][q][3] * Bf[q][3];
+                acc[q][0] += A[PAR][q][0] * Bf[q][0] + A[PAR][q][3] * Bf[q][3];
 #endif
-            W4_SB();
+                W4_SB();
 #ifndef W4_ABL_NOW
-            A[PAR][q] = ld_piece(wrs, lane_off, (c2 * 3 + q) * W4_PIECE_BYTES);
+                A[PAR][q] = ld_piece(wrs, lane_off, (c2 * 3 + q) * W4_PIECE_BYTES);
 #endif
 #ifndef W4_ABL_NOBREAD
-            Bf[q] = *reinterpret_cast<const f32x4*>(bsrc + slot1 * W4_VBUF + q * 256);
+                {
+                    const float* __restrict__ bq = bsrc + slot1 * W4_VBUF + q * 256;
+                    Bf[q] = f32x4{bq[0], bq[64], bq[128], bq[192]};
+                }
 #endif
-            W4_SB();
-        }
+                W4_SB();
+            }
 #ifndef W4_ABL_NOBAR
-        asm volatile("s_waitcnt lgkmcnt(1)\n\ts_barrier" ::: "memory");
+            // all but the three weight requests of this iteration: the raw rows requested above have landed
+            asm volatile("s_waitcnt vmcnt(3) lgkmcnt(2)\n\ts_barrier" ::: "memory");
 #endif
-        slot = slot1;
-    };
-    int c = 0;
-    for (; c + 1 < n; c += 2) {
-        iter(IC<0>{}, c);
-        iter(IC<1>{}, c + 1);
-    }
-    if (c < n) iter(IC<0>{}, c);
-    __syncthreads();
+            slot1 = slot1 == 2 ? 0 : slot1 + 1;
+        };
+        int c = 0;
+        for (; c + 1 < n; c += 2) {
+            iter(IC<0>{}, c);
+            iter(IC<1>{}, c + 1);
+        }
+        if (c < n) iter(IC<0>{}, c);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // nothing may land in the raw slots any more: the exchange buffer lies over them
 
-    // ---- A^T (.) A through LDS: [pos][register pair rp][lane][2]
+        // the 36 positions meet through LDS: [pos][accumulator register 16][lane]
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int rp = 0; rp < 8; ++rp)
-            *reinterpret_cast<f32x2*>(lds + ((3 * wave + q) * 8 + rp) * 128 + lane * 2) = f32x2{acc[q][2 * rp], acc[q][2 * rp + 1]};
+            for (int r = 0; r < 16; ++r) lds[((3 * wave + q) * 16 + r) * 64 + lane] = acc[q][r];
+    }
     __syncthreads();
-    if (wave < 8) {
-        // wave: accumulator registers 2 wave, 2 wave + 1; lane (h, m): tile m, output channels 32 hh0 + 8 (r >> 2) + 4 h + (r & 3)
-        const int h = lane >> 5, m = lane & 31;
+    {
+        // ---- A^T (.) A, one (tile, output channel) per thread: wave = accumulator register r; lane (h, m): tile m,
+        // output channel 32 hh0 + 8 (r >> 2) + 4 h + (r & 3)
+        const int h = lane >> 5, m = lane & 31, r = wave;
         const int tx = tx0 + (m & (W4_TX - 1)), ty = ty0 + m / W4_TX;
-        const float* __restrict__ src = lds + wave * 128 + lane * 2;
-        f32x2 z[6][4], y[4][4];
+        const float* __restrict__ src = lds + r * 64 + lane;
+        float z[6][4], y[4][4];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            f32x2 mm[6];
+            float mm[6];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) mm[j] = *reinterpret_cast<const f32x2*>(src + (6 * i + j) * 1024);
-            w4_at<f32x2>(mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], z[i][0], z[i][1], z[i][2], z[i][3]);
+            for (int j = 0; j < 6; ++j) mm[j] = src[(6 * i + j) * 1024];
+            w4_at<float>(mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], z[i][0], z[i][1], z[i][2], z[i][3]);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            w4_at<f32x2>(z[0][j], z[1][j], z[2][j], z[3][j], z[4][j], z[5][j], y[0][j], y[1][j], y[2][j], y[3][j]);
+            w4_at<float>(z[0][j], z[1][j], z[2][j], z[3][j], z[4][j], z[5][j], y[0][j], y[1][j], y[2][j], y[3][j]);
         const int ox = 4 * tx, oy0 = 4 * ty;
         const bool vec = !ragged && (p.out_bs & 3) == 0 && (((size_t)p.out) & 15) == 0 &&
                          (!p.res || ((p.res_bs & 3) == 0 && (((size_t)p.res) & 15) == 0));
+        const int co = 32 * hh0 + 8 * (r >> 2) + 4 * h + (r & 3);
+        const float bias = p.bias[co];
+        float* __restrict__ op = p.out + (size_t)b * p.out_bs + (size_t)co * plane;
+        const float* __restrict__ rp = p.res ? p.res + (size_t)b * p.res_bs + (size_t)co * plane : nullptr;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int r = 2 * wave + s;
-            const int co = 32 * hh0 + 8 * (r >> 2) + 4 * h + (r & 3);
-            const float bias = p.bias[co];
-            float* __restrict__ op = p.out + (size_t)b * p.out_bs + (size_t)co * plane;
-            const float* __restrict__ rp = p.res ? p.res + (size_t)b * p.res_bs + (size_t)co * plane : nullptr;
+        for (int a = 0; a < 4; ++a) {
+            const int oy = oy0 + a;
+            if (oy >= p.H || ox >= p.W) continue;
+            f32x4 v = {y[a][0] + bias, y[a][1] + bias, y[a][2] + bias, y[a][3] + bias};
+            if (p.relu) v = f32x4{relu0(v[0]), relu0(v[1]), relu0(v[2]), relu0(v[3])};
+            const size_t o = (size_t)oy * p.W + ox;
+            if (vec) {
+                if (rp) v += *reinterpret_cast<const f32x4*>(rp + o);
+                *reinterpret_cast<f32x4*>(op + o) = v;
+            } else {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int oy = oy0 + a;
-                if (oy >= p.H || ox >= p.W) continue;
-                f32x4 v = {y[a][0][s] + bias, y[a][1][s] + bias, y[a][2][s] + bias, y[a][3][s] + bias};
-                if (p.relu) v = f32x4{relu0(v[0]), relu0(v[1]), relu0(v[2]), relu0(v[3])};
-                const size_t o = (size_t)oy * p.W + ox;
-                if (vec) {
-                    if (rp) v += *reinterpret_cast<const f32x4*>(rp + o);
-                    *reinterpret_cast<f32x4*>(op + o) = v;
-                } else {
-#pragma unroll
-                    for (int x = 0; x < 4; ++x)
-                        if (ox + x < p.W) op[o + x] = rp ? v[x] + rp[o + x] : v[x];
-                }
+                for (int x = 0; x < 4; ++x)
+                    if (ox + x < p.W) op[o + x] = rp ? v[x] + rp[o + x] : v[x];
             }
         }
     }

@@ -2,7 +2,7 @@
 # timing ablations of conv_wino4_kernel (tools/ubench/wino4_bench.hip); built here, run on the GPU box:
 #   bash tools/r04_wino4_abl.sh build ; gpurun -- 'bash tools/r04_wino4_abl.sh run [SIZE]'
 cd "$(dirname "$0")/.."
-VARS="base LINEAR NOSIDE NOTRANSFORM NOPATCH NOMFMA NOW NOBREAD NOBAR NOTRANSFORM+NOPATCH NOW+NOTRANSFORM+NOPATCH NOMFMA+NOW"
+VARS="base NOPRIO NOTRANSFORM NOPATCH NOMFMA NOW NOBREAD NOBAR NOTRANSFORM+NOPATCH NOW+NOTRANSFORM+NOPATCH NOMFMA+NOW"
 if [ "$1" = build ]; then
   for v in $VARS; do
     fl=""; for a in ${v//+/ }; do [ $a = base ] || fl="$fl -DW4_ABL_$a"; done
