@@ -107,6 +107,7 @@ SIGNATURES = {
     "diinn_conv_wino4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_rdn_wino4_packed_floats": (C.c_size_t, []),
+    "diinn_rdn_wino4_applies": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "diinn_rdn_forward_wino4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "diinn_rdn_forward_wino": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -640,6 +640,19 @@ size_t diinn_rdn_x3_packed_floats(void) {
     return n + (size_t)16 * 64 * 576;
 }
 
+int diinn_rdn_wino4_applies(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const long long px = (long long)B * H * W;
+    if (px < knob(diinn_knobs().enc_wino_min)) return 0;         // the split-K kernel's maps
+    const long long forced = knob(diinn_knobs().enc_wino4_min);
+    if (forced >= 0) return px >= forced;
+    const long long items4 = 2LL * B * (((W + 3) / 4 + 31) / 32) * ((H + 3) / 4);
+    const long long blocks2 = (long long)B * (((W + 1) / 2 + 7) / 8) * (((H + 1) / 2 + 3) / 4);
+    const double r4 = 1.44 * (double)((items4 + 255) / 256);
+    const double r2w = (double)((blocks2 + 255) / 256), r2h = 0.57 * (double)((2 * blocks2 + 255) / 256);
+    return r4 < 0.97 * (r2w < r2h ? r2w : r2h);
+}
+
 static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
                             const float* packed_wino4_dev, const float* packed_x3_dev,
                             const float* biases_dev, float* workspace_dev, float* out_dev, int B, int H, int W) {
@@ -651,9 +664,11 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     // about 90 x 90 pixels up (tools/r02_ab_env.sh: 96x96 3.6 vs 4.5 ms, 64x64 3.4 vs 2.1 ms per trunk)
     const long long wino_min = knob(diinn_knobs().enc_wino_min);
     const bool wino = packed_wino_dev && (long long)B * hw >= wino_min;
-    // F(4x4, 3x3) (csrc/diinn_winograd4.hip): 1.78x fewer MFMAs again, blocks of 32 x 16 pixels x one output half: from the
-    // map size on where those fill the chip better than F(2x2)'s (DIINN_ENC_WINO4_MIN pixels)
-    const bool wino4 = packed_wino4_dev && (long long)B * hw >= knob(diinn_knobs().enc_wino4_min);
+    // F(4x4, 3x3) (csrc/diinn_winograd4.hip): 1.78x fewer MFMAs again, in work items of 128 x 4 pixels x one output half.
+    // Both kernels run in rounds of one workgroup per CU, and measured over 192 .. 512-pixel maps one F(4x4) round
+    // costs 1.44 F(2x2) rounds of whole blocks (16 x 8 pixels x both halves; a round of halves 0.57): the cheaper one
+    // by that count runs.  DIINN_ENC_WINO4_MIN = n >= 0 replaces the rule by "from n pixels on".
+    const bool wino4 = packed_wino4_dev && wino && diinn_rdn_wino4_applies(B, H, W);
     float* buf[2] = {workspace_dev, workspace_dev + (size_t)B * 576 * hw};     // dense buffers [B,576,H,W]
     float* gff_in = workspace_dev + (size_t)2 * B * 576 * hw;                    // [B,1024,H,W]
     float* tmp = gff_in + (size_t)B * 1024 * hw;                                 // [B,64,H,W]

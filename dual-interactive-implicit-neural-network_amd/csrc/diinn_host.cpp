@@ -28,7 +28,7 @@ const KnobDef KNOBS[] = {
     {"DIINN_ENC_NO_STREAM1X1", &DiinnKnobs::enc_no_stream1x1, 0, true},
     {"DIINN_ENC_LAT_MAX_TILES", &DiinnKnobs::enc_lat_max_tiles, 256, false},
     {"DIINN_ENC_WINO_MIN", &DiinnKnobs::enc_wino_min, 8192, false},
-    {"DIINN_ENC_WINO4_MIN", &DiinnKnobs::enc_wino4_min, 36864, false},
+    {"DIINN_ENC_WINO4_MIN", &DiinnKnobs::enc_wino4_min, -1, false},
     {"DIINN_ENC_X3_MIN", &DiinnKnobs::enc_x3_min, 32768, false},
     {"DIINN_ENC_X3_ROWS", &DiinnKnobs::enc_x3_rows, 0, false},
     {"DIINN_ENC_WINO_HALF_MAX", &DiinnKnobs::enc_wino_half_max, -1, false},

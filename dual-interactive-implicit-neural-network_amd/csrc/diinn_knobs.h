@@ -19,7 +19,7 @@ struct DiinnKnobs {
     std::atomic<long long> enc_no_stream1x1;    // DIINN_ENC_NO_STREAM1X1 (default 0)
     std::atomic<long long> enc_lat_max_tiles;   // DIINN_ENC_LAT_MAX_TILES (default 256)
     std::atomic<long long> enc_wino_min;        // DIINN_ENC_WINO_MIN (default 8192 pixels)
-    std::atomic<long long> enc_wino4_min;       // DIINN_ENC_WINO4_MIN (default 36864 pixels): Winograd F(4x4,3x3) 3x3 layers from that map size on
+    std::atomic<long long> enc_wino4_min;       // DIINN_ENC_WINO4_MIN (default -1: by the round count of the two Winograd kernels): n >= 0 = F(4x4,3x3) 3x3 layers from n pixels on
     std::atomic<long long> enc_x3_min;          // DIINN_ENC_X3_MIN (default 32768 pixels): split-bf16 3x3 layers from that map size on
     std::atomic<long long> enc_x3_rows;         // DIINN_ENC_X3_ROWS: split-bf16 3x3 kernel form: 1 / 2 pixel rows per wave, 3 = 2 rows + a group's weights in registers, 4 = that with eight waves (0: auto)
     std::atomic<long long> enc_wino_half_max;   // DIINN_ENC_WINO_HALF_MAX (default -1: by the busiest CU's load)

@@ -27,7 +27,10 @@
 #include "diinn_device.h"
 
 constexpr int W4_TX = 32, W4_TY = 1;                 // Winograd tiles per block (x, y): 32 = one MFMA N-tile, one tile row (128 x 4 output pixels)
-constexpr int W4_MFMA_WAVES = 12, W4_THREADS = 1024;  // + 4 transform waves
+constexpr int W4_THREADS = 1024;                      // 12 MFMA waves + 4 transform waves
+#ifdef W4_ABL_MIXED
+constexpr int W4_MFMA_WAVES = 12;
+#endif
 constexpr int W4_VBUF = 36 * 256;                    // floats of one chunk's transformed data: [pos 36][e 4][h 2][tile 32]
 constexpr int W4_RAW0 = 3 * W4_VBUF;                     // raw input slots behind the ring: [slot 2][transform wave 4][6 rows x 256 + 64 edge values]
 constexpr int W4_RAW_WAVE = 6 * 256 + 64;
@@ -53,7 +56,22 @@ struct ConvWino4Params {
     float* out;              // out + b*out_bs + co*H*W
     long long in_bs, out_bs, res_bs;
     int Cin, B, H, W, relu;
+#ifdef W4_STAMPS
+    unsigned long long* stamps;   // tools/ubench/wino4_bench.hip -DW4_STAMPS: s_memtime of workgroup 0's waves 0 and 12, [wave 2][iteration 80][4]
+#endif
 };
+#ifdef W4_STAMPS
+#define W4_STAMP(role, it, i)                                                                        \
+    do {                                                                                             \
+        if (blockIdx.x == 0 && lane == 0 && (it) < 80) {                                             \
+            unsigned long long t_;                                                                   \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            p.stamps[((role) * 80 + (it)) * 4 + (i)] = t_;                                           \
+        }                                                                                            \
+    } while (0)
+#else
+#define W4_STAMP(role, it, i) do {} while (0)
+#endif
 
 // one dimension of B^T (6 -> 6) and of A^T (6 -> 4); T = float or f32x2 (two columns at a time: v_pk_* instructions)
 template <typename T>
@@ -87,14 +105,24 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
     constexpr unsigned OUTSIDE = 0x80000000u;
     const bool ragged = (p.W & 3) != 0;                          // uniform: only then can a 16-byte access cross a row's end
 
-    if (wave >= W4_MFMA_WAVES) {
+    // Roles by SIMD (a workgroup's wave i runs on SIMD i % 4): the four transform waves share SIMD 3, the twelve MFMA waves
+    // SIMDs 0..2.  The fp32 MFMA and the VALU are one pipe: beside three MFMA waves a transform took 3,500 cycles (1,670
+    // alone) and set the iteration time (W4_ABL_MIXED keeps that layout: one transform wave per SIMD).
+#ifdef W4_ABL_MIXED
+    const bool producer = wave >= W4_MFMA_WAVES;
+    const int wt_ = wave - W4_MFMA_WAVES, mw = wave;
+#else
+    const bool producer = (wave & 3) == 3;
+    const int wt_ = wave >> 2, mw = (wave >> 2) * 3 + (wave & 3);
+#endif
+    if (producer) {
         // ---- transform waves: one (tile, channel of the chunk) patch per thread: wave wt takes the chunk's channels
         // 2 wt and 2 wt + 1 (= k-step wt of the MFMAs), a lane one of the block's 32 tiles.  Its input is in LDS already
         // (raw slots, filled by the MFMA waves' LDS-DMA requests): per chunk and wave six 1-KiB rows [row k][channel 2]
         // [128 columns] + the 24 values left and right of the block (6 rows x 2 channels x 2 sides).  These waves issue no
         // vector-memory instruction at all: a chunk's transform is one serial instruction stream per SIMD and sets the
         // iteration time, so nothing that can stall goes into it.
-        const int wt = wave - W4_MFMA_WAVES;
+        const int wt = wt_;
 #ifndef W4_ABL_NOPRIO
         __builtin_amdgcn_s_setprio(3);                           // the chunk's critical path: ahead of the MFMA waves' issue
 #endif
@@ -148,13 +176,16 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // P3: chunks 0 and 1 transformed, chunk 2 landed
         int slot2 = 2;
         for (int c = 0; c < n; ++c) {
+            if (wt == 0) W4_STAMP(1, c, 0);
 #ifndef W4_ABL_NOTRANSFORM
             if (c + 2 < n) transform(c & 1, lds + slot2 * W4_VBUF);
 #endif
             slot2 = slot2 == 2 ? 0 : slot2 + 1;
+            if (wt == 0) W4_STAMP(1, c, 1);
 #ifndef W4_ABL_NOBAR
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the raw slot is read, the transformed data stored
 #endif
+            if (wt == 0) W4_STAMP(1, c, 2);
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
@@ -162,7 +193,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         // ---- MFMA waves: positions 3 wave .. 3 wave + 2; A = weights (32 outputs of half hh0 x 2 channels), B =
         // transformed data (2 channels x 32 tiles)
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(p.wu + (size_t)(wave * 2 + hh0) * n * (3 * W4_PIECE_BYTES / 4)), 0, n * 3 * W4_PIECE_BYTES, 0x00020000);
+            (void*)(p.wu + (size_t)(mw * 2 + hh0) * n * (3 * W4_PIECE_BYTES / 4)), 0, n * 3 * W4_PIECE_BYTES, 0x00020000);
         const int lane_off = lane * 16;
         // The raw input of chunk c + 3 is requested here, one iteration ahead, by LDS-DMA (buffer_load ... lds: no
         // registers; range-checked -- an out-of-range lane deposits zero, which is the zero padding): wave w takes rows
@@ -177,7 +208,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
             const int th = lane >> 5, ptx = tx0 + (lane & 31);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int idx = 2 * wave + i, cp = idx / 6, k = idx - 6 * cp;
+                const int idx = 2 * mw + i, cp = idx / 6, k = idx - 6 * cp;
                 const int y = 4 * ty0 - 1 + k;
                 dvoff[i] = (y >= 0 && y < p.H && 4 * ptx < p.W) ? (unsigned)(2 * cp + th) * plane_b + (unsigned)(y * p.W + 4 * ptx) * 4u : OUTSIDE;
                 dlds[i] = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + W4_RAW0 + cp * W4_RAW_WAVE + k * 256);
@@ -185,9 +216,9 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
             const int ek = lane % 6, ew = lane / 6;              // the edge load: lane < 24 -> row ek, (channel, side) ew
             const int ex = (ew & 1) ? 4 * (tx0 + W4_TX) : 4 * tx0 - 1;
             const int ey = 4 * ty0 - 1 + ek;
-            if (wave < 4 && lane < 24 && ey >= 0 && ey < p.H && ex >= 0 && ex < p.W)
-                dvoffe = (unsigned)(2 * wave + (ew >> 1)) * plane_b + (unsigned)(ey * p.W + ex) * 4u;
-            dldse = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + W4_RAW0 + (wave & 3) * W4_RAW_WAVE + 1536);
+            if (mw < 4 && lane < 24 && ey >= 0 && ey < p.H && ex >= 0 && ex < p.W)
+                dvoffe = (unsigned)(2 * mw + (ew >> 1)) * plane_b + (unsigned)(ey * p.W + ex) * 4u;
+            dldse = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + W4_RAW0 + (mw & 3) * W4_RAW_WAVE + 1536);
         }
         auto fetch = [&](int slot, int c) {
 #ifndef W4_ABL_NOPATCH
@@ -195,12 +226,12 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
             const unsigned so = (unsigned)slot * (4 * W4_RAW_WAVE * 4);
             asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(dlds[0] + so), "v"(dvoff[0]), "s"(irs) : "memory", "m0");
             asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(dlds[1] + so), "v"(dvoff[1]), "s"(irs) : "memory", "m0");
-            if (wave < 4)
+            if (mw < 4)
                 asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" :: "s"(dldse + so), "v"(dvoffe), "s"(irs) : "memory", "m0");
 #endif
         };
         auto chunk_of = [&](int k) { return k < n ? k : n - 1; };
-        const float* __restrict__ bsrc = lds + 3 * wave * 256 + lane;      // + 64 e: [pos][e][h][tile]
+        const float* __restrict__ bsrc = lds + 3 * mw * 256 + lane;      // + 64 e: [pos][e][h][tile]
         f32x16 acc[3];
         f32x4 A[2][3], Bf[3];    // weights of chunks c, c + 1 (ring of two: a request has a whole iteration to arrive); B operands of chunk c
 #pragma unroll
@@ -229,8 +260,10 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         auto iter = [&](auto PAR_, int c) {
             constexpr int PAR = decltype(PAR_)::value;
             const int c2 = c + 2 < n ? c + 2 : n - 1;
+            if (mw == 0) W4_STAMP(0, c, 0);
             fetch((c + 1) & 1, chunk_of(c + 3));                 // always issued (past the end: the last chunk again): the count below relies on it
             W4_SB();
+            if (mw == 0) W4_STAMP(0, c, 1);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
 #ifndef W4_ABL_NOMFMA
@@ -252,9 +285,11 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
                 W4_SB();
             }
 #ifndef W4_ABL_NOBAR
+            if (mw == 0) W4_STAMP(0, c, 2);
             // all but the three weight requests of this iteration: the raw rows requested above have landed
             asm volatile("s_waitcnt vmcnt(3) lgkmcnt(2)\n\ts_barrier" ::: "memory");
 #endif
+            if (mw == 0) W4_STAMP(0, c, 3);
             slot1 = slot1 == 2 ? 0 : slot1 + 1;
         };
         int c = 0;
@@ -269,7 +304,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) lds[((3 * wave + q) * 16 + r) * 64 + lane] = acc[q][r];
+            for (int r = 0; r < 16; ++r) lds[((3 * mw + q) * 16 + r) * 64 + lane] = acc[q][r];
     }
     __syncthreads();
     {
@@ -338,6 +373,10 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvWino4P
     }
 }
 
+#ifdef W4_STAMPS
+unsigned long long* g_w4_stamps = nullptr;
+#endif
+
 extern "C" {
 
 int diinn_conv_wino4(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
@@ -357,6 +396,9 @@ int diinn_conv_wino4(void* stream, const float* in_dev, long long in_batch_strid
     p.in = in_dev; p.wu = packed_u_dev; p.bias = bias_dev; p.res = res_dev; p.out = out_dev;
     p.in_bs = in_batch_stride; p.out_bs = out_batch_stride; p.res_bs = res_batch_stride;
     p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0;
+#ifdef W4_STAMPS
+    p.stamps = g_w4_stamps;
+#endif
     hipLaunchKernelGGL(conv_wino4_kernel, dim3((unsigned)((2 * blocks + 7) / 8 * 8)), dim3(W4_THREADS), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }

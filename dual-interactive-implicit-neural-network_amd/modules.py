@@ -144,9 +144,10 @@ class RDN(nn.Module):
     # 3x3 layers as Winograd F(2x2, 3x3) (csrc/diinn_winograd.hip) on maps of >= 8192 pixels: 2.25x fewer MFMAs, fp32,
     # equal to the direct sum up to reassociation (~1e-6 relative).  False keeps every layer on the direct kernel.
     hip_winograd: bool = True
-    # ... and as Winograd F(4x4, 3x3) (csrc/diinn_winograd4.hip) on maps of >= 36,864 pixels: 1.78x fewer MFMAs again;
-    # through the whole trunk 3e-6 of max|feat| against float64 (F(2x2): 3e-7; the parity bound is 2e-5).  False keeps
-    # F(2x2, 3x3) on every map size.
+    # ... and as Winograd F(4x4, 3x3) (csrc/diinn_winograd4.hip) where that kernel needs fewer rounds of workgroups (from
+    # about 190 x 190 pixels on: diinn_rdn_wino4_applies): 1.78x fewer MFMAs again; 256x256 11.8 -> 8.7 ms, 512x512 46.0 ->
+    # 34.1 ms.  Per layer ~1e-5 of max|out| on unit-variance inputs (F(2x2): 4e-7); through the whole trunk 2e-6 absolute
+    # at max|feat| 1.6 against MIOpen (F(2x2): 6e-7; the parity bound is 2e-5 x max).  False keeps F(2x2, 3x3) everywhere.
     hip_winograd4: bool = True
     # optional: the 3x3 layers in split-bf16 arithmetic on the bf16 MFMA (csrc/diinn_conv_x3.hip) on maps of >= 32,768
     # pixels: hi + lo bf16 operands, three products per term, fp32 accumulation; inside a dense block the activations are
@@ -154,7 +155,6 @@ class RDN(nn.Module):
     # ~3e-6 of max|feat| and the decoded image by ~3e-8.  Measured per trunk: 192x192 9.4 -> 6.7 ms,
     # 256x256 11.85 -> 7.9 ms, 384x384 28.1 -> 20.1 ms, 512x512 46.6 -> 31.4 ms; below ~180x180 the Winograd kernels stay faster and are used.
     hip_split_bf16: bool = False
-    _WINO4_MIN_PIXELS = 8192                                    # below that the library never takes the F(4x4) kernels: no image is built
 
     def __init__(self, G0: int = 64, RDNkSize: int = 3, RDNconfig: str = "B", n_colors: int = 3):
         super().__init__()
@@ -225,7 +225,7 @@ class RDN(nn.Module):
                                                        C.c_void_p(packed_wino.data_ptr()), C.c_void_p(px3.data_ptr()),
                                                        C.c_void_p(biases.data_ptr()), C.c_void_p(ws.data_ptr()),
                                                        C.c_void_p(out.data_ptr()), b, h, w), "diinn_rdn_forward_x3")
-            elif self.hip_winograd and self.hip_winograd4 and b * h * w >= self._WINO4_MIN_PIXELS:
+            elif self.hip_winograd and self.hip_winograd4 and lib.diinn_rdn_wino4_applies(b, h, w):
                 pw4 = self._hip_packed_wino4(shallow.device)
                 _native.check(lib.diinn_rdn_forward_wino4(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
                                                           C.c_void_p(packed_wino.data_ptr()), C.c_void_p(pw4.data_ptr()),

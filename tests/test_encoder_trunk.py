@@ -78,7 +78,8 @@ def test_conv_wino4_kernel_matches_fp64_conv():
     """diinn_conv_wino4 (Winograd F(4x4,3x3)): ReLU, residual, strided channel-plane views, odd / ragged maps (partial
     tiles, partial blocks, one-pixel maps, widths that are not multiples of 4: the scalar store path), batch > 1, 8 ..
     576 input channels (1 .. 72 chunks: every phase of the three-slot ring), and more work items than workgroups.
-    Bound 2e-5 of max|out| (measured ~1e-6: the F(4x4) transforms cost about a digit against F(2x2))."""
+    Bound 4e-5 of max|out| on these unit-variance inputs (measured <= 2.0e-5, typically 1e-5: the F(4x4) transforms --
+    4 and 5 in B^T, 8 in A^T -- cost a good digit against F(2x2)'s 4e-7; tools/conv_wino4_error.py lists every case)."""
     import ctypes as C
     import diinn_amd._native as N
     import diinn_amd.modules as M
@@ -108,7 +109,7 @@ def test_conv_wino4_kernel_matches_fp64_conv():
             ref = ref + res.double()
         err = float((out[:, 32:].double() - ref).abs().max())
         scale = max(1.0, float(ref.abs().max()))
-        assert err <= 2e-5 * scale, (cin, h, w, err)
+        assert err <= 4e-5 * scale, (cin, h, w, err)
         worst = max(worst, err / scale)
         assert torch.isnan(out[:, :32]).all()
     print(f"diinn_conv_wino4: worst error {worst:.2e} of max|out|")
@@ -146,7 +147,26 @@ def test_conv_wino4_kernel_fuzz():
         if use_res:
             ref = ref + res.double()
         err = float((out.double() - ref).abs().max())
-        assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (b, cin, h, w, relu, use_res, err)
+        assert err <= 4e-5 * max(1.0, float(ref.abs().max())), (b, cin, h, w, relu, use_res, err)
+
+
+def test_wino4_dispatch_rule(knobs):
+    """diinn_rdn_wino4_applies: the F(4x4) kernel where it needs fewer rounds of workgroups (one round = 1.44 F(2x2) rounds
+    of whole blocks); never on the split-K kernel's small maps; DIINN_ENC_WINO4_MIN = n replaces the rule."""
+    import diinn_amd._native as N
+    lib = N.load()
+    want = {(1, 256, 256): 1, (1, 512, 512): 1, (1, 224, 224): 1, (1, 192, 192): 1, (1, 384, 384): 1, (1, 240, 256): 1,
+            (1, 128, 128): 0, (1, 160, 160): 0, (1, 96, 100): 0, (1, 48, 48): 0, (2, 128, 130): 1, (1, 270, 480): 0,
+            (1, 320, 180): 0,            # 45 tile columns: the second 32-tile work item of a row is 60 % empty
+            (4, 256, 256): 1, (0, 4, 4): 0}
+    for (b, h, w), yes in want.items():
+        assert lib.diinn_rdn_wino4_applies(b, h, w) == yes, (b, h, w)
+    knobs("DIINN_ENC_WINO4_MIN", 0)
+    assert lib.diinn_rdn_wino4_applies(1, 128, 128) == 1 and lib.diinn_rdn_wino4_applies(1, 48, 48) == 0
+    knobs("DIINN_ENC_WINO_MIN", 0)
+    assert lib.diinn_rdn_wino4_applies(1, 48, 48) == 1
+    knobs("DIINN_ENC_WINO4_MIN", 1 << 40)
+    assert lib.diinn_rdn_wino4_applies(1, 512, 512) == 0
 
 
 @pytest.mark.gpu
@@ -334,6 +354,47 @@ def test_rdn_hip_trunk_odd_shapes():
         assert got.shape == ref.shape == (b, 64, h, w)
         err = float((got - ref).abs().max())
         assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (b, h, w, err)
+
+
+@pytest.mark.gpu
+def test_rdn_trunk_on_wino4_layers(knobs):
+    """The whole encoder with its 130 3x3 layers on diinn_conv_wino4 (forced on at small / ragged maps through the knobs;
+    the last three take it by the dispatch rule) against MIOpen: features within 2e-5 of max|feat|
+    (measured 1.5e-6; F(2x2): 4e-7), and the image decoded from them within 1e-6 of the one from the F(2x2) features
+    (the north_star bound is 1e-4).  RDN.hip_winograd4 = False switches it off."""
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    net = M.DIINN(mode=3, init_q=False).to(dev).eval()
+    enc = net.encoder
+    worst = 0.0
+    with torch.no_grad():
+        for (b, h, w, force) in [(1, 48, 48, 1), (2, 20, 33, 1), (1, 37, 5, 1), (3, 9, 10, 1), (1, 70, 112, 1), (1, 130, 129, 1),
+                                 (1, 250, 256, 0), (1, 200, 180, 0), (4, 96, 100, 0)]:
+            if force:
+                knobs("DIINN_ENC_WINO_MIN", 0)
+                knobs("DIINN_ENC_WINO4_MIN", 0)
+            else:
+                knobs("DIINN_ENC_WINO_MIN", 8192)
+                knobs("DIINN_ENC_WINO4_MIN", -1)
+            x = torch.rand(b, 3, h, w, device=dev)
+            enc.hip_winograd4 = True
+            f4 = enc(x)
+            enc.hip_winograd4 = False
+            f2 = enc(x)
+            enc.hip_trunk_max_pixels = None
+            ref = enc(x)
+            enc.hip_trunk_max_pixels = M.RDN.hip_trunk_max_pixels
+            enc.hip_winograd4 = True
+            scale = max(1.0, float(ref.abs().max()))
+            err = float((f4 - ref).abs().max())
+            assert err <= 2e-5 * scale, (b, h, w, err)
+            worst = max(worst, err / scale)
+            assert not torch.equal(f4, f2), (b, h, w)             # the other kernel did run
+            if h * w <= 130 * 129:
+                size = (2 * h + 3, 3 * w - 1)
+                assert float((net.decoder(f4, size, 30000) - net.decoder(f2, size, 30000)).abs().max()) <= 1e-6, (b, h, w)
+    print(f"trunk on F(4x4,3x3) layers: worst error {worst:.2e} of max|feat|")
 
 
 @pytest.mark.gpu

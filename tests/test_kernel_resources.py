@@ -26,6 +26,7 @@ DESIGN_OCCUPANCY = {
     "precompute_P_kernel": 2,            # two workgroups per CU hide each other's waits (4.2)
     "precompute_P_bf16_wide_kernel": 2,
     "conv_wino_half_kernel": 2,          # two workgroups per CU cover prologue / epilogue (4.8)
+    "conv_wino4_kernel": 4,              # one workgroup of 16 waves per CU: 12 MFMA waves on three SIMDs, 4 transform waves on the fourth (3.9)
     "conv1x1_stream_kernel": 2,
     "conv_ksplit_kernel_3x3": 2,
     "conv_ksplit_kernel_3x3_lat": 2,
@@ -91,7 +92,7 @@ def test_no_shipped_kernel_uses_scratch_and_occupancy_is_as_designed(tmp_path):
     names = {base_name(k[".name"]) for k in ks}
     # the hot-path kernels are all in the library that was inspected
     for must in ("decode_kernel", "decode_coop_kernel", "precompute_P_wino_kernel", "precompute_P_kernel", "liif_kernel",
-                 "metasr_kernel", "decode_bf16x2_kernel", "decode_bf16_coop8_kernel", "conv_wino_kernel", "bwd_layer_kernel"):
+                 "metasr_kernel", "decode_bf16x2_kernel", "decode_bf16_coop8_kernel", "conv_wino_kernel", "conv_wino4_kernel", "bwd_layer_kernel"):
         assert must in names, f"{must} not found in {N.LIB_PATH}"
     assert len(ks) >= 50
     bad = []
