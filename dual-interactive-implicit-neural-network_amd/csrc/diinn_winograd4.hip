@@ -11,18 +11,19 @@
 // whole trunk (tools/enc_wino43_error.py, against float64): max error 2.9e-6 of max|feat| 1.6 against 3e-7 for
 // F(2x2, 3x3) and 3.6e-7 for the direct sum; the trunk's parity bound is 2e-5 x max|ref| (tests/test_encoder_hip.py).
 //
-// Work split: a workgroup owns a block of 8 x 4 Winograd tiles (32 x 16 output pixels) = one 32-wide MFMA N-tile, and
-// ONE half of the 64 outputs (a 256 x 256 map is 128 blocks x 2 halves = one workgroup per CU).  It has 12 waves, three
-// per SIMD; wave w owns positions 3 w .. 3 w + 2 of the 36: three accumulators.  Unlike the F(2x2) kernel the data
-// transform is shared: per chunk of 8 input channels the 256 (tile, channel) patches are transformed ONCE, by the four
-// waves of one of three wave groups in rotation (one thread per patch: 18 loads, ~110 VALU instructions, 36 LDS
-// stores), and every wave reads the B operands of its positions from LDS (one 16-byte read per position and chunk).
-// Chunk k is transformed by group k % 3 during iteration k - 2 into a ring of three LDS buffers, so one barrier per
-// iteration orders everything and nobody waits for LDS data behind it; each SIMD always holds one transforming wave and
-// two that keep its matrix core busy.  Weights: 1 KiB per position and chunk, straight from L2 into registers, requested
-// one chunk ahead behind the last MFMA that used the register.
-// (W4_ABL_* are timing-ablation hooks for tools/ubench/wino4_bench.hip: wrong results when defined, never in the library.)
-// Epilogue: the 36 positions meet through LDS (144 KiB, over the ring), one thread per (tile, output channel):
+// Work split (every step measured: profiles/r04_wino4_ablation.txt): a work item is a block of 32 x 1
+// Winograd tiles (128 x 4 output pixels) = one 32-wide MFMA N-tile, and ONE half of the 64 outputs (a 256 x 256 map is 128
+// blocks x 2 halves = one workgroup per CU).  A workgroup has 16 waves.  Twelve MFMA waves own positions 3 w .. 3 w + 2 of the
+// 36: three accumulators each, weights 1 KiB per position and chunk of 8 input channels straight from L2 into a register
+// ring of two, B operands from LDS.  Four transform waves compute B^T d B ONCE per (tile, channel) -- one thread per patch,
+// ~110 VALU instructions -- into a ring of three LDS buffers two chunks ahead, so one barrier per chunk orders everything.
+// Their input arrives by LDS-DMA (buffer_load ... lds, range-checked: out-of-range lanes deposit zero = the padding), six
+// 1-KiB rows + one edge load per wave and chunk, requested two chunks ahead; no patch lives in registers.
+// The transform waves are the waves with (wave & 3) == 3: all on SIMD 3, the MFMA waves on SIMDs 0..2 -- the fp32 MFMA
+// and the VALU are one pipe, and a transform beside three MFMA waves took 2.7x its time and set the iteration.
+// (W4_ABL_* / W4_STAMPS / W4_MFMA_FETCH are timing-ablation and diagnosis hooks for tools/ubench/wino4_bench.hip: never in
+// the library, W4_ABL_* give wrong results.)
+// Epilogue: the 36 positions meet through LDS (144 KiB, over ring and raw slots), one thread per (tile, output channel):
 // A^T (.) A, bias, ReLU / residual, 16-byte stores.
 #include "diinn_device.h"
 
@@ -130,7 +131,40 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         const int ptx = tx0 + tm;
         const bool first = tm == 0, last = tm == W4_TX - 1;
         const bool ok1 = 4 * ptx + 1 < p.W, ok2 = 4 * ptx + 2 < p.W, ok3 = 4 * ptx + 3 < p.W;
-        const float* __restrict__ raw = lds + W4_RAW0 + wt * W4_RAW_WAVE;     // + slot * 4 * W4_RAW_WAVE
+        float* __restrict__ raw = lds + W4_RAW0 + wt * W4_RAW_WAVE;           // + slot * 4 * W4_RAW_WAVE
+#ifndef W4_MFMA_FETCH
+        // The wave requests exactly the input it transforms, by LDS-DMA (buffer_load ... lds: no registers; range-checked
+        // -- an out-of-range lane deposits zero, which is the zero padding), two chunks ahead: six 16-byte loads per chunk
+        // (one per patch row: 2 channels x 512 contiguous bytes) and one 4-byte load whose lanes 0..23 fetch the columns
+        // left and right of the block for 6 rows x 2 channels.  On their own SIMD the transform waves idle more than half
+        // of an iteration; the requests cost the MFMA waves nothing there.
+        const float* __restrict__ in_b = p.in + (size_t)b * p.in_bs;
+        unsigned voff[6], voffe;
+        {
+            const int ek = lane % 6, ew = lane / 6;              // the edge load: lane < 24 -> row ek, (channel, side) ew
+            const int ex = (ew & 1) ? 4 * (tx0 + W4_TX) : 4 * tx0 - 1;
+            const int ey = 4 * ty0 - 1 + ek;
+            voffe = (lane < 24 && ey >= 0 && ey < p.H && ex >= 0 && ex < p.W)
+                        ? (unsigned)(2 * wt + (ew >> 1)) * plane_b + (unsigned)(ey * p.W + ex) * 4u : OUTSIDE;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int y = 4 * ty0 - 1 + k;
+            voff[k] = (y >= 0 && y < p.H && 4 * ptx < p.W) ? (unsigned)(2 * wt + th) * plane_b + (unsigned)(y * p.W + 4 * ptx) * 4u : OUTSIDE;
+        }
+        auto fetch = [&](int slot, int c) {
+#ifndef W4_ABL_NOPATCH
+            const __amdgpu_buffer_rsrc_t irs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(in_b + (size_t)8 * c * plane), 0, (int)(8u * plane_b), 0x00020000);
+            float* dst = raw + slot * 4 * W4_RAW_WAVE;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (__attribute__((address_space(3))) void*)(dst + k * 256), 16, (int)voff[k], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (__attribute__((address_space(3))) void*)(dst + 1536), 4, (int)voffe, 0, 0, 0);
+#endif
+        };
+        auto chunk_of = [&](int k) { return k < n ? k : n - 1; };
+#endif
         // the outer columns: the neighbouring tiles' values in the row, for the block's first / last tile the edge values
         const int la = first ? 1536 + 12 * th : th * 128 + tm * 4 - 1, lstep = first ? 1 : 256;
         const int ra = last ? 1536 + 12 * th + 6 : th * 128 + tm * 4 + 4, rstep = last ? 1 : 256;
@@ -167,6 +201,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
                 dst[(6 * i + 5) * 256] = v5;
             }
         };
+#ifdef W4_MFMA_FETCH
         // chunk k arrives in raw slot k & 1 (requested by the MFMA waves one iteration ahead) and is transformed into ring
         // slot k % 3; iteration c (the MFMA waves compute chunk c) transforms chunk c + 2
         __builtin_amdgcn_s_barrier();                            // P1: chunks 0 and 1 have landed
@@ -187,6 +222,39 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
 #endif
             if (wt == 0) W4_STAMP(1, c, 2);
         }
+#else
+        // chunk k is requested into raw slot k & 1 and transformed into ring slot k % 3; iteration c (the MFMA waves compute
+        // chunk c) transforms chunk c + 2 and then requests chunk c + 4 into the raw slot just read (7 requests per chunk,
+        // always issued -- past the end the last chunk again -- so that "all but the newest 7" names a chunk)
+        fetch(0, 0);
+        fetch(1, chunk_of(1));
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        transform(0, lds);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        fetch(0, chunk_of(2));
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        transform(1, lds + W4_VBUF);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        fetch(1, chunk_of(3));
+        __builtin_amdgcn_s_barrier();                            // P: chunks 0 and 1 are transformed
+        int slot2 = 2;
+        for (int c = 0; c < n; ++c) {
+            if (wt == 0) W4_STAMP(1, c, 0);
+            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");     // chunk c + 2 has landed (chunk c + 3 may be in flight)
+#ifndef W4_ABL_NOTRANSFORM
+            if (c + 2 < n) transform(c & 1, lds + slot2 * W4_VBUF);
+#endif
+            slot2 = slot2 == 2 ? 0 : slot2 + 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the raw slot is read, the transformed data stored
+            fetch(c & 1, chunk_of(c + 4));
+            if (wt == 0) W4_STAMP(1, c, 1);
+#ifndef W4_ABL_NOBAR
+            __builtin_amdgcn_s_barrier();
+#endif
+            if (wt == 0) W4_STAMP(1, c, 2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // nothing may land in the raw slots any more: the exchange buffer lies over them
+#endif
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     } else {
@@ -195,6 +263,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(p.wu + (size_t)(mw * 2 + hh0) * n * (3 * W4_PIECE_BYTES / 4)), 0, n * 3 * W4_PIECE_BYTES, 0x00020000);
         const int lane_off = lane * 16;
+#ifdef W4_MFMA_FETCH
         // The raw input of chunk c + 3 is requested here, one iteration ahead, by LDS-DMA (buffer_load ... lds: no
         // registers; range-checked -- an out-of-range lane deposits zero, which is the zero padding): wave w takes rows
         // 2 w and 2 w + 1 of the chunk's 24 (channel pair cp, patch row k) rows -- one 16-byte load per tile: 2 channels
@@ -231,6 +300,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
 #endif
         };
         auto chunk_of = [&](int k) { return k < n ? k : n - 1; };
+#endif
         const float* __restrict__ bsrc = lds + 3 * mw * 256 + lane;      // + 64 e: [pos][e][h][tile]
         f32x16 acc[3];
         f32x4 A[2][3], Bf[3];    // weights of chunks c, c + 1 (ring of two: a request has a whole iteration to arrive); B operands of chunk c
@@ -238,17 +308,21 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+#ifdef W4_MFMA_FETCH
         fetch(0, 0);
         fetch(1, chunk_of(1));
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // P1: chunks 0 and 1 have landed
+#endif
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             A[0][q] = ld_piece(wrs, lane_off, q * W4_PIECE_BYTES);
             A[1][q] = ld_piece(wrs, lane_off, ((n > 1 ? 3 : 0) + q) * W4_PIECE_BYTES);
         }
-        __builtin_amdgcn_s_barrier();                            // P2: raw slot 0 is free again
+        __builtin_amdgcn_s_barrier();                            // P (P2): chunks 0 and 1 are transformed (raw slot 0 is free again)
+#ifdef W4_MFMA_FETCH
         fetch(0, chunk_of(2));
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // P3: chunks 0 and 1 transformed, chunk 2 landed
+#endif
 #pragma unroll
         for (int q = 0; q < 3; ++q) Bf[q] = f32x4{bsrc[q * 256], bsrc[q * 256 + 64], bsrc[q * 256 + 128], bsrc[q * 256 + 192]};
 
@@ -261,8 +335,10 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
             constexpr int PAR = decltype(PAR_)::value;
             const int c2 = c + 2 < n ? c + 2 : n - 1;
             if (mw == 0) W4_STAMP(0, c, 0);
+#ifdef W4_MFMA_FETCH
             fetch((c + 1) & 1, chunk_of(c + 3));                 // always issued (past the end: the last chunk again): the count below relies on it
             W4_SB();
+#endif
             if (mw == 0) W4_STAMP(0, c, 1);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -286,8 +362,12 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
             }
 #ifndef W4_ABL_NOBAR
             if (mw == 0) W4_STAMP(0, c, 2);
+#ifdef W4_MFMA_FETCH
             // all but the three weight requests of this iteration: the raw rows requested above have landed
             asm volatile("s_waitcnt vmcnt(3) lgkmcnt(2)\n\ts_barrier" ::: "memory");
+#else
+            asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory");
+#endif
 #endif
             if (mw == 0) W4_STAMP(0, c, 3);
             slot1 = slot1 == 2 ? 0 : slot1 + 1;
@@ -298,7 +378,11 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
             iter(IC<1>{}, c + 1);
         }
         if (c < n) iter(IC<0>{}, c);
+#ifdef W4_MFMA_FETCH
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // nothing may land in the raw slots any more: the exchange buffer lies over them
+#else
+        __builtin_amdgcn_s_barrier();
+#endif
 
         // the 36 positions meet through LDS: [pos][accumulator register 16][lane]
 #pragma unroll
