@@ -646,7 +646,7 @@ int diinn_rdn_wino4_applies(int B, int H, int W) {
     if (px < knob(diinn_knobs().enc_wino_min)) return 0;         // the split-K kernel's maps
     const long long forced = knob(diinn_knobs().enc_wino4_min);
     if (forced >= 0) return px >= forced;
-    const long long items4 = 2LL * B * (((W + 3) / 4 + 31) / 32) * ((H + 3) / 4);
+    const long long items4 = 2LL * B * (((long long)((W + 3) / 4) * ((H + 3) / 4) + 31) / 32);   // blocks of 32 consecutive tiles x 2 output halves
     const long long blocks2 = (long long)B * (((W + 1) / 2 + 7) / 8) * (((H + 1) / 2 + 3) / 4);
     const double r4 = 1.44 * (double)((items4 + 255) / 256);
     const double r2w = (double)((blocks2 + 255) / 256), r2h = 0.57 * (double)((2 * blocks2 + 255) / 256);

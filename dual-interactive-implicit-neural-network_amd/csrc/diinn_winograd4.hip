@@ -9,10 +9,10 @@
 // 4 in F(2x2, 3x3) (diinn_winograd.hip): 1.78x fewer MFMAs.  fp32 throughout; G g G^T is computed in float64 on the host
 // and rounded once.  The price is accuracy: B^T holds 4 and 5, A^T up to 8, so the sums cancel more -- measured over the
 // whole trunk (tools/enc_wino43_error.py, against float64): max error 2.9e-6 of max|feat| 1.6 against 3e-7 for
-// F(2x2, 3x3) and 3.6e-7 for the direct sum; the trunk's parity bound is 2e-5 x max|ref| (tests/test_encoder_hip.py).
+// F(2x2, 3x3) and 3.6e-7 for the direct sum; the trunk's parity bound is 2e-5 x max|ref| (tests/test_encoder_trunk.py).
 //
-// Work split (every step measured: profiles/r04_wino4_ablation.txt): a work item is a block of 32 x 1
-// Winograd tiles (128 x 4 output pixels) = one 32-wide MFMA N-tile, and ONE half of the 64 outputs (a 256 x 256 map is 128
+// Work split (every step measured: profiles/r04_wino4_ablation.txt): a work item is a block of 32
+// consecutive Winograd tiles of the row-major tile grid (128 x 4 output pixels) = one 32-wide MFMA N-tile, and ONE half of the 64 outputs (a 256 x 256 map is 128
 // blocks x 2 halves = one workgroup per CU).  A workgroup has 16 waves.  Twelve MFMA waves own positions 3 w .. 3 w + 2 of the
 // 36: three accumulators each, weights 1 KiB per position and chunk of 8 input channels straight from L2 into a register
 // ring of two, B operands from LDS.  Four transform waves compute B^T d B ONCE per (tile, channel) -- one thread per patch,
@@ -27,7 +27,7 @@
 // A^T (.) A, bias, ReLU / residual, 16-byte stores.
 #include "diinn_device.h"
 
-constexpr int W4_TX = 32, W4_TY = 1;                 // Winograd tiles per block (x, y): 32 = one MFMA N-tile, one tile row (128 x 4 output pixels)
+constexpr int W4_TX = 32;                            // Winograd tiles per block: 32 = one MFMA N-tile; consecutive tiles of the row-major tile grid (128 x 4 output pixels; a block may wrap into the next tile row)
 constexpr int W4_THREADS = 1024;                      // 12 MFMA waves + 4 transform waves
 #ifdef W4_ABL_MIXED
 constexpr int W4_MFMA_WAVES = 12;
@@ -97,7 +97,15 @@ __device__ __forceinline__ void w4_at(const T m0, const T m1, const T m2, const 
     y3 = __builtin_elementwise_fma(T(8.0f), v, d) + m5;
 }
 
-__device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float* __restrict__ lds, int b, int tx0, int ty0, int hh0) {
+__device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float* __restrict__ lds, int b, int blk, int hh0) {
+    // the block's tiles: blk * 32 .. + 31 of the image's row-major tile grid (a run that reaches the end of a tile row goes
+    // on in the next one: no work item is left part empty by the map's width); tiles past the last one load zeros and store nothing
+    const int tiles_x = (p.W + 3) / 4, tiles_n = tiles_x * ((p.H + 3) / 4);
+    auto tile_xy = [&](int tile, int& tx, int& ty) {
+        ty = tile / tiles_x;
+        tx = tile - ty * tiles_x;
+        return tile < tiles_n;
+    };
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..11: MFMA waves; 12..15: transform waves
     const size_t plane = (size_t)p.H * p.W;
@@ -128,8 +136,11 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         __builtin_amdgcn_s_setprio(3);                           // the chunk's critical path: ahead of the MFMA waves' issue
 #endif
         const int th = lane >> 5, tm = lane & 31;
-        const int ptx = tx0 + tm;
+        int ptx, pty;
+        const bool pin = tile_xy(blk * W4_TX + tm, ptx, pty);
+        (void)pin;
         const bool first = tm == 0, last = tm == W4_TX - 1;
+        const bool row_start = ptx == 0, row_end = 4 * ptx + 4 >= p.W;   // the map's border: the outer column is padding (a wrapped block's neighbour lane holds another row's tile)
         const bool ok1 = 4 * ptx + 1 < p.W, ok2 = 4 * ptx + 2 < p.W, ok3 = 4 * ptx + 3 < p.W;
         float* __restrict__ raw = lds + W4_RAW0 + wt * W4_RAW_WAVE;           // + slot * 4 * W4_RAW_WAVE
 #ifndef W4_MFMA_FETCH
@@ -142,15 +153,17 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         unsigned voff[6], voffe;
         {
             const int ek = lane % 6, ew = lane / 6;              // the edge load: lane < 24 -> row ek, (channel, side) ew
-            const int ex = (ew & 1) ? 4 * (tx0 + W4_TX) : 4 * tx0 - 1;
-            const int ey = 4 * ty0 - 1 + ek;
-            voffe = (lane < 24 && ey >= 0 && ey < p.H && ex >= 0 && ex < p.W)
+            int etx, ety;                                        // the block's first (left side) / last (right side) tile
+            const bool ein = tile_xy(blk * W4_TX + ((ew & 1) ? W4_TX - 1 : 0), etx, ety);
+            const int ex = (ew & 1) ? 4 * etx + 4 : 4 * etx - 1;
+            const int ey = 4 * ety - 1 + ek;
+            voffe = (lane < 24 && ein && ey >= 0 && ey < p.H && ex >= 0 && ex < p.W)
                         ? (unsigned)(2 * wt + (ew >> 1)) * plane_b + (unsigned)(ey * p.W + ex) * 4u : OUTSIDE;
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            const int y = 4 * ty0 - 1 + k;
-            voff[k] = (y >= 0 && y < p.H && 4 * ptx < p.W) ? (unsigned)(2 * wt + th) * plane_b + (unsigned)(y * p.W + 4 * ptx) * 4u : OUTSIDE;
+            const int y = 4 * pty - 1 + k;
+            voff[k] = (pin && y >= 0 && y < p.H) ? (unsigned)(2 * wt + th) * plane_b + (unsigned)(y * p.W + 4 * ptx) * 4u : OUTSIDE;
         }
         auto fetch = [&](int slot, int c) {
 #ifndef W4_ABL_NOPATCH
@@ -181,9 +194,9 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
                     c2 = ok2 ? c2 : 0.0f;
                     c3 = ok3 ? c3 : 0.0f;
                 }
-                d[k][0] = f32x2{src[la + k * lstep], c4[0]};
+                d[k][0] = f32x2{row_start ? 0.0f : src[la + k * lstep], c4[0]};
                 d[k][1] = f32x2{c1, c2};
-                d[k][2] = f32x2{c3, src[ra + k * rstep]};
+                d[k][2] = f32x2{c3, row_end ? 0.0f : src[ra + k * rstep]};
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j)
@@ -274,18 +287,22 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         unsigned dvoff[2], dvoffe = OUTSIDE;
         unsigned dlds[2], dldse;
         {
-            const int th = lane >> 5, ptx = tx0 + (lane & 31);
+            const int th = lane >> 5;
+            int ptx, pty;
+            const bool pin = tile_xy(blk * W4_TX + (lane & 31), ptx, pty);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int idx = 2 * mw + i, cp = idx / 6, k = idx - 6 * cp;
-                const int y = 4 * ty0 - 1 + k;
-                dvoff[i] = (y >= 0 && y < p.H && 4 * ptx < p.W) ? (unsigned)(2 * cp + th) * plane_b + (unsigned)(y * p.W + 4 * ptx) * 4u : OUTSIDE;
+                const int y = 4 * pty - 1 + k;
+                dvoff[i] = (pin && y >= 0 && y < p.H) ? (unsigned)(2 * cp + th) * plane_b + (unsigned)(y * p.W + 4 * ptx) * 4u : OUTSIDE;
                 dlds[i] = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + W4_RAW0 + cp * W4_RAW_WAVE + k * 256);
             }
             const int ek = lane % 6, ew = lane / 6;              // the edge load: lane < 24 -> row ek, (channel, side) ew
-            const int ex = (ew & 1) ? 4 * (tx0 + W4_TX) : 4 * tx0 - 1;
-            const int ey = 4 * ty0 - 1 + ek;
-            if (mw < 4 && lane < 24 && ey >= 0 && ey < p.H && ex >= 0 && ex < p.W)
+            int etx, ety;
+            const bool ein = tile_xy(blk * W4_TX + ((ew & 1) ? W4_TX - 1 : 0), etx, ety);
+            const int ex = (ew & 1) ? 4 * etx + 4 : 4 * etx - 1;
+            const int ey = 4 * ety - 1 + ek;
+            if (mw < 4 && lane < 24 && ein && ey >= 0 && ey < p.H && ex >= 0 && ex < p.W)
                 dvoffe = (unsigned)(2 * mw + (ew >> 1)) * plane_b + (unsigned)(ey * p.W + ex) * 4u;
             dldse = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + W4_RAW0 + (mw & 3) * W4_RAW_WAVE + 1536);
         }
@@ -395,7 +412,8 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         // ---- A^T (.) A, one (tile, output channel) per thread: wave = accumulator register r; lane (h, m): tile m,
         // output channel 32 hh0 + 8 (r >> 2) + 4 h + (r & 3)
         const int h = lane >> 5, m = lane & 31, r = wave;
-        const int tx = tx0 + (m & (W4_TX - 1)), ty = ty0 + m / W4_TX;
+        int tx, ty;
+        const bool tin = tile_xy(blk * W4_TX + m, tx, ty);
         const float* __restrict__ src = lds + r * 64 + lane;
         float z[6][4], y[4][4];
 #pragma unroll
@@ -418,7 +436,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int oy = oy0 + a;
-            if (oy >= p.H || ox >= p.W) continue;
+            if (!tin || oy >= p.H || ox >= p.W) continue;
             f32x4 v = {y[a][0] + bias, y[a][1] + bias, y[a][2] + bias, y[a][3] + bias};
             if (p.relu) v = f32x4{relu0(v[0]), relu0(v[1]), relu0(v[2]), relu0(v[3])};
             const size_t o = (size_t)oy * p.W + ox;
@@ -436,9 +454,8 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
 
 __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvWino4Params p) {
     __shared__ __attribute__((aligned(16))) float lds[W4_LDS_FLOATS];
-    const int tiles_x = (p.W + 3) / 4, tiles_y = (p.H + 3) / 4;
-    const int bx_n = (tiles_x + W4_TX - 1) / W4_TX, by_n = (tiles_y + W4_TY - 1) / W4_TY;
-    const int total = p.B * bx_n * by_n * 2;
+    const int nblk = (((p.W + 3) / 4) * ((p.H + 3) / 4) + W4_TX - 1) / W4_TX;   // blocks of 32 consecutive tiles per image
+    const int total = p.B * nblk * 2;
     // every XCD takes a contiguous run of work items (as conv_wino_entry): neighbours share patch rows in one L2, and
     // the two halves of a block sit next to each other
     const int wg_per_xcd = gridDim.x >> 3;
@@ -449,10 +466,8 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvWino4P
         if (t >= total) break;
         const int hh0 = t & 1;
         t >>= 1;
-        const int b = __builtin_amdgcn_readfirstlane(t / (bx_n * by_n));
-        t -= b * bx_n * by_n;
-        const int by = __builtin_amdgcn_readfirstlane(t / bx_n), bx = t - by * bx_n;
-        conv_wino4_body(p, lds, b, bx * W4_TX, by * W4_TY, hh0);
+        const int b = __builtin_amdgcn_readfirstlane(t / nblk);
+        conv_wino4_body(p, lds, b, t - b * nblk, hh0);
         __syncthreads();                                         // the exchange buffer is free again
     }
 }
@@ -472,7 +487,7 @@ int diinn_conv_wino4(void* stream, const float* in_dev, long long in_batch_strid
     if (Cin <= 0 || Cin % 8) return DIINN_ERR_UNSUPPORTED;
     if ((((size_t)in_dev) & 3) || (((size_t)packed_u_dev) & 15) || (((size_t)bias_dev) & 3))
         return DIINN_ERR_INVALID_ARG;
-    const long long blocks = (long long)(((W + 3) / 4 + W4_TX - 1) / W4_TX) * (((H + 3) / 4 + W4_TY - 1) / W4_TY) * B;
+    const long long blocks = (((long long)((W + 3) / 4) * ((H + 3) / 4) + W4_TX - 1) / W4_TX) * B;
     if (2 * blocks > 2147483000LL) return DIINN_ERR_TOO_LARGE;
     if ((long long)H * W * 4 * 64 > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;     // planes are addressed with 32-bit byte offsets
     if ((long long)Cin / 8 * 3 * W4_PIECE_BYTES > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;

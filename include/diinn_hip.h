@@ -389,8 +389,8 @@ int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* 
  *   value = U[32 half + (lane&31)][8 chunk + 2 e + (lane>>5)][i][j] with 6 i + j = 3 wave + q     (36 * 64 * Cin floats).
  * diinn_rdn_wino4_packed_floats: floats of the 130 such weights of the trunk, in execution order.
  * diinn_rdn_forward_wino4: diinn_rdn_forward_wino with the 3x3 layers on diinn_conv_wino4 where that kernel needs fewer
- *   rounds of workgroups than diinn_conv_wino (one F(4x4) round = 1.44 F(2x2) rounds; from about 190 x 190 pixels on,
- *   depending on how the map divides into 128 x 4-pixel work items; DIINN_ENC_WINO4_MIN = n: from n pixels on); other
+ *   rounds of workgroups than diinn_conv_wino (one F(4x4) round = 1.44 F(2x2) rounds; from about 35,000 pixels on,
+ *   depending on how its 2 * ceil(tiles / 32) work items per image fill the last round; DIINN_ENC_WINO4_MIN = n: from n pixels on); other
  *   maps run exactly as diinn_rdn_forward_wino. */
 int    diinn_conv_wino4(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
                         const float* packed_u_dev, const float* bias_dev,

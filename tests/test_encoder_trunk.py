@@ -156,8 +156,9 @@ def test_wino4_dispatch_rule(knobs):
     import diinn_amd._native as N
     lib = N.load()
     want = {(1, 256, 256): 1, (1, 512, 512): 1, (1, 224, 224): 1, (1, 192, 192): 1, (1, 384, 384): 1, (1, 240, 256): 1,
-            (1, 128, 128): 0, (1, 160, 160): 0, (1, 96, 100): 0, (1, 48, 48): 0, (2, 128, 130): 1, (1, 270, 480): 0,
-            (1, 320, 180): 0,            # 45 tile columns: the second 32-tile work item of a row is 60 % empty
+            (1, 128, 128): 0, (1, 160, 160): 0, (1, 176, 176): 0, (1, 96, 100): 0, (1, 48, 48): 0, (2, 128, 130): 1,
+            (1, 270, 480): 1, (1, 320, 180): 1,      # work items are runs of 32 consecutive tiles: the map's width leaves none part empty
+            (2, 200, 180): 0,                        # 284 work items = two rounds, the second 11 % full
             (4, 256, 256): 1, (0, 4, 4): 0}
     for (b, h, w), yes in want.items():
         assert lib.diinn_rdn_wino4_applies(b, h, w) == yes, (b, h, w)
