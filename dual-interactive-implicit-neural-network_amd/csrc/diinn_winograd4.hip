@@ -124,6 +124,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
     const bool producer = (wave & 3) == 3;
     const int wt_ = wave >> 2, mw = (wave >> 2) * 3 + (wave & 3);
 #endif
+    if (threadIdx.x == 0) W4_STAMP(0, 76, 0);                     // body start
     if (producer) {
         // ---- transform waves: one (tile, channel of the chunk) patch per thread: wave wt takes the chunk's channels
         // 2 wt and 2 wt + 1 (= k-step wt of the MFMAs), a lane one of the block's 32 tiles.  Its input is in LDS already
@@ -343,6 +344,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
 #pragma unroll
         for (int q = 0; q < 3; ++q) Bf[q] = f32x4{bsrc[q * 256], bsrc[q * 256 + 64], bsrc[q * 256 + 128], bsrc[q * 256 + 192]};
 
+        if (mw == 0) W4_STAMP(0, 76, 1);                          // prologue done
         int slot1 = 1;                                           // ring slot of chunk c + 1
         // One iteration = one chunk: per position its four MFMAs, behind them the request of the position's weights of
         // chunk c + 2 into the registers just used and the read of its B operands of chunk c + 1; one barrier.  The
@@ -401,6 +403,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         __builtin_amdgcn_s_barrier();
 #endif
 
+        if (mw == 0) W4_STAMP(0, 76, 2);                          // loop done
         // the 36 positions meet through LDS: [pos][accumulator register 16][lane]
 #pragma unroll
         for (int q = 0; q < 3; ++q)
@@ -450,6 +453,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
             }
         }
     }
+    if (threadIdx.x == 0) W4_STAMP(0, 76, 3);                     // wave 0 stored its outputs
 }
 
 __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvWino4Params p) {

@@ -48,6 +48,8 @@ int main(int argc, char** argv) {
             const unsigned long long* qn = &st[(1 * 80 + i + 1) * 4];
             pr[0] += q[1] - q[0]; pr[1] += q[2] - q[1]; pr[2] += qn[0] - q[0];
         }
+        const unsigned long long* f = &st[(0 * 80 + 76) * 4];
+        printf("  workgroup 0, wave 0 (Cin = 512 launch): prologue %llu cycles, loop %llu, epilogue %llu\n", f[1] - f[0], f[2] - f[1], f[3] - f[2]);
         const double k = 1.0 / (i1 - i0);
         printf("  stamps (s_memtime ticks per iteration, 100 MHz?): MFMA wave 0: fetch issue %.0f, MFMAs+requests %.0f, barrier wait %.0f, iteration %.0f | transform wave: transform %.0f, barrier wait %.0f, iteration %.0f\n",
                m[0] * k, m[1] * k, m[2] * k, m[3] * k, pr[0] * k, pr[1] * k, pr[2] * k);
