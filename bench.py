@@ -555,6 +555,44 @@ def side_leg(job, name, compute, steps, warmup, check=True):
     return leg
 
 
+def whole_model_leg(device, steps=5, warmup=2):
+    """Informational, never part of `value`: the callers' path -- DIINN.forward (reference: diinn.py:9-30: RDN encoder, then the
+    implicit decoder) on a random 256x256 image, x4 (BASELINE config 2's geometry with the encoder the reference pairs it with),
+    random-init weights: whole forward, encoder alone, decoder alone, in ms (torch events on the current stream)."""
+    import diinn_amd.modules as M
+    torch.manual_seed(0)
+    net = M.DIINN(mode=3, init_q=False).to(device).eval()
+    x = torch.rand(1, 3, 256, 256, device=device)
+    size = (1024, 1024)
+
+    def t_ms(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(device)
+        return e0.elapsed_time(e1) / steps
+
+    with torch.no_grad():
+        feat = net.encoder(x)
+        fwd = t_ms(lambda: net(x, size))
+        enc = t_ms(lambda: net.encoder(x))
+        dec = t_ms(lambda: net.decoder(feat, size, 30000))
+        out = net(x, size)
+    leg = {"workload": "DIINN.forward: RDN encoder + implicit decoder, 256x256 LR x4 (1024x1024), B = 1, random-init weights",
+           "steps": steps, "warmup": warmup, "forward_ms": round(fwd, 3), "encoder_ms": round(enc, 3), "decoder_ms": round(dec, 3),
+           "finite": bool(torch.isfinite(out).all()),
+           "encoder_3x3_layers": "Winograd F(4x4,3x3)" if net.encoder.hip_winograd4 else "Winograd F(2x2,3x3)",
+           "note": "parity of this path: tests/test_modules.py (reference DIINN fixture), tests/test_encoder_trunk.py (the real reference's encoder)"}
+    del net, x, feat, out
+    torch.cuda.empty_cache()
+    return leg
+
+
 def main():
     args = parse()
     # stdout carries exactly ONE line, the JSON result: the collective libraries print banners to stdout when they
@@ -618,9 +656,13 @@ def main():
         del t
         torch.cuda.empty_cache()
 
-    side = None
+    side = whole = None
     if world == 1 and args.workload == "c2" and args.compute == "f32" and not args.no_side_legs:
         side = [side_leg(job, n, c, st, wu_, check=not args.no_check) for (n, c, st, wu_) in SIDE_LEGS]
+        try:
+            whole = whole_model_leg(job.dev)
+        except Exception as e:                                   # informational leg: report, do not lose the line
+            whole = {"error": f"{type(e).__name__}: {e}"}
 
     k_ms = sum(k_ms_all) / max(len(k_ms_all), 1)
     px_launch = (bd.y1 - bd.y0) * WU
@@ -730,6 +772,8 @@ def main():
             res["target_shape"] = target
         if side is not None:
             res["side_legs"] = side
+        if whole is not None:
+            res["whole_model"] = whole
         if strong is not None:
             res["strong"] = strong
         if feat_cpu is not None:

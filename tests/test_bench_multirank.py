@@ -97,6 +97,8 @@ def test_one_rank_torchrun_constructs_the_rccl_path():
     res, _ = _run_driver_command(1, steps=2, warmup=1, backend="nccl")
     assert res["n_gpus"] == 1 and res["checked"]["ok"] and "strong" not in res
     assert "target_shape" in res and "side_legs" in res and "cpu_baseline" in res
+    whole = res["whole_model"]                                   # the informational DIINN.forward leg (encoder + decoder)
+    assert whole["finite"] and 0 < whole["decoder_ms"] < whole["forward_ms"] and 0 < whole["encoder_ms"] < whole["forward_ms"]
 
 
 def test_two_ranks_weak_c1_with_strong_leg():
