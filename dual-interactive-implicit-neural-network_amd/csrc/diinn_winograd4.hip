@@ -321,7 +321,11 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
 #endif
         const float* __restrict__ bsrc = lds + 3 * mw * 256 + lane;      // + 64 e: [pos][e][h][tile]
         f32x16 acc[3];
-        f32x4 A[2][3], Bf[3];    // weights of chunks c, c + 1 (ring of two: a request has a whole iteration to arrive); B operands of chunk c
+#ifndef W4_EMAJOR
+        f32x4 A[2][3], Bf[1][3]; // weights of chunks c, c + 1 (ring of two: a request has a whole iteration to arrive); B operands of chunk c
+#else
+        f32x4 A[2][3], Bf[2][3]; // weights and B operands of chunks c, c + 1 (rings of two: a request has a whole iteration to arrive)
+#endif
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -342,7 +346,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // P3: chunks 0 and 1 transformed, chunk 2 landed
 #endif
 #pragma unroll
-        for (int q = 0; q < 3; ++q) Bf[q] = f32x4{bsrc[q * 256], bsrc[q * 256 + 64], bsrc[q * 256 + 128], bsrc[q * 256 + 192]};
+        for (int q = 0; q < 3; ++q) Bf[0][q] = f32x4{bsrc[q * 256], bsrc[q * 256 + 64], bsrc[q * 256 + 128], bsrc[q * 256 + 192]};
 
         if (mw == 0) W4_STAMP(0, 76, 1);                          // prologue done
         int slot1 = 1;                                           // ring slot of chunk c + 1
@@ -350,6 +354,9 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         // chunk c + 2 into the registers just used and the read of its B operands of chunk c + 1; one barrier.  The
         // barrier waits for all but the two newest LDS operations (the last position's reads of slot c + 1, which
         // nobody writes before the NEXT barrier): no wave sits behind an LDS round trip with the matrix core idle.
+        // (W4_EMAJOR: the twelve MFMAs k-step by k-step over double-buffered B registers, so that consecutive MFMAs of a
+        // wave are independent: measured 2.5 % SLOWER -- 3,447 against 3,362 cycles per iteration; four waves per SIMD keep
+        // the pipe busy either way.)
         auto iter = [&](auto PAR_, int c) {
             constexpr int PAR = decltype(PAR_)::value;
             const int c2 = c + 2 < n ? c + 2 : n - 1;
@@ -359,33 +366,61 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
             W4_SB();
 #endif
             if (mw == 0) W4_STAMP(0, c, 1);
+#ifndef W4_EMAJOR
+            // per position its four MFMAs, behind them the request of the position's weights of chunk c + 2 into the
+            // registers just used and the read of its B operands of chunk c + 1
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-#ifndef W4_ABL_NOMFMA
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[q] = MFMA32(A[PAR][q][e], Bf[q][e], acc[q]);
-#else
-                acc[q][0] += A[PAR][q][0] * Bf[q][0] + A[PAR][q][3] * Bf[q][3];
-#endif
+                for (int e = 0; e < 4; ++e) acc[q] = MFMA32(A[PAR][q][e], Bf[0][q][e], acc[q]);
                 W4_SB();
-#ifndef W4_ABL_NOW
                 A[PAR][q] = ld_piece(wrs, lane_off, (c2 * 3 + q) * W4_PIECE_BYTES);
-#endif
-#ifndef W4_ABL_NOBREAD
                 {
                     const float* __restrict__ bq = bsrc + slot1 * W4_VBUF + q * 256;
-                    Bf[q] = f32x4{bq[0], bq[64], bq[128], bq[192]};
+                    Bf[0][q] = f32x4{bq[0], bq[64], bq[128], bq[192]};
                 }
-#endif
                 W4_SB();
             }
+#else
+            // the B operands of chunk c + 1 first (their ring slot is complete since the last barrier; used next iteration),
+            // then the twelve MFMAs k-step by k-step, behind a position's last MFMA the request of its weights of chunk c + 2
+#ifndef W4_ABL_NOBREAD
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float* __restrict__ bq = bsrc + slot1 * W4_VBUF + q * 256;
+                Bf[PAR ^ 1][q] = f32x4{bq[0], bq[64], bq[128], bq[192]};
+            }
+            W4_SB();
+#endif
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+#ifndef W4_ABL_NOMFMA
+                    acc[q] = MFMA32(A[PAR][q][e], Bf[PAR][q][e], acc[q]);
+#else
+                    acc[q][e] += A[PAR][q][e] * Bf[PAR][q][e];
+#endif
+#ifndef W4_ABL_NOW
+                    if (e == 3) {
+                        W4_SB();
+                        A[PAR][q] = ld_piece(wrs, lane_off, (c2 * 3 + q) * W4_PIECE_BYTES);
+                        W4_SB();
+                    }
+#endif
+                }
+#endif
 #ifndef W4_ABL_NOBAR
             if (mw == 0) W4_STAMP(0, c, 2);
 #ifdef W4_MFMA_FETCH
             // all but the three weight requests of this iteration: the raw rows requested above have landed
             asm volatile("s_waitcnt vmcnt(3) lgkmcnt(2)\n\ts_barrier" ::: "memory");
 #else
+#ifndef W4_EMAJOR
             asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory");
+#else
+            __builtin_amdgcn_s_barrier();                        // (this wave's LDS reads were issued at the top of the iteration)
+#endif
 #endif
 #endif
             if (mw == 0) W4_STAMP(0, c, 3);
