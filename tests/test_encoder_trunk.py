@@ -399,6 +399,25 @@ def test_rdn_trunk_on_wino4_layers(knobs):
 
 
 @pytest.mark.gpu
+def test_graph_capture_with_wino4_layers():
+    """DIINN(graphs=True) on a map whose 3x3 layers take diinn_conv_wino4 (the F(4x4) weight image is packed in the warm-up,
+    kept alive by the graph entry): replays equal the eager forward bit for bit, also for new input contents."""
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = M.DIINN(mode=3, init_q=False).to(dev).eval()
+    assert N.load().diinn_rdn_wino4_applies(1, 200, 180) == 1
+    x, x2 = torch.rand(1, 3, 200, 180, device=dev), torch.rand(1, 3, 200, 180, device=dev)
+    with torch.no_grad():
+        ref, ref2 = net(x, (400, 360)), net(x2, (400, 360))
+        net.graphs = True
+        assert torch.equal(net(x, (400, 360)), ref) and torch.equal(net(x, (400, 360)), ref)
+        assert torch.equal(net(x2, (400, 360)), ref2)
+        net.graphs = False
+
+
+@pytest.mark.gpu
 def test_rdn_hip_trunk_matches_the_reference_on_big_maps():
     """RDN.forward on maps that take the Winograd 3x3 kernels (one half / both halves per workgroup) and the streaming
     1x1 kernel, against the REAL reference's encoder run on the CPU: 16,384 sampled outputs and per-channel sums from
