@@ -238,23 +238,24 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         }
 #else
         // chunk k is requested into raw slot k & 1 and transformed into ring slot k % 3; iteration c (the MFMA waves compute
-        // chunk c) transforms chunk c + 2 and then requests chunk c + 4 into the raw slot just read (7 requests per chunk,
-        // always issued -- past the end the last chunk again -- so that "all but the newest 7" names a chunk)
+        // chunk c) transforms chunk c + 2, then requests chunk c + 4 into the raw slot just read (7 requests per chunk,
+        // always issued -- past the end the last chunk again -- so that "all but the newest 7" names a chunk) and retires
+        // chunk c + 3 BEFORE the barrier: LDS-DMA data is ordered for a ds_read only by the issuing wave's counted vmcnt
+        // followed by a barrier the reader has passed (cdna_hip_programming.md: "read a staged buffer one phase after the
+        // wait that retires it") -- a read right behind the wait passes every check whenever the data happens to land first.
         fetch(0, 0);
         fetch(1, chunk_of(1));
-        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");     // P0: chunk 0 has landed
         transform(0, lds);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        fetch(0, chunk_of(2));
-        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // P1: chunk 1 has landed
         transform(1, lds + W4_VBUF);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // both raw slots are read
+        fetch(0, chunk_of(2));
         fetch(1, chunk_of(3));
-        __builtin_amdgcn_s_barrier();                            // P: chunks 0 and 1 are transformed
+        asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");     // P: chunks 0 and 1 are transformed, chunk 2 has landed
         int slot2 = 2;
         for (int c = 0; c < n; ++c) {
             if (wt == 0) W4_STAMP(1, c, 0);
-            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");     // chunk c + 2 has landed (chunk c + 3 may be in flight)
 #ifndef W4_ABL_NOTRANSFORM
             if (c + 2 < n) transform(c & 1, lds + slot2 * W4_VBUF);
 #endif
@@ -263,7 +264,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
             fetch(c & 1, chunk_of(c + 4));
             if (wt == 0) W4_STAMP(1, c, 1);
 #ifndef W4_ABL_NOBAR
-            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");  // chunk c + 3 has landed (chunk c + 4 may be in flight)
 #endif
             if (wt == 0) W4_STAMP(1, c, 2);
         }
@@ -334,6 +335,9 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         fetch(0, 0);
         fetch(1, chunk_of(1));
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // P1: chunks 0 and 1 have landed
+#else
+        __builtin_amdgcn_s_barrier();                            // P0, P1: (the transform waves' first requests have landed)
+        __builtin_amdgcn_s_barrier();
 #endif
 #pragma unroll
         for (int q = 0; q < 3; ++q) {

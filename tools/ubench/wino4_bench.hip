@@ -1,11 +1,55 @@
 // Times conv_wino4_kernel alone (random data, no checking) for timing ablations of its phases:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include [-DW4_ABL_...] tools/ubench/wino4_bench.hip -o wino4_bench
 //   ./wino4_bench [SIZE=256]
+#ifdef W4_SYM_KERNEL
+#include "wino4_sym_kernel.hip"
+#else
 #include "../../dual-interactive-implicit-neural-network_amd/csrc/diinn_winograd4.hip"
+#endif
 thread_local int g_last_hip_error = 0;
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
+
+// naive reference in the Winograd domain (the harness feeds random TRANSFORMED weights): one thread per (tile, output channel)
+__global__ void w4_reference(const float* in, const float* wu, float* out, int Cin, int S) {
+    const int tiles_x = S / 4, t = blockIdx.x * blockDim.x + threadIdx.x, co = blockIdx.y;
+    if (t >= tiles_x * tiles_x) return;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const size_t hw = (size_t)S * S;
+    const int n = Cin / 8, half = co >> 5, m = co & 31;
+    static const float BT[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0}, {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+    static const float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+    double M[36];
+    for (int i = 0; i < 36; ++i) M[i] = 0;
+    for (int c = 0; c < Cin; ++c) {
+        float d[6][6], tmp[6][6];
+        for (int a = 0; a < 6; ++a)
+            for (int b = 0; b < 6; ++b) {
+                const int y = 4 * ty - 1 + a, x = 4 * tx - 1 + b;
+                d[a][b] = (y >= 0 && y < S && x >= 0 && x < S) ? in[c * hw + (size_t)y * S + x] : 0.0f;
+            }
+        for (int i = 0; i < 6; ++i)
+            for (int b = 0; b < 6; ++b) { float v = 0; for (int a = 0; a < 6; ++a) v += BT[i][a] * d[a][b]; tmp[i][b] = v; }
+        const int chunk = c >> 3, e = (c & 7) >> 1, h = c & 1;
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) {
+                float v = 0;
+                for (int b = 0; b < 6; ++b) v += tmp[i][b] * BT[j][b];
+                const int pos = 6 * i + j, wave = pos / 3, q = pos % 3;
+                const float u = wu[((((size_t)(wave * 2 + half) * n + chunk) * 3 + q) * 64 + (h * 32 + m)) * 4 + e];
+                M[pos] += (double)u * v;
+            }
+    }
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+            double v = 0;
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) v += AT[a][i] * M[6 * i + j] * AT[b][j];
+            out[co * hw + (size_t)(4 * ty + a) * S + 4 * tx + b] = v > 0 ? (float)v : 0.0f;
+        }
+}
 
 int main(int argc, char** argv) {
     const int S = argc > 1 ? atoi(argv[1]) : 256;
@@ -32,6 +76,34 @@ int main(int argc, char** argv) {
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("  Cin %3d: %7.1f us", cin, ms / n * 1e3);
+        if (cin == 512 && getenv("W4_CHECKSUM")) {                // compare builds: same seeded input and weights
+            std::vector<float> o(64 * hw);
+            hipMemcpy(o.data(), out, o.size() * 4, hipMemcpyDeviceToHost);
+            double s1 = 0, s2 = 0;
+            for (size_t i = 0; i < o.size(); ++i) { s1 += o[i]; s2 += (double)o[i] * o[i] * (1 + (i % 7)); }
+            printf("  [checksum %.6e %.6e]", s1, s2);
+            float* out2; hipMalloc(&out2, 64 * hw * 4);
+            if (S % 4 == 0) {
+                hipLaunchKernelGGL(w4_reference, dim3((S / 4 * (S / 4) + 63) / 64, 64), dim3(64), 0, nullptr, in, w, out2, cin, S);
+                std::vector<float> r(64 * hw);
+                hipMemcpy(r.data(), out2, r.size() * 4, hipMemcpyDeviceToHost);
+                double mx = 0, worst_e = 0; size_t nbad = 0;
+                for (size_t i = 0; i < r.size(); ++i) { if (fabs(r[i]) > mx) mx = fabs(r[i]); }
+                for (size_t i = 0; i < r.size(); ++i) { const double e_ = fabs((double)o[i] - r[i]); if (e_ > worst_e) worst_e = e_; if (e_ > 1e-3 * mx) ++nbad; }
+                printf("  [vs naive reference: max err %.3e of max %.3e, %zu outputs beyond 1e-3]", worst_e, mx, nbad);
+            }
+            size_t worst = 0;
+            for (int rep = 0; rep < 30; ++rep) {
+                diinn_conv_wino4(nullptr, in, 576 * hw, cin, w, bias, nullptr, 0, out2, 64 * hw, 1, 1, S, S);
+                std::vector<float> o2(64 * hw);
+                hipMemcpy(o2.data(), out2, o2.size() * 4, hipMemcpyDeviceToHost);
+                size_t nd = 0, firstd = 0;
+                for (size_t i = 0; i < o.size(); ++i) if (o[i] != o2[i]) { if (!nd) firstd = i; ++nd; }
+                if (nd) printf("\n    rep %d: %zu outputs differ from the first result, first at channel %zu row %zu col %zu", rep, nd, firstd / hw, (firstd % hw) / S, firstd % S);
+                if (nd > worst) worst = nd;
+            }
+            printf("  [in-process repeats: worst %zu differing outputs]", worst);
+        }
     }
     printf("\n");
 #ifdef W4_STAMPS
