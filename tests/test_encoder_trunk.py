@@ -150,6 +150,33 @@ def test_conv_wino4_kernel_fuzz():
         assert err <= 4e-5 * max(1.0, float(ref.abs().max())), (b, cin, h, w, relu, use_res, err)
 
 
+@pytest.mark.gpu
+def test_conv_wino4_back_to_back_launches_are_bit_identical():
+    """Race screen for the kernel's LDS-DMA / barrier structure: 90 back-to-back launches on the same input (two shapes: one
+    workgroup per CU with 64 chunk iterations; ragged, more work items than CUs) all equal the first result bit for bit -- a read
+    of staged data in the wrong barrier phase shows up as rare differing tiles, not as a failed tolerance."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    gen = torch.Generator(device=dev).manual_seed(3)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
+    for (b, cin, h, w) in [(1, 512, 256, 256), (2, 136, 203, 310)]:
+        x = torch.rand((b, cin, h, w), device=dev, generator=gen)
+        wt = torch.rand((64, cin, 3, 3), device=dev, generator=gen) - 0.5
+        bias = torch.randn(64, device=dev, generator=gen)
+        packed = M.pack_conv_wino4(wt).to(dev)
+        outs = [torch.empty((b, 64, h, w), device=dev) for _ in range(4)]
+        for i in range(91):
+            assert lib.diinn_conv_wino4(stream, ptr(x), cin * h * w, cin, ptr(packed), ptr(bias), None, 0,
+                                        ptr(outs[0 if i == 0 else 1 + i % 3]), 64 * h * w, 1, b, h, w) == 0
+            if i and i % 3 == 0:
+                torch.cuda.synchronize()
+                assert all(torch.equal(o, outs[0]) for o in outs[1:]), (cin, h, w, i)
+
+
 def test_wino4_dispatch_rule(knobs):
     """diinn_rdn_wino4_applies: the F(4x4) kernel where it needs fewer rounds of workgroups (one round = 1.44 F(2x2) rounds
     of whole blocks); never on the split-K kernel's small maps; DIINN_ENC_WINO4_MIN = n replaces the rule."""
