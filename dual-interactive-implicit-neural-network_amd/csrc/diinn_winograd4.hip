@@ -247,10 +247,11 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         fetch(1, chunk_of(1));
         asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");     // P0: chunk 0 has landed
         transform(0, lds);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // P1: chunk 1 has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // raw slot 0 is read:
+        fetch(0, chunk_of(2));                                   // chunk 2 lands while chunk 1 is transformed
+        asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");     // P1: chunk 1 has landed
         transform(1, lds + W4_VBUF);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // both raw slots are read
-        fetch(0, chunk_of(2));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         fetch(1, chunk_of(3));
         asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");     // P: chunks 0 and 1 are transformed, chunk 2 has landed
         int slot2 = 2;
