@@ -82,7 +82,7 @@ def pack_conv_ksplit(weight: torch.Tensor) -> torch.Tensor:
     return w.permute(0, 2, 6, 3, 5, 1, 4).reshape(-1)                               # [half, wave, tap, g, h, i, e]
 
 
-def pack_conv_wino(weight: torch.Tensor) -> torch.Tensor:
+def pack_conv_wino(weight: torch.Tensor, dtype: torch.dtype = torch.float64) -> torch.Tensor:
     """3x3 conv weight [64, Cin, 3, 3] (Cin % 8 == 0) -> the Winograd F(2x2, 3x3) image ``diinn_conv_wino`` reads
     (include/diinn_hip.h): U = G W G^T per (output, input) pair, computed in float64 and rounded once, laid out
     [row i 4][chunk Cin/8][col j 4][half 2][lane 64][4] with cout = 32 half + (lane & 31) and input channel =
@@ -90,9 +90,9 @@ def pack_conv_wino(weight: torch.Tensor) -> torch.Tensor:
     co, cin, kh, kw = weight.shape
     if co != 64 or cin % 8 or (kh, kw) != (3, 3):
         raise ValueError(f"unsupported convolution shape {tuple(weight.shape)}")
-    g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64,
+    g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=dtype,
                      device=weight.device)                       # on the weight's device: 1.4 s for the trunk on the CPU, ms on the GPU
-    u = torch.einsum("ia,ocab,jb->ocij", g, weight.detach().to(torch.float64), g).to(torch.float32)
+    u = torch.einsum("ia,ocab,jb->ocij", g, weight.detach().to(dtype), g).to(torch.float32)
     u[..., 2] = -u[..., 2]                                      # the kernel's input transform produces column 2 negated
     u = u.reshape(2, 32, cin // 8, 4, 2, 4, 4)                  # [half, m, chunk, e, h, i, j]
     return u.permute(5, 2, 6, 0, 4, 1, 3).reshape(-1)           # [i, chunk, j, half, h, m, e]
@@ -101,7 +101,7 @@ def pack_conv_wino(weight: torch.Tensor) -> torch.Tensor:
 _WINO4_G = ((1 / 4, 0, 0), (-1 / 6, -1 / 6, -1 / 6), (-1 / 6, 1 / 6, -1 / 6), (1 / 24, 1 / 12, 1 / 6), (1 / 24, -1 / 12, 1 / 6), (0, 0, 1))
 
 
-def pack_conv_wino4(weight: torch.Tensor) -> torch.Tensor:
+def pack_conv_wino4(weight: torch.Tensor, dtype: torch.dtype = torch.float64) -> torch.Tensor:
     """3x3 conv weight [64, Cin, 3, 3] (Cin % 8 == 0) -> the Winograd F(4x4, 3x3) image ``diinn_conv_wino4`` reads
     (include/diinn_hip.h): U = G W G^T (6x6 per (output, input) pair), computed in float64 and rounded once, laid out
     [wave 12][half 2][chunk Cin/8][q 3][lane 64][4] with position 6 i + j = 3 wave + q, cout = 32 half + (lane & 31)
@@ -109,8 +109,8 @@ def pack_conv_wino4(weight: torch.Tensor) -> torch.Tensor:
     co, cin, kh, kw = weight.shape
     if co != 64 or cin % 8 or (kh, kw) != (3, 3):
         raise ValueError(f"unsupported convolution shape {tuple(weight.shape)}")
-    g = torch.tensor(_WINO4_G, dtype=torch.float64, device=weight.device)
-    u = torch.einsum("ia,ocab,jb->ocij", g, weight.detach().to(torch.float64), g).to(torch.float32)
+    g = torch.tensor(_WINO4_G, dtype=dtype, device=weight.device)
+    u = torch.einsum("ia,ocab,jb->ocij", g, weight.detach().to(dtype), g).to(torch.float32)
     u = u.reshape(2, 32, cin // 8, 4, 2, 12, 3)                 # [half, m, chunk, e, h, wave, q]
     return u.permute(5, 0, 2, 6, 4, 1, 3).reshape(-1)           # [wave, half, chunk, q, h, m, e]
 

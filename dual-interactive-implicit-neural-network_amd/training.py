@@ -52,6 +52,12 @@ PARAM_SHAPES: Dict[str, Tuple[int, ...]] = {
     "last_layer.weight": (3, HIDDEN, 1, 1), "last_layer.bias": (3,),
 }
 
+# backward_fused: the hoisted conv's gradients on the library's own kernels instead of torch.nn.grad (MIOpen).  Measured at B = 16,
+# 48x48 x4 (tools/train_conv_grads_ab.py): the input gradient is a 1024 -> 64 3x3 convolution = the encoder's Winograd kernel
+# (0.19 ms against MIOpen's 0.39); the weight gradient as unfold + plane GEMM costs 0.5 ms MORE than MIOpen's implicit GEMM
+# (im2col and two layout copies of 85-151 MB around a 0.42 ms GEMM), so it is available, not the default.
+NATIVE_CONV_DGRAD = True
+NATIVE_CONV_WGRAD = False
 WGRAD_KSPLIT = 64          # pixel-axis splits of the weight-gradient GEMM: 4 output blocks x 64 = one workgroup per CU
 ROWDOT_SPLITS = 1024       # workgroups of the skinny products (HBM-bound)
 
@@ -219,15 +225,82 @@ def backward_from_saved(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tens
     return d_feat, [grads[name] for name in PARAM_NAMES]
 
 
+WGRAD_CONV_KSPLIT = 12     # pixel-axis splits of the hoisted conv's weight-gradient GEMM (20 output blocks x 12)
+
+
+def _conv_grads_native(feat: torch.Tensor, wx: torch.Tensor, dp: torch.Tensor, need_feat_grad: bool, want_weight: bool = True):
+    """Gradients of P = conv3x3(feat; Wx[1024,64,3,3]) on the library's own kernels (no MIOpen in the decoder's step):
+      weight:  dWx[o, (c,ky,kx)] = sum over cells of dP[o, cell] * unfold3x3(feat)[(c,ky,kx), cell] -- the plane GEMM over the
+               cell axis (plane_gemm_kernel; the 576 unfolded rows padded to 640 = 5 x 128);
+      input :  d_feat = conv3x3(dP; Wx transposed and flipped) -- a 64-output 3x3 convolution over 1024 planes, i.e. the
+               encoder's convolution kernels (Winograd F(4x4) / F(2x2) / split-K by the same rule as the trunk)."""
+    from . import modules as M                                   # (pack functions; imported late: modules imports the decoder)
+    lib = _native.load()
+    b, c, h, w = feat.shape
+    n = b * h * w
+    dev = feat.device
+    ptr = lambda x: C.c_void_p(x.data_ptr())                      # noqa: E731
+    dp = dp.contiguous()
+    d_wx = None
+    if want_weight:
+        unf = F.unfold(feat, 3, padding=1)                       # [B, 576, H*W], rows (c, ky, kx): the reference's unfold order
+        if (h * w) % PLANE_TILE == 0:                            # one copy each straight into the tiled layout [tile][row][32]
+            tpi = h * w // PLANE_TILE
+            b_t = torch.empty((b * tpi, 640, PLANE_TILE), dtype=torch.float32, device=dev)
+            b_t[:, UNFOLD:] = 0
+            b_t.view(b, tpi, 640, PLANE_TILE)[:, :, :UNFOLD] = unf.view(b, UNFOLD, tpi, PLANE_TILE).permute(0, 2, 1, 3)
+            a_t = dp.view(b, 4 * HIDDEN, tpi, PLANE_TILE).permute(0, 2, 1, 3).contiguous().view(b * tpi, 4 * HIDDEN, PLANE_TILE)
+        else:
+            unf = unf.permute(1, 0, 2).reshape(UNFOLD, n)
+            b_t = tile_planes(torch.cat([unf, unf.new_zeros((640 - UNFOLD, n))], 0))
+            a_t = tile_planes(dp.permute(1, 0, 2, 3).reshape(4 * HIDDEN, n))
+        # the product is taken transposed, dWx^T [640 x 1024] = unfold . dP^T: with 1024 = 4 x 256 columns it runs on the kernel's
+        # 128 x 256 block form (113 TFLOP/s; the 128 x 128 form the 640 columns of dWx would need: 70)
+        ks = max(1, min(WGRAD_CONV_KSPLIT, a_t.shape[0]))
+        part = torch.empty((ks, 640, 4 * HIDDEN), dtype=torch.float32, device=dev)
+    d_feat = None
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if want_weight:
+            _native.check(lib.diinn_plane_gemm_nt(stream, ptr(b_t), 640, 0, ptr(a_t), 4 * HIDDEN, 0, ptr(part), 640, 4 * HIDDEN, n, ks, 0),
+                          "diinn_plane_gemm_nt")
+            d_wx = part.sum(0)[:UNFOLD].t()
+        if need_feat_grad:
+            wt = wx.flip(2, 3).permute(1, 0, 2, 3).contiguous()          # [64, 1024, 3, 3]
+            d_feat = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
+            zero = torch.zeros(64, dtype=torch.float32, device=dev)
+            cin = 4 * HIDDEN
+            if lib.diinn_rdn_wino4_applies(b, h, w):
+                pk = M.pack_conv_wino4(wt, dtype=torch.float32)  # (the gradient's 1e-4 bound does not need the float64 transform)
+                _native.check(lib.diinn_conv_wino4(stream, ptr(dp), cin * h * w, cin, ptr(pk), ptr(zero), None, 0, ptr(d_feat),
+                                                   c * h * w, 0, b, h, w), "diinn_conv_wino4")
+            elif n >= 8192:
+                pk = M.pack_conv_wino(wt, dtype=torch.float32)
+                _native.check(lib.diinn_conv_wino(stream, ptr(dp), cin * h * w, cin, ptr(pk), ptr(zero), None, 0, ptr(d_feat),
+                                                  c * h * w, 0, b, h, w), "diinn_conv_wino")
+            else:
+                pk = M.pack_conv_ksplit(wt)
+                _native.check(lib.diinn_conv_ksplit(stream, ptr(dp), cin * h * w, cin, 9, ptr(pk), ptr(zero), None, 0, ptr(d_feat),
+                                                    c * h * w, None, 0, 0, b, h, w), "diinn_conv_ksplit")
+    return d_wx, d_feat
+
+
 def _conv_and_assemble(p: Dict[str, torch.Tensor], feat: torch.Tensor, dp: torch.Tensor, d_wq, d_bk,
-                       grads: Dict[str, torch.Tensor], need_feat_grad: bool) -> Optional[torch.Tensor]:
-    """P = conv3x3(feat; Wx[1024,64,3,3]) + bK: weight / input gradients of that one convolution (MIOpen),
-    then the K.i gradients in the reference's [256, 256+576] layout."""
+                       grads: Dict[str, torch.Tensor], need_feat_grad: bool, native: bool = False) -> Optional[torch.Tensor]:
+    """P = conv3x3(feat; Wx[1024,64,3,3]) + bK: weight / input gradients of that one convolution (``native``: the
+    library's kernels, else torch.nn.grad = MIOpen on the GPU), then the K.i gradients in the reference's [256, 256+576] layout."""
     wx = torch.cat([p["K.0.0.weight"].reshape(HIDDEN, UNFOLD)]
                    + [p[f"K.{i}.0.weight"].reshape(HIDDEN, HIDDEN + UNFOLD)[:, HIDDEN:] for i in (1, 2, 3)], 0)
     wx = wx.reshape(4 * HIDDEN, IN_CHANNELS, 3, 3).contiguous()
-    d_wx = torch.nn.grad.conv2d_weight(feat, wx.shape, dp, padding=1).reshape(4, HIDDEN, UNFOLD)
-    d_feat = torch.nn.grad.conv2d_input(feat.shape, wx, dp, padding=1) if need_feat_grad else None
+    nat_w, nat_d = (native if isinstance(native, tuple) else (bool(native), bool(native)))
+    d_wx = d_feat = None
+    if nat_w or (nat_d and need_feat_grad):
+        d_wx, d_feat = _conv_grads_native(feat, wx, dp, need_feat_grad and nat_d, want_weight=nat_w)
+    if d_wx is None:
+        d_wx = torch.nn.grad.conv2d_weight(feat, wx.shape, dp, padding=1)
+    if d_feat is None and need_feat_grad:
+        d_feat = torch.nn.grad.conv2d_input(feat.shape, wx, dp, padding=1)
+    d_wx = d_wx.reshape(4, HIDDEN, UNFOLD)
     grads["K.0.0.weight"] = d_wx[0].reshape(HIDDEN, UNFOLD, 1, 1)
     grads["K.0.0.bias"] = d_bk[0]
     for i in (1, 2, 3):
@@ -347,7 +420,7 @@ def backward_fused(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tensor, p
     d_bk[0] = d0[:HIDDEN, 3]
     grads["Q.0.0.weight"] = d0[HIDDEN:, :3].reshape(HIDDEN, 3, 1, 1)
     grads["Q.0.0.bias"] = d0[HIDDEN:, 3]
-    d_feat = _conv_and_assemble(p, feat, dp, d_wq, d_bk, grads, need_feat_grad)
+    d_feat = _conv_and_assemble(p, feat, dp, d_wq, d_bk, grads, need_feat_grad, native=(NATIVE_CONV_WGRAD, NATIVE_CONV_DGRAD))
     return d_feat, [grads[name] for name in PARAM_NAMES]
 
 

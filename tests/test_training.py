@@ -316,3 +316,26 @@ def test_plane_gemm_kernel():
         assert float((pr.double().sum(0) - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * max(1.0, (npix / 1000) ** 0.5)
     assert lib.diinn_plane_gemm_nt(None, ptr(a_t), 128, 0, ptr(b_t), 256, 0, ptr(part), 256, 256, 31, 1, 0) == N.ERR_INVALID_ARG
     assert lib.diinn_plane_gemm_nt(None, ptr(a_t), 128, 0, ptr(b_t), 256, 0, ptr(part), 64, 256, 31, 1, 0) == N.ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+def test_hoisted_conv_gradients_on_the_library_kernels():
+    """training._conv_grads_native: the hoisted 3x3 convolution's input gradient as a 1024 -> 64 convolution on the encoder's
+    kernels (split-K / Winograd F(2x2) / F(4x4) by map size) and its weight gradient as unfold + plane GEMM, against
+    torch.nn.grad (MIOpen): batch 1 (a permuted view that needs its copy), ragged maps (the untiled fallback), the training
+    geometry.  The F(4x4) input gradient at B = 16, 48x48 differs by 2.5e-5 of its maximum (F(2x2) / split-K: 1e-6)."""
+    import diinn_amd.training as T
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    for (b, h, w) in [(1, 8, 8), (2, 8, 8), (1, 6, 5), (2, 12, 16), (3, 7, 9), (1, 96, 100), (16, 48, 48)]:
+        feat = torch.randn(b, 64, h, w, device=dev)
+        wx = torch.randn(1024, 64, 3, 3, device=dev) * 0.05
+        dp = torch.randn(b, 1024, h, w, device=dev)
+        dw_ref = torch.nn.grad.conv2d_weight(feat, wx.shape, dp, padding=1).reshape(1024, 576)
+        df_ref = torch.nn.grad.conv2d_input(feat.shape, wx, dp, padding=1)
+        dw, df = T._conv_grads_native(feat, wx, dp, True)
+        torch.cuda.synchronize()
+        assert float((dw - dw_ref).abs().max()) <= 1e-5 * float(dw_ref.abs().max()), (b, h, w)
+        assert float((df - df_ref).abs().max()) <= 5e-5 * float(df_ref.abs().max()), (b, h, w)
+        dw2, df2 = T._conv_grads_native(feat, wx, dp, True, want_weight=False)
+        assert dw2 is None and torch.equal(df2, df)
