@@ -107,7 +107,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         return tile < tiles_n;
     };
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..11: MFMA waves; 12..15: transform waves
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..15: the role follows from wave & 3 (below)
     const size_t plane = (size_t)p.H * p.W;
     const unsigned plane_b = (unsigned)(plane * sizeof(float));
     const int n = p.Cin / 8;                                     // chunks of 8 input channels
@@ -127,11 +127,9 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
     if (threadIdx.x == 0) W4_STAMP(0, 76, 0);                     // body start
     if (producer) {
         // ---- transform waves: one (tile, channel of the chunk) patch per thread: wave wt takes the chunk's channels
-        // 2 wt and 2 wt + 1 (= k-step wt of the MFMAs), a lane one of the block's 32 tiles.  Its input is in LDS already
-        // (raw slots, filled by the MFMA waves' LDS-DMA requests): per chunk and wave six 1-KiB rows [row k][channel 2]
-        // [128 columns] + the 24 values left and right of the block (6 rows x 2 channels x 2 sides).  These waves issue no
-        // vector-memory instruction at all: a chunk's transform is one serial instruction stream per SIMD and sets the
-        // iteration time, so nothing that can stall goes into it.
+        // 2 wt and 2 wt + 1 (= k-step wt of the MFMAs), a lane one of the block's 32 tiles.  Its input comes through LDS
+        // (raw slots, filled by LDS-DMA): per chunk and wave six 1-KiB rows [row k][channel 2][128 columns] + the 24
+        // values left and right of the block (6 rows x 2 channels x 2 sides); no patch is held in registers.
         const int wt = wt_;
 #ifndef W4_ABL_NOPRIO
         __builtin_amdgcn_s_setprio(3);                           // the chunk's critical path: ahead of the MFMA waves' issue
