@@ -306,3 +306,19 @@ def test_tile_entry_point_validates_ranges_and_strides(lib):
     assert tile(0, 8, 0, 40, *ok_strides, p_row0=5, p_rows=4) == 1   # the P window does not hold the tile's LR rows
     assert tile(0, 8, 0, 40, *ok_strides, compute=99) == 2      # unsupported arithmetic
     assert tile(0, 8, 0, 40, *ok_strides, sin=7) == 2
+
+
+def test_conv_wino4_entry_point_validates_its_arguments(lib):
+    """diinn_conv_wino4 / diinn_rdn_forward_wino4 (Winograd F(4x4,3x3) encoder layers): null pointers, channel counts that are
+    not multiples of 8, unaligned images and empty maps are refused before anything is launched (no GPU needed)."""
+    import ctypes as C
+    d = C.c_void_p(4096)                                         # never dereferenced: every call below fails validation
+
+    def conv(inp=d, cin=64, packed=d, bias=d, out=d, b=1, h=64, w=64):
+        return lib.diinn_conv_wino4(None, inp, cin * h * w, cin, packed, bias, None, 0, out, 64 * h * w, 1, b, h, w)
+    assert conv(inp=None) == 1 and conv(packed=None) == 1 and conv(bias=None) == 1 and conv(out=None) == 1
+    assert conv(cin=12) == 2 and conv(cin=0) == 2
+    assert conv(packed=C.c_void_p(4100)) == 1                    # the weight image is read with 16-byte loads
+    assert conv(b=0) == 1 and conv(h=0) == 1
+    assert lib.diinn_rdn_forward_wino4(None, d, d, d, None, d, d, d, 1, 64, 64) == 1     # without the F(4x4) image
+    assert lib.diinn_rdn_wino4_packed_floats() == lib.diinn_rdn_wino_packed_floats() // 16 * 36
