@@ -151,6 +151,40 @@ def test_conv_wino4_kernel_fuzz():
 
 
 @pytest.mark.gpu
+def test_conv_wino4_kernel_fuzz_large_maps():
+    """Seeded random LARGE shapes (several rounds of workgroups, work items that wrap across tile rows, batch 1..3, widths that
+    are / are not multiples of 4) through diinn_conv_wino4 against a float64 convolution."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    rng = np.random.default_rng(21)
+    gen = torch.Generator(device=dev).manual_seed(21)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
+    for _ in range(10):
+        b, cin = int(rng.integers(1, 4)), 8 * int(rng.integers(1, 9))
+        h, w = int(rng.integers(100, 330)), int(rng.integers(100, 420))
+        relu, use_res = int(rng.integers(2)), int(rng.integers(2))
+        x = torch.randn((b, cin, h, w), device=dev, generator=gen)
+        wt = torch.randn((64, cin, 3, 3), device=dev, generator=gen) / (cin * 9) ** 0.5
+        bias = torch.randn(64, device=dev, generator=gen)
+        res = torch.randn((b, 64, h, w), device=dev, generator=gen) if use_res else None
+        out = torch.full((b, 64, h, w), float("nan"), device=dev)
+        packed = M.pack_conv_wino4(wt).to(dev)
+        assert lib.diinn_conv_wino4(stream, ptr(x), cin * h * w, cin, ptr(packed), ptr(bias), ptr(res) if use_res else None,
+                                    64 * h * w, ptr(out), 64 * h * w, relu, b, h, w) == 0
+        ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+        if relu:
+            ref = torch.relu(ref)
+        if use_res:
+            ref = ref + res.double()
+        err = float((out.double() - ref).abs().max())
+        assert err <= 4e-5 * max(1.0, float(ref.abs().max())), (b, cin, h, w, relu, use_res, err)
+
+
+@pytest.mark.gpu
 def test_conv_wino4_back_to_back_launches_are_bit_identical():
     """Race screen for the kernel's LDS-DMA / barrier structure: 90 back-to-back launches on the same input (two shapes: one
     workgroup per CU with 64 chunk iterations; ragged, more work items than CUs) all equal the first result bit for bit -- a read
