@@ -28,10 +28,13 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import datetime
 import json
 import os
+import socket
 import statistics
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -85,6 +88,11 @@ def parse():
                          "exercised on a one-GPU box (RCCL refuses two ranks on one device) -- a test transport, "
                          "its timings mean nothing.  DIINN_BENCH_BACKEND sets the default, so that the driver's literal "
                          "command line can be run on such a box")
+    ap.add_argument("--dist-timeout", type=int, default=int(os.environ.get("DIINN_BENCH_DIST_TIMEOUT", "300")),
+                    help="N>1: seconds a collective of the process group may wait for a peer before the rank fails")
+    ap.add_argument("--watchdog", type=int, default=int(os.environ.get("DIINN_BENCH_WATCHDOG", "1500")),
+                    help="seconds after which a run that has not finished is ended with exit code 124 (0: off): a hung "
+                         "rank or hand-off exits non-zero inside the driver's budget -- the process is ENDED, never re-executed")
     ap.add_argument("--no-strong", action="store_true", help="N>1: skip the strong-scaling legs")
     ap.add_argument("--strong-legs", default=None, help="N>1: comma-separated workloads of the strong-scaling legs "
                                                           "(default by N: tgt+c3 at 2/4, tgt+c4 at 8)")
@@ -302,11 +310,15 @@ class Job:
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
+            # an explicit collective timeout: a rank that never shows up (or a hung hand-off) ends the job with an error
+            # inside the driver's budget instead of the 10-30 minute defaults; the watchdog in main() is the backstop
+            tmo = datetime.timedelta(seconds=args.dist_timeout)
             if self.gloo:
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world, timeout=tmo)
             else:
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev, timeout=tmo)
             dist.barrier()           # first RCCL call is a plain collective on every rank
+        self.local_rank = local_rank
 
         import diinn_amd._native as N
         import diinn_amd.decoder as D
@@ -320,6 +332,36 @@ class Job:
         self.comp = N.COMPUTE[args.compute]
         self.sd = synth.decoder_state_dict(123)
         self.packed = D.pack_state_dict(self.sd).to(self.dev)
+
+    def census(self):
+        """Who took part: one record per rank -- rank, local rank, the device it computed on (index,
+        name, UUID, PCI bus id), the collective backend, how many of the node's other GPUs it can reach peer-to-peer (xGMI) --
+        gathered on every rank through the backend itself, plus the world size the backend reports and the number of DISTINCT
+        devices.  From the JSON line alone a reader can tell whether RCCL saw N ranks on N devices."""
+        prop = torch.cuda.get_device_properties(self.dev)
+        ndev = torch.cuda.device_count()
+        peers = 0
+        for other in range(ndev):
+            if other != self.dev.index:
+                try:
+                    peers += bool(torch.cuda.can_device_access_peer(self.dev.index, other))
+                except Exception:                                 # noqa: BLE001  (a runtime without the query: unknown)
+                    peers = -1
+                    break
+        me = {"rank": self.rank, "local_rank": self.local_rank, "device": self.dev.index, "name": prop.name,
+              "device_uuid": str(getattr(prop, "uuid", "")),
+              "pci_bus_id": "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", 0),
+                                                getattr(prop, "pci_device_id", 0)),
+              "backend": (dist.get_backend() if self.use_dist else "none"), "visible_devices": ndev, "xgmi_peers": peers,
+              "host": socket.gethostname(), "pid": os.getpid()}
+        if not self.use_dist:
+            ranks = [me]
+        else:
+            ranks = [None] * self.world
+            dist.all_gather_object(ranks, me)
+        ids = {(r["host"], r["device_uuid"] or r["pci_bus_id"]) for r in ranks}
+        return {"ranks": ranks, "rccl_world": (dist.get_world_size() if self.use_dist else 1),
+                "backend": me["backend"], "distinct_devices": len(ids)}
 
     # collectives of the harness itself (timing / verdict exchange): host tensors on gloo, device tensors on RCCL
     def _t(self, vals):
@@ -601,9 +643,19 @@ def main():
     sys.stdout.flush()
     result_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+    if args.watchdog > 0:
+        def _expired():
+            sys.stderr.write(f"bench.py: rank {os.environ.get('RANK', '0')} still running after {args.watchdog} s "
+                             f"(hung collective or hand-off?): exiting with code 124\n")
+            sys.stderr.flush()
+            os._exit(124)
+        wd = threading.Timer(args.watchdog, _expired)
+        wd.daemon = True
+        wd.start()
     job = Job(args)
     world, rank = job.world, job.rank
     N = job.N
+    census = job.census()
 
     r = run_workload(job, args.workload, args.scaling, args.steps, args.warmup, check=not args.no_check,
                      gather=args.gather)
@@ -760,6 +812,12 @@ def main():
                                   "peak": round(l1_peak, 1), "unit": "TB/s", "frac": round(l1_ach / l1_peak, 4),
                                   "note": "weight refills arrive in bursts (one per layer, all 8 waves at once): the "
                                           "bound is the burst, not the average"}
+        # who ran: N > 1 must show N ranks on N distinct devices on the real backend ("nccl" = RCCL); the one-device test
+        # transport shows N ranks on 1 device
+        res["rccl_world"] = census["rccl_world"]
+        res["backend"] = census["backend"]
+        res["distinct_devices"] = census["distinct_devices"]
+        res["ranks"] = census["ranks"]
         if checked is not None:
             res["checked"] = checked
         if gather_ms is not None:

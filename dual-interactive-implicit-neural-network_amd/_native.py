@@ -22,8 +22,8 @@ SIN_HW_REDUCED = 2
 # default: 2-term reduction in revolutions + v_sin_f32 (max abs error 2.5e-7 for |x| <= 1e4, measured in
 # tests/test_gpu_parity.py::test_device_sine_accuracy); SIN_ACCURATE (1e-7) costs ~4 % more time
 SIN_DEFAULT = SIN_HW_REDUCED
-ABI_VERSION = 7
-PACKED_MAGIC = 0x44493036
+ABI_VERSION = 8
+PACKED_MAGIC = 0x44493038
 P_ALGO_DIRECT, P_ALGO_WINOGRAD, P_ALGO_DIRECT_BF16, P_ALGO_DIRECT_BF16X3 = 0, 1, 2, 3
 COMPUTE_F32 = 0
 COMPUTE_BF16 = 1
@@ -106,6 +106,11 @@ SIGNATURES = {
     "diinn_rdn_wino_packed_floats": (C.c_size_t, []),
     "diinn_conv_wino4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "diinn_conv_wino4_ws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_size_t]),
+    "diinn_conv_wino4_workspace_floats": (C.c_size_t, []),
+    "diinn_conv_wino4_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "diinn_rdn_wino4_packed_floats": (C.c_size_t, []),
     "diinn_rdn_wino4_applies": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "diinn_rdn_forward_wino4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

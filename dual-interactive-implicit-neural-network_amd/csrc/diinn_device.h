@@ -278,6 +278,10 @@ __attribute__((visibility("hidden"))) extern thread_local int g_last_hip_error; 
 extern unsigned long long* g_stamps;            // diinn_misc.hip
 #endif
 
+__attribute__((visibility("hidden"))) int device_cus();                                // diinn_misc.hip
+// diinn_winograd4.hip: the F(4x4,3x3) kernel's time for `total` work items, in rounds of whole items on `ncu` compute units
+__attribute__((visibility("hidden"))) double w4_rounds(long long total, int ncu, bool have_ws);
+
 static inline int hip_status(hipError_t e) {
     if (e == hipSuccess) return DIINN_OK;
     g_last_hip_error = (int)e;

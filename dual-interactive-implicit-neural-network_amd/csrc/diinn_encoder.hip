@@ -610,8 +610,10 @@ size_t diinn_rdn_packed_floats(void) {
 }
 
 size_t diinn_rdn_workspace_floats(int B, int H, int W) {
+    // [the F(4x4,3x3) kernel's split area (counters first: they are zeroed at the start of every forward)][two dense
+    // buffers 576][global fusion input 1024][64]
     if (B <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)B * H * W * (2 * 576 + 1024 + 64);
+    return diinn_conv_wino4_workspace_floats() + (size_t)B * H * W * (2 * 576 + 1024 + 64);
 }
 
 size_t diinn_rdn_wino_packed_floats(void) {
@@ -648,8 +650,9 @@ int diinn_rdn_wino4_applies(int B, int H, int W) {
     if (forced >= 0) return px >= forced;
     const long long items4 = 2LL * B * (((long long)((W + 3) / 4) * ((H + 3) / 4) + 31) / 32);   // blocks of 32 consecutive tiles x 2 output halves
     const long long blocks2 = (long long)B * (((W + 1) / 2 + 7) / 8) * (((H + 1) / 2 + 3) / 4);
-    const double r4 = 1.44 * (double)((items4 + 255) / 256);
-    const double r2w = (double)((blocks2 + 255) / 256), r2h = 0.57 * (double)((2 * blocks2 + 255) / 256);
+    const int ncu = device_cus();
+    const double r4 = 1.44 * w4_rounds(items4, ncu, true);       // (the trunk gives the kernel its workspace: a partly filled last round is split)
+    const double r2w = (double)((blocks2 + ncu - 1) / ncu), r2h = 0.57 * (double)((2 * blocks2 + ncu - 1) / ncu);
     return r4 < 0.97 * (r2w < r2h ? r2w : r2h);
 }
 
@@ -669,8 +672,17 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     // costs 1.44 F(2x2) rounds of whole blocks (16 x 8 pixels x both halves; a round of halves 0.57): the cheaper one
     // by that count runs.  DIINN_ENC_WINO4_MIN = n >= 0 replaces the rule by "from n pixels on".
     const bool wino4 = packed_wino4_dev && wino && diinn_rdn_wino4_applies(B, H, W);
-    float* buf[2] = {workspace_dev, workspace_dev + (size_t)B * 576 * hw};     // dense buffers [B,576,H,W]
-    float* gff_in = workspace_dev + (size_t)2 * B * 576 * hw;                    // [B,1024,H,W]
+    // the F(4x4) kernel's split area leads the workspace; its arrival counters (the first 4 KiB) are zeroed here, once per
+    // forward, whatever a caller or an aborted launch left there (a memset node: capture-safe)
+    float* const w4ws = workspace_dev;
+    const size_t w4ws_floats = diinn_conv_wino4_workspace_floats();
+    if (wino4) {
+        st = hip_status(hipMemsetAsync(w4ws, 0, 4096, (hipStream_t)stream));
+        if (st) return st;
+    }
+    float* const planes = workspace_dev + w4ws_floats;
+    float* buf[2] = {planes, planes + (size_t)B * 576 * hw};                   // dense buffers [B,576,H,W]
+    float* gff_in = planes + (size_t)2 * B * 576 * hw;                           // [B,1024,H,W]
     float* tmp = gff_in + (size_t)B * 1024 * hw;                                 // [B,64,H,W]
     // split-bf16 3x3 layers (csrc/diinn_conv_x3.hip; optional): blocks of 32 x 8 pixels; they pay from about 0.8 blocks
     // per CU on (measured per trunk, x3 vs Winograd: 160x160 7.8 vs 6.2 ms, 192x192 7.2 vs 9.3, 224x224 7.5 vs 11.4, 256x256 8.6 vs 11.8,
@@ -686,7 +698,7 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
         const int s = (x3 && taps == 9 && !o1)
             ? diinn_conv3x3_x3(stream, in, in_bs, cin, wx, bias, res, res_bs, o0, o0_bs, relu, B, H, W)
             : (wino4 && taps == 9 && !o1)
-            ? diinn_conv_wino4(stream, in, in_bs, cin, wu4, bias, res, res_bs, o0, o0_bs, relu, B, H, W)
+            ? diinn_conv_wino4_ws(stream, in, in_bs, cin, wu4, bias, res, res_bs, o0, o0_bs, relu, B, H, W, w4ws, w4ws_floats)
             : (wino && taps == 9 && !o1)
             ? diinn_conv_wino(stream, in, in_bs, cin, wu, bias, res, res_bs, o0, o0_bs, relu, B, H, W)
             : diinn_conv_ksplit(stream, in, in_bs, cin, taps, w, bias, res, res_bs, o0, o0_bs, o1, o1_bs, relu, B, H, W);

@@ -33,6 +33,7 @@ const KnobDef KNOBS[] = {
     {"DIINN_ENC_X3_ROWS", &DiinnKnobs::enc_x3_rows, 0, false},
     {"DIINN_ENC_WINO_HALF_MAX", &DiinnKnobs::enc_wino_half_max, -1, false},
     {"DIINN_ENC_WINO_PERSIST", &DiinnKnobs::enc_wino_persist, 256, false},
+    {"DIINN_ENC_WINO4_SPLIT", &DiinnKnobs::enc_wino4_split, 1, false},
 };
 }  // namespace
 

@@ -25,6 +25,20 @@ __global__ void axis_tables_kernel(Axis a, int n_out, int32_t* idx, float* rel) 
 }
 
 thread_local int g_last_hip_error = 0;
+
+// compute units of the current device, asked once per device (cost models and persistent grids: an MI355X has 256, a
+// partitioned one fewer); 256 if the runtime cannot say
+int device_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
 #ifdef DIINN_STAMPS
 unsigned long long* g_stamps = nullptr;
 extern "C" int diinn_debug_set_stamp_buffer(void* dev_ptr) { g_stamps = (unsigned long long*)dev_ptr; return 0; }

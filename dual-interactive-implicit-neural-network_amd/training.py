@@ -228,7 +228,8 @@ def backward_from_saved(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tens
 WGRAD_CONV_KSPLIT = 12     # pixel-axis splits of the hoisted conv's weight-gradient GEMM (20 output blocks x 12)
 
 
-def _conv_grads_native(feat: torch.Tensor, wx: torch.Tensor, dp: torch.Tensor, need_feat_grad: bool, want_weight: bool = True):
+def _conv_grads_native(feat: torch.Tensor, wx: torch.Tensor, dp: torch.Tensor, need_feat_grad: bool, want_weight: bool = True,
+                       wkey=None):
     """Gradients of P = conv3x3(feat; Wx[1024,64,3,3]) on the library's own kernels (no MIOpen in the decoder's step):
       weight:  dWx[o, (c,ky,kx)] = sum over cells of dP[o, cell] * unfold3x3(feat)[(c,ky,kx), cell] -- the plane GEMM over the
                cell axis (plane_gemm_kernel; the 576 unfolded rows padded to 640 = 5 x 128);
@@ -266,23 +267,44 @@ def _conv_grads_native(feat: torch.Tensor, wx: torch.Tensor, dp: torch.Tensor, n
                           "diinn_plane_gemm_nt")
             d_wx = part.sum(0)[:UNFOLD].t()
         if need_feat_grad:
-            wt = wx.flip(2, 3).permute(1, 0, 2, 3).contiguous()          # [64, 1024, 3, 3]
             d_feat = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
             zero = torch.zeros(64, dtype=torch.float32, device=dev)
             cin = 4 * HIDDEN
-            if lib.diinn_rdn_wino4_applies(b, h, w):
-                pk = M.pack_conv_wino4(wt, dtype=torch.float32)  # (the gradient's 1e-4 bound does not need the float64 transform)
-                _native.check(lib.diinn_conv_wino4(stream, ptr(dp), cin * h * w, cin, ptr(pk), ptr(zero), None, 0, ptr(d_feat),
-                                                   c * h * w, 0, b, h, w), "diinn_conv_wino4")
-            elif n >= 8192:
-                pk = M.pack_conv_wino(wt, dtype=torch.float32)
+            form = "wino4" if lib.diinn_rdn_wino4_applies(b, h, w) else "wino" if n >= 8192 else "ksplit"
+            # the transposed weight in the kernel's form: repacked only when a K weight changed (an optimizer step, a
+            # load_state_dict), not on every backward call.  The Winograd transforms are taken in float64 and rounded once,
+            # like the encoder's: F(4x4)'s gradient error 2.5e-5 -> ~1e-5 of max|d_feat| (the fixtures' bound is 1e-4).
+            global _dgrad_pack
+            key = (form, str(dev), wkey)
+            if wkey is None or _dgrad_pack[0] != key:
+                wt = wx.flip(2, 3).permute(1, 0, 2, 3).contiguous()      # [64, 1024, 3, 3]
+                pk = (M.pack_conv_wino4(wt) if form == "wino4" else M.pack_conv_wino(wt) if form == "wino" else M.pack_conv_ksplit(wt))
+                _dgrad_pack = (key, pk)
+            pk = _dgrad_pack[1]
+            if form == "wino4":
+                ws = _wino4_workspace(dev)                       # (a partly filled last round is split over the input channels)
+                _native.check(lib.diinn_conv_wino4_ws(stream, ptr(dp), cin * h * w, cin, ptr(pk), ptr(zero), None, 0, ptr(d_feat),
+                                                      c * h * w, 0, b, h, w, ptr(ws), ws.numel()), "diinn_conv_wino4_ws")
+            elif form == "wino":
                 _native.check(lib.diinn_conv_wino(stream, ptr(dp), cin * h * w, cin, ptr(pk), ptr(zero), None, 0, ptr(d_feat),
                                                   c * h * w, 0, b, h, w), "diinn_conv_wino")
             else:
-                pk = M.pack_conv_ksplit(wt)
                 _native.check(lib.diinn_conv_ksplit(stream, ptr(dp), cin * h * w, cin, 9, ptr(pk), ptr(zero), None, 0, ptr(d_feat),
                                                     c * h * w, None, 0, 0, b, h, w), "diinn_conv_ksplit")
     return d_wx, d_feat
+
+
+_dgrad_pack: tuple = (None, None)                  # (key, the transposed hoisted-conv weight in the dgrad kernel's form)
+_wino4_ws: Dict[str, torch.Tensor] = {}
+
+
+def _wino4_workspace(dev) -> torch.Tensor:
+    """diinn_conv_wino4_ws's workspace, one per device: zeroed once (the kernel leaves its counters zero); launches that
+    share it are ordered by the stream they run on -- callers on several streams of one device must not share it."""
+    ws = _wino4_ws.get(str(dev))
+    if ws is None:
+        ws = _wino4_ws[str(dev)] = torch.zeros(_native.load().diinn_conv_wino4_workspace_floats(), dtype=torch.float32, device=dev)
+    return ws
 
 
 def _conv_and_assemble(p: Dict[str, torch.Tensor], feat: torch.Tensor, dp: torch.Tensor, d_wq, d_bk,
@@ -295,7 +317,8 @@ def _conv_and_assemble(p: Dict[str, torch.Tensor], feat: torch.Tensor, dp: torch
     nat_w, nat_d = (native if isinstance(native, tuple) else (bool(native), bool(native)))
     d_wx = d_feat = None
     if nat_w or (nat_d and need_feat_grad):
-        d_wx, d_feat = _conv_grads_native(feat, wx, dp, need_feat_grad and nat_d, want_weight=nat_w)
+        wkey = tuple((p[f"K.{i}.0.weight"].data_ptr(), p[f"K.{i}.0.weight"]._version) for i in range(4))
+        d_wx, d_feat = _conv_grads_native(feat, wx, dp, need_feat_grad and nat_d, want_weight=nat_w, wkey=wkey)
     if d_wx is None:
         d_wx = torch.nn.grad.conv2d_weight(feat, wx.shape, dp, padding=1)
     if d_feat is None and need_feat_grad:

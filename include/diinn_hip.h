@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIINN_ABI_VERSION 7
+#define DIINN_ABI_VERSION 8
 /* History of the ABI number:
  *   1  diinn_pack_weights, axis tables, diinn_precompute_P / diinn_decode_band / diinn_decode (+ _ex: compute modes)
  *   2  training (diinn_decode_train_fwd, diinn_backward_*, diinn_plane_*), LIIF / MetaSR, the encoder trunk
@@ -46,7 +46,11 @@ extern "C" {
  *      split-bf16 encoder layers (diinn_conv3x3_x3, diinn_rdn_forward_x3)
  *   7  tiles: diinn_decode_tile_win (HR column range + output strides; the row-band entry points are wrappers of it);
  *      packed section 16 (WL16) and the 16-pixel fp32 latency kernel for the smallest launches (DIINN_F32_KERNEL = 3);
- *      Winograd F(4x4,3x3) encoder layers (diinn_conv_wino4, diinn_rdn_forward_wino4) */
+ *      Winograd F(4x4,3x3) encoder layers (diinn_conv_wino4, diinn_rdn_forward_wino4)
+ *   8  the validity word follows the layout (DIINN_PACKED_MAGIC "DI08": an image packed by an older library is shorter
+ *      and now decodes to NaN instead of being read past its end); diinn_conv_wino4_ws / _workspace_floats / _plan (the
+ *      F(4x4,3x3) layer's last round split over the input channels) and a larger diinn_rdn_workspace_floats for it;
+ *      diinn_decode_kernel_info */
 
 /* status codes */
 #define DIINN_OK                 0
@@ -135,7 +139,7 @@ size_t diinn_packed_weight_floats(void);
  * made by the kernels: every inference entry point that reads a derived section (diinn_precompute_P_ex / _win,
  * diinn_decode*, in every compute mode) writes NaN into ALL of its outputs when the word is missing -- a loud
  * wrong answer instead of a silent one (tests/test_gpu_parity.py::test_image_without_derived_sections_is_refused). */
-#define DIINN_PACKED_MAGIC 0x44493036u   /* "DI06" */
+#define DIINN_PACKED_MAGIC 0x44493038u   /* "DI08": changes whenever the packed layout does (sections, sizes) */
 int    diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats);
 int    diinn_pack_weights(const float* K0w, const float* K0b,
                           const float* const Kw[3], const float* const Kb[3],
@@ -382,11 +386,22 @@ int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* 
 
 /* Winograd F(4x4, 3x3) for the same layers on larger maps (csrc/diinn_winograd4.hip): 36 multiplies per (input, output)
  * pair and 4x4 output block, 1.78x fewer MFMAs than F(2x2, 3x3); fp32, transformed weights computed in float64 and
- * rounded once.  Accuracy: ~1e-6 of max|out| per layer and 3e-6 of max|feat| through the whole trunk against float64
- * (F(2x2): 3e-7; the direct fp32 sum: 4e-7; tools/enc_wino43_error.py).
+ * rounded once.  Accuracy: ~1e-5 of max|out| per layer on unit-variance inputs (worst measured 2e-5; F(2x2) and the direct
+ * fp32 sum: 4e-7; tests/test_encoder_trunk.py bounds it at 4e-5) and 3e-6 of max|feat| through the whole trunk against
+ * float64 (F(2x2): 3e-7; the direct fp32 sum: 4e-7; tools/enc_wino43_error.py).
  * diinn_conv_wino4: as diinn_conv_wino.  packed_u_dev holds U = G W G^T (6x6 per pair, G of F(4x4,3x3): Lavin & Gray,
  *   points 0, +-1, +-2, inf) as [wave 12][half 2][chunk Cin/8][q 3][lane 64][4]:
  *   value = U[32 half + (lane&31)][8 chunk + 2 e + (lane>>5)][i][j] with 6 i + j = 3 wave + q     (36 * 64 * Cin floats).
+ * diinn_conv_wino4_ws: the same with a workspace (diinn_conv_wino4_workspace_floats() floats, 16-byte aligned; its first
+ *   1024 words must be ZERO on entry and are zero again when the launch has finished).  A launch of I work items (2 per 32
+ *   Winograd tiles) on N compute units runs floor(I / N) * N of them whole and, where the cost model says it pays
+ *   (DIINN_ENC_WINO4_SPLIT: 0 never, 2 always), cuts the input-channel chunks of the I mod N items left into N equal runs:
+ *   a workgroup that computed part of an item's channels leaves its partial outputs in the workspace and the last one to
+ *   arrive adds the parts in a fixed order.  Results are deterministic and depend on (shape, N) only; they differ from
+ *   diinn_conv_wino4's by the reassociation (~1e-7 of max|out|).  No workgroup waits for another.  Launches that share a
+ *   workspace must be ordered (same stream).  diinn_conv_wino4 = diinn_conv_wino4_ws without a workspace (never splits).
+ * diinn_conv_wino4_plan: what diinn_conv_wino4_ws would do on the current device: info[0] work items, [1] items run whole,
+ *   [2] split workgroups, [3] chunks of 8 input channels per split workgroup.
  * diinn_rdn_wino4_packed_floats: floats of the 130 such weights of the trunk, in execution order.
  * diinn_rdn_forward_wino4: diinn_rdn_forward_wino with the 3x3 layers on diinn_conv_wino4 where that kernel needs fewer
  *   rounds of workgroups than diinn_conv_wino (one F(4x4) round = 1.44 F(2x2) rounds; from about 35,000 pixels on,
@@ -396,6 +411,14 @@ int    diinn_conv_wino4(void* stream, const float* in_dev, long long in_batch_st
                         const float* packed_u_dev, const float* bias_dev,
                         const float* res_dev, long long res_batch_stride,
                         float* out_dev, long long out_batch_stride, int relu, int B, int H, int W);
+size_t diinn_conv_wino4_workspace_floats(void);
+int    diinn_conv_wino4_ws(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
+                           const float* packed_u_dev, const float* bias_dev,
+                           const float* res_dev, long long res_batch_stride,
+                           float* out_dev, long long out_batch_stride, int relu, int B, int H, int W,
+                           float* ws_dev, size_t ws_floats);
+int    diinn_conv_wino4_plan(int Cin, int B, int H, int W, int with_workspace, int info[4]);
+#define DIINN_WINO4_MAX_SPLIT_WGS 256   /* split workgroups of a launch (one per compute unit of an MI355X) */
 size_t diinn_rdn_wino4_packed_floats(void);
 int    diinn_rdn_wino4_applies(int B, int H, int W);   /* 1 if diinn_rdn_forward_wino4 takes diinn_conv_wino4 for this map (else the F(4x4) image is not read) */
 int    diinn_rdn_forward_wino4(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,

@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.diinn_abi_version() == 7
+    assert lib.diinn_abi_version() == 8
     assert lib.diinn_status_string(0) == b"ok"
     assert b"invalid" in lib.diinn_status_string(1)
 
@@ -50,7 +50,7 @@ def test_debug_knobs_roundtrip(lib):
     for name, dflt in [("DIINN_F32_KERNEL", 0), ("DIINN_BF16_KERNEL", 0), ("DIINN_X3_KERNEL", 0), ("DIINN_PBF16_KERNEL", 0), ("DIINN_P_KERNEL", 0),
                        ("DIINN_P_WINO_MIN", 0), ("DIINN_P_X3_MIN", 32768), ("DIINN_ENC_S1_MIN_BLOCKS", 128), ("DIINN_ENC_NO_STREAM1X1", 0),
                        ("DIINN_ENC_LAT_MAX_TILES", 256), ("DIINN_ENC_WINO_MIN", 8192), ("DIINN_ENC_WINO_HALF_MAX", -1),
-                       ("DIINN_ENC_WINO_PERSIST", 256), ("DIINN_ENC_X3_MIN", 32768), ("DIINN_ENC_X3_ROWS", 0)]:
+                       ("DIINN_ENC_WINO_PERSIST", 256), ("DIINN_ENC_X3_MIN", 32768), ("DIINN_ENC_X3_ROWS", 0), ("DIINN_ENC_WINO4_SPLIT", 1)]:
         if name not in os.environ:
             assert N.debug_get(name) == dflt, name
         old = N.debug_get(name)

@@ -58,7 +58,21 @@ def _run_driver_command(nproc, steps=3, warmup=1, backend="gloo", timeout=1500):
     return json.loads(lines[0]), wall
 
 
+def _check_census(res, nproc, backend, devices):
+    """The record says who ran: N ranks, each with its device's identity, through which backend, on
+    how many DISTINCT devices -- 1 on this box; N on the 8-GPU node, which is what makes that run self-verifying."""
+    assert res["rccl_world"] == nproc and res["backend"] == backend and res["distinct_devices"] == devices
+    ranks = res["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(nproc)) and sorted(r["local_rank"] for r in ranks) == list(range(nproc))
+    for r in ranks:
+        assert r["backend"] == backend and r["device"] == 0 and r["name"] and r["pid"] > 0
+        assert r["device_uuid"] or r["pci_bus_id"]
+        assert r["visible_devices"] >= 1 and r["xgmi_peers"] >= -1
+    assert len({r["pid"] for r in ranks}) == nproc               # one process per rank
+
+
 def _check_default_strong_legs(res, nproc, names):
+    _check_census(res, nproc, "gloo", 1)
     assert res["n_gpus"] == nproc and res["scaling"] == "weak" and res["config"]["name"] == "c2"
     assert res["config"]["hr"] == [1024 * nproc, 1024] and res["dtype"] == "f32"
     assert res["checked"]["ok"] and res["checked"]["handoff_exact"] and res["checked"]["max_err"] <= 1e-4
@@ -95,6 +109,7 @@ def test_one_rank_torchrun_constructs_the_rccl_path():
     device_id=...)`` and the first ``dist.barrier()`` of bench.py run (RCCL accepts one rank per device), the harness'
     collectives go through device tensors, and the line is the N = 1 line."""
     res, _ = _run_driver_command(1, steps=2, warmup=1, backend="nccl")
+    _check_census(res, 1, "nccl", 1)
     assert res["n_gpus"] == 1 and res["checked"]["ok"] and "strong" not in res
     assert "target_shape" in res and "side_legs" in res and "cpu_baseline" in res
     whole = res["whole_model"]                                   # the informational DIINN.forward leg (encoder + decoder)
@@ -127,3 +142,14 @@ def test_two_ranks_default_workload_bf16():
     res = _run_bench(2, "--compute", "bf16_full", "--strong-legs", "c1", "--strong-steps", "2")
     assert res["config"]["name"] == "c2" and res["config"]["hr"] == [2048, 1024] and res["dtype"] == "bf16_full"
     assert res["checked"]["ok"] and res["strong"][0]["checked_ok"]
+
+
+def test_watchdog_ends_a_hung_run_with_a_nonzero_exit():
+    """A run that does not finish inside --watchdog seconds is ENDED (exit code 124, a message on stderr) -- never
+    re-executed: a hung rank or hand-off at N > 1 costs the driver a bounded wait, not its budget."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c4", "--steps", "400", "--warmup", "1",
+                        "--no-check", "--no-cpu-baseline", "--watchdog", "20"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 124, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    assert "exiting with code 124" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -78,8 +78,10 @@ def test_conv_wino4_kernel_matches_fp64_conv():
     """diinn_conv_wino4 (Winograd F(4x4,3x3)): ReLU, residual, strided channel-plane views, odd / ragged maps (partial
     tiles, partial blocks, one-pixel maps, widths that are not multiples of 4: the scalar store path), batch > 1, 8 ..
     576 input channels (1 .. 72 chunks: every phase of the three-slot ring), and more work items than workgroups.
-    Bound 4e-5 of max|out| on these unit-variance inputs (measured <= 2.0e-5, typically 1e-5: the F(4x4) transforms --
-    4 and 5 in B^T, 8 in A^T -- cost a good digit against F(2x2)'s 4e-7; tools/conv_wino4_error.py lists every case)."""
+    Bound 2.5e-5 of max|out| on these unit-variance inputs (measured <= 2.0e-5, typically 1e-5: the F(4x4) transforms --
+    4 and 5 in B^T, 8 in A^T -- cost a good digit against F(2x2)'s 4e-7; tools/conv_wino4_error.py lists every case).  The
+    inputs are seeded and the kernel's sums have a fixed order, so the measured figure reproduces to the bit on every box:
+    the 25 % margin covers a different torch build's random stream, nothing else; a larger error is a code change."""
     import ctypes as C
     import diinn_amd._native as N
     import diinn_amd.modules as M
@@ -109,7 +111,7 @@ def test_conv_wino4_kernel_matches_fp64_conv():
             ref = ref + res.double()
         err = float((out[:, 32:].double() - ref).abs().max())
         scale = max(1.0, float(ref.abs().max()))
-        assert err <= 4e-5 * scale, (cin, h, w, err)
+        assert err <= 2.5e-5 * scale, (cin, h, w, err)
         worst = max(worst, err / scale)
         assert torch.isnan(out[:, :32]).all()
     print(f"diinn_conv_wino4: worst error {worst:.2e} of max|out|")
@@ -147,7 +149,7 @@ def test_conv_wino4_kernel_fuzz():
         if use_res:
             ref = ref + res.double()
         err = float((out.double() - ref).abs().max())
-        assert err <= 4e-5 * max(1.0, float(ref.abs().max())), (b, cin, h, w, relu, use_res, err)
+        assert err <= 3e-5 * max(1.0, float(ref.abs().max())), (b, cin, h, w, relu, use_res, err)
 
 
 @pytest.mark.gpu
@@ -181,7 +183,7 @@ def test_conv_wino4_kernel_fuzz_large_maps():
         if use_res:
             ref = ref + res.double()
         err = float((out.double() - ref).abs().max())
-        assert err <= 4e-5 * max(1.0, float(ref.abs().max())), (b, cin, h, w, relu, use_res, err)
+        assert err <= 3e-5 * max(1.0, float(ref.abs().max())), (b, cin, h, w, relu, use_res, err)
 
 
 @pytest.mark.gpu
@@ -211,15 +213,108 @@ def test_conv_wino4_back_to_back_launches_are_bit_identical():
                 assert all(torch.equal(o, outs[0]) for o in outs[1:]), (cin, h, w, i)
 
 
+@pytest.mark.gpu
+def test_conv_wino4_split_last_round(knobs):
+    """diinn_conv_wino4_ws with the last round split over the input channels (forced: DIINN_ENC_WINO4_SPLIT = 2): maps of less
+    than one round (every workgroup has part of an item, most of two), of one round and a remainder, ragged widths, batches,
+    8 .. 512 input channels (runs of 1 chunk up to 36), ReLU / residual.  Against a float64 convolution at the kernel's own
+    bound; against the unsplit launch within 2e-6 of max|out| (a reassociation of the sum over input channels); 30
+    back-to-back launches bit-identical (the parts are added in part order, whoever arrives last); the workspace's counter
+    words (tickets, ready counts, the gave-up-waiting mark) all zero afterwards; diinn_conv_wino4_plan says a split happened."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    gen = torch.Generator(device=dev).manual_seed(9)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
+    wsf = lib.diinn_conv_wino4_workspace_floats()
+    ws = torch.zeros(wsf, device=dev)
+    info = (C.c_int * 4)()
+    nsplit = 0
+    for (b, cin, h, w, relu, use_res) in [(1, 512, 192, 192, 1, 0), (1, 64, 100, 100, 0, 1), (1, 8, 64, 64, 1, 0), (1, 136, 97, 203, 1, 1),
+                                          (2, 256, 200, 180, 0, 0), (1, 320, 320, 324, 1, 0), (3, 72, 50, 90, 0, 1), (1, 16, 12, 9, 1, 0),
+                                          (1, 576, 130, 129, 1, 0)]:
+        x = torch.randn((b, cin, h, w), device=dev, generator=gen)
+        wt = torch.randn((64, cin, 3, 3), device=dev, generator=gen) / (cin * 9) ** 0.5
+        bias = torch.randn(64, device=dev, generator=gen)
+        res = torch.randn((b, 64, h, w), device=dev, generator=gen) if use_res else None
+        packed = M.pack_conv_wino4(wt).to(dev)
+        rp = ptr(res) if use_res else None
+        ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+        if relu:
+            ref = torch.relu(ref)
+        if use_res:
+            ref = ref + res.double()
+        scale = max(1.0, float(ref.abs().max()))
+        whole = torch.empty((b, 64, h, w), device=dev)
+        assert lib.diinn_conv_wino4(stream, ptr(x), cin * h * w, cin, ptr(packed), ptr(bias), rp, 64 * h * w, ptr(whole), 64 * h * w,
+                                    relu, b, h, w) == 0
+        knobs("DIINN_ENC_WINO4_SPLIT", 2)
+        assert lib.diinn_conv_wino4_plan(cin, b, h, w, 1, info) == 0
+        nsplit += info[2] > 0
+        outs = [torch.full((b, 64, h, w), float("nan"), device=dev) for _ in range(4)]
+        for i in range(31):
+            assert lib.diinn_conv_wino4_ws(stream, ptr(x), cin * h * w, cin, ptr(packed), ptr(bias), rp, 64 * h * w,
+                                           ptr(outs[0 if i == 0 else 1 + i % 3]), 64 * h * w, relu, b, h, w, ptr(ws), wsf) == 0
+            if i and i % 3 == 0:
+                torch.cuda.synchronize()
+                assert all(torch.equal(o, outs[0]) for o in outs[1:]), (cin, h, w, i)
+        knobs("DIINN_ENC_WINO4_SPLIT", 0)
+        off = torch.empty((b, 64, h, w), device=dev)
+        assert lib.diinn_conv_wino4_ws(stream, ptr(x), cin * h * w, cin, ptr(packed), ptr(bias), rp, 64 * h * w, ptr(off), 64 * h * w,
+                                       relu, b, h, w, ptr(ws), wsf) == 0
+        assert torch.equal(off, whole)                           # without a split the workspace form IS diinn_conv_wino4
+        err = float((outs[0].double() - ref).abs().max())
+        assert err <= 2.5e-5 * scale, (cin, h, w, err)
+        assert float((outs[0] - whole).abs().max()) <= 2e-6 * scale, (cin, h, w)
+        if info[2]:
+            assert not torch.equal(outs[0], whole), (cin, h, w)   # the split form did run
+        assert int(ws[:1024].view(torch.int32).abs().sum()) == 0, (cin, h, w)
+    assert nsplit >= 7
+    # argument checks of the workspace form: too small a workspace, a misaligned one
+    assert lib.diinn_conv_wino4_ws(stream, ptr(x), cin * h * w, cin, ptr(packed), ptr(bias), None, 0, ptr(off), 64 * h * w, 0, b, h, w,
+                                   ptr(ws), wsf - 1) == N.ERR_INVALID_ARG
+    assert lib.diinn_conv_wino4_ws(stream, ptr(x), cin * h * w, cin, ptr(packed), ptr(bias), None, 0, ptr(off), 64 * h * w, 0, b, h, w,
+                                   C.c_void_p(ws.data_ptr() + 4), wsf) == N.ERR_INVALID_ARG
+
+
+def test_wino4_split_plan():
+    """diinn_conv_wino4_plan (host only; no device: 256 compute units assumed): whole rounds stay whole, the remainder is cut into
+    equal runs over pairs of workgroups (the two output halves of a block side by side), never for a full last round, never
+    without a workspace; the cost model leaves thin layers of a half-filled round whole."""
+    import ctypes as C
+    import diinn_amd._native as N
+    lib = N.load()
+    info = (C.c_int * 4)()
+
+    def plan(cin, b, h, w, ws=1):
+        assert lib.diinn_conv_wino4_plan(cin, b, h, w, ws, info) == 0
+        return list(info)
+    assert plan(512, 1, 256, 256) == [256, 256, 0, 0]            # exactly one round
+    assert plan(512, 1, 192, 192, 0) == [144, 144, 0, 0]         # no workspace, no split
+    items, whole, wgs, u = plan(512, 1, 192, 192)
+    assert (items, whole, wgs, u) == (144, 0, 256, 36)           # 72 blocks x 64 chunks over 128 pairs
+    assert plan(64, 1, 192, 192)[2] == 0                          # 8 chunks: two prologues cost more than the split saves
+    items, whole, wgs, u = plan(512, 1, 384, 384)
+    assert (items, whole) == (576, 512) and wgs == 256 and u == 16
+    assert plan(512, 1, 320, 320)[:2] == [400, 256]
+    assert lib.diinn_conv_wino4_plan(12, 1, 8, 8, 1, info) == N.ERR_INVALID_ARG
+
+
 def test_wino4_dispatch_rule(knobs):
     """diinn_rdn_wino4_applies: the F(4x4) kernel where it needs fewer rounds of workgroups (one round = 1.44 F(2x2) rounds
-    of whole blocks); never on the split-K kernel's small maps; DIINN_ENC_WINO4_MIN = n replaces the rule."""
+    of whole blocks; a last round filled to r costs 0.26 + 0.97 r of one since round 5: it is split over the input channels);
+    never on the split-K kernel's small maps; DIINN_ENC_WINO4_MIN = n replaces the rule.  Measured on 32 shapes
+    (profiles/r05_enc_trunk_times.txt): right in 31, 4 % off at 176 x 176."""
     import diinn_amd._native as N
     lib = N.load()
     want = {(1, 256, 256): 1, (1, 512, 512): 1, (1, 224, 224): 1, (1, 192, 192): 1, (1, 384, 384): 1, (1, 240, 256): 1,
-            (1, 128, 128): 0, (1, 160, 160): 0, (1, 176, 176): 0, (1, 96, 100): 0, (1, 48, 48): 0, (2, 128, 130): 1,
+            (1, 128, 128): 0, (1, 144, 144): 1, (1, 160, 160): 1, (1, 176, 176): 0, (1, 96, 100): 0, (1, 48, 48): 0, (2, 128, 130): 1,
             (1, 270, 480): 1, (1, 320, 180): 1,      # work items are runs of 32 consecutive tiles: the map's width leaves none part empty
-            (2, 200, 180): 0,                        # 284 work items = two rounds, the second 11 % full
+            (2, 200, 180): 1,                        # 284 work items = one round and 28 items: split, 12.2 ms (whole 15.6; F(2x2) 14.6)
+            (16, 48, 48): 1,                         # the training batch's input gradient (160 items)
             (4, 256, 256): 1, (0, 4, 4): 0}
     for (b, h, w), yes in want.items():
         assert lib.diinn_rdn_wino4_applies(b, h, w) == yes, (b, h, w)
@@ -504,6 +599,115 @@ def test_rdn_hip_trunk_matches_the_reference_on_big_maps():
         assert err <= 2e-5 * scale, (key, err)
         sums = y.astype(np.float64).sum(axis=(0, 2, 3))
         assert float(np.abs(sums - gold[f"rdn/{key}/channel_sums"]).max()) <= 1e-6 * b * h * w * scale, key
+
+
+def _gold_r5():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "diinn_golden_r5.npz"))
+
+
+@pytest.mark.gpu
+def test_rdn_trunk_regression_bound_on_big_maps():
+    """The regression-level bound beside the 2e-5 contract of test_rdn_hip_trunk_matches_the_reference_on_big_maps (VERDICT r04
+    item 4c): on the 240 x 256 fixture -- F(4x4,3x3) layers, the default arithmetic of big maps -- the sampled features are
+    within 6e-6 of max|ref| of the real reference's (3x the 2e-6 measured when the kernel shipped); on the two maps that run
+    F(2x2,3x3) within 2e-6 (measured 5e-7)."""
+    import json
+    import os
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rdn_big_golden.npz"))
+    dev = torch.device("cuda:0")
+    enc = M.make_rdn()
+    shapes = json.loads(str(gold["rdn/shapes_json"]))
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_for(shapes, 123, "enc.").items()})
+    enc = enc.to(dev).eval()
+    lib = N.load()
+    for (b, h, w) in [(1, 96, 100), (1, 240, 256), (2, 50, 90)]:
+        key = f"{b}x{h}x{w}"
+        x = torch.from_numpy(synth.uniform(7, f"img:{b}x{h}x{w}", (b, 3, h, w), 0.5) + np.float32(0.5)).to(dev)
+        with torch.no_grad():
+            y = enc(x).cpu().numpy()
+        idx = np.random.default_rng(1000 * h + w).choice(y.size, size=min(16384, y.size), replace=False)
+        scale = max(1.0, float(gold[f"rdn/{key}/absmax"]))
+        err = float(np.abs(y.reshape(-1)[idx] - gold[f"rdn/{key}/values"]).max())
+        f4 = bool(lib.diinn_rdn_wino4_applies(b, h, w))
+        print(f"{key}: F({'4x4' if f4 else '2x2'},3x3) layers, |hip - ref| {err:.2e} of max|ref| {scale:.2f}")
+        assert err <= (6e-6 if f4 else 2e-6) * scale, (key, err)
+
+
+@pytest.mark.gpu
+def test_diinn_forward_matches_the_reference_on_a_map_with_wino4_layers():
+    """ONE assertion for the whole model on a map whose encoder takes the default arithmetic of big maps:
+    DIINN.forward (RDN encoder with F(4x4,3x3) layers, the last round split over the input channels; then the implicit decoder) on
+    a 200 x 180 image -> 431 x 377 against the REAL reference's DIINN (src/models/components/diinn.py:8-19) run on the CPU: 16,384
+    sampled outputs from tests/golden/diinn_golden_r5.npz (make_golden_r5.py), per-channel sums; north_star bound
+    1e-4 x max(1, |ref|), and -- informational -- the distance to the same model run in float64 beside the reference's own."""
+    import json
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    gold = _gold_r5()
+    dev = torch.device("cuda:0")
+    net = M.DIINN(mode=3, init_q=False)
+    full = json.loads(str(gold["diinn/shapes_json"]))
+    assert full == {k: list(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_for(full, 123, "diinn.").items()})
+    net = net.to(dev).eval()
+    b, h, w, hu, wu = 1, 200, 180, 431, 377
+    assert N.load().diinn_rdn_wino4_applies(b, h, w) == 1
+    key = f"diinn/{h}x{w}_{hu}x{wu}"
+    x = torch.from_numpy(synth.uniform(11, f"img:{b}x{h}x{w}", (b, 3, h, w), 0.5) + np.float32(0.5)).to(dev)
+    with torch.no_grad():
+        y = net(x, [hu, wu], 30000).cpu().numpy()
+    assert y.shape == (b, 3, hu, wu)
+    idx = np.random.default_rng(1000 * hu + wu).choice(y.size, size=16384, replace=False)
+    got = y.reshape(-1)[idx]
+    ref, ref64 = gold[f"{key}/values"], gold[f"{key}/values64"]
+    scale = max(1.0, float(gold[f"{key}/absmax"]))
+    err = float(np.abs(got - ref).max())
+    err64, ref_err64 = float(np.abs(got - ref64).max()), float(np.abs(ref - ref64).max())
+    print(f"DIINN 200x180 -> 431x377: |hip - ref32| {err:.2e}; against float64: hip {err64:.2e}, the reference itself {ref_err64:.2e}")
+    assert err <= 1e-4 * scale, err
+    assert err64 <= 5e-6, err64                                  # regression level: F(4x4) features cost the image ~1e-6 (F(2x2): 1e-7)
+    sums = y.astype(np.float64).sum(axis=(0, 2, 3))
+    assert float(np.abs(sums - gold[f"{key}/channel_sums"]).max()) <= 1e-6 * hu * wu * scale
+
+
+@pytest.mark.gpu
+def test_rdn_trunk_off_default_init_gains(knobs):
+    """How the F(4x4,3x3) error grows off the default initialisation: the reference's encoder with every
+    weight and bias scaled by 1.5 and by 2.0 (max|feat| 1.5 -> 4.4 -> 75; a trained RDN has per-layer gains of its own and
+    no checkpoint is shipped) on a 192 x 200 map, fixtures from the real reference in fp32 and float64.  Contract: 2e-5 x
+    max|ref| against the fp32 reference.  Regression level, against float64: within 8x the reference's own fp32 distance
+    (measured ~3x: the F(4x4) transforms cost a digit at any gain, and the relative error does NOT grow with the gain);
+    the same trunk on F(2x2) layers within 2x."""
+    import json
+    import diinn_amd.modules as M
+    gold = _gold_r5()
+    dev = torch.device("cuda:0")
+    enc = M.make_rdn()
+    shapes = json.loads(str(gold["rdn/shapes_json"]))
+    b, h, w = 1, 192, 200
+    x = torch.from_numpy(synth.uniform(7, f"img:{b}x{h}x{w}", (b, 3, h, w), 0.5) + np.float32(0.5)).to(dev)
+    for gain in (1.5, 2.0):
+        enc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_for(shapes, 123, "enc.", gain=gain).items()})
+        enc = enc.to(dev).eval()
+        key = f"rdn_gain/{gain}/{b}x{h}x{w}"
+        ref, ref64 = gold[f"{key}/values"], gold[f"{key}/values64"]
+        scale = max(1.0, float(gold[f"{key}/absmax"]))
+        ref_err64 = float(np.abs(ref - ref64).max())
+        for f4 in (True, False):
+            enc.hip_winograd4 = f4
+            with torch.no_grad():
+                y = enc(x).cpu().numpy()
+            idx = np.random.default_rng(1000 * h + w).choice(y.size, size=16384, replace=False)
+            got = y.reshape(-1)[idx]
+            err, err64 = float(np.abs(got - ref).max()), float(np.abs(got - ref64).max())
+            print(f"gain {gain}, F({'4x4' if f4 else '2x2'},3x3): |hip - ref32| {err / scale:.2e} of max|ref| {scale:.1f}; against float64 "
+                  f"{err64 / scale:.2e} (the reference itself {ref_err64 / scale:.2e})")
+            assert err <= 2e-5 * scale, (gain, f4, err)
+            assert err64 <= (8.0 if f4 else 2.0) * ref_err64 + 1e-7 * scale, (gain, f4, err64, ref_err64)
+    enc.hip_winograd4 = True
 
 
 # ---------------------------------------------------------------------------------------------------------------------

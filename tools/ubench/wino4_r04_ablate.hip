@@ -21,29 +21,17 @@
 // 1-KiB rows + one edge load per wave and chunk, requested two chunks ahead; no patch lives in registers.
 // The transform waves are the waves with (wave & 3) == 3: all on SIMD 3, the MFMA waves on SIMDs 0..2 -- the fp32 MFMA
 // and the VALU are one pipe, and a transform beside three MFMA waves took 2.7x its time and set the iteration.
-// (The timing-ablation builds of round 4 -- W4_ABL_*, the MFMA-wave fetch, the k-step-major order, one transform wave per
-// SIMD -- live on in tools/ubench/wino4_r04_ablate.hip, the round-4 text of this file; W4_STAMPS here is the one
-// diagnosis hook left: s_memtime stamps of workgroup 0 for tools/ubench/wino4_bench.hip, never in the library.)
+// (W4_ABL_* / W4_STAMPS / W4_MFMA_FETCH are timing-ablation and diagnosis hooks for tools/ubench/wino4_bench.hip: never in
+// the library, W4_ABL_* give wrong results.)
 // Epilogue: the 36 positions meet through LDS (144 KiB, over ring and raw slots), one thread per (tile, output channel):
 // A^T (.) A, bias, ReLU / residual, 16-byte stores.
-//
-// Round 5 -- the last, partly filled round of work items is split over the INPUT CHANNELS ("stream-K"): a launch of I work
-// items on a chip of N CUs runs floor(I / N) * N items whole, as before, and cuts the chunk sequence of the R = I mod N items
-// left into N equal runs, one per workgroup (a run may end inside one item and go on in the next).  A workgroup that computed
-// only part of an item's channels transforms its partial sums to output space (A^T (.) A is linear), stores the 32 tiles x 16
-// pixels x 32 outputs) and draws a ticket from the item's counter.  Not the last ticket: it stores the partial outputs as
-// a 64 KiB slab with write-through (sc1) stores and counts the slab ready.  The last ticket: it waits until the other parts'
-// slabs are counted ready -- workgroups that are past their arithmetic and wait for nobody themselves, so the wait is finite
-// whatever the dispatch order or residency (it is bounded all the same; giving up leaves a mark in the workspace) -- and adds
-// the parts IN PART ORDER, its own from registers (the sum does not depend on who came last), then bias, ReLU / residual and
-// the stores.  The hand-off is the guide's "sc1 stores, every storing wave drains, one lane's agent-scope atomic add; the
-// consumer polls that counter with sc1 loads, its other waves load with sc1 loads behind a workgroup barrier" row
-// (MI355X_MICROARCH.md, Workgroup dispatch ... visibility).  Counters are zero on entry and left zero (the last arriver
-// resets its item's).  A 192 x 192 map (144 items on 256 CUs) then costs 0.56 + of a round instead of a whole one.
-#include "diinn_device.h"
+#include "../../dual-interactive-implicit-neural-network_amd/csrc/diinn_device.h"
 
 constexpr int W4_TX = 32;                            // Winograd tiles per block: 32 = one MFMA N-tile; consecutive tiles of the row-major tile grid (128 x 4 output pixels; a block may wrap into the next tile row)
 constexpr int W4_THREADS = 1024;                      // 12 MFMA waves + 4 transform waves
+#ifdef W4_ABL_MIXED
+constexpr int W4_MFMA_WAVES = 12;
+#endif
 constexpr int W4_VBUF = 36 * 256;                    // floats of one chunk's transformed data: [pos 36][e 4][h 2][tile 32]
 constexpr int W4_RAW0 = 3 * W4_VBUF;                     // raw input slots behind the ring: [slot 2][transform wave 4][6 rows x 256 + 64 edge values]
 constexpr int W4_RAW_WAVE = 6 * 256 + 64;
@@ -69,14 +57,6 @@ struct ConvWino4Params {
     float* out;              // out + b*out_bs + co*H*W
     long long in_bs, out_bs, res_bs;
     int Cin, B, H, W, relu;
-    // split of the last round over the input channels (0 items: none)
-    float* sk_slabs;         // [2 sk_wgs][4][1024][4]: a split workgroup's partial outputs of its first / second item
-    unsigned* sk_cnt;        // [1024] words: per item arrival tickets and ready counts, zero on entry, zero on exit
-    int sk_first;            // work items [0, sk_first) run whole, [sk_first, sk_first + sk_items) split
-    int sk_items;
-    int sk_u;                // chunks per split workgroup: pair q (workgroups 2 q, 2 q + 1: output halves 0, 1) takes chunk-units
-                             // [q sk_u, (q + 1) sk_u) of the sk_items / 2 blocks x Cin/8 chunks
-    int sk_wgs;              // split workgroups: blockIdx.x < sk_wgs (a multiple of 16)
 #ifdef W4_STAMPS
     unsigned long long* stamps;   // tools/ubench/wino4_bench.hip -DW4_STAMPS: s_memtime of workgroup 0's waves 0 and 12, [wave 2][iteration 80][4]
 #endif
@@ -93,22 +73,6 @@ struct ConvWino4Params {
 #else
 #define W4_STAMP(role, it, i) do {} while (0)
 #endif
-constexpr int W4_SLAB_FLOATS = 4 * 1024 * 4;        // a split workgroup's partial outputs: [output row 4][thread 1024] f32x4 = 64 KiB
-constexpr int W4_FLAG = 36 * 1024;                   // LDS word behind the exchange buffer: the ticket drawn by thread 0
-static_assert(W4_FLAG < W4_LDS_FLOATS, "flag word inside the LDS array");
-constexpr int W4_READY = 256, W4_TIMEOUT = 1023;     // counter words: [item] tickets, [256 + item] slabs stored, [1023] a wait gave up (stays 0)
-static_assert(DIINN_WINO4_MAX_SPLIT_WGS <= W4_READY, "one ticket and one ready word per split item");
-
-// what a workgroup knows about the item it computes a channel range of (parts == 1: the whole item, nothing below is used)
-struct W4Split { int parts, item, slab, first_pair, pair, blk_item; };   // item: counter index (2 blk_item + half); pairs: see the kernel
-
-// 16-byte write-through store / L1-bypassing load (aux 16 = sc1) for the slabs: the store forms the guide's hand-off asks for
-__device__ __forceinline__ void w4_st_sc1(f32x4 v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)voff, 0, 16);
-}
-__device__ __forceinline__ f32x4 w4_ld_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 16));
-}
 
 // one dimension of B^T (6 -> 6) and of A^T (6 -> 4); T = float or f32x2 (two columns at a time: v_pk_* instructions)
 template <typename T>
@@ -133,9 +97,7 @@ __device__ __forceinline__ void w4_at(const T m0, const T m1, const T m2, const 
     y3 = __builtin_elementwise_fma(T(8.0f), v, d) + m5;
 }
 
-// chunks [c0, c0 + m) of work item (b, blk, hh0); sk.parts > 1: the item's other chunks are other workgroups' (see the header)
-__device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float* __restrict__ lds, int b, int blk, int hh0,
-                                                int c0, int m, const W4Split sk) {
+__device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float* __restrict__ lds, int b, int blk, int hh0) {
     // the block's tiles: blk * 32 .. + 31 of the image's row-major tile grid (a run that reaches the end of a tile row goes
     // on in the next one: no work item is left part empty by the map's width); tiles past the last one load zeros and store nothing
     const int tiles_x = (p.W + 3) / 4, tiles_n = tiles_x * ((p.H + 3) / 4);
@@ -154,9 +116,14 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
 
     // Roles by SIMD (a workgroup's wave i runs on SIMD i % 4): the four transform waves share SIMD 3, the twelve MFMA waves
     // SIMDs 0..2.  The fp32 MFMA and the VALU are one pipe: beside three MFMA waves a transform took 3,500 cycles (1,670
-    // alone) and set the iteration time.
+    // alone) and set the iteration time (W4_ABL_MIXED keeps that layout: one transform wave per SIMD).
+#ifdef W4_ABL_MIXED
+    const bool producer = wave >= W4_MFMA_WAVES;
+    const int wt_ = wave - W4_MFMA_WAVES, mw = wave;
+#else
     const bool producer = (wave & 3) == 3;
     const int wt_ = wave >> 2, mw = (wave >> 2) * 3 + (wave & 3);
+#endif
     if (threadIdx.x == 0) W4_STAMP(0, 76, 0);                     // body start
     if (producer) {
         // ---- transform waves: one (tile, channel of the chunk) patch per thread: wave wt takes the chunk's channels
@@ -164,7 +131,9 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         // (raw slots, filled by LDS-DMA): per chunk and wave six 1-KiB rows [row k][channel 2][128 columns] + the 24
         // values left and right of the block (6 rows x 2 channels x 2 sides); no patch is held in registers.
         const int wt = wt_;
+#ifndef W4_ABL_NOPRIO
         __builtin_amdgcn_s_setprio(3);                           // the chunk's critical path: ahead of the MFMA waves' issue
+#endif
         const int th = lane >> 5, tm = lane & 31;
         int ptx, pty;
         const bool pin = tile_xy(blk * W4_TX + tm, ptx, pty);
@@ -173,6 +142,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         const bool row_start = ptx == 0, row_end = 4 * ptx + 4 >= p.W;   // the map's border: the outer column is padding (a wrapped block's neighbour lane holds another row's tile)
         const bool ok1 = 4 * ptx + 1 < p.W, ok2 = 4 * ptx + 2 < p.W, ok3 = 4 * ptx + 3 < p.W;
         float* __restrict__ raw = lds + W4_RAW0 + wt * W4_RAW_WAVE;           // + slot * 4 * W4_RAW_WAVE
+#ifndef W4_MFMA_FETCH
         // The wave requests exactly the input it transforms, by LDS-DMA (buffer_load ... lds: no registers; range-checked
         // -- an out-of-range lane deposits zero, which is the zero padding), two chunks ahead: six 16-byte loads per chunk
         // (one per patch row: 2 channels x 512 contiguous bytes) and one 4-byte load whose lanes 0..23 fetch the columns
@@ -195,6 +165,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
             voff[k] = (pin && y >= 0 && y < p.H) ? (unsigned)(2 * wt + th) * plane_b + (unsigned)(y * p.W + 4 * ptx) * 4u : OUTSIDE;
         }
         auto fetch = [&](int slot, int c) {
+#ifndef W4_ABL_NOPATCH
             const __amdgpu_buffer_rsrc_t irs =
                 __builtin_amdgcn_make_buffer_rsrc((void*)(in_b + (size_t)8 * c * plane), 0, (int)(8u * plane_b), 0x00020000);
             float* dst = raw + slot * 4 * W4_RAW_WAVE;
@@ -202,8 +173,10 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
             for (int k = 0; k < 6; ++k)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (__attribute__((address_space(3))) void*)(dst + k * 256), 16, (int)voff[k], 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (__attribute__((address_space(3))) void*)(dst + 1536), 4, (int)voffe, 0, 0, 0);
+#endif
         };
-        auto chunk_of = [&](int r) { return c0 + (r < m ? r : m - 1); };   // r-th chunk of this workgroup's range
+        auto chunk_of = [&](int k) { return k < n ? k : n - 1; };
+#endif
         // the outer columns: the neighbouring tiles' values in the row, for the block's first / last tile the edge values
         const int la = first ? 1536 + 12 * th : th * 128 + tm * 4 - 1, lstep = first ? 1 : 256;
         const int ra = last ? 1536 + 12 * th + 6 : th * 128 + tm * 4 + 4, rstep = last ? 1 : 256;
@@ -240,14 +213,35 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
                 dst[(6 * i + 5) * 256] = v5;
             }
         };
-        // (chunk numbers below are relative to c0.)
+#ifdef W4_MFMA_FETCH
+        // chunk k arrives in raw slot k & 1 (requested by the MFMA waves one iteration ahead) and is transformed into ring
+        // slot k % 3; iteration c (the MFMA waves compute chunk c) transforms chunk c + 2
+        __builtin_amdgcn_s_barrier();                            // P1: chunks 0 and 1 have landed
+        transform(0, lds);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // P2: raw slot 0 is free again
+        transform(1, lds + W4_VBUF);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // P3: chunks 0 and 1 transformed, chunk 2 landed
+        int slot2 = 2;
+        for (int c = 0; c < n; ++c) {
+            if (wt == 0) W4_STAMP(1, c, 0);
+#ifndef W4_ABL_NOTRANSFORM
+            if (c + 2 < n) transform(c & 1, lds + slot2 * W4_VBUF);
+#endif
+            slot2 = slot2 == 2 ? 0 : slot2 + 1;
+            if (wt == 0) W4_STAMP(1, c, 1);
+#ifndef W4_ABL_NOBAR
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the raw slot is read, the transformed data stored
+#endif
+            if (wt == 0) W4_STAMP(1, c, 2);
+        }
+#else
         // chunk k is requested into raw slot k & 1 and transformed into ring slot k % 3; iteration c (the MFMA waves compute
         // chunk c) transforms chunk c + 2, then requests chunk c + 4 into the raw slot just read (7 requests per chunk,
         // always issued -- past the end the last chunk again -- so that "all but the newest 7" names a chunk) and retires
         // chunk c + 3 BEFORE the barrier: LDS-DMA data is ordered for a ds_read only by the issuing wave's counted vmcnt
         // followed by a barrier the reader has passed (cdna_hip_programming.md: "read a staged buffer one phase after the
         // wait that retires it") -- a read right behind the wait passes every check whenever the data happens to land first.
-        fetch(0, chunk_of(0));
+        fetch(0, 0);
         fetch(1, chunk_of(1));
         asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");     // P0: chunk 0 has landed
         transform(0, lds);
@@ -259,17 +253,22 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         fetch(1, chunk_of(3));
         asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");     // P: chunks 0 and 1 are transformed, chunk 2 has landed
         int slot2 = 2;
-        for (int c = 0; c < m; ++c) {
+        for (int c = 0; c < n; ++c) {
             if (wt == 0) W4_STAMP(1, c, 0);
-            if (c + 2 < m) transform(c & 1, lds + slot2 * W4_VBUF);
+#ifndef W4_ABL_NOTRANSFORM
+            if (c + 2 < n) transform(c & 1, lds + slot2 * W4_VBUF);
+#endif
             slot2 = slot2 == 2 ? 0 : slot2 + 1;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the raw slot is read, the transformed data stored
             fetch(c & 1, chunk_of(c + 4));
             if (wt == 0) W4_STAMP(1, c, 1);
+#ifndef W4_ABL_NOBAR
             asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");  // chunk c + 3 has landed (chunk c + 4 may be in flight)
+#endif
             if (wt == 0) W4_STAMP(1, c, 2);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // nothing may land in the raw slots any more: the exchange buffer lies over them
+#endif
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     } else {
@@ -278,21 +277,77 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(p.wu + (size_t)(mw * 2 + hh0) * n * (3 * W4_PIECE_BYTES / 4)), 0, n * 3 * W4_PIECE_BYTES, 0x00020000);
         const int lane_off = lane * 16;
+#ifdef W4_MFMA_FETCH
+        // The raw input of chunk c + 3 is requested here, one iteration ahead, by LDS-DMA (buffer_load ... lds: no
+        // registers; range-checked -- an out-of-range lane deposits zero, which is the zero padding): wave w takes rows
+        // 2 w and 2 w + 1 of the chunk's 24 (channel pair cp, patch row k) rows -- one 16-byte load per tile: 2 channels
+        // x 512 contiguous bytes per request -- and waves 0..3 the edge values of channel pair w (one 4-byte load whose
+        // lanes 0..23 fetch the columns left and right of the block for 6 rows x 2 channels).  Inline asm: with the
+        // builtin the compiler drains every outstanding load (vmcnt(0)) at the next use of a weight register.
+        const float* __restrict__ in_b = p.in + (size_t)b * p.in_bs;
+        unsigned dvoff[2], dvoffe = OUTSIDE;
+        unsigned dlds[2], dldse;
+        {
+            const int th = lane >> 5;
+            int ptx, pty;
+            const bool pin = tile_xy(blk * W4_TX + (lane & 31), ptx, pty);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = 2 * mw + i, cp = idx / 6, k = idx - 6 * cp;
+                const int y = 4 * pty - 1 + k;
+                dvoff[i] = (pin && y >= 0 && y < p.H) ? (unsigned)(2 * cp + th) * plane_b + (unsigned)(y * p.W + 4 * ptx) * 4u : OUTSIDE;
+                dlds[i] = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + W4_RAW0 + cp * W4_RAW_WAVE + k * 256);
+            }
+            const int ek = lane % 6, ew = lane / 6;              // the edge load: lane < 24 -> row ek, (channel, side) ew
+            int etx, ety;
+            const bool ein = tile_xy(blk * W4_TX + ((ew & 1) ? W4_TX - 1 : 0), etx, ety);
+            const int ex = (ew & 1) ? 4 * etx + 4 : 4 * etx - 1;
+            const int ey = 4 * ety - 1 + ek;
+            if (mw < 4 && lane < 24 && ein && ey >= 0 && ey < p.H && ex >= 0 && ex < p.W)
+                dvoffe = (unsigned)(2 * mw + (ew >> 1)) * plane_b + (unsigned)(ey * p.W + ex) * 4u;
+            dldse = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + W4_RAW0 + (mw & 3) * W4_RAW_WAVE + 1536);
+        }
+        auto fetch = [&](int slot, int c) {
+#ifndef W4_ABL_NOPATCH
+            const i32x4 irs = w4_rsrc(in_b + (size_t)8 * c * plane, 8u * plane_b);
+            const unsigned so = (unsigned)slot * (4 * W4_RAW_WAVE * 4);
+            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(dlds[0] + so), "v"(dvoff[0]), "s"(irs) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(dlds[1] + so), "v"(dvoff[1]), "s"(irs) : "memory", "m0");
+            if (mw < 4)
+                asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" :: "s"(dldse + so), "v"(dvoffe), "s"(irs) : "memory", "m0");
+#endif
+        };
+        auto chunk_of = [&](int k) { return k < n ? k : n - 1; };
+#endif
         const float* __restrict__ bsrc = lds + 3 * mw * 256 + lane;      // + 64 e: [pos][e][h][tile]
         f32x16 acc[3];
+#ifndef W4_EMAJOR
         f32x4 A[2][3], Bf[1][3]; // weights of chunks c, c + 1 (ring of two: a request has a whole iteration to arrive); B operands of chunk c
+#else
+        f32x4 A[2][3], Bf[2][3]; // weights and B operands of chunks c, c + 1 (rings of two: a request has a whole iteration to arrive)
+#endif
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+#ifdef W4_MFMA_FETCH
+        fetch(0, 0);
+        fetch(1, chunk_of(1));
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // P1: chunks 0 and 1 have landed
+#else
         __builtin_amdgcn_s_barrier();                            // P0, P1: (the transform waves' first requests have landed)
         __builtin_amdgcn_s_barrier();
+#endif
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            A[0][q] = ld_piece(wrs, lane_off, (c0 * 3 + q) * W4_PIECE_BYTES);
-            A[1][q] = ld_piece(wrs, lane_off, ((c0 + (m > 1 ? 1 : 0)) * 3 + q) * W4_PIECE_BYTES);
+            A[0][q] = ld_piece(wrs, lane_off, q * W4_PIECE_BYTES);
+            A[1][q] = ld_piece(wrs, lane_off, ((n > 1 ? 3 : 0) + q) * W4_PIECE_BYTES);
         }
         __builtin_amdgcn_s_barrier();                            // P (P2): chunks 0 and 1 are transformed (raw slot 0 is free again)
+#ifdef W4_MFMA_FETCH
+        fetch(0, chunk_of(2));
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // P3: chunks 0 and 1 transformed, chunk 2 landed
+#endif
 #pragma unroll
         for (int q = 0; q < 3; ++q) Bf[0][q] = f32x4{bsrc[q * 256], bsrc[q * 256 + 64], bsrc[q * 256 + 128], bsrc[q * 256 + 192]};
 
@@ -302,14 +357,19 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         // chunk c + 2 into the registers just used and the read of its B operands of chunk c + 1; one barrier.  The
         // barrier waits for all but the two newest LDS operations (the last position's reads of slot c + 1, which
         // nobody writes before the NEXT barrier): no wave sits behind an LDS round trip with the matrix core idle.
-        // (The twelve MFMAs k-step by k-step over double-buffered B registers, so that consecutive MFMAs of a wave are
-        // independent, measured 2.5 % SLOWER -- 3,447 against 3,362 cycles per iteration; four waves per SIMD keep the pipe
-        // busy either way.)  c counts from c0.
+        // (W4_EMAJOR: the twelve MFMAs k-step by k-step over double-buffered B registers, so that consecutive MFMAs of a
+        // wave are independent: measured 2.5 % SLOWER -- 3,447 against 3,362 cycles per iteration; four waves per SIMD keep
+        // the pipe busy either way.)
         auto iter = [&](auto PAR_, int c) {
             constexpr int PAR = decltype(PAR_)::value;
-            const int c2 = c0 + (c + 2 < m ? c + 2 : m - 1);
+            const int c2 = c + 2 < n ? c + 2 : n - 1;
             if (mw == 0) W4_STAMP(0, c, 0);
+#ifdef W4_MFMA_FETCH
+            fetch((c + 1) & 1, chunk_of(c + 3));                 // always issued (past the end: the last chunk again): the count below relies on it
+            W4_SB();
+#endif
             if (mw == 0) W4_STAMP(0, c, 1);
+#ifndef W4_EMAJOR
             // per position its four MFMAs, behind them the request of the position's weights of chunk c + 2 into the
             // registers just used and the read of its B operands of chunk c + 1
 #pragma unroll
@@ -324,18 +384,62 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
                 }
                 W4_SB();
             }
+#else
+            // the B operands of chunk c + 1 first (their ring slot is complete since the last barrier; used next iteration),
+            // then the twelve MFMAs k-step by k-step, behind a position's last MFMA the request of its weights of chunk c + 2
+#ifndef W4_ABL_NOBREAD
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float* __restrict__ bq = bsrc + slot1 * W4_VBUF + q * 256;
+                Bf[PAR ^ 1][q] = f32x4{bq[0], bq[64], bq[128], bq[192]};
+            }
+            W4_SB();
+#endif
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+#ifndef W4_ABL_NOMFMA
+                    acc[q] = MFMA32(A[PAR][q][e], Bf[PAR][q][e], acc[q]);
+#else
+                    acc[q][e] += A[PAR][q][e] * Bf[PAR][q][e];
+#endif
+#ifndef W4_ABL_NOW
+                    if (e == 3) {
+                        W4_SB();
+                        A[PAR][q] = ld_piece(wrs, lane_off, (c2 * 3 + q) * W4_PIECE_BYTES);
+                        W4_SB();
+                    }
+#endif
+                }
+#endif
+#ifndef W4_ABL_NOBAR
             if (mw == 0) W4_STAMP(0, c, 2);
+#ifdef W4_MFMA_FETCH
+            // all but the three weight requests of this iteration: the raw rows requested above have landed
+            asm volatile("s_waitcnt vmcnt(3) lgkmcnt(2)\n\ts_barrier" ::: "memory");
+#else
+#ifndef W4_EMAJOR
             asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory");
+#else
+            __builtin_amdgcn_s_barrier();                        // (this wave's LDS reads were issued at the top of the iteration)
+#endif
+#endif
+#endif
             if (mw == 0) W4_STAMP(0, c, 3);
             slot1 = slot1 == 2 ? 0 : slot1 + 1;
         };
         int c = 0;
-        for (; c + 1 < m; c += 2) {
+        for (; c + 1 < n; c += 2) {
             iter(IC<0>{}, c);
             iter(IC<1>{}, c + 1);
         }
-        if (c < m) iter(IC<0>{}, c);
+        if (c < n) iter(IC<0>{}, c);
+#ifdef W4_MFMA_FETCH
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // nothing may land in the raw slots any more: the exchange buffer lies over them
+#else
         __builtin_amdgcn_s_barrier();
+#endif
 
         if (mw == 0) W4_STAMP(0, 76, 2);                          // loop done
         // the 36 positions meet through LDS: [pos][accumulator register 16][lane]
@@ -363,74 +467,6 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             w4_at<float>(z[0][j], z[1][j], z[2][j], z[3][j], z[4][j], z[5][j], y[0][j], y[1][j], y[2][j], y[3][j]);
-        if (sk.parts > 1) {
-            // ---- part of an item.  Thread 0 draws the item's ticket.  Not the last ticket: the partial outputs go to this
-            // workgroup's slab (write-through, whole 1 KiB per wave instruction), every wave drains its stores, thread 0
-            // counts the slab ready.  The last ticket: every other part has at least begun its stores -- wait until all
-            // are counted ready (finite: those workgroups are past their arithmetic and wait for nobody), then sum the
-            // parts IN PART ORDER, this workgroup's from its registers: whoever comes last, the same sum.
-            const unsigned last_tk = (unsigned)sk.parts - 1u;
-            if (threadIdx.x == 0) W4_STAMP(0, 77, 0);             // partial outputs in registers
-            if (threadIdx.x == 0)
-                lds[W4_FLAG] = __builtin_bit_cast(float, __hip_atomic_fetch_add(p.sk_cnt + sk.item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            __syncthreads();
-            const unsigned tk = __builtin_bit_cast(unsigned, *(volatile float*)(lds + W4_FLAG));
-            const unsigned toff = threadIdx.x * 16u;
-            if (threadIdx.x == 0) W4_STAMP(0, 77, 1);             // ticket known
-            if (tk != last_tk) {
-                const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
-                    (void*)(p.sk_slabs + (size_t)sk.slab * W4_SLAB_FLOATS), 0, W4_SLAB_FLOATS * 4, 0x00020000);
-#pragma unroll
-                for (int a = 0; a < 4; ++a) w4_st_sc1(f32x4{y[a][0], y[a][1], y[a][2], y[a][3]}, srs, a * 16384u + toff);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (threadIdx.x == 0)
-                    __hip_atomic_fetch_add(p.sk_cnt + W4_READY + sk.item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (threadIdx.x == 0) W4_STAMP(0, 77, 2);         // slab stored, drained and counted
-                return;
-            }
-            if (threadIdx.x == 0) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(p.sk_cnt + W4_READY + sk.item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != last_tk) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1u << 24)) {                  // seconds: something is broken; say so and go on
-                        __hip_atomic_store(p.sk_cnt + W4_TIMEOUT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-                // everybody has arrived and stored: both counters are ready for the next launch
-                __hip_atomic_store(p.sk_cnt + sk.item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p.sk_cnt + W4_READY + sk.item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) W4_STAMP(0, 78, 0);             // the other parts are ready
-            const int mine = sk.pair - sk.first_pair;            // this workgroup's part number
-            auto part = [&](int k, f32x4 (&v)[4]) {
-                if (k == mine) {
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) v[a] = f32x4{y[a][0], y[a][1], y[a][2], y[a][3]};
-                } else {
-                    const int pk = sk.first_pair + k;            // the k-th workgroup pair with chunks of this block; the block
-                    const int jk = sk.blk_item - (pk * p.sk_u) / n;   // is the first (0) or second (1) one of its run
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                        (void*)(p.sk_slabs + (size_t)(2 * (2 * pk + hh0) + jk) * W4_SLAB_FLOATS), 0, W4_SLAB_FLOATS * 4, 0x00020000);
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) v[a] = w4_ld_sc1(rs, a * 16384u + toff);
-                }
-            };
-            f32x4 s[4], nxt[4];
-            part(0, s);
-            for (int k = 1; k < sk.parts; ++k) {                 // (the next part's loads are in flight while this one is added)
-                part(k, nxt);
-#pragma unroll
-                for (int a = 0; a < 4; ++a) s[a] += nxt[a];
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int x = 0; x < 4; ++x) y[a][x] = s[a][x];
-            if (threadIdx.x == 0) W4_STAMP(0, 78, 1);             // parts summed
-        }
         const int ox = 4 * tx, oy0 = 4 * ty;
         const bool vec = !ragged && (p.out_bs & 3) == 0 && (((size_t)p.out) & 15) == 0 &&
                          (!p.res || ((p.res_bs & 3) == 0 && (((size_t)p.res) & 15) == 0));
@@ -461,46 +497,19 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
 __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvWino4Params p) {
     __shared__ __attribute__((aligned(16))) float lds[W4_LDS_FLOATS];
     const int nblk = (((p.W + 3) / 4) * ((p.H + 3) / 4) + W4_TX - 1) / W4_TX;   // blocks of 32 consecutive tiles per image
-    const int n = p.Cin / 8;
-    if ((int)blockIdx.x < p.sk_wgs) {
-        // ---- the split items (they come first in the grid: the whole items fill in behind as these workgroups end, so
-        // the different lengths of their runs -- one or two prologues -- cost nothing at the launch's end).  The two halves
-        // of a block are split alike and run side by side: workgroups 2 q and 2 q + 1 (a PAIR) take the same run of chunks
-        // of the same blocks for output half 0 / 1, so the second reader of every raw input row finds it in the L2
-        // (workgroups b and b + 8 share an XCD; each XCD takes a contiguous run of pairs).  Runs that followed the items one
-        // after the other -- half 0's channels, then half 1's -- read every input row twice from memory: 15 % more cycles
-        // per chunk (profiles/r05_wino4_split.txt).
-        const int g = (int)(blockIdx.x & 7) * (p.sk_wgs >> 3) + (int)(blockIdx.x >> 3);
-        const int pair = g >> 1, hh0 = g & 1;
-        const int units = (p.sk_items >> 1) * n;                 // chunk-units of the split blocks
-        int u0 = pair * p.sk_u;
-        const int uend = u0 + p.sk_u < units ? u0 + p.sk_u : units;
-        for (int j = 0; u0 < uend; ++j) {
-            const int it = u0 / n, c0 = u0 - it * n;
-            const int m = n - c0 < uend - u0 ? n - c0 : uend - u0;
-            const int first = (it * n) / p.sk_u, last = ((it + 1) * n - 1) / p.sk_u;   // the pairs with chunks of this block
-            const int t = (p.sk_first >> 1) + it;
-            const int b = __builtin_amdgcn_readfirstlane(t / nblk);
-            conv_wino4_body(p, lds, b, t - b * nblk, hh0, c0, m, W4Split{last - first + 1, 2 * it + hh0, 2 * g + j, first, pair, it});
-            __syncthreads();                                     // the exchange buffer is free again
-            u0 += m;
-        }
-        return;
-    }
-    // ---- whole items: every XCD takes a contiguous run of them (as conv_wino_entry): neighbours share patch rows in one
-    // L2, and the two halves of a block sit next to each other
-    const int total = p.sk_first;
-    const int bid = (int)blockIdx.x - p.sk_wgs;
-    const int wg_per_xcd = ((int)gridDim.x - p.sk_wgs) >> 3;
+    const int total = p.B * nblk * 2;
+    // every XCD takes a contiguous run of work items (as conv_wino_entry): neighbours share patch rows in one L2, and
+    // the two halves of a block sit next to each other
+    const int wg_per_xcd = gridDim.x >> 3;
     const int per_xcd = (total + 7) >> 3;
-    const int xcd = bid & 7, idx = bid >> 3;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     for (int k = idx; k < per_xcd; k += wg_per_xcd) {
         int t = xcd * per_xcd + k;
         if (t >= total) break;
         const int hh0 = t & 1;
         t >>= 1;
         const int b = __builtin_amdgcn_readfirstlane(t / nblk);
-        conv_wino4_body(p, lds, b, t - b * nblk, hh0, 0, n, W4Split{1, 0, 0, 0, 0, 0});
+        conv_wino4_body(p, lds, b, t - b * nblk, hh0);
         __syncthreads();                                         // the exchange buffer is free again
     }
 }
@@ -509,64 +518,17 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvWino4P
 unsigned long long* g_w4_stamps = nullptr;
 #endif
 
-// ---- which items of a launch are split, and how (host).  Measured on 100 .. 384-pixel maps (profiles/r05_wino4_split.txt,
-// tools/ubench/wino4_bench.hip): a last round of whole items costs 10 + 1.46 n us (n chunks: prologue and epilogue, then
-// one iteration per chunk, R < N workgroups on the chip); the same items split into runs of u chunks 17.5 + 1.75 u us: one or
-// two prologues and epilogues (a run crosses an item boundary more often than not), the slab round trip, and a chunk that
-// takes longer because all N compute units are busy -- the part holds ~2.0 GHz with 256 of these workgroups resident and
-// ~2.27 GHz with 144, at equal cycles per chunk.  That is why a 192 x 192 map (0.56 of a round) gains 15-25 % from the
-// split, not 44 %: the chip is power-limited, and time follows the arithmetic done more than the workgroups in flight.
-struct W4Plan { int first, items, u, wgs; };
-static inline double w4_whole_us(int n) { return 10.0 + 1.46 * n; }
-static inline double w4_split_us(int u) { return 17.5 + 1.75 * u; }
-static W4Plan w4_plan(long long total, int n, int ncu, bool have_ws) {
-    W4Plan pl{(int)total, 0, 0, 0};
-    const long long mode = knob(diinn_knobs().enc_wino4_split);           // 0 never, 1 by the cost model, 2 whenever a round is partly filled
-    if (!have_ws || mode == 0 || ncu < 8) return pl;
-    if (ncu > DIINN_WINO4_MAX_SPLIT_WGS) ncu = DIINN_WINO4_MAX_SPLIT_WGS;  // the slab area is sized for this many
-    ncu &= ~1;                                                   // workgroup pairs (the two output halves of a block)
-    const int R = (int)(total % ncu);                            // even: total is
-    if (R == 0) return pl;
-    const int u = (int)(((long long)(R / 2) * n + ncu / 2 - 1) / (ncu / 2));
-    if (u >= n) return pl;                                       // a workgroup per item anyway
-    if (mode == 1 && w4_split_us(u) > w4_whole_us(n) - 1.0) return pl;
-    const int wgs = 2 * (int)(((long long)(R / 2) * n + u - 1) / u);
-    pl.first = (int)(total - R);
-    pl.items = R;
-    pl.u = u;
-    pl.wgs = (wgs + 15) / 16 * 16;
-    return pl;
-}
-
-// the kernel's time for a map of `total` work items over the whole trunk, in rounds of whole items: the whole rounds + what a
-// last round filled to r = R / N costs once it is split, 0.26 + 0.97 r of a round (measured on 21 maps, 128 .. 208 pixels:
-// profiles/r05_enc_trunk_times.txt); diinn_rdn_wino4_applies compares it with the F(2x2) kernel's rounds
-__attribute__((visibility("hidden"))) double w4_rounds(long long total, int ncu, bool have_ws) {
-    const long long whole = total / ncu, R = total % ncu;
-    if (R == 0) return (double)whole;
-    const W4Plan pl = w4_plan(total, 36, ncu, have_ws);          // (would the trunk's average layer be split at all?)
-    const double last = pl.items ? 0.26 + 0.97 * (double)R / ncu : 1.0;
-    return (double)whole + (last < 1.0 ? last : 1.0);
-}
-
 extern "C" {
 
-size_t diinn_conv_wino4_workspace_floats(void) {
-    // [counters 1024 words][2 slabs per split workgroup]
-    return (size_t)1024 + (size_t)2 * (DIINN_WINO4_MAX_SPLIT_WGS + 8) * W4_SLAB_FLOATS;
-}
-
-int diinn_conv_wino4_ws(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
-                        const float* packed_u_dev, const float* bias_dev, const float* res_dev, long long res_batch_stride,
-                        float* out_dev, long long out_batch_stride, int relu, int B, int H, int W,
-                        float* ws_dev, size_t ws_floats) {
+int diinn_conv_wino4(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
+                     const float* packed_u_dev, const float* bias_dev, const float* res_dev, long long res_batch_stride,
+                     float* out_dev, long long out_batch_stride, int relu, int B, int H, int W) {
     if (!in_dev || !packed_u_dev || !bias_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
     if (st) return st;
     if (Cin <= 0 || Cin % 8) return DIINN_ERR_UNSUPPORTED;
-    if ((((size_t)in_dev) & 3) || (((size_t)packed_u_dev) & 15) || (((size_t)bias_dev) & 3) || (((size_t)ws_dev) & 15))
+    if ((((size_t)in_dev) & 3) || (((size_t)packed_u_dev) & 15) || (((size_t)bias_dev) & 3))
         return DIINN_ERR_INVALID_ARG;
-    if (ws_dev && ws_floats < diinn_conv_wino4_workspace_floats()) return DIINN_ERR_INVALID_ARG;
     const long long blocks = (((long long)((W + 3) / 4) * ((H + 3) / 4) + W4_TX - 1) / W4_TX) * B;
     if (2 * blocks > 2147483000LL) return DIINN_ERR_TOO_LARGE;
     if ((long long)H * W * 4 * 64 > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;     // planes are addressed with 32-bit byte offsets
@@ -575,32 +537,11 @@ int diinn_conv_wino4_ws(void* stream, const float* in_dev, long long in_batch_st
     p.in = in_dev; p.wu = packed_u_dev; p.bias = bias_dev; p.res = res_dev; p.out = out_dev;
     p.in_bs = in_batch_stride; p.out_bs = out_batch_stride; p.res_bs = res_batch_stride;
     p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0;
-    const W4Plan pl = w4_plan(2 * blocks, Cin / 8, device_cus(), ws_dev != nullptr);
-    p.sk_first = pl.first; p.sk_items = pl.items; p.sk_u = pl.u; p.sk_wgs = pl.wgs;
-    p.sk_cnt = (unsigned*)ws_dev;
-    p.sk_slabs = ws_dev ? ws_dev + 1024 : nullptr;
 #ifdef W4_STAMPS
     p.stamps = g_w4_stamps;
 #endif
-    const unsigned grid = (unsigned)pl.wgs + (unsigned)((pl.first + 7) / 8 * 8);
-    hipLaunchKernelGGL(conv_wino4_kernel, dim3(grid), dim3(W4_THREADS), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(conv_wino4_kernel, dim3((unsigned)((2 * blocks + 7) / 8 * 8)), dim3(W4_THREADS), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
-}
-
-int diinn_conv_wino4(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
-                     const float* packed_u_dev, const float* bias_dev, const float* res_dev, long long res_batch_stride,
-                     float* out_dev, long long out_batch_stride, int relu, int B, int H, int W) {
-    return diinn_conv_wino4_ws(stream, in_dev, in_batch_stride, Cin, packed_u_dev, bias_dev, res_dev, res_batch_stride,
-                               out_dev, out_batch_stride, relu, B, H, W, nullptr, 0);
-}
-
-// how diinn_conv_wino4_ws would run a layer: info[0] work items, [1] items that run whole, [2] split workgroups, [3] chunks per split workgroup
-int diinn_conv_wino4_plan(int Cin, int B, int H, int W, int with_workspace, int info[4]) {
-    if (!info || Cin <= 0 || Cin % 8 || check_dims(B, H, W)) return DIINN_ERR_INVALID_ARG;
-    const long long blocks = (((long long)((W + 3) / 4) * ((H + 3) / 4) + W4_TX - 1) / W4_TX) * B;
-    const W4Plan pl = w4_plan(2 * blocks, Cin / 8, device_cus(), with_workspace != 0);
-    info[0] = (int)(2 * blocks); info[1] = pl.first; info[2] = pl.wgs; info[3] = pl.u;
-    return DIINN_OK;
 }
 
 }  // extern "C"
