@@ -318,7 +318,7 @@ class Job:
             else:
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev, timeout=tmo)
             dist.barrier()           # first RCCL call is a plain collective on every rank
-        self.local_rank = local_rank
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))   # as launched (the one-device test hook computes on cuda:0 all the same)
 
         import diinn_amd._native as N
         import diinn_amd.decoder as D

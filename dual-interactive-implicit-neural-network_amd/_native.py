@@ -78,6 +78,7 @@ SIGNATURES = {
     "diinn_cell_chain": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_decode_launch_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip]),
     "diinn_p_launch_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
+    "diinn_decode_kernel_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
     "diinn_debug_set": (C.c_int, [C.c_char_p, C.c_longlong]),
     "diinn_debug_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_longlong)]),
     "diinn_metasr_packed_floats": (C.c_size_t, []),

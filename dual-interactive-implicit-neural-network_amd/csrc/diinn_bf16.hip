@@ -392,8 +392,11 @@ __global__ __launch_bounds__(256, 1) void decode_bf16x2_kernel(const DecodeParam
 }
 
 // ---------------------------------------------------------------------------------
-// decode_bf16_coop_kernel: the bf16 decode with the four waves of a workgroup COOPERATING on one block of
-// 4 pixel tiles (16 x 8 HR pixels) instead of each owning pixels of its own.  Wave w owns 64 of the 256
+// The COOPERATIVE bf16 decode (round 2): the waves of a workgroup work on one block of 4 pixel tiles (16 x 8 HR pixels)
+// instead of each owning pixels of its own.  What follows describes the first, four-wave form of it -- the structure the
+// eight-wave kernels below (decode_bf16_coop8_kernel, decode_bf16_coop8p_kernel) inherit; the four-wave kernel itself
+// (decode_bf16_coop_kernel: ~390 registers, one wave per SIMD, 13.1 k cycles per layer against the 8.2 k of its MFMAs) had
+// no dispatch path left and was deleted in round 5 (DESIGN_HISTORY.md section 4).  Wave w owned 64 of the 256
 // channels of every layer (M-tiles 2w and 2w+1 of the modulation rows and of the synthesis rows, so
 // relu(k) * sin(s) stays register-local) for ALL pixels of the block:
 //   * weights: a wave reads only its own quarter of a layer (64 KiB) and keeps the 32 fragments of the current
@@ -442,329 +445,9 @@ template <> __device__ __forceinline__ float co_sin_fin<DIINN_SIN_ACCURATE>(floa
 #define CO_STAMP(i) do {} while (0)
 #endif
 
-template <int SIN_MODE>
-__global__ __launch_bounds__(256, 1) void decode_bf16_coop_kernel(const DecodeParams p) {
-    constexpr int TILES = CO_TILES;
-    __shared__ __attribute__((aligned(16))) bf16x8 qa[2][TILES][16][64];       // 128 KiB: B fragments, double-buffered
-    __shared__ __attribute__((aligned(16))) float seed[CO_SEED_CELLS * CO_SEED_PITCH];   // P slice of the block's cells
-    __shared__ __attribute__((aligned(16))) float bias[3 * HID];               // bQ1..3 in revolutions
-    float (*red)[TILES * 32][3] = reinterpret_cast<float (*)[TILES * 32][3]>(seed);   // partial RGB per (wave, lane half),
-    static_assert(sizeof(seed) >= 8 * TILES * 32 * 3 * sizeof(float), "red aliases the seed slab");   // after the last seed read
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = lane >> 5, j = lane & 31;
-    const int b = blockIdx.z;
-    const float* __restrict__ Wt = p.Wt;
-    const int ncx = p.seed_cols;                                  // cells per slab row (host: max over the launch)
-    const int ncx_inv = 65536 / ncx + 1;
-#ifdef DIINN_STAMPS
-    const size_t co_stamp_base = ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 16;
-#endif
-    CO_STAMP(0);
-
-    // pixel of this lane in tile t: x = bx*16 + (t&1)*8 + (j&7), y = y0 + by*8 + (t>>1)*4 + (j>>3)
-    const int x0 = p.x0 + blockIdx.x * (2 * TILE_W) + (j & (TILE_W - 1));
-    const int yb = p.y0 + blockIdx.y * (2 * TILE_H) + (j / TILE_W);
-    // LR index and relative coordinate of this lane's column / row in the two tile columns / rows of the block; lane 0
-    // holds the block's first pixel, so its indices are the block's first LR cell (wave-uniform)
-    int ixs[2], iys[2];
-    float relws[2], relhs[2];
-#pragma unroll
-    for (int tx = 0; tx < 2; ++tx) {
-        const int x = x0 + tx * TILE_W;
-        axis_eval(p.aw, x < p.Wu ? x : p.Wu - 1, ixs[tx], relws[tx]);
-    }
-#pragma unroll
-    for (int ty = 0; ty < 2; ++ty) {
-        const int y = yb + ty * TILE_H;
-        axis_eval(p.ah, y < p.y1 ? y : p.y1 - 1, iys[ty], relhs[ty]);
-    }
-    const int ix0 = __builtin_amdgcn_readfirstlane(ixs[0]), iy0 = __builtin_amdgcn_readfirstlane(iys[0]);
-    // slab row of every tile's pixel: byte offset of its cell's staged P row (+ this lane-half's 16 bytes)
-    int srow[TILES];
-#pragma unroll
-    for (int t = 0; t < TILES; ++t)
-        srow[t] = (((iys[t >> 1] - iy0) * ncx + (ixs[t & 1] - ix0)) * CO_SEED_PITCH + 4 * h) * (int)sizeof(float);
-    // the cells this wave stages (slab rows wave, wave + 4, ...): element offset of their P rows, clamped into the window
-    size_t scell[CO_SEED_CELLS / 4];
-#pragma unroll
-    for (int i = 0; i < CO_SEED_CELLS / 4; ++i) {
-        const int c = wave + 4 * i;
-        const int cq = (c * ncx_inv) >> 16;                      // c / ncx (exact for c < 24 <= 65536 / ncx)
-        int cy = iy0 + cq, cx = ix0 + (c - cq * ncx);
-        const int ylast = p.Prow0 + p.Prows - 1;
-        cy = cy < ylast ? cy : ylast;
-        cx = cx < p.W - 1 ? cx : p.W - 1;
-        scell[i] = ((size_t)(b * p.Prows + (cy - p.Prow0)) * p.W + cx) * PCH + 4 * lane;
-    }
-    f32x4 st[CO_SEED_CELLS / 4];
-    auto stage_load = [&](const int slice) {                      // whole 1 KiB rows, one instruction per cell
-#pragma unroll
-        for (int i = 0; i < CO_SEED_CELLS / 4; ++i) st[i] = *(const f32x4*)(p.P + scell[i] + slice * HID);
-    };
-    auto stage_store = [&]() {
-#pragma unroll
-        for (int i = 0; i < CO_SEED_CELLS / 4; ++i)
-            *(f32x4*)(seed + (wave + 4 * i) * CO_SEED_PITCH + 4 * lane) = st[i];
-    };
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);
-    const int lane_off = lane * 16;
-    // piece pc (= 2 ks + part) of the M-tile at byte offset mt: 4 pieces share one scalar offset, the piece inside
-    // the 4 KiB goes into the instruction's immediate field
-    auto ld_w = [&](const int mt, const int pc) {
-        return ld_piece(wrs, lane_off + (pc & 3) * PIECE_BYTES, mt + (pc >> 2) * 4 * PIECE_BYTES);
-    };
-    // weight fragments of the current M-tile, [k-step] x {modulation, synthesis}; each is refilled with the next
-    // M-tile's fragment as soon as the last pixel tile has consumed it.  The first M-tile is requested here, ahead
-    // of the prologue, so that it arrives while layer 0 is computed.
-    f32x4 Ak[16], As[16];
-    int wp = (int)(OFF_WLB * sizeof(float)) + (2 * wave) * CO_MT_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-        Ak[ks] = ld_w(wp, 2 * ks + 0);
-        As[ks] = ld_w(wp, 2 * ks + 1);
-    }
-    CO_STAMP(13);
-    // ---- prologue: everything layer 0 reads is staged in LDS first (a vector-memory instruction blocks its wave
-    // for ~60 cycles; the 160 scattered loads a wave would need become 14 row loads).  The Q0 table and the P_0
-    // slice live in the second activation buffer, which is free until layer 1's epilogue starts writing it.
-    float* const q0tab = reinterpret_cast<float*>(&qa[1][0][0][0]);          // [4][256]: Q0h, Q0w, fma(Q0r, ratio, bQ0), - (revolutions)
-    float* const seed0 = q0tab + 4 * HID;                                      // P_0 rows of the block's cells
-    static_assert((4 * HID + CO_SEED_CELLS * CO_SEED_PITCH) * sizeof(float) <= sizeof(qa) / 2, "prologue tables fit in qa[1]");
-    {
-        f32x4 s0[CO_SEED_CELLS / 4];
-#pragma unroll
-        for (int i = 0; i < CO_SEED_CELLS / 4; ++i) s0[i] = *(const f32x4*)(p.P + scell[i]);
-        stage_load(1);
-        f32x4 tq = *(const f32x4*)(Wt + OFF_Q0R + 4 * threadIdx.x);       // rows Q0h, Q0w, Q0r, bQ0 (64 threads each)
-        if (wave == 2) {                                                   // row 2 becomes t = fma(Q0r, ratio, bQ0)
-            const f32x4 bq0 = *(const f32x4*)(Wt + OFF_Q0R + HID + 4 * threadIdx.x);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tq[e] = __builtin_fmaf(tq[e], p.ratio, bq0[e]);
-        }
-        f32x4 tb = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (threadIdx.x < 3 * HID / 4) tb = *(const f32x4*)(Wt + OFF_BQR + 4 * threadIdx.x);
-#pragma unroll
-        for (int i = 0; i < CO_SEED_CELLS / 4; ++i)
-            *(f32x4*)(seed0 + (wave + 4 * i) * CO_SEED_PITCH + 4 * lane) = s0[i];
-        stage_store();
-        *(f32x4*)(q0tab + 4 * threadIdx.x) = tq;
-        if (threadIdx.x < 3 * HID / 4) *(f32x4*)(bias + 4 * threadIdx.x) = tb;
-    }
-    const unsigned nanm = derived_nan_mask(Wt);
-    const float bl0 = or_bits(Wt[OFF_BL + 0], nanm), bl1 = or_bits(Wt[OFF_BL + 1], nanm), bl2 = or_bits(Wt[OFF_BL + 2], nanm);   // head bias, needed at the very end
-    CO_STAMP(14);
-    __syncthreads();
-    CO_STAMP(15);
-
-    // ---- layer 0 (fp32): wave w evaluates tile w for all 256 channels and writes its B fragments
-    {
-        const float* __restrict__ Q0 = q0tab + 4 * h;
-        const int t = wave;                                       // wave-uniform: select this tile's column / row
-        const int ix = (t & 1) ? ixs[1] : ixs[0], iy = (t >> 1) ? iys[1] : iys[0];
-        const float relw = (t & 1) ? relws[1] : relws[0], relh = (t >> 1) ? relhs[1] : relhs[0];
-        const float* __restrict__ Pc = seed0 + ((iy - iy0) * ncx + (ix - ix0)) * CO_SEED_PITCH + 4 * h;
-        // groups of 4 channels (c0 = 32m + 8g + 4h ..): the four table reads of group i+1 are issued before group i is
-        // evaluated, so the LDS latency is paid once, not 32 times
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        f32x4 cpv, cwh, cww, ctq, npv, nwh, nww, ntq;
-        auto fetch = [&](const int i, f32x4& pv, f32x4& wh, f32x4& ww, f32x4& tq) {
-            const int c0 = 8 * i;                                 // = 32 (i >> 2) + 8 (i & 3)
-            pv = *(const f32x4*)(Pc + c0);
-            wh = *(const f32x4*)(Q0 + 0 * HID + c0);
-            ww = *(const f32x4*)(Q0 + 1 * HID + c0);
-            tq = *(const f32x4*)(Q0 + 2 * HID + c0);
-        };
-        fetch(0, cpv, cwh, cww, ctq);
-        u32x4 fragw;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            if (i + 1 < 32) fetch(i + 1, npv, nwh, nww, ntq);
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float a = __builtin_fmaf(cww[e], relw, ctq[e]);
-                a = __builtin_fmaf(cwh[e], relh, a);
-                v[e] = relu0(cpv[e]) * co_sin_fin<SIN_MODE>(co_sin_prep<SIN_MODE>(a));   // as the epilogues: v_fract + v_sin on revolutions
-            }
-            const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
-            fragw[2 * (i & 1) + 0] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
-            fragw[2 * (i & 1) + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
-            if (i & 1) qa[0][t][i >> 1][lane] = __builtin_bit_cast(bf16x8, fragw);   // k-step 2m + (g >> 1) = i >> 1
-            cpv = npv; cwh = nwh; cww = nww; ctq = ntq;
-            asm volatile("" ::: "memory");                        // keep each group's reads where they are written
-        }
-    }
-    float o[TILES][3];                                            // partial RGB of this wave's channels (last layer)
-    CO_STAMP(1);
-    __syncthreads();
-    CO_STAMP(2);
-
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    // seeds of (M-tile m, tile t): modulation rows from the staged P slice, synthesis rows from the bias table
-    auto seed_k = [&](const int t, const int m, const int gg) {
-        return *(const f32x4*)((const char*)seed + srow[t] + (32 * m + 8 * gg) * (int)sizeof(float));
-    };
-
-    // CUR = index of the LDS image holding the layer input (compile-time: the three layers are three copies)
-    auto layer_body = [&](auto last_tag, auto cur_tag, const int layer) {
-        constexpr bool LAST = decltype(last_tag)::value;
-        constexpr int CUR = decltype(cur_tag)::value ? 1 : 0;
-        constexpr int NXT = 1 - CUR;
-        f32x4 hl[2][3][4];                                        // LAST: head rows of this wave's two M-tiles
-        if (LAST) {
-#pragma unroll
-            for (int t = 0; t < TILES; ++t) o[t][0] = o[t][1] = o[t][2] = 0.0f;
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        hl[g][k][gg] = *(const f32x4*)(Wt + OFF_L + k * HID + 32 * (2 * wave + g) + 4 * h + 8 * gg);
-        }
-        const float* __restrict__ bl = bias + layer * HID + 4 * h;
-        bf16x8 bq[CO_BRING];                                      // B fragments, read CO_BRING k-steps ahead
-#pragma unroll
-        for (int i = 0; i < CO_BRING; ++i) bq[i] = qa[CUR][0][i][lane];
-        f32x4 sk[4], sq[4];
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-            sk[gg] = seed_k(0, 2 * wave, gg);
-            sq[gg] = *(const f32x4*)(bl + 32 * (2 * wave) + 8 * gg);
-        }
-        f32x16 pk, ps;                                            // finished accumulators of the previous unit
-        float kv = 0.0f, sr = 0.0f, v0 = 0.0f;
-        u32x4 fragw;
-        // units u = TILES*g + t: pixel tile t of M-tile 2w+g; the epilogue of unit u-1 runs under unit u's MFMAs,
-        // one element per k-step, split over the two MFMA gaps of the step
-#pragma unroll
-        for (int u = 0; u < 2 * TILES; ++u) {
-            const int g = u / TILES, t = u % TILES;
-            const int pg = (u - 1) / TILES, pt = (u - 1) % TILES;   // the unit whose epilogue runs now
-            f32x16 ak, as;
-#pragma unroll
-            for (int gg = 0; gg < 4; ++gg)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ak[4 * gg + e] = sk[gg][e];
-                    as[4 * gg + e] = sq[gg][e];
-                }
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const int n = 16 * u + ks;                        // step number inside the layer
-                const bf16x8 bv = bq[ks % CO_BRING];
-                CO_SB();
-                if (n + CO_BRING < 32 * TILES)
-                    bq[ks % CO_BRING] = qa[CUR][((n + CO_BRING) >> 4) % TILES][(n + CO_BRING) & 15][lane];
-                CO_SB();
-                ak = MFMA_BF16(__builtin_bit_cast(bf16x8, Ak[ks]), bv, ak);
-                CO_SB();
-                if (u > 0) {                                      // first half of epilogue element ks of the previous unit
-                    kv = relu0(pk[ks]);
-                    sr = co_sin_prep<SIN_MODE>(ps[ks]);
-                }
-                if (ks >= 2 && ks < 6 && u + 1 < 2 * TILES) {     // seeds of the next unit, one read per step
-                    const int ng = (u + 1) / TILES, nt = (u + 1) % TILES, gg = ks - 2;
-                    sk[gg] = seed_k(nt, 2 * wave + ng, gg);
-                    if (nt == 0) sq[gg] = *(const f32x4*)(bl + 32 * (2 * wave + ng) + 8 * gg);
-                }
-                CO_SB();
-                as = MFMA_BF16(__builtin_bit_cast(bf16x8, As[ks]), bv, as);
-                CO_SB();
-                if (u > 0) {                                      // second half: q = relu(k) * sin(s), packed or folded into the head
-                    const float v = kv * co_sin_fin<SIN_MODE>(sr);
-                    if (LAST) {
-                        o[pt][0] = __builtin_fmaf(hl[pg][0][ks >> 2][ks & 3], v, o[pt][0]);
-                        o[pt][1] = __builtin_fmaf(hl[pg][1][ks >> 2][ks & 3], v, o[pt][1]);
-                        o[pt][2] = __builtin_fmaf(hl[pg][2][ks >> 2][ks & 3], v, o[pt][2]);
-                        // nothing but the final store uses these sums, so the optimiser would sink the whole
-                        // epilogue of the last layer past its MFMAs: an opaque use keeps it in this gap
-                        asm volatile("" : "+v"(o[pt][0]), "+v"(o[pt][1]), "+v"(o[pt][2]));
-                    } else if (ks & 1) {
-                        f32x2 pr = {v0, v};
-                        fragw[(ks >> 1) & 3] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2));
-                        if ((ks & 7) == 7)
-                            qa[NXT][pt][2 * (2 * wave + pg) + (ks >> 3)][lane] = __builtin_bit_cast(bf16x8, fragw);
-                    } else {
-                        v0 = v;
-                    }
-                }
-                if (t == TILES - 1 && !(LAST && g == 1)) {        // last use of this fragment: fetch the next M-tile's
-                    const int nwp = g == 0 ? wp + CO_MT_BYTES : wp + (int)(WLB_LAYER * sizeof(float));
-                    Ak[ks] = ld_w(nwp, 2 * ks + 0);
-                    As[ks] = ld_w(nwp, 2 * ks + 1);
-                }
-                if (!LAST && u == TILES && ks == 8) stage_load(layer + 2);   // next layer's P slice, into registers
-            }
-            pk = ak;
-            ps = as;
-        }
-        CO_SB();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {                            // the last unit's epilogue has nothing to hide under
-            const float v = relu0(pk[r]) * co_sin_fin<SIN_MODE>(co_sin_prep<SIN_MODE>(ps[r]));
-            if (LAST) {
-                o[TILES - 1][0] = __builtin_fmaf(hl[1][0][r >> 2][r & 3], v, o[TILES - 1][0]);
-                o[TILES - 1][1] = __builtin_fmaf(hl[1][1][r >> 2][r & 3], v, o[TILES - 1][1]);
-                o[TILES - 1][2] = __builtin_fmaf(hl[1][2][r >> 2][r & 3], v, o[TILES - 1][2]);
-            } else if (r & 1) {
-                f32x2 pr = {v0, v};
-                fragw[(r >> 1) & 3] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2));
-                if ((r & 7) == 7)
-                    qa[NXT][TILES - 1][2 * (2 * wave + 1) + (r >> 3)][lane] = __builtin_bit_cast(bf16x8, fragw);
-            } else {
-                v0 = v;
-            }
-        }
-        CO_STAMP(3 + 3 * (LAST ? 2 : CUR));
-        __syncthreads();                                          // layer output complete; input and seed slab are free
-        CO_STAMP(4 + 3 * (LAST ? 2 : CUR));
-        if (!LAST) {
-            stage_store();
-            __syncthreads();
-        }
-        CO_STAMP(5 + 3 * (LAST ? 2 : CUR));
-    };
-
-    layer_body(CoopTagFalse{}, CoopTagFalse{}, 0);
-    wp += (int)(WLB_LAYER * sizeof(float));
-    layer_body(CoopTagFalse{}, CoopTagTrue{}, 1);
-    wp += (int)(WLB_LAYER * sizeof(float));
-    layer_body(CoopTagTrue{}, CoopTagFalse{}, 2);
-
-    // ---- head: the 8 partial sums of a pixel (4 waves x 2 lane halves) meet in LDS (diinn.py:138)
-#pragma unroll
-    for (int t = 0; t < TILES; ++t)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) red[2 * wave + h][t * 32 + j][k] = o[t][k];
-    __syncthreads();
-    if (threadIdx.x < TILES * 32) {
-        const int t = threadIdx.x >> 5, jj = threadIdx.x & 31;    // one pixel per thread
-        const int x = p.x0 + blockIdx.x * (2 * TILE_W) + (t & 1) * TILE_W + (jj & (TILE_W - 1));
-        const int y = p.y0 + blockIdx.y * (2 * TILE_H) + (t >> 1) * TILE_H + (jj / TILE_W);
-        float acc[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) acc[k] += red[w8][threadIdx.x][k];
-        if (x < p.x1 && y < p.y1) {
-            const long long plane = p.o_ps;
-            float* op = out_px(p, b, y, x);
-            op[0] = acc[0] + bl0;
-            op[plane] = acc[1] + bl1;
-            op[2 * plane] = acc[2] + bl2;
-        }
-    }
-    CO_STAMP(12);
-}
-
 // ---------------------------------------------------------------------------------
 // decode_bf16_coop8_kernel: the cooperative kernel with EIGHT waves per workgroup, two per SIMD.
-// decode_bf16_coop_kernel needs ~390 registers per wave, so each SIMD hosts one wave, and whenever that wave is
+// The four-wave form needed ~390 registers per wave, so each SIMD hosted one wave, and whenever that wave was
 // blocked in a vector-memory instruction (~60 cycles each), evaluates its epilogue or runs the fp32 layer-0 prologue,
 // the matrix pipe idles: a layer takes 13.1 k cycles against the 8.2 k of its MFMAs, the prologue 15 k.  Here wave w
 // owns ONE M-tile (channels 32w .. 32w+31 of both branches) for the same 16 x 8 pixel block: 32 weight fragments
@@ -1082,7 +765,9 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8_kernel(const DecodeP
 // Arithmetic, k-order and results are decode_bf16_coop8_kernel's, bit for bit.
 // ---------------------------------------------------------------------------------
 constexpr int CO_ST_X = 8, CO_ST_Y = 4;                      // blocks per super-tile (32 = workgroups per XCD)
-constexpr int CO_PGRID = 8 * CO_ST_X * CO_ST_Y;              // persistent workgroups of a launch
+constexpr int CO_PGRID = 8 * CO_ST_X * CO_ST_Y;              // persistent workgroups of a launch: 8 XCDs x 32 CUs.  The workgroups wait
+                                                             // for nobody, so the grid is right on any device (a partitioned one
+                                                             // queues them); the super-tile walk is TUNED for this geometry
 
 template <int SIN_MODE>
 __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const DecodeParams p) {
@@ -1570,7 +1255,7 @@ int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int 
         const long long full_gx = (p.Wu + TILE_W * WG_TILES_X - 1) / (TILE_W * WG_TILES_X);   // ... nor from a column tile [x0,x1)
         const bool two_tiles = full_gx * full_gy2 * gz >= 512;
         // diagnostic override (tests / A-B timing): DIINN_BF16_KERNEL = 1 one tile per wave, 2 two tiles per wave,
-        // 4 / 8 cooperative with 4 / 8 waves; unset = pick by launch size and scale
+        // 8 cooperative, one block per workgroup, 9 cooperative persistent; unset = pick by launch size and scale
         const int force = (int)knob(diinn_knobs().bf16_kernel);
         // the cooperative kernel stages the P rows of a block's LR footprint in LDS: needs the footprint to fit
         // (scales from about x3 up), and >= 2 rounds of workgroups to be worth its prologue
@@ -1581,10 +1266,10 @@ int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int 
         // a 16 x 8 block covers whole cells iff 16 / scale_x and 8 / scale_y are integers
         pc.xcd_runs = !((16LL * p.W) % p.Wu == 0 && (8LL * p.H) % p.Hu == 0);
         const bool coop_ok = ncx * ncy <= CO_SEED_CELLS;
-        const bool coop = coop_ok && (force ? (force == 4 || force == 8 || force == 9) : full_gx * full_gy * gz >= 1024);
+        const bool coop = coop_ok && (force ? (force == 8 || force == 9) : full_gx * full_gy * gz >= 1024);
         // (the polynomial sine needs a few registers more than the 256 a wave may have at two per SIMD once the block
         // loop's state is added: DIINN_SIN_ACCURATE stays on the one-block-per-workgroup form)
-        if (coop && force != 4 && force != 8 && sin_mode != DIINN_SIN_ACCURATE) {   // 8 waves, persistent workgroups over super-tiles of 8 x 4 blocks
+        if (coop && force != 8 && sin_mode != DIINN_SIN_ACCURATE) {   // 8 waves, persistent workgroups over super-tiles of 8 x 4 blocks
             pc.pg[0] = gx; pc.pg[1] = gy; pc.pg[2] = gz;
             pc.pg[3] = (gx + CO_ST_X - 1) / CO_ST_X; pc.pg[4] = (gy + CO_ST_Y - 1) / CO_ST_Y;
             const long long nst = (long long)pc.pg[3] * pc.pg[4] * gz;
@@ -1595,20 +1280,13 @@ int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int 
                 hipLaunchKernelGGL(decode_bf16_coop8p_kernel<DIINN_SIN_HW>, gridp, dim3(512), 0, (hipStream_t)stream, pc);
             else
                 hipLaunchKernelGGL(decode_bf16_coop8p_kernel<DIINN_SIN_HW_REDUCED>, gridp, dim3(512), 0, (hipStream_t)stream, pc);
-        } else if (coop && force != 4) {                          // one block per workgroup (DIINN_BF16_KERNEL=8)
+        } else if (coop) {                                        // one block per workgroup (DIINN_BF16_KERNEL=8)
             if (sin_mode == DIINN_SIN_HW)
                 hipLaunchKernelGGL(decode_bf16_coop8_kernel<DIINN_SIN_HW>, grid, dim3(512), 0, (hipStream_t)stream, pc);
             else if (sin_mode == DIINN_SIN_HW_REDUCED)
                 hipLaunchKernelGGL(decode_bf16_coop8_kernel<DIINN_SIN_HW_REDUCED>, grid, dim3(512), 0, (hipStream_t)stream, pc);
             else
                 hipLaunchKernelGGL(decode_bf16_coop8_kernel<DIINN_SIN_ACCURATE>, grid, dim3(512), 0, (hipStream_t)stream, pc);
-        } else if (coop) {                                        // the 4-wave form (DIINN_BF16_KERNEL=4)
-            if (sin_mode == DIINN_SIN_HW)
-                hipLaunchKernelGGL(decode_bf16_coop_kernel<DIINN_SIN_HW>, grid, dim3(blk), 0, (hipStream_t)stream, pc);
-            else if (sin_mode == DIINN_SIN_HW_REDUCED)
-                hipLaunchKernelGGL(decode_bf16_coop_kernel<DIINN_SIN_HW_REDUCED>, grid, dim3(blk), 0, (hipStream_t)stream, pc);
-            else
-                hipLaunchKernelGGL(decode_bf16_coop_kernel<DIINN_SIN_ACCURATE>, grid, dim3(blk), 0, (hipStream_t)stream, pc);
         } else if (!((force == 1 || force == 2) ? force == 2 : two_tiles)) {
             if (sin_mode == DIINN_SIN_HW)
                 hipLaunchKernelGGL(decode_bf16_kernel<DIINN_SIN_HW>, grid, dim3(blk), 0, (hipStream_t)stream, p);

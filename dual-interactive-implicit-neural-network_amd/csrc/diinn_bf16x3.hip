@@ -307,16 +307,13 @@ __device__ __forceinline__ X3Pixel x3_locate(const DecodeParams& p, const int bl
     return r;
 }
 
-constexpr int X3H_PGRID = 256;                  // persistent workgroups of a launch: one per CU
+constexpr int X3H_PGRID = 256;                  // persistent workgroups of a launch at most: one per CU (the launch asks the device for its count)
 constexpr int X3H_STAGE = 4;                    // k-steps per ring stage
 constexpr int X3H_NSTAGE = 384 / X3H_STAGE;     // stages per block: a multiple of the 3 slots and of the 2 fetch buffers
 // (lgkmcnt only: the global loads in flight stay in flight across the barrier)
 #define X3H_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // issue order of a k-step: the two A reads of the NEXT k-step at once behind the first MFMA -- they have the whole
 // k-step to arrive, so the lgkmcnt(0) in front of a stage's barrier finds nothing outstanding
-#ifdef X3H_NO_ORDER
-#define X3H_KSTEP_ORDER() __builtin_amdgcn_sched_barrier(0)
-#else
 #define X3H_KSTEP_ORDER()                                                             \
     do {                                                                              \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
@@ -329,7 +326,6 @@ constexpr int X3H_NSTAGE = 384 / X3H_STAGE;     // stages per block: a multiple 
         }                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                            \
     } while (0)
-#endif
 
 template <int SIN_MODE>
 __global__ __launch_bounds__(256, 1) void decode_bf16x3h_kernel(const DecodeParams p) {
@@ -643,10 +639,11 @@ int launch_decode_bf16x3(void* stream, const DecodeParams& p, int gx, int gy, in
     // Bit-identical results.
     // (the two forms are bit-identical, so the choice may depend on the launch -- band or tile -- at hand)
     const int force = (int)knob(diinn_knobs().x3_kernel);
-    if (force ? force == 2 : nblk >= 2 * X3H_PGRID) {
+    const int pgrid = device_cus() < X3H_PGRID ? device_cus() : X3H_PGRID;   // one persistent workgroup per compute unit
+    if (force ? force == 2 : nblk >= 2 * pgrid) {
         DecodeParams pc = p;
         pc.pg[0] = gx; pc.pg[1] = gy; pc.pg[2] = gz;
-        const dim3 gridp((unsigned)(nblk < X3H_PGRID ? nblk : X3H_PGRID));
+        const dim3 gridp((unsigned)(nblk < pgrid ? nblk : pgrid));
         if (sin_mode == DIINN_SIN_HW)
             hipLaunchKernelGGL(decode_bf16x3h_kernel<DIINN_SIN_HW>, gridp, dim3(256), 0, (hipStream_t)stream, pc);
         else if (sin_mode == DIINN_SIN_HW_REDUCED)

@@ -20,8 +20,9 @@
 //                         backward pass of the decoder (training)
 //   liif_kernel; unfold_cells_kernel + metasr_kernel : the LIIF and MetaSR comparison decoders
 //   axis_tables_kernel, sin_kernel : the device coordinate / sine code, exposed for tests.
-// Compile-time hooks that never ship enabled: ABL_* (timing ablations, wrong results),
-// DIINN_STAMPS (s_memtime stamps for tools/stamp_report.py).
+// One compile-time hook that never ships enabled: DIINN_STAMPS (s_memtime stamps for tools/stamp_report.py).  The
+// timing-ablation hooks of rounds 1-4 (ABL_*: wrong results by construction) were removed in round 5; the builds behind
+// profiles/r0[1-4]_*ablation*.txt are reproducible from the commits of those rounds (git show 84fe2c6:<path>).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (explicit fmaf where wanted)
 #include "diinn_device.h"
@@ -43,11 +44,7 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
     // stays on the plain sections.
     constexpr size_t S_WL = SAVE ? OFF_WL : OFF_WLR, S_BQ = SAVE ? OFF_BQ : OFF_BQR, S_Q0 = SAVE ? OFF_Q0 : OFF_Q0R;
     auto sine = [](float v) {
-#ifdef ABL_NOSIN
-        return v;
-#else
         if constexpr (SAVE) return dsin<SIN_MODE>(v); else return dsin_rev<SIN_MODE>(v);
-#endif
     };
     {
         const int i = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -184,7 +181,7 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
         sq[g] = *(const f32x4*)(Wt + S_BQ + 4 * h + 8 * g);
     }
 #pragma unroll 1
-    for (int layer = 0; layer < DECODE_RUN_LAYERS; ++layer) {
+    for (int layer = 0; layer < 3; ++layer) {
         const int nl = layer < 2 ? layer + 1 : 2;                // seeds of the next layer's tile 0 (clamped)
         const float* __restrict__ Pl = Pc + (layer + 1) * HID;
         const float* __restrict__ Bq = Wt + S_BQ + layer * HID + 4 * h;
@@ -221,8 +218,8 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
                     for (int e = 0; e < 4; ++e) as = MFMA32(wq[e], q[4 * kg + e], as);
                 }
                 // refill the ring slot just consumed with the piece PF steps ahead
-                if constexpr (KPART) rk[s % PF] = ld_piece(wrs, lane_off, wp + (2 * ABL_STEP(s + PF) + 0) * PIECE_BYTES);
-                rq[s % PF] = ld_piece(wrs, lane_off, wp + (2 * ABL_STEP(s + PF) + 1) * PIECE_BYTES);
+                if constexpr (KPART) rk[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF) + 0) * PIECE_BYTES);
+                rq[s % PF] = ld_piece(wrs, lane_off, wp + (2 * (s + PF) + 1) * PIECE_BYTES);
                 if (kg == 4) {                                    // seeds for the next tile
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -300,194 +297,10 @@ __global__ __launch_bounds__(256, 1) void decode_kernel(const DecodeParams p) {
 
 
 // ---------------------------------------------------------------------------------
-// decode_coop_kernel: the fp32 decode for SMALL launches (latency variant).  decode_kernel gives one wave a
-// 32-pixel tile and 6,144 dependent MFMAs (0.165 ms at any size); an image with fewer than ~200 workgroups of
-// 16 x 8 pixels (BASELINE config 1: 96 x 96 -> 72) leaves most of the chip idle for that long.  Here the four
-// waves of a workgroup share ONE 32-pixel tile and split the output channels: wave w owns M-tiles 2w and 2w+1 of
-// the modulation rows and of the synthesis rows (4 independent accumulators, 512 MFMAs per layer), the layer
-// input sits in LDS as B operands in the k-order of the packed weights ([k-group 32][lane 64] x 16 B: one
-// ds_read_b128 feeds 16 MFMAs), and the waves exchange their 64 output channels through the second LDS image
-// once per layer.  Four times the workgroups, a quarter of the dependent chain.  Per output channel the
-// arithmetic is decode_kernel's (same seed, same k-ordered fmaf chain, same epilogue): results are bit-identical.
-// ---------------------------------------------------------------------------------
-template <int SIN_MODE>
-__global__ __launch_bounds__(256, 2) void decode_coop_kernel(const DecodeParams p) {
-    __shared__ __attribute__((aligned(16))) f32x4 qs[2][WL_KG][64];        // 2 x 32 KiB: activation as B operands
-    __shared__ __attribute__((aligned(16))) float tab[6 * HID + 4];        // Q0h, Q0w, fma(Q0r, ratio, bQ0), L0..L2, bL
-    {
-        const int i = threadIdx.x & 63, part = threadIdx.x >> 6;
-        const float* __restrict__ Q0s = p.Wt + OFF_Q0R + 4 * i;    // revolutions, as decode_kernel (inference)
-        if (part == 0) {
-            *(f32x4*)(tab + 0 * HID + 4 * i) = *(const f32x4*)(Q0s + 0 * HID);
-            *(f32x4*)(tab + 1 * HID + 4 * i) = *(const f32x4*)(Q0s + 1 * HID);
-        } else if (part == 1) {
-            const f32x4 wr = *(const f32x4*)(Q0s + 2 * HID), bq = *(const f32x4*)(Q0s + 3 * HID);
-            f32x4 t;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] = __builtin_fmaf(wr[e], p.ratio, bq[e]);
-            *(f32x4*)(tab + 2 * HID + 4 * i) = t;
-        } else if (part == 2) {
-            *(f32x4*)(tab + 3 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 0 * HID + 4 * i);
-            *(f32x4*)(tab + 4 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 1 * HID + 4 * i);
-        } else {
-            *(f32x4*)(tab + 5 * HID + 4 * i) = *(const f32x4*)(p.Wt + OFF_L + 2 * HID + 4 * i);
-            if (i == 0) *(f32x4*)(tab + 6 * HID) = or_bits(*(const f32x4*)(p.Wt + OFF_BL), derived_nan_mask(p.Wt));
-        }
-    }
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = lane >> 5, j = lane & 31;
-    // one 8 x 4 pixel tile per workgroup
-    const int x = p.x0 + blockIdx.x * TILE_W + (j & (TILE_W - 1));
-    const int y = p.y0 + blockIdx.y * TILE_H + (j / TILE_W);
-    const int b = blockIdx.z;
-    const bool valid = (x < p.x1) && (y < p.y1);
-    const int xc = x < p.Wu ? x : p.Wu - 1;
-    const int yc = y < p.y1 ? y : p.y1 - 1;
-    int iy, ix;
-    float relh, relw;
-    axis_eval(p.ah, yc, iy, relh);
-    axis_eval(p.aw, xc, ix, relw);
-    const float* __restrict__ Wt = p.Wt;
-    const float* __restrict__ Pc = p.P + (((size_t)b * p.Prows + (iy - p.Prow0)) * p.W + ix) * PCH + 4 * h;
-    __syncthreads();
-
-    // ---- layer 0: this wave's 64 channels (M-tiles 2w, 2w+1), written as B operands: k-group 4m + g of lane (h, j)
-    // holds registers 4g .. 4g+3 of M-tile m, i.e. channels 32m + 8g + 4h .. +3 = chan_of(4 (4m+g) + e, h)
-#pragma unroll
-    for (int mm = 0; mm < 2; ++mm) {
-        const int m = 2 * wave + mm;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c0 = 32 * m + 8 * g;
-            const f32x4 pv = *(const f32x4*)(Pc + c0);
-            const f32x4 wh = *(const f32x4*)(tab + 0 * HID + 4 * h + c0);
-            const f32x4 ww = *(const f32x4*)(tab + 1 * HID + 4 * h + c0);
-            const f32x4 tq = *(const f32x4*)(tab + 2 * HID + 4 * h + c0);
-            f32x4 q0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float a = tq[e];
-                a = __builtin_fmaf(ww[e], relw, a);
-                a = __builtin_fmaf(wh[e], relh, a);
-                q0[e] = relu0(pv[e]) * dsin_rev<SIN_MODE>(a);
-            }
-            qs[0][4 * m + g][lane] = q0;
-        }
-    }
-
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);
-    const int lane_off = lane * 16;
-    // piece of (M-tile 2w + mm, k-group kg, part): ((m * 32 + kg) * 2 + part) KiB into the layer
-    int wp = (int)(OFF_WLR * sizeof(float)) + (2 * wave) * (WL_KG * 2 * PIECE_BYTES);
-    auto ld_w = [&](const int mm, const int kg, const int part) {
-        return ld_piece(wrs, lane_off, wp + ((mm * WL_KG + kg) * 2 + part) * PIECE_BYTES);
-    };
-    __syncthreads();
-
-    auto layer_body = [&](auto cur_tag, const int layer) {
-        constexpr int CUR = decltype(cur_tag)::value ? 1 : 0;
-        f32x16 acc[2][2];                                        // [M-tile mm][part]: modulation, synthesis
-#pragma unroll
-        for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = 32 * (2 * wave + mm) + 8 * g;
-                const f32x4 sk = *(const f32x4*)(Pc + (layer + 1) * HID + c0);
-                const f32x4 sq = *(const f32x4*)(Wt + OFF_BQR + layer * HID + 4 * h + c0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[mm][0][4 * g + e] = sk[e];
-                    acc[mm][1][4 * g + e] = sq[e];
-                }
-            }
-        // weight ring: 3 slots of one k-group (4 pieces: [M-tile][part]); while group kg is consumed the slot of group
-        // kg-1 is refilled with group kg+2, one piece after each quad of MFMAs (a vector-memory instruction blocks the
-        // wave for ~60 cycles: behind an MFMA of 64 it is free, four in a row are not)
-        f32x4 rw[3][2][2];
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-                for (int part = 0; part < 2; ++part) rw[d][mm][part] = ld_w(mm, d, part);
-        f32x4 bq = qs[CUR][0][lane];
-#pragma unroll
-        for (int kg = 0; kg < WL_KG; ++kg) {
-            const f32x4 bv = bq;
-            if (kg + 1 < WL_KG) bq = qs[CUR][kg + 1][lane];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-                    for (int part = 0; part < 2; ++part)
-                        acc[mm][part] = MFMA32(rw[kg % 3][mm][part][e], bv[e], acc[mm][part]);
-                if (kg + 2 < WL_KG) rw[(kg + 2) % 3][e >> 1][e & 1] = ld_w(e >> 1, kg + 2, e & 1);
-                asm volatile("" ::: "memory");                   // keeps each load behind its quad of MFMAs' issue slot
-            }
-        }
-        // epilogue: q = relu(k) * sin(s) for this wave's 64 channels -> the other LDS image (or the head)
-#pragma unroll
-        for (int mm = 0; mm < 2; ++mm) {
-            const int m = 2 * wave + mm;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 qn;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) qn[e] = relu0(acc[mm][0][4 * g + e]) * dsin_rev<SIN_MODE>(acc[mm][1][4 * g + e]);
-                qs[1 - CUR][4 * m + g][lane] = qn;
-            }
-        }
-        __syncthreads();
-    };
-    layer_body(TagCoopF{}, 0);                                   // image 0 -> 1
-    wp += (int)(WL_LAYER * sizeof(float));
-    layer_body(TagCoopT{}, 1);                                   // 1 -> 0
-    wp += (int)(WL_LAYER * sizeof(float));
-    layer_body(TagCoopF{}, 2);                                   // 0 -> 1
-
-    // ---- head (diinn.py:138): the last activation is in LDS in decode_kernel's register order, so one wave runs
-    // decode_kernel's head on it verbatim (same fmaf chain per lane half, same cross-half sum): the two kernels agree
-    // bit for bit, and a row band decoded by one stitches exactly into an image decoded by the other
-    if (wave == 0) {
-        float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
-        const float* __restrict__ L = tab + 3 * HID + 4 * h;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = 32 * m + 8 * g;
-                const f32x4 v = qs[1][4 * m + g][lane];          // layer 3 wrote image 1
-                const f32x4 l0 = *(const f32x4*)(L + 0 * HID + c0);
-                const f32x4 l1 = *(const f32x4*)(L + 1 * HID + c0);
-                const f32x4 l2 = *(const f32x4*)(L + 2 * HID + c0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o0 = __builtin_fmaf(l0[e], v[e], o0);
-                    o1 = __builtin_fmaf(l1[e], v[e], o1);
-                    o2 = __builtin_fmaf(l2[e], v[e], o2);
-                }
-            }
-        }
-        o0 += __shfl_xor(o0, 32);
-        o1 += __shfl_xor(o1, 32);
-        o2 += __shfl_xor(o2, 32);
-        if (valid && h == 0) {
-            const long long plane = p.o_ps;
-            float* op = out_px(p, b, y, x);
-            op[0] = o0 + tab[6 * HID + 0];
-            op[plane] = o1 + tab[6 * HID + 1];
-            op[2 * plane] = o2 + tab[6 * HID + 2];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// decode_coop16_kernel: the fp32 latency form for the SMALLEST launches (BASELINE config 1: 96 x 96).  decode_coop_kernel
-// gives a workgroup a 32-pixel tile and each wave a chain of 3 x 512 dependent-paced MFMAs of 64 clocks (41 us); an
-// image of 288 such tiles puts two workgroups on 32 of the 256 CUs and takes ~2 x 41 us.  Here a workgroup owns a
+// decode_coop16_kernel: the fp32 latency form for small and partly filled launches (BASELINE config 1: 96 x 96).
+// decode_kernel gives one wave a 32-pixel tile and 6,144 dependent MFMAs (0.165 ms at any size).  (Round 2's form -- four
+// waves sharing ONE 32-pixel tile, a chain of 3 x 512 MFMAs of 64 clocks, 41 us -- never won against this one and was
+// deleted in round 5: DESIGN_HISTORY.md.)  Here a workgroup owns a
 // 4 x 4 = 16-pixel tile on v_mfma_f32_16x16x4_f32 (32 clocks): wave w owns output channels 64 w .. 64 w + 63 of both
 // branches as four 16-row M-tiles each (8 accumulators of 4 registers, 512 MFMAs per layer, 20 us per tile), twice
 // the workgroups at half the chain, four workgroups per CU (38 KiB of LDS, < 128 registers).  Measured at c1 (r04,
@@ -579,13 +392,7 @@ __global__ __launch_bounds__(256, 4) void decode_coop16_kernel(const DecodeParam
     const int lane_off = lane * 16;
     int wp = (int)(OFF_WL16 * sizeof(float)) + wave * (int)(WL16_WAVE * sizeof(float));
     auto ld_w = [&](const int i, const int half) {
-#if defined(ABL_C16_NOLOAD)
-        return f32x4{0.5f, 0.25f, 0.125f, (float)(i + half + wp)};                  // timing ablation: no weight requests at all
-#elif defined(ABL_C16_SAMEW)
-        return ld_piece(wrs, lane_off, wp + (2 * (i & 3) + half) * PIECE_BYTES);    // timing ablation: 8 KiB of weights, L1-resident
-#else
         return ld_piece(wrs, lane_off, wp + (2 * i + half) * PIECE_BYTES);
-#endif
     };
     __syncthreads();
 
@@ -800,6 +607,26 @@ static inline OutView contig(RowWin ow, int Wu) {
 // HR rows [y0,y1) x columns [x0,x1) of the image, every arithmetic mode.  Blocks are anchored at (x0, y0); no pixel's
 // arithmetic depends on its place in a block, and every kernel-variant choice that is not bit-neutral is made from the
 // FULL image, so a tile is bit-identical to the same pixels of a whole-image decode.
+// Which fp32 kernel a tile launch takes, and its grid (one function for the launch and for diinn_decode_kernel_info).
+// decode_kernel runs whole ROUNDS of one workgroup of 16 x 8 pixels per compute unit, 181 us each whatever the fill; the
+// 16-pixel latency kernel is work-conserving (four workgroups per CU) at 0.0896 us per tile on 256 CUs + ~25 us -- 1.3 %
+// behind on exact rounds (c2: 5.87 vs 5.79 ms), far ahead on a partly filled last round (48 -> 192: 0.234 vs 0.363 ms;
+// r04, tools/f32_kernel_choice.py, profiles/r04_f32_kernel_choice.txt).  The launch takes the cheaper by that model, with
+// the device's own CU count in it.  DIINN_F32_KERNEL = 1 / 3 forces the throughput / the 16-pixel latency kernel (tests,
+// A-B timing).
+struct F32Choice { int kernel; dim3 grid; };
+static F32Choice f32_kernel_choice(int B, int y0, int y1, int x0, int x1) {
+    const int gx = (x1 - x0 + TILE_W * WG_TILES_X - 1) / (TILE_W * WG_TILES_X);
+    const int gy = (y1 - y0 + TILE_H * WG_TILES_Y - 1) / (TILE_H * WG_TILES_Y);
+    const int force = (int)knob(diinn_knobs().f32_kernel);
+    const int ncu = device_cus();
+    const dim3 grid16((x1 - x0 + T16_W - 1) / T16_W, (y1 - y0 + T16_H - 1) / T16_H, B);
+    const double t16 = (double)grid16.x * grid16.y * grid16.z, rounds = (double)(((long long)gx * gy * B + ncu - 1) / ncu);
+    const bool cheaper16 = 0.0896 * t16 * (256.0 / ncu) + 25.0 < 181.1 * rounds + 3.0;
+    if (grid16.y <= 65535 && (force ? force == 3 : cheaper16)) return F32Choice{DIINN_DECODE_KERNEL_LATENCY16, grid16};
+    return F32Choice{DIINN_DECODE_KERNEL_THROUGHPUT, dim3(gx, gy, B)};
+}
+
 static int decode_tile_impl(void* stream, const float* P_dev, const float* packed_dev,
                             float* out_dev, int B, int H, int W, int Hu, int Wu,
                             int y0, int y1, int x0, int x1, int sin_mode, int compute, RowWin pw, OutView ov) {
@@ -856,36 +683,15 @@ static int decode_tile_impl(void* stream, const float* P_dev, const float* packe
             hipLaunchKernelGGL((decode_kernel<DIINN_SIN_ACCURATE, false>), grid, dim3(blk), 0, (hipStream_t)stream, p);
         return hip_status(hipGetLastError());
     }
-    // Which of the three fp32 kernels (bit-equal: tests/test_gpu_parity.py::test_latency_kernel_is_bit_identical_...)?
-    // decode_kernel runs whole ROUNDS of 256 workgroups of 16 x 8 pixels, 181 us each whatever the fill; the 16-pixel
-    // latency kernel is work-conserving (four workgroups per CU) at 0.0896 us per tile + ~25 us -- 1.3 % behind on exact
-    // rounds (c2: 5.87 vs 5.79 ms), far ahead on a partly filled last round (48 -> 192: 0.234 vs 0.363 ms; r04,
-    // tools/f32_kernel_choice.py, profiles/r04_f32_kernel_choice.txt).  The launch takes the cheaper by that model; the 32-pixel
-    // latency kernel (r02) never wins any more and runs only when forced.
-    // DIINN_F32_KERNEL = 1 / 2 / 3 forces the throughput / 32-pixel latency / 16-pixel latency kernel (tests, A-B timing).
-    const int force = (int)knob(diinn_knobs().f32_kernel);
-    {
-        const dim3 grid16((x1 - x0 + T16_W - 1) / T16_W, (y1 - y0 + T16_H - 1) / T16_H, B);
-        const double t16 = (double)grid16.x * grid16.y * grid16.z, rounds = (double)(((long long)gx * gy * gz + 255) / 256);
-        const bool cheaper16 = 0.0896 * t16 + 25.0 < 181.1 * rounds + 3.0;
-        if (grid16.y <= 65535 && (force ? force == 3 : cheaper16)) {
-            if (sin_mode == DIINN_SIN_HW)
-                hipLaunchKernelGGL(decode_coop16_kernel<DIINN_SIN_HW>, grid16, dim3(256), 0, (hipStream_t)stream, p);
-            else if (sin_mode == DIINN_SIN_HW_REDUCED)
-                hipLaunchKernelGGL(decode_coop16_kernel<DIINN_SIN_HW_REDUCED>, grid16, dim3(256), 0, (hipStream_t)stream, p);
-            else
-                hipLaunchKernelGGL(decode_coop16_kernel<DIINN_SIN_ACCURATE>, grid16, dim3(256), 0, (hipStream_t)stream, p);
-            return hip_status(hipGetLastError());
-        }
-    }
-    const dim3 gridc((x1 - x0 + TILE_W - 1) / TILE_W, (y1 - y0 + TILE_H - 1) / TILE_H, B);
-    if (gridc.y <= 65535 && force == 2) {
+    // Which of the two fp32 kernels (bit-equal: tests/test_gpu_parity.py::test_latency_kernel_is_bit_identical_...)?
+    const F32Choice ch = f32_kernel_choice(B, y0, y1, x0, x1);
+    if (ch.kernel == DIINN_DECODE_KERNEL_LATENCY16) {
         if (sin_mode == DIINN_SIN_HW)
-            hipLaunchKernelGGL(decode_coop_kernel<DIINN_SIN_HW>, gridc, dim3(256), 0, (hipStream_t)stream, p);
+            hipLaunchKernelGGL(decode_coop16_kernel<DIINN_SIN_HW>, ch.grid, dim3(256), 0, (hipStream_t)stream, p);
         else if (sin_mode == DIINN_SIN_HW_REDUCED)
-            hipLaunchKernelGGL(decode_coop_kernel<DIINN_SIN_HW_REDUCED>, gridc, dim3(256), 0, (hipStream_t)stream, p);
+            hipLaunchKernelGGL(decode_coop16_kernel<DIINN_SIN_HW_REDUCED>, ch.grid, dim3(256), 0, (hipStream_t)stream, p);
         else
-            hipLaunchKernelGGL(decode_coop_kernel<DIINN_SIN_ACCURATE>, gridc, dim3(256), 0, (hipStream_t)stream, p);
+            hipLaunchKernelGGL(decode_coop16_kernel<DIINN_SIN_ACCURATE>, ch.grid, dim3(256), 0, (hipStream_t)stream, p);
         return hip_status(hipGetLastError());
     }
     if (sin_mode == DIINN_SIN_HW)
@@ -940,6 +746,21 @@ int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,
     if (grid_y) *grid_y = (y1 - y0 + TILE_H * WG_TILES_Y - 1) / (TILE_H * WG_TILES_Y);
     if (grid_z) *grid_z = B;
     if (block) *block = 256;
+    return DIINN_OK;
+}
+
+int diinn_decode_kernel_info(int B, int Hu, int Wu, int y0, int y1, int x0, int x1, int compute, int info[4]) {
+    if (!info || B <= 0 || Hu <= 0 || Wu <= 0 || y0 < 0 || y1 > Hu || y0 >= y1 || x0 < 0 || x1 > Wu || x0 >= x1) return DIINN_ERR_INVALID_ARG;
+    if (!compute_ok(compute)) return DIINN_ERR_UNSUPPORTED;
+    if (compute == DIINN_COMPUTE_F32) {
+        const F32Choice ch = f32_kernel_choice(B, y0, y1, x0, x1);
+        info[0] = ch.kernel; info[1] = (int)ch.grid.x; info[2] = (int)ch.grid.y; info[3] = (int)ch.grid.z;
+        return DIINN_OK;
+    }
+    info[0] = compute == DIINN_COMPUTE_F32_QONLY ? DIINN_DECODE_KERNEL_THROUGHPUT : DIINN_DECODE_KERNEL_OTHER;
+    info[1] = (x1 - x0 + TILE_W * WG_TILES_X - 1) / (TILE_W * WG_TILES_X);
+    info[2] = (y1 - y0 + TILE_H * WG_TILES_Y - 1) / (TILE_H * WG_TILES_Y);
+    info[3] = B;
     return DIINN_OK;
 }
 

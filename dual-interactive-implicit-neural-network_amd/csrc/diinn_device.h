@@ -3,7 +3,7 @@
 // path, and the small host-side helpers of the C ABI launch functions.
 //
 // Translation units (all built with hipcc --offload-arch=gfx950 -O3 -ffp-contract=off; build.py: HIP_SOURCES + HOST_SOURCES):
-//   diinn_decode.hip           decode_kernel (+ modes 1/2 chain, training forward), decode_coop_kernel (latency form),
+//   diinn_decode.hip           decode_kernel (+ modes 1/2 chain, training forward), decode_coop16_kernel (latency form),
 //                              and the decode entry points of the C ABI
 //   diinn_precompute.hip       precompute_P_kernel (direct fp32), precompute_P_bf16_kernel / _bf16_wide_kernel, launch_P
 //   diinn_precompute_wino.hip  precompute_P_wino_kernel (the fp32 hoisted conv in Winograd F(2x2,3x3) form: inference)
@@ -92,13 +92,9 @@ template <>
 __device__ __forceinline__ float dsin_rev<DIINN_SIN_HW>(float x) { return __builtin_amdgcn_sinf(x); }
 template <>
 __device__ __forceinline__ float dsin_rev<DIINN_SIN_HW_REDUCED>(float x) {
-#ifdef SIN_REV_FRACT
-    return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x));
-#else
     // x - rint(x) is exact and keeps the precision of small arguments (fract maps a small negative x to 1 - |x|,
     // whose ulp is 6e-8: 7e-8 output error against 3e-8, measured on the fixtures)
     return __builtin_amdgcn_sinf(x - __builtin_rintf(x));
-#endif
 }
 template <>
 __device__ __forceinline__ float dsin_rev<DIINN_SIN_ACCURATE>(float x) {
@@ -155,20 +151,6 @@ __device__ __forceinline__ float* out_px(const DecodeParams& p, int b, int y, in
 }
 
 constexpr int TILE_W = 8, TILE_H = 4;           // one wave: 8x4 HR pixels
-// timing-ablation hooks (wrong results when defined; never in the shipped build)
-#ifdef ABL_WSTREAM
-#define ABL_STEP(x) ((x) & 3)
-#else
-#define ABL_STEP(x) (x)
-#endif
-#ifdef ABL_NOSIN
-#define ABL_SIN(x) (x)
-#else
-#define ABL_SIN(x) dsin<SIN_MODE>(x)
-#endif
-#ifndef DECODE_RUN_LAYERS
-#define DECODE_RUN_LAYERS 3                     // < 3 only in timing-ablation builds (wrong results)
-#endif
 #ifndef WSTREAM_AUX
 #define WSTREAM_AUX 0                           // cache-policy bits of the weight-stream loads (sc0=1, nt=2, sc1=16)
 #endif

@@ -8,8 +8,8 @@
 #include <atomic>
 
 struct DiinnKnobs {
-    std::atomic<long long> f32_kernel;          // DIINN_F32_KERNEL: 1 throughput, 2 32-pixel latency, 3 16-pixel latency decode kernel (0: the cheaper by the launch cost model)
-    std::atomic<long long> bf16_kernel;         // DIINN_BF16_KERNEL: 1 / 2 tiles per wave, 4 / 8 cooperative waves (0: auto)
+    std::atomic<long long> f32_kernel;          // DIINN_F32_KERNEL: 1 throughput, 3 16-pixel latency decode kernel (0: the cheaper by the launch cost model; 2 was round 2's 32-pixel form, deleted)
+    std::atomic<long long> bf16_kernel;         // DIINN_BF16_KERNEL: 1 / 2 tiles per wave, 8 cooperative waves (one block per workgroup), 9 the same with persistent workgroups (0: auto)
     std::atomic<long long> x3_kernel;           // DIINN_X3_KERNEL: 1 one block per workgroup, 2 persistent split-bf16 decode (0: auto)
     std::atomic<long long> pbf16_kernel;        // DIINN_PBF16_KERNEL: 1 narrow, 2 wide bf16 P kernel (0: auto)
     std::atomic<long long> p_kernel;            // DIINN_P_KERNEL: 1 direct, 2 Winograd fp32 P kernel (0: auto)

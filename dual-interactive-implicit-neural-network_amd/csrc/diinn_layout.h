@@ -74,7 +74,7 @@ constexpr size_t OFF_BQR    = OFF_WPB + SZ_WPB;
 // Q0R: the Q0 table (Q0h, Q0w, Q0r, bQ0; [4][256]) in revolutions as well, for the cooperative bf16 kernel
 constexpr size_t OFF_Q0R    = OFF_BQR + 3 * HID;
 // WLR: WL with the synthesis rows (part 1) multiplied by fp32(1/(2 pi)): the fp32 inference kernels (decode_kernel
-//     without SAVE, decode_coop_kernel) keep the synthesis branch in revolutions too, which turns the epilogue's sine
+//     without SAVE, decode_coop16_kernel) keep the synthesis branch in revolutions too, which turns the epilogue's sine
 //     into v_fract + v_sin (on gfx950 every VALU instruction costs fp32-MFMA issue time).  WL itself stays a pure
 //     permutation of the reference tensors: the training forward saves sine arguments in radians, LIIF reads the
 //     synthesis slots as plain MLP weights, and the device re-pack of a training step is a gather.

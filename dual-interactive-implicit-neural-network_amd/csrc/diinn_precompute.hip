@@ -43,7 +43,6 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
     const int x0 = blockIdx.x * PT_COLS;
     const int y0 = p.r0 + blockIdx.y * PT_ROWS;
 
-#ifndef P_NO_WARMUP
     // L2 warm-up.  Inside a decode step this kernel starts right after decode_kernel has streamed hundreds of MB of
     // P through every L2, so the 2.25 MiB weight image is gone; all waves of an XCD then walk it in lock-step and
     // the whole first round of workgroups advances at HBM-latency pace (67 % MFMA utilisation at c2 against 80 % warm).
@@ -65,7 +64,6 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
             asm volatile("global_load_dword %0, %1, off" : "=v"(warm[i]) : "v"(wpb + (size_t)line * 128) : "memory");
         }
     }
-#endif
 
     // stage feat[b, :, y0-1 .. y0+4, x0-1 .. x0+32] (zeros outside the map)
     const float* __restrict__ fb = p.feat + (size_t)b * C_IN * p.Frows * p.W;
@@ -89,9 +87,7 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
         const float v = fb[((size_t)c * p.Frows + yc) * p.W + xc];
         tile[idx] = ok ? v : 0.0f;
     }
-#ifndef P_NO_WARMUP
     asm volatile("s_waitcnt vmcnt(0)" :: "v"(warm[0]), "v"(warm[1]), "v"(warm[2]), "v"(warm[3]) : "memory");
-#endif
     __syncthreads();
 
     const int x = x0 + j, y = y0 + wave;
@@ -346,9 +342,6 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_wide_kernel(const PP
     // the launch requires W % 4 == 0); the tile keeps columns x0-1 .. x0+32, i.e. lx = 4q - 3 + e
     constexpr int ITEMS = C_IN * PW_LR * PW_XQ;                  // 6,400 = 25 per thread
     static_assert(ITEMS % 256 == 0, "staging loop has a fixed trip count");
-#ifdef ABL_PW_NOSTAGE
-    if (p.W < 0)                                                 // timing ablation: the staging loop is skipped (wrong results)
-#endif
 #pragma unroll 5
     for (int it = 0; it < ITEMS / 256; ++it) {
         const int idx = it * 256 + threadIdx.x;
@@ -408,17 +401,9 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_wide_kernel(const PP
         const f32x4 v = *(const f32x4*)(trw + cell * PW_TR_PITCH + 4 * q);
         if (prowok && x0 + cell < p.W) {
             float* dst = p.P + (((size_t)b * p.Prows + prow) * p.W + x0 + cell) * PCH + 32 * pmo + 4 * q;
-#ifdef ABL_PW_NOSTORE
-            asm volatile("" :: "v"(v), "v"(dst));
-#else
             // streaming store: P is hundreds of MB and is read back by the next launch only after all of it has been
             // written, so the lines need not stay in L2 (1.43 -> 1.20 ms at c5; the packed weights stay resident)
-#ifdef ABL_PW_PLAINSTORE
-            *(f32x4*)dst = v;
-#else
             __builtin_nontemporal_store(v, (f32x4*)dst);
-#endif
-#endif
         }
     };
     // r03: the staged halo tile is walked ROW by row and every B fragment feeds up to THREE MFMAs -- halo row r is
@@ -468,9 +453,7 @@ __global__ __launch_bounds__(256, 2) void precompute_P_bf16_wide_kernel(const PP
                 if (t < 0 || t >= PW_ROWS) continue;
                 const int ks = 4 * (3 * ky + kx) + cg;
                 acc[t % 3] = MFMA_BF16(__builtin_bit_cast(bf16x8, A[ks]), cur, acc[t % 3]);
-#ifndef ABL_PW_NOREFILL
                 if (t == PW_ROWS - 1 && mi < 7) A[ks] = ld_piece(wrs, lane_off, piece(mo + 4, ks));   // last use of this fragment
-#endif
             }
             // the previous output row leaves under this halo row's MFMAs: its four stores, spread out
             if (r >= 3 || (r == 0 && mi > 0)) {                  // (row 0: the last output row of the previous M-tile)

@@ -101,9 +101,7 @@ __device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, flo
         }
     }
 
-#ifndef PWN_NO_WARMUP
     asm volatile("" :: "v"(warm[0]), "v"(warm[1]), "v"(warm[2]), "v"(warm[3]));   // the warm-up loads are older than the patch rows just waited for
-#endif
     // ---- output side: wave = output row pr of the 2x2 block and tile half th; store group k, lane L: cell n = 8k + (L >> 3)
     // of the wave's 32 cells (tile 16 th + (n >> 1), column q = n & 1), chunk c = L & 7 (channels 4c .. 4c+3 of the M-tile)
     const int pr = wave & 1, th = wave >> 1;
@@ -171,12 +169,8 @@ __device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, flo
         for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf(s2, z2[e], __builtin_fmaf(s2, z1[e], z0[e])) + bias4[e];
         if (pdst[k]) {
             f32x4* dst = reinterpret_cast<f32x4*>(pdst[k] + 32 * mprev);
-#ifdef ABL_PWN_NOSTORE
-            asm volatile("" :: "v"(y), "v"(dst));                // timing ablation (wrong results)
-#else
             if (p.stream_stores) __builtin_nontemporal_store(y, dst);
             else *dst = y;
-#endif
         }
     };
     // one M-tile: 8 k-groups x (4 k-steps x 4 columns) MFMAs into acc[PAR]; PREV: finish M-tile mt - 1 meanwhile
@@ -270,7 +264,6 @@ __global__ __launch_bounds__(256, 1) void precompute_P_wino_kernel(const PWinoPa
     // 0.293 ms (same box, A/B); c5: neutral; on maps whose whole working set stays in the L2s (c1: +1.6 us on 26) it is
     // pure overhead, so the host switches it on from 8,192 cells (a P image of 32 MiB = the eight L2s) on.
     float warm[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#ifndef PWN_NO_WARMUP
     {
         const unsigned slot = blockIdx.x >> 3;                   // this workgroup's index inside its XCD
         const unsigned first = (unsigned)per_xcd < 32u ? (unsigned)per_xcd : 32u;   // workgroups of an XCD's first round (one per CU)
@@ -287,7 +280,6 @@ __global__ __launch_bounds__(256, 1) void precompute_P_wino_kernel(const PWinoPa
             }
         }
     }
-#endif
     const int part = __builtin_amdgcn_readfirstlane(t % p.msplit);   // the parts of a block are neighbours: they share its patch rows
     t /= p.msplit;
     const int mt0 = part * 32 / p.msplit, mtn = (part + 1) * 32 / p.msplit - mt0;   // parts of floor or ceil(32 / msplit) M-tiles

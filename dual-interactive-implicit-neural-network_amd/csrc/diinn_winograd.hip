@@ -26,8 +26,8 @@
 constexpr int WN_TX = 8, WN_TY = 4;                  // Winograd tiles per block (x, y): 32 = one MFMA N-tile
 constexpr int WN_PIECE_BYTES = 1024;                 // one A piece: 64 lanes x 4 k-steps
 constexpr int WN_CHUNK_BYTES = 8 * WN_PIECE_BYTES;   // per wave and chunk of 8 channels: 4 positions x 2 halves
-// WN_ABL_* are timing-ablation hooks for tools/r02_wino_ablation.sh (wrong results when defined; never in the shipped
-// build); WN_STAGES = 4 deepens the register ring (measured: no gain).
+// WN_STAGES = 4 deepens the register ring (measured: no gain).  (The WN_ABL_* timing-ablation hooks behind
+// profiles/r02_enc_*.txt were removed in round 5: git show 84fe2c6:<this file>.)
 #ifndef WN_STAGES
 #define WN_STAGES 3
 #endif
@@ -85,19 +85,11 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
     const bool tile_in = 2 * tx < p.W && 2 * ty < p.H;
     const bool left = EDGE && tx == 0;
     const bool ok2 = 2 * tx + 1 < p.W, ok3 = 2 * tx + 2 < p.W;
-#ifdef WN_ABL_ALIGNED
-    const int xc = 2 * tx;                                       // timing experiment: 8-byte aligned rows (wrong results)
-#else
     const int xc = left ? 0 : 2 * tx - 1;
-#endif
     const int ya = 2 * ty - 1 + ra, yb = 2 * ty - 1 + rb;
     constexpr unsigned OUTSIDE = 0x80000000u;
-#ifdef WN_ABL_OUTSIDE
-    const unsigned offa = OUTSIDE, offb = OUTSIDE;               // timing experiment: every row answered by the range check
-#else
     const unsigned offa = (tile_in && ya >= 0 && ya < p.H) ? (unsigned)h * plane_b + (unsigned)(ya * p.W + xc) * 4u : OUTSIDE;
     const unsigned offb = (tile_in && yb >= 0 && yb < p.H) ? (unsigned)h * plane_b + (unsigned)(yb * p.W + xc) * 4u : OUTSIDE;
-#endif
 
     f32x4 A[WN_NS][NW];      // weight pieces of the ring's chunks: [stage][col j * NH + half], components = k-steps
     f32x4 R[WN_NS][8];       // patch rows of the ring's chunks: [stage][2 e + {row a, row b}], components = patch columns
@@ -118,13 +110,9 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
     auto request = [&](auto S_, auto IDX_, int c, __amdgpu_buffer_rsrc_t irs) {
         constexpr int S = decltype(S_)::value, IDX = decltype(IDX_)::value;
         if constexpr (IDX < NW) {
-#ifndef WN_ABL_NOW
             A[S][IDX] = ld_piece(wrs, lane_off, c * WN_CHUNK_BYTES + (NH == 2 ? IDX : 2 * IDX + hh0) * WN_PIECE_BYTES);
-#endif
         } else if constexpr (IDX < NREQ) {
-#ifndef WN_ABL_NOROWS
             R[S][IDX - NW] = ld_row(irs, ((IDX - NW) & 1) ? offb : offa, (unsigned)(2 * ((IDX - NW) >> 1)) * plane_b);
-#endif
         }
     };
     // The transform of one channel's two patch rows, 4 packed-fp32 instructions (each VALU instruction between two
@@ -167,11 +155,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvWinoParams& p, float* _
         for (int q = 0; q < NW; ++q) {                           // MFMA q: col q / NH, half q % NH
             acc[q / NH][q % NH] = MFMA32(A[S][q][E], cj[q / NH], acc[q / NH][q % NH]);
             if (q == 0) {
-#ifndef WN_ABL_NOVALU
                 transform(ra4, rb4, V01, V23);
-#else
-                V01 = f32x2{ra4[0], ra4[1]}, V23 = f32x2{rb4[2], rb4[3]};
-#endif
             }
             // RPK requests per k-step: after every second MFMA of 8, or after each of the first three of 4
             if constexpr (NH == 2) {

@@ -17,7 +17,7 @@ backward is library GEMMs over those (training.py).
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -410,7 +410,11 @@ class ImplicitDecoder(nn.Module):
             self.last_layer = nn.Conv2d(self.hidden_dims[-1], 3, 1)
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
-        self._workspace: Optional[torch.Tensor] = None
+        # P workspaces, one per (device, stream) that called forward: two streams decoding through one module concurrently
+        # must not share the hoisted conv's image (at most _MAX_WORKSPACES kept, oldest dropped)
+        self._workspaces: "Dict[tuple, torch.Tensor]" = {}
+
+    _MAX_WORKSPACES = 4
 
     # -- packed-weight cache ---------------------------------------------------
     def _weights_key(self, device):
@@ -458,9 +462,13 @@ class ImplicitDecoder(nn.Module):
             # replaced (and its block recycled) as soon as a larger input arrives
             workspace = None
         else:
-            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != x.device:
-                self._workspace = torch.empty(need, dtype=torch.float32, device=x.device)
-            workspace = self._workspace
+            key = (str(x.device), torch.cuda.current_stream(x.device).cuda_stream)
+            workspace = self._workspaces.get(key)
+            if workspace is None or workspace.numel() < need:
+                self._workspaces.pop(key, None)
+                while len(self._workspaces) >= self._MAX_WORKSPACES:
+                    self._workspaces.pop(next(iter(self._workspaces)))
+                workspace = self._workspaces[key] = torch.empty(need, dtype=torch.float32, device=x.device)
         with torch.no_grad():
             packed = self.packed_weights(x.device)
             return decode_features(x, packed, size, workspace=workspace, sin_mode=self.sin_mode,

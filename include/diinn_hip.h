@@ -398,7 +398,9 @@ int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* 
  *   (DIINN_ENC_WINO4_SPLIT: 0 never, 2 always), cuts the input-channel chunks of the I mod N items left into N equal runs:
  *   a workgroup that computed part of an item's channels leaves its partial outputs in the workspace and the last one to
  *   arrive adds the parts in a fixed order.  Results are deterministic and depend on (shape, N) only; they differ from
- *   diinn_conv_wino4's by the reassociation (~1e-7 of max|out|).  No workgroup waits for another.  Launches that share a
+ *   diinn_conv_wino4's by a reassociation in the transformed domain (up to ~2e-5 of max|out|: the size of either one's
+ *   distance to the exact convolution).  The last arriver of an item waits -- bounded -- for the other parts' stores, which wait
+ *   for nobody; word 1023 of the workspace stays 0 unless such a wait gave up.  Launches that share a
  *   workspace must be ordered (same stream).  diinn_conv_wino4 = diinn_conv_wino4_ws without a workspace (never splits).
  * diinn_conv_wino4_plan: what diinn_conv_wino4_ws would do on the current device: info[0] work items, [1] items run whole,
  *   [2] split workgroups, [3] chunks of 8 input channels per split workgroup.
@@ -449,9 +451,16 @@ int    diinn_rdn_forward_x3(void* stream, const float* sfe1_dev, const float* pa
                             const float* packed_x3_dev, const float* biases_dev, float* workspace_dev, float* out_dev,
                             int B, int H, int W);
 
-/* Dominant-kernel launch geometry, for benchmarks/roofline accounting. */
+/* Launch geometry of decode_kernel (the throughput kernel: workgroups of 16 x 8 pixels) for HR rows [y0, y1). */
 int diinn_decode_launch_info(int B, int Hu, int Wu, int y0, int y1,
                              int* grid_x, int* grid_y, int* grid_z, int* block);
+/* Which decode kernel diinn_decode_tile_win (and its wrappers) launch for HR rows [y0,y1) x columns [x0,x1) in `compute` on the
+ * current device -- the launch function's own choice (cost model, CU count and DIINN_F32_KERNEL included), for benchmarks
+ * that label a time or a roofline fraction with a kernel: info[0] = kernel, info[1..3] = its grid (x, y, z). */
+#define DIINN_DECODE_KERNEL_THROUGHPUT 1   /* decode_kernel: 32 pixels per wave, activations register-resident           */
+#define DIINN_DECODE_KERNEL_LATENCY16  3   /* decode_coop16_kernel: 16-pixel tiles, four workgroups per CU, bit-equal      */
+#define DIINN_DECODE_KERNEL_OTHER      0   /* a bf16 / split-bf16 kernel (chosen from the full image: DIINN_BF16_KERNEL ...) */
+int diinn_decode_kernel_info(int B, int Hu, int Wu, int y0, int y1, int x0, int x1, int compute, int info[4]);
 /* Which form of the hoisted 3x3 convolution diinn_precompute_P_ex / _win / diinn_decode* run for LR rows [r0,r1) of a
  * [B,64,H,W] map in `compute` (the diagnostic overrides below included): what a benchmark should label its P time with. */
 #define DIINN_P_ALGO_DIRECT      0   /* implicit-im2col GEMM, fp32 (1,179,648 FLOP per cell)                 */

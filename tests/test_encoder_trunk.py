@@ -218,7 +218,8 @@ def test_conv_wino4_split_last_round(knobs):
     """diinn_conv_wino4_ws with the last round split over the input channels (forced: DIINN_ENC_WINO4_SPLIT = 2): maps of less
     than one round (every workgroup has part of an item, most of two), of one round and a remainder, ragged widths, batches,
     8 .. 512 input channels (runs of 1 chunk up to 36), ReLU / residual.  Against a float64 convolution at the kernel's own
-    bound; against the unsplit launch within 2e-6 of max|out| (a reassociation of the sum over input channels); 30
+    bound; against the unsplit launch within 3e-5 of max|out| (the sum over input channels reassociated in the TRANSFORMED
+    domain, where either evaluation carries F(4x4)'s ~1e-5: measured 1.8e-5 at 512 channels); 30
     back-to-back launches bit-identical (the parts are added in part order, whoever arrives last); the workspace's counter
     words (tickets, ready counts, the gave-up-waiting mark) all zero afterwards; diinn_conv_wino4_plan says a split happened."""
     import ctypes as C
@@ -268,7 +269,7 @@ def test_conv_wino4_split_last_round(knobs):
         assert torch.equal(off, whole)                           # without a split the workspace form IS diinn_conv_wino4
         err = float((outs[0].double() - ref).abs().max())
         assert err <= 2.5e-5 * scale, (cin, h, w, err)
-        assert float((outs[0] - whole).abs().max()) <= 2e-6 * scale, (cin, h, w)
+        assert float((outs[0] - whole).abs().max()) <= 3e-5 * scale, (cin, h, w)   # two F(4x4) evaluations, each ~1e-5 from the truth
         if info[2]:
             assert not torch.equal(outs[0], whole), (cin, h, w)   # the split form did run
         assert int(ws[:1024].view(torch.int32).abs().sum()) == 0, (cin, h, w)
@@ -668,7 +669,8 @@ def test_diinn_forward_matches_the_reference_on_a_map_with_wino4_layers():
     err64, ref_err64 = float(np.abs(got - ref64).max()), float(np.abs(ref - ref64).max())
     print(f"DIINN 200x180 -> 431x377: |hip - ref32| {err:.2e}; against float64: hip {err64:.2e}, the reference itself {ref_err64:.2e}")
     assert err <= 1e-4 * scale, err
-    assert err64 <= 5e-6, err64                                  # regression level: F(4x4) features cost the image ~1e-6 (F(2x2): 1e-7)
+    assert err <= 5e-7, err                                      # regression level (measured 4.8e-8 when the fixture was made)
+    assert err64 <= 1e-7, err64                                  # ... and against float64 8e-9: closer than the reference itself (4.7e-8)
     sums = y.astype(np.float64).sum(axis=(0, 2, 3))
     assert float(np.abs(sums - gold[f"{key}/channel_sums"]).max()) <= 1e-6 * hu * wu * scale
 
@@ -678,9 +680,10 @@ def test_rdn_trunk_off_default_init_gains(knobs):
     """How the F(4x4,3x3) error grows off the default initialisation: the reference's encoder with every
     weight and bias scaled by 1.5 and by 2.0 (max|feat| 1.5 -> 4.4 -> 75; a trained RDN has per-layer gains of its own and
     no checkpoint is shipped) on a 192 x 200 map, fixtures from the real reference in fp32 and float64.  Contract: 2e-5 x
-    max|ref| against the fp32 reference.  Regression level, against float64: within 8x the reference's own fp32 distance
-    (measured ~3x: the F(4x4) transforms cost a digit at any gain, and the relative error does NOT grow with the gain);
-    the same trunk on F(2x2) layers within 2x."""
+    max|ref| against the fp32 reference.  Measured against float64, relative to max|ref| (gain 1 -> 1.5 -> 2.0): F(4x4) layers
+    1.5e-6 -> 3.4e-6 -> 4.4e-6, F(2x2) layers 4e-7 -> 4.9e-7 -> 1.3e-6, the fp32 reference itself 3e-7 -> 4.6e-7 -> 1.2e-6: the
+    F(4x4) error grows no faster than the reference's own rounding noise and stays 4-7x above it, a factor 4 inside the
+    contract at gain 2.  Regression bounds: 8e-6 (F(4x4)) and 2.5e-6 (F(2x2)) of max|ref| against float64."""
     import json
     import diinn_amd.modules as M
     gold = _gold_r5()
@@ -706,7 +709,7 @@ def test_rdn_trunk_off_default_init_gains(knobs):
             print(f"gain {gain}, F({'4x4' if f4 else '2x2'},3x3): |hip - ref32| {err / scale:.2e} of max|ref| {scale:.1f}; against float64 "
                   f"{err64 / scale:.2e} (the reference itself {ref_err64 / scale:.2e})")
             assert err <= 2e-5 * scale, (gain, f4, err)
-            assert err64 <= (8.0 if f4 else 2.0) * ref_err64 + 1e-7 * scale, (gain, f4, err64, ref_err64)
+            assert err64 <= (8e-6 if f4 else 2.5e-6) * scale, (gain, f4, err64, ref_err64)
     enc.hip_winograd4 = True
 
 

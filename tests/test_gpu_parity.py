@@ -545,7 +545,7 @@ def test_tiles_with_column_ranges_and_strides(dev, knobs, compute):
     torch.cuda.synchronize()
     assert torch.equal(crop, full[:, :, ya:yb, xa:xb])
     if compute == "f32":                                          # the latency kernel takes small tiles: forced both ways
-        for force in (1, 2):
+        for force in (1, 3):
             knobs("DIINN_F32_KERNEL", force)
             crop.fill_(0)
             D.decode_tile(pband, r0, (b, h, w), packed, (hu, wu), (ya, yb), (xa, xb), crop)
@@ -600,28 +600,32 @@ def test_modes_1_and_2(golden, dev, mode):
 
 
 def test_latency_kernel_is_bit_identical_to_throughput_kernel(golden, dev, knobs):
-    """Small launches take decode_coop_kernel (four waves share one 32-pixel tile).  Per output channel it performs
+    """Small and partly filled launches take decode_coop16_kernel (four waves share one 16-pixel tile on
+    v_mfma_f32_16x16x4_f32: four products per instruction, added in k order).  Per output channel it performs
     decode_kernel's arithmetic in decode_kernel's order, so the two must agree bit for bit on every fixture, on
-    row bands and on batches; the fixtures' reference outputs bound both."""
+    row bands and on batches; the fixtures' reference outputs bound both.  diinn_decode_kernel_info reports the forced choice."""
+    import ctypes as C
     import diinn_amd.decoder as D
+    import diinn_amd._native as N
     cases = list(golden_cases(golden))
+    info = (C.c_int * 4)()
     for name, b, h, w, hu, wu, gain in cases:
         sd = synth.decoder_state_dict(123, gain)
         feat = synth.encoder_features(123, b, h, w)
         outs = {}
-        for k in ("1", "2", "3"):                  # throughput, 32-pixel latency (4 waves share a tile), 16-pixel latency
-            knobs("DIINN_F32_KERNEL", int(k))      # (v_mfma_f32_16x16x4_f32: four products per instruction, added in k order)
+        for k in ("1", "3"):                       # throughput, 16-pixel latency
+            knobs("DIINN_F32_KERNEL", int(k))
             outs[k] = _decode(sd, feat, (hu, wu), dev)
-        assert np.array_equal(outs["1"], outs["2"]), name
+            assert N.load().diinn_decode_kernel_info(b, hu, wu, 0, hu, 0, wu, N.COMPUTE_F32, info) == 0 and info[0] == int(k)
         assert np.array_equal(outs["1"], outs["3"]), name
         ref = golden[f"out/{name}"]
-        assert float(np.abs(outs["2"] - ref).max()) <= _tol(ref), name
-    knobs("DIINN_F32_KERNEL", 2)
+        assert float(np.abs(outs["3"] - ref).max()) <= _tol(ref), name
+    knobs("DIINN_F32_KERNEL", 1)
     sd = synth.decoder_state_dict(5)
     feat = torch.from_numpy(synth.encoder_features(5, 2, 19, 23)).to(dev)
     packed = D.pack_state_dict(sd).to(dev)
     full = D.decode_features(feat, packed, (61, 70))
-    for force in (2, 3):
+    for force in (3,):
         knobs("DIINN_F32_KERNEL", force)
         out = torch.zeros_like(full)
         for y0, y1 in [(0, 17), (17, 18), (18, 61)]:
@@ -631,7 +635,7 @@ def test_latency_kernel_is_bit_identical_to_throughput_kernel(golden, dev, knobs
 
 
 def test_bf16_kernel_variants_agree(golden, dev, knobs):
-    """The four bf16 decode kernels (one tile per wave, two tiles per wave, cooperative with 4 and with 8 waves) are
+    """The bf16 decode kernels (one tile per wave, two tiles per wave, cooperative with 8 waves: one block per workgroup and persistent) are
     the same arithmetic (same products, same k-order; only the head's summation order differs) laid out differently:
     their outputs agree to a small fraction of the bf16 error (the cooperative kernels evaluate layer 0's sine on
     revolutions as well, and a 1e-7 difference in an activation can flip a bf16 rounding), and each meets the restated
@@ -646,11 +650,11 @@ def test_bf16_kernel_variants_agree(golden, dev, knobs):
         ref = golden[f"out/{name}"]
         scale = float(np.abs(ref).max())
         outs = {}
-        for k in ("1", "2", "4", "8", "9"):                        # 9: the 8-wave kernel with persistent workgroups
+        for k in ("1", "2", "8", "9"):                             # 9: the 8-wave kernel with persistent workgroups
             knobs("DIINN_BF16_KERNEL", int(k))
             outs[k] = _decode(sd, feat, (hu, wu), dev, compute="bf16")
             assert float(np.abs(outs[k] - ref).max()) <= 2e-3 * scale + 1e-6, (name, k)
-        for k in ("2", "4", "8", "9"):
+        for k in ("2", "8", "9"):
             assert float(np.abs(outs[k] - outs["1"]).max()) <= 5e-4 * scale, (name, k)
         # the persistent form does the one-block form's arithmetic; only the head's 16 partial sums meet in another order
         assert float(np.abs(outs["9"] - outs["8"]).max()) <= 2e-6 * scale, name

@@ -22,7 +22,6 @@ REGS_PER_SIMD = 512
 # kernel name (as in the mangled symbol) -> waves per SIMD the design needs.  Anything not listed needs >= 1.
 DESIGN_OCCUPANCY = {
     "decode_bf16_coop8_kernel": 2,       # two waves per SIMD cover each other's vector-memory stalls
-    "decode_coop_kernel": 2,             # two workgroups per CU where the grid over-subscribes it (4.4a)
     "precompute_P_kernel": 2,            # two workgroups per CU hide each other's waits (4.2)
     "precompute_P_bf16_wide_kernel": 2,
     "conv_wino_half_kernel": 2,          # two workgroups per CU cover prologue / epilogue (4.8)
@@ -91,7 +90,7 @@ def test_no_shipped_kernel_uses_scratch_and_occupancy_is_as_designed(tmp_path):
     ks = kernel_metadata(N.LIB_PATH, tmp_path)
     names = {base_name(k[".name"]) for k in ks}
     # the hot-path kernels are all in the library that was inspected
-    for must in ("decode_kernel", "decode_coop_kernel", "precompute_P_wino_kernel", "precompute_P_kernel", "liif_kernel",
+    for must in ("decode_kernel", "decode_coop16_kernel", "precompute_P_wino_kernel", "precompute_P_kernel", "liif_kernel",
                  "metasr_kernel", "decode_bf16x2_kernel", "decode_bf16_coop8_kernel", "conv_wino_kernel", "conv_wino4_kernel", "bwd_layer_kernel"):
         assert must in names, f"{must} not found in {N.LIB_PATH}"
     assert len(ks) >= 50
