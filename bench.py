@@ -572,7 +572,19 @@ def strong_legs(job):
 
 # Driver-timed side legs of the default N = 1 run: the other single-GPU BASELINE configs, a few
 # steps each, so that their numbers are measured by the same run that produces the headline -- never part of `value`.
-SIDE_LEGS = [("c5", "f32", 2, 1), ("c5", "bf16_full", 5, 2), ("c1", "f32", 200, 20)]
+SIDE_LEGS = [("c5", "f32", 2, 1), ("c5", "bf16_full", 5, 2), ("c5", "bf16", 5, 2), ("c1", "f32", 200, 20)]   # c5 bf16 = SURVEY d4's 2e-3 variant
+
+
+def decode_kernel_name(job, b, hu, wu, y0, y1, compute):
+    """The decode kernel the library launches for these rows (its own choice: diinn_decode_kernel_info), for labels."""
+    N = job.N
+    info = (C.c_int * 4)()
+    N.check(job.lib.diinn_decode_kernel_info(b, hu, wu, y0, y1, 0, wu, N.COMPUTE[compute], info), "diinn_decode_kernel_info")
+    if info[0] == 1:
+        return "decode_kernel"
+    if info[0] == 3:
+        return "decode_coop16_kernel"
+    return "decode_bf16x3 kernel" if compute == "bf16x3" else "decode_bf16 kernel"
 
 
 def side_leg(job, name, compute, steps, warmup, check=True):
@@ -588,6 +600,7 @@ def side_leg(job, name, compute, steps, warmup, check=True):
            "mpix_s": round(hu * wu * steps / t["elapsed"] / 1e6, 2),
            "kernel_ms": round(t_k, 4), "kernel_ms_min": round(min(t["k_ms_all"]), 4), "p_kernel_ms": round(p_ms, 4),
            "achieved": round(ach, 2), "peak": peak, "frac": round(ach / peak, 4),
+           "kernel": decode_kernel_name(job, 1, hu, wu, 0, hu, compute),
            "of": f"decode kernel, HIP events on {t['event_steps']} of the {steps} steps; frac = 789,504 FLOP/px x pixels / "
                  f"kernel time / the dense {'bf16' if bf else 'fp32'} MFMA peak"}
     if "checked" in t:
@@ -597,15 +610,16 @@ def side_leg(job, name, compute, steps, warmup, check=True):
     return leg
 
 
-def whole_model_leg(device, steps=5, warmup=2):
+def whole_model_leg(device, steps=5, warmup=2, lr=256, scale=4):
     """Informational, never part of `value`: the callers' path -- DIINN.forward (reference: diinn.py:9-30: RDN encoder, then the
-    implicit decoder) on a random 256x256 image, x4 (BASELINE config 2's geometry with the encoder the reference pairs it with),
-    random-init weights: whole forward, encoder alone, decoder alone, in ms (torch events on the current stream)."""
+    implicit decoder) on a random lr x lr image (256 x4: BASELINE config 2's geometry with the encoder the reference pairs it
+    with; 48 x2 / x4: the reference's own timing protocol, runtime_test.py:13,31-33,59-62, and its training crops), random-init
+    weights: whole forward, encoder alone, decoder alone, in ms (torch events on the current stream)."""
     import diinn_amd.modules as M
     torch.manual_seed(0)
     net = M.DIINN(mode=3, init_q=False).to(device).eval()
-    x = torch.rand(1, 3, 256, 256, device=device)
-    size = (1024, 1024)
+    x = torch.rand(1, 3, lr, lr, device=device)
+    size = (lr * scale, lr * scale)
 
     def t_ms(fn):
         for _ in range(warmup):
@@ -625,10 +639,12 @@ def whole_model_leg(device, steps=5, warmup=2):
         enc = t_ms(lambda: net.encoder(x))
         dec = t_ms(lambda: net.decoder(feat, size, 30000))
         out = net(x, size)
-    leg = {"workload": "DIINN.forward: RDN encoder + implicit decoder, 256x256 LR x4 (1024x1024), B = 1, random-init weights",
+    import diinn_amd._native as N
+    leg = {"workload": f"DIINN.forward: RDN encoder + implicit decoder, {lr}x{lr} LR x{scale} ({size[0]}x{size[1]}), B = 1, random-init weights",
            "steps": steps, "warmup": warmup, "forward_ms": round(fwd, 3), "encoder_ms": round(enc, 3), "decoder_ms": round(dec, 3),
            "finite": bool(torch.isfinite(out).all()),
-           "encoder_3x3_layers": "Winograd F(4x4,3x3)" if net.encoder.hip_winograd4 else "Winograd F(2x2,3x3)",
+           "encoder_3x3_layers": ("Winograd F(4x4,3x3)" if net.encoder.hip_winograd4 and N.load().diinn_rdn_wino4_applies(1, lr, lr)
+                                  else "Winograd F(2x2,3x3)" if lr * lr >= 8192 else "direct, split-K"),
            "note": "parity of this path: tests/test_modules.py (reference DIINN fixture), tests/test_encoder_trunk.py (the real reference's encoder)"}
     del net, x, feat, out
     torch.cuda.empty_cache()
@@ -713,6 +729,9 @@ def main():
         side = [side_leg(job, n, c, st, wu_, check=not args.no_check) for (n, c, st, wu_) in SIDE_LEGS]
         try:
             whole = whole_model_leg(job.dev)
+            # the reference's own timing protocol (runtime_test.py: a 48 x 48 crop) at x2 and x4: encoder-bound
+            whole["small_inputs"] = [whole_model_leg(job.dev, steps=20, warmup=5, lr=48, scale=2),
+                                     whole_model_leg(job.dev, steps=20, warmup=5, lr=48, scale=4)]
         except Exception as e:                                   # informational leg: report, do not lose the line
             whole = {"error": f"{type(e).__name__}: {e}"}
 
@@ -772,7 +791,7 @@ def main():
                         "of": f"rank 0, HIP events on {event_steps} of the {args.steps} timed steps"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "decode_kernel" if not bf else ("decode_bf16x3_kernel" if args.compute == "bf16x3" else "decode_bf16 kernel"),
+                "kernel": decode_kernel_name(job, 1, HU, WU, bd.y0, bd.y1, args.compute),
                 "achieved": round(achieved, 3),
                 "peak": peak,
                 "unit": "TFLOP/s",

@@ -68,7 +68,7 @@ def test_traffic_probe_parses_and_corrects_the_counters(bench, tmp_path, monkeyp
 
 
 def test_leg_tables_and_helpers(bench):
-    assert [leg[:2] for leg in bench.SIDE_LEGS] == [("c5", "f32"), ("c5", "bf16_full"), ("c1", "f32")]
+    assert [leg[:2] for leg in bench.SIDE_LEGS] == [("c5", "f32"), ("c5", "bf16_full"), ("c5", "bf16"), ("c1", "f32")]
     assert bench.STRONG_LEGS == {2: ["tgt", "c3"], 4: ["tgt", "c3"], 8: ["tgt", "c4"]}
     assert set(bench.WORKLOADS) == {"c1", "c2", "c3", "tgt", "c4", "c5"} and set(bench.METRIC) == set(bench.WORKLOADS)
     assert bench.WORKLOADS["c2"][:2] == ((256, 256), (1024, 1024))           # BASELINE.json's metric is quoted on c2

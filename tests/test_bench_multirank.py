@@ -114,6 +114,11 @@ def test_one_rank_torchrun_constructs_the_rccl_path():
     assert "target_shape" in res and "side_legs" in res and "cpu_baseline" in res
     whole = res["whole_model"]                                   # the informational DIINN.forward leg (encoder + decoder)
     assert whole["finite"] and 0 < whole["decoder_ms"] < whole["forward_ms"] and 0 < whole["encoder_ms"] < whole["forward_ms"]
+    assert [leg["workload"].split(",")[1].strip() for leg in whole["small_inputs"]] == ["48x48 LR x2 (96x96)", "48x48 LR x4 (192x192)"]
+    assert all(leg["finite"] and leg["forward_ms"] > 0 for leg in whole["small_inputs"])
+    assert res["roofline"]["kernel"] == "decode_kernel"          # c2: the throughput kernel (the library's own answer)
+    legs = {(leg["name"], leg["compute"]): leg for leg in res["side_legs"]}
+    assert legs[("c1", "f32")]["kernel"] == "decode_coop16_kernel" and legs[("c5", "bf16")]["checked"]["ok"]
 
 
 def test_two_ranks_weak_c1_with_strong_leg():
