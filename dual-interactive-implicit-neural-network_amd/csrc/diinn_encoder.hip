@@ -666,12 +666,13 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     // Winograd blocks are 16 x 8 pixels and a workgroup walks all input channels: faster than the split-K kernel from
     // about 90 x 90 pixels up (tools/r02_ab_env.sh: 96x96 3.6 vs 4.5 ms, 64x64 3.4 vs 2.1 ms per trunk)
     const long long wino_min = knob(diinn_knobs().enc_wino_min);
-    const bool wino = packed_wino_dev && (long long)B * hw >= wino_min;
+    const bool wino = (packed_wino_dev || packed_wino4_dev) && (long long)B * hw >= wino_min;
     // F(4x4, 3x3) (csrc/diinn_winograd4.hip): 1.78x fewer MFMAs again, in work items of 128 x 4 pixels x one output half.
     // Both kernels run in rounds of one workgroup per CU, and measured over 192 .. 512-pixel maps one F(4x4) round
     // costs 1.44 F(2x2) rounds of whole blocks (16 x 8 pixels x both halves; a round of halves 0.57): the cheaper one
     // by that count runs.  DIINN_ENC_WINO4_MIN = n >= 0 replaces the rule by "from n pixels on".
     const bool wino4 = packed_wino4_dev && wino && diinn_rdn_wino4_applies(B, H, W);
+    if (wino && !wino4 && !packed_wino_dev) return DIINN_ERR_INVALID_ARG;   // this map runs F(2x2): its image is needed
     // the F(4x4) kernel's split area leads the workspace; its arrival counters (the first 4 KiB) are zeroed here, once per
     // forward, whatever a caller or an aborted launch left there (a memset node: capture-safe)
     float* const w4ws = workspace_dev;
@@ -778,7 +779,9 @@ int diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* pac
 int diinn_rdn_forward_wino4(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
                             const float* packed_wino4_dev, const float* biases_dev, float* workspace_dev, float* out_dev,
                             int B, int H, int W) {
-    if (!packed_wino_dev || !packed_wino4_dev) return DIINN_ERR_INVALID_ARG;
+    // packed_wino_dev may be null when diinn_rdn_wino4_applies(B, H, W): every 3x3 layer then runs F(4x4) and the F(2x2) image
+    // is never read (a caller that only sees such maps need not build or keep it: 152 MB)
+    if (!packed_wino4_dev) return DIINN_ERR_INVALID_ARG;
     return rdn_forward_impl(stream, sfe1_dev, packed_dev, packed_wino_dev, packed_wino4_dev, nullptr, biases_dev, workspace_dev, out_dev,
                             B, H, W);
 }

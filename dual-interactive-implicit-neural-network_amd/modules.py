@@ -184,9 +184,26 @@ class RDN(nn.Module):
         if self._hip_pack is None or self._hip_key != key:
             w = torch.cat([pack_conv_ksplit(l.weight) for l in layers]).to(device)
             b = torch.cat([l.bias.detach().to(torch.float32) for l in layers]).to(device)
-            wu = torch.cat([pack_conv_wino(l.weight) for l in layers if l.kernel_size == (3, 3)]).to(device)
-            self._hip_pack, self._hip_key, self._hip_x3, self._hip_wu4 = (w, b, wu), key, None, None
+            self._hip_pack, self._hip_key, self._hip_x3, self._hip_wu4, self._hip_wu2 = (w, b), key, None, None, None
         return self._hip_pack
+
+    def _hip_packed_wino(self, device):
+        """The F(2x2, 3x3) image of the 130 3x3 weights (152 MB), built on first use: a model that only sees maps whose
+        3x3 layers run F(4x4, 3x3) (341 MB) or the split-K kernel (the 85 MB permutation above) never builds it.
+        ``RDN.free_unused_images()`` drops the images again."""
+        self._hip_packed(device)
+        if getattr(self, "_hip_wu2", None) is None:
+            self._hip_wu2 = torch.cat([pack_conv_wino(l.weight.to(device)) for l in self._trunk_layers()
+                                       if l.kernel_size == (3, 3)]).to(device)
+        return self._hip_wu2
+
+    def free_unused_images(self, keep=()):
+        """Drop the derived weight images (``"wino"`` F(2x2): 152 MB, ``"wino4"`` F(4x4): 341 MB, ``"x3"`` split bf16: 88 MB)
+        that are not named in ``keep``; they are rebuilt on the next forward that needs them.  Images captured by a hipGraph
+        entry stay alive with it."""
+        for name, attr in (("wino", "_hip_wu2"), ("wino4", "_hip_wu4"), ("x3", "_hip_x3")):
+            if name not in keep:
+                setattr(self, attr, None)
 
     def _hip_packed_wino4(self, device):
         """The F(4x4, 3x3) image of the 130 3x3 weights, built on first use (and again when a weight changes)."""
@@ -212,8 +229,13 @@ class RDN(nn.Module):
         lib = _native.load()
         b, _, h, w = shallow.shape
         shallow = shallow.contiguous()
-        packed, biases, packed_wino = self._hip_packed(shallow.device)
+        packed, biases = self._hip_packed(shallow.device)
         x3 = self.hip_winograd and self.hip_split_bf16
+        w4 = self.hip_winograd and self.hip_winograd4 and not x3 and bool(lib.diinn_rdn_wino4_applies(b, h, w))
+        # the F(2x2) image only where a kernel reads it (~0.6 GB of weight copies for an 88 MB encoder otherwise)
+        needs_wino = self.hip_winograd and not w4 and (x3 or b * h * w >= _native.debug_get("DIINN_ENC_WINO_MIN"))
+        packed_wino = self._hip_packed_wino(shallow.device) if needs_wino else None
+        pwp = C.c_void_p(packed_wino.data_ptr()) if packed_wino is not None else None
         ws_floats = lib.diinn_rdn_x3_workspace_floats(b, h, w) if x3 else lib.diinn_rdn_workspace_floats(b, h, w)
         ws = torch.empty(ws_floats, dtype=torch.float32, device=shallow.device)
         out = torch.empty_like(shallow)
@@ -222,18 +244,18 @@ class RDN(nn.Module):
             if self.hip_winograd and self.hip_split_bf16:
                 px3 = self._hip_packed_x3(shallow.device)
                 _native.check(lib.diinn_rdn_forward_x3(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                                       C.c_void_p(packed_wino.data_ptr()), C.c_void_p(px3.data_ptr()),
+                                                       pwp, C.c_void_p(px3.data_ptr()),
                                                        C.c_void_p(biases.data_ptr()), C.c_void_p(ws.data_ptr()),
                                                        C.c_void_p(out.data_ptr()), b, h, w), "diinn_rdn_forward_x3")
-            elif self.hip_winograd and self.hip_winograd4 and lib.diinn_rdn_wino4_applies(b, h, w):
+            elif w4:
                 pw4 = self._hip_packed_wino4(shallow.device)
                 _native.check(lib.diinn_rdn_forward_wino4(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                                          C.c_void_p(packed_wino.data_ptr()), C.c_void_p(pw4.data_ptr()),
+                                                          pwp, C.c_void_p(pw4.data_ptr()),
                                                           C.c_void_p(biases.data_ptr()), C.c_void_p(ws.data_ptr()),
                                                           C.c_void_p(out.data_ptr()), b, h, w), "diinn_rdn_forward_wino4")
-            elif self.hip_winograd:
+            elif self.hip_winograd and packed_wino is not None:
                 _native.check(lib.diinn_rdn_forward_wino(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                                         C.c_void_p(packed_wino.data_ptr()), C.c_void_p(biases.data_ptr()),
+                                                         pwp, C.c_void_p(biases.data_ptr()),
                                                          C.c_void_p(ws.data_ptr()), C.c_void_p(out.data_ptr()), b, h, w),
                               "diinn_rdn_forward_wino")
             else:
@@ -329,7 +351,7 @@ class _GraphReplay:
                 # private pool: workspaces, activations, the result) or kept alive by the entry below (packed
                 # weight images, which live in module caches that a later call may replace)
                 static_y = self._forward_eager(static_x, size, bsize)
-            keep = [getattr(m, a, None) for m in self.modules() for a in ("_packed", "_hip_pack", "_hip_x3", "_hip_wu4")]
+            keep = [getattr(m, a, None) for m in self.modules() for a in ("_packed", "_hip_pack", "_hip_x3", "_hip_wu4", "_hip_wu2")]
             entry = (graph, static_x, static_y, keep)
             self._graph_cache[key] = entry
         graph, static_x, static_y = entry[:3]

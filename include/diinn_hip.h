@@ -408,7 +408,8 @@ int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* 
  * diinn_rdn_forward_wino4: diinn_rdn_forward_wino with the 3x3 layers on diinn_conv_wino4 where that kernel needs fewer
  *   rounds of workgroups than diinn_conv_wino (one F(4x4) round = 1.44 F(2x2) rounds; from about 35,000 pixels on,
  *   depending on how its 2 * ceil(tiles / 32) work items per image fill the last round; DIINN_ENC_WINO4_MIN = n: from n pixels on); other
- *   maps run exactly as diinn_rdn_forward_wino. */
+ *   maps run exactly as diinn_rdn_forward_wino.  packed_wino_dev may be NULL for a map with diinn_rdn_wino4_applies(B, H, W)
+ *   == 1 (the F(2x2) image is not read then); for any other map a NULL is DIINN_ERR_INVALID_ARG. */
 int    diinn_conv_wino4(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
                         const float* packed_u_dev, const float* bias_dev,
                         const float* res_dev, long long res_batch_stride,
