@@ -663,10 +663,8 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8_kernel(const DecodeP
                 const bf16x8 bv = bq[ks % CO_BRING];
                 ak = MFMA_BF16(__builtin_bit_cast(bf16x8, Ak[ks]), bv, ak);
                 as = MFMA_BF16(__builtin_bit_cast(bf16x8, As[ks]), bv, as);
-#ifndef ABL_CO8_NOLDS
                 if (ks + CO_BRING < 16) bq[ks % CO_BRING] = qin[qoff[ti] + (ks + CO_BRING) * 64];
                 else if (ti + 1 < TILES) bq[ks % CO_BRING] = qin[qoff[ti + 1] + (ks + CO_BRING - 16) * 64];
-#endif
                 if (ti == TILES - 1 && !LAST) {                   // last use of this fragment: fetch the next layer's
                     const int nwp = wp + (int)(WLB_LAYER * sizeof(float));
                     Ak[ks] = ld_w(nwp, 2 * ks + 0);
@@ -682,11 +680,7 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8_kernel(const DecodeP
                 f32x2 v;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-#ifdef ABL_CO8_NOEPI
-                    v[i] = ak[r + i] + as[r + i];
-#else
                     v[i] = relu0(ak[r + i]) * co_sin_fin<SIN_MODE>(co_sin_prep<SIN_MODE>(as[r + i]));
-#endif
                 if (LAST) {                                       // head rows of this element's channel, from the LDS table
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
@@ -1013,25 +1007,16 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
                 const bf16x8 bv = bq[ks % CO_BRING];
                 ak = MFMA_BF16(__builtin_bit_cast(bf16x8, Ak[ks]), bv, ak);
                 as = MFMA_BF16(__builtin_bit_cast(bf16x8, As[ks]), bv, as);
-#ifndef ABL_P_NOLDS
                 if (ks + CO_BRING < 16) bq[ks % CO_BRING] = qin[qoff[ti] + (ks + CO_BRING) * 64];
                 else if (ti + 1 < TILES) bq[ks % CO_BRING] = qin[qoff[ti + 1] + (ks + CO_BRING - 16) * 64];
-#endif
                 if (ti == TILES - 1) {                            // last use of this fragment: fetch the next layer's --
                     const int nwp = LAST ? wp0 : wp + (int)(WLB_LAYER * sizeof(float));   // or the next block's first layer
-#ifndef ABL_P_NOREFILL
                     if (!LAST || has_next) {
                         Ak[ks] = ld_w(nwp, 2 * ks + 0);
                         As[ks] = ld_w(nwp, 2 * ks + 1);
                     }
-#else
-                    (void)nwp;
-#endif
                 }
-#ifndef ABL_P_NOSEED
                 if (!LAST && ti == 1 && ks == 8) stage_load(layer + 2, ix0, iy0, blk.z);   // next layer's seed column, into registers
-#endif
-#ifndef ABL_P_NOPARK
                 if (LAST && ks == 0 && has_next) {
                     if (ti == 0) {
                         na = *(const f32x4*)nrow(0);
@@ -1044,7 +1029,6 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
                         stage_load(1, ncx0, ncy0, nblk.z);        // the next block's P_1 column
                     }
                 }
-#endif
                 if ((ks & 3) == 3) asm volatile("" ::: "memory");
             }
             // epilogue of this tile (the other wave of the SIMD has the matrix pipe): q = relu(k) * sin(s)
@@ -1055,15 +1039,8 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
                 f32x2 v;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-#ifdef ABL_P_NOEPI
-                    v[i] = ak[r + i] + as[r + i];
-#else
                     v[i] = relu0(ak[r + i]) * co_sin_fin<SIN_MODE>(co_sin_prep<SIN_MODE>(as[r + i]));
-#endif
                 if (LAST) {                                       // head rows of this element's channel, from the LDS table
-#ifdef ABL_P_NOHEAD
-                    o0 += v[0] + v[1];
-#else
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const int c = 8 * ((r + i) >> 2) + ((r + i) & 3);
@@ -1071,7 +1048,6 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
                         o1 = __builtin_fmaf(hl[1 * HID + c], v[i], o1);
                         o2 = __builtin_fmaf(hl[2 * HID + c], v[i], o2);
                     }
-#endif
                 } else {
                     fragw[(r >> 1) & 3] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
                     if ((r & 7) == 6)
@@ -1080,17 +1056,14 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
             }
             if (LAST) {                                           // this wave's 32 channels of the head, both lane halves
                 asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2));
-#ifndef ABL_P_NOHEAD
                 o0 += __shfl_xor(o0, 32);
                 o1 += __shfl_xor(o1, 32);
                 o2 += __shfl_xor(o2, 32);
-#endif
                 if (h == 0) {
                     float* r3 = red[wave][(ti ^ (2 * grp)) * 32 + j];    // visit ti of this wave's group is tile ti ^ (2 grp)
                     r3[0] = o0; r3[1] = o1; r3[2] = o2;
                 }
             }
-#ifndef ABL_P_NOPARK
             if (LAST && has_next) {                               // ... parked
                 if (ti == 0) {
                     *(f32x4*)nslot(0) = na;
@@ -1103,19 +1076,12 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
                     stage_store();
                 }
             }
-#endif
         }
-#ifndef ABL_P_NOBAR
         __syncthreads();                                          // layer output complete, its input image is free
-#endif
     };
 
     for (;;) {
-#ifdef ABL_P_NOCOORD
-        if (stile == xcd * per) coords(blk);
-#else
         coords(blk);
-#endif
         // (no barrier here: the tables and P_0 / P_1 slices of this block were parked inside the previous block's last layer,
         // whose closing barrier made them visible -- the first block's prologue is followed by a barrier of its own; nothing
         // writes the second image again before the barrier behind layer 0)
@@ -1140,13 +1106,8 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
             };
             fetch(0, cpv, cwh, cww, ctq);
             u32x4 fragw;
-#ifdef ABL_P_NOL0
-#pragma unroll 1
-            for (int i = 0; i < 0; ++i) {
-#else
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-#endif
                 if (i + 1 < 16) fetch(i + 1, npv, nwh, nww, ntq2);
                 f32x4 v;
 #pragma unroll
@@ -1166,9 +1127,7 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
         // the block after this one (wave-uniform scalar work, overlaps the barrier)
         int nst_i = stile + 1;
         has_next = next_block(nst_i, nblk);
-#ifndef ABL_P_NOSYNC0
         __syncthreads();
-#endif
 
         wp = wp0;
         layer_body(CoopTagFalse{}, CoopTagFalse{}, 0);
@@ -1190,12 +1149,8 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
             const int x = p.x0 + blk.x * (2 * TILE_W) + (t & 1) * TILE_W + (jj & (TILE_W - 1));
             const int y = p.y0 + blk.y * (2 * TILE_H) + (t >> 1) * TILE_H + (jj / TILE_W);
             float acc[3] = {0.0f, 0.0f, 0.0f};
-#ifdef ABL_P_NOHEAD
-            for (int w8 = 0; w8 < 1; ++w8)
-#else
 #pragma unroll
             for (int w8 = 0; w8 < 8; ++w8)
-#endif
 #pragma unroll
                 for (int k = 0; k < 3; ++k) acc[k] += red[w8][tid][k];
             if (x < p.x1 && y < p.y1) {
@@ -1208,6 +1163,7 @@ __global__ __launch_bounds__(512, 2) void decode_bf16_coop8p_kernel(const Decode
                 op[2 * plane] = acc[2] + bl2;
             }
         }
+        // (r05: the head spread over six waves -- one (pixel, colour) per thread -- changed nothing: 7.69 vs 7.76 ms at c5)
         if (!has_next) break;
         blk = nblk;
         stile = nst_i;
