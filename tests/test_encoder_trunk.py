@@ -281,6 +281,54 @@ def test_conv_wino4_split_last_round(knobs):
                                    C.c_void_p(ws.data_ptr() + 4), wsf) == N.ERR_INVALID_ARG
 
 
+@pytest.mark.gpu
+def test_conv_wino4_split_handoff_under_load_and_changing_inputs(knobs):
+    """The slab hand-off of the split form, screened the way the guide asks (cdna_hip_programming.md, Guideline 16: "test every
+    hand-off under UNEVEN load ... checking every word"): the SAME workspace serves launches on ALTERNATING inputs -- a part
+    summed from a stale slab (the previous launch's bytes at the same address, still in some L1 or L2) would reproduce the
+    previous input's partial sums, which a repeat on one input can never show -- while a second stream keeps half the chip
+    busy with decode launches of changing size, so the parts of an item arrive in changing order.  Every launch must equal,
+    bit for bit, the first launch on its input; counters end at zero."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.decoder as D
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    gen = torch.Generator(device=dev).manual_seed(17)
+    ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
+    wsf = lib.diinn_conv_wino4_workspace_floats()
+    ws = torch.zeros(wsf, device=dev)
+    knobs("DIINN_ENC_WINO4_SPLIT", 2)
+    # background load: decodes of a small map at changing output sizes on a side stream
+    packed_dec = D.pack_state_dict(synth.decoder_state_dict(3)).to(dev)
+    feat = torch.from_numpy(synth.encoder_features(3, 1, 64, 64)).to(dev)
+    side = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    for (b, cin, h, w) in [(1, 256, 192, 192), (1, 512, 100, 100), (2, 128, 200, 180)]:
+        xs = [torch.randn((b, cin, h, w), device=dev, generator=gen) for _ in range(2)]
+        wt = torch.randn((64, cin, 3, 3), device=dev, generator=gen) / (cin * 9) ** 0.5
+        bias = torch.randn(64, device=dev, generator=gen)
+        packed = M.pack_conv_wino4(wt).to(dev)
+        first = [None, None]
+        stream = C.c_void_p(main.cuda_stream)
+        for i in range(24):
+            k = i & 1
+            if i % 3 == 0:                                       # uneven load: another kernel takes CUs for a while
+                with torch.cuda.stream(side):
+                    D.decode_features(feat, packed_dec, (96 + 32 * (i % 5), 160))
+            out = torch.empty((b, 64, h, w), device=dev)
+            assert lib.diinn_conv_wino4_ws(stream, ptr(xs[k]), cin * h * w, cin, ptr(packed), ptr(bias), None, 0, ptr(out), 64 * h * w,
+                                           1, b, h, w, ptr(ws), wsf) == 0
+            if first[k] is None:
+                first[k] = out
+            else:
+                assert torch.equal(out, first[k]), (cin, h, w, i)
+        torch.cuda.synchronize()
+        assert not torch.equal(first[0], first[1])
+        assert int(ws[:1024].view(torch.int32).abs().sum()) == 0, (cin, h, w)
+
+
 def test_wino4_split_plan():
     """diinn_conv_wino4_plan (host only; no device: 256 compute units assumed): whole rounds stay whole, the remainder is cut into
     equal runs over pairs of workgroups (the two output halves of a block side by side), never for a full last round, never
