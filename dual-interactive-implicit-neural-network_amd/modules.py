@@ -139,7 +139,7 @@ class RDN(nn.Module):
     # kernel on small maps, Winograd 3x3 + streaming 1x1 kernels from 8192 pixels on.  Measured (tools/enc_trunk_time.py,
     # HIP vs MIOpen eager): 1.95 vs 7.6 ms at 48x48, 3.6 vs 7.6 at 96x96, 3.9 vs 8.1 at 128x128, 9.3 vs 20.2 at 192x192,
     # 11.8 vs 28.6 at 256x256, 28.3 vs 61.6 at 384x384, 47.0 vs 109.5 at 512x512.  The attribute caps the batch*H*W
-    # that takes this path (workspace: 2,240 floats per pixel); None disables it (MIOpen everywhere).
+    # that takes this path (workspace: 2,240 floats per pixel + 34.6 MB for the F(4x4) kernel's split); None disables it (MIOpen everywhere).
     hip_trunk_max_pixels: Optional[int] = 1024 * 1024          # byte offsets of a wave's channel slice stay far below 2^31
     # 3x3 layers as Winograd F(2x2, 3x3) (csrc/diinn_winograd.hip) on maps of >= 8192 pixels: 2.25x fewer MFMAs, fp32,
     # equal to the direct sum up to reassociation (~1e-6 relative).  False keeps every layer on the direct kernel.

@@ -347,8 +347,9 @@ int    diinn_metasr_make_axis_tables(int n_in, int n_out, int32_t* idx, float* r
  *   value = W[32 half + (lane&31)][wave*Cin/8 + 8 group + 2 e + (lane>>5)][tap]   (MFMA A-operand order per K-slice).
  * diinn_rdn_forward: the whole trunk as 147 launches: sfe1_dev [B,64,H,W] = SFENet1(x) (computed by the
  *   caller), packed_dev = the 147 packed weights in execution order (SFENet2; per block: 8 dense convs, LFF;
- *   GFF.0, GFF.1), biases_dev = their 147 x 64 biases, workspace_dev = diinn_rdn_workspace_floats floats,
- *   out_dev [B,64,H,W]. */
+ *   GFF.0, GFF.1), biases_dev = their 147 x 64 biases, workspace_dev = diinn_rdn_workspace_floats floats
+ *   (16-byte aligned; 2,240 floats per pixel + diinn_conv_wino4_workspace_floats(), which leads it and whose first 4 KiB
+ *   diinn_rdn_forward_wino4 zeroes itself), out_dev [B,64,H,W]. */
 int    diinn_conv_ksplit(void* stream, const float* in_dev, long long in_batch_stride, int Cin, int taps,
                         const float* packed_w_dev, const float* bias_dev,
                         const float* res_dev, long long res_batch_stride,
