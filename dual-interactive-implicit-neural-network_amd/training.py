@@ -283,6 +283,7 @@ def _conv_grads_native(feat: torch.Tensor, wx: torch.Tensor, dp: torch.Tensor, n
             pk = _dgrad_pack[1]
             if form == "wino4":
                 ws = _wino4_workspace(dev)                       # (a partly filled last round is split over the input channels)
+                ws[:1024].zero_()                                # the counter words, whatever an aborted launch may have left (as the trunk does)
                 _native.check(lib.diinn_conv_wino4_ws(stream, ptr(dp), cin * h * w, cin, ptr(pk), ptr(zero), None, 0, ptr(d_feat),
                                                       c * h * w, 0, b, h, w, ptr(ws), ws.numel()), "diinn_conv_wino4_ws")
             elif form == "wino":
