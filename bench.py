@@ -338,28 +338,31 @@ class Job:
         name, UUID, PCI bus id), the collective backend, how many of the node's other GPUs it can reach peer-to-peer (xGMI) --
         gathered on every rank through the backend itself, plus the world size the backend reports and the number of DISTINCT
         devices.  From the JSON line alone a reader can tell whether RCCL saw N ranks on N devices."""
-        prop = torch.cuda.get_device_properties(self.dev)
-        ndev = torch.cuda.device_count()
-        peers = 0
-        for other in range(ndev):
-            if other != self.dev.index:
-                try:
-                    peers += bool(torch.cuda.can_device_access_peer(self.dev.index, other))
-                except Exception:                                 # noqa: BLE001  (a runtime without the query: unknown)
-                    peers = -1
-                    break
-        me = {"rank": self.rank, "local_rank": self.local_rank, "device": self.dev.index, "name": prop.name,
-              "device_uuid": str(getattr(prop, "uuid", "")),
-              "pci_bus_id": "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", 0),
-                                                getattr(prop, "pci_device_id", 0)),
-              "backend": (dist.get_backend() if self.use_dist else "none"), "visible_devices": ndev, "xgmi_peers": peers,
-              "host": socket.gethostname(), "pid": os.getpid()}
-        if not self.use_dist:
-            ranks = [me]
-        else:
-            ranks = [None] * self.world
-            dist.all_gather_object(ranks, me)
-        ids = {(r["host"], r["device_uuid"] or r["pci_bus_id"]) for r in ranks}
+        # (the local part never raises: every rank must reach the collective below; a query the runtime lacks reads "unknown")
+        me = {"rank": self.rank, "local_rank": self.local_rank, "device": self.dev.index, "name": "unknown", "device_uuid": "",
+              "pci_bus_id": "", "backend": "none", "visible_devices": -1, "xgmi_peers": -1, "host": socket.gethostname(),
+              "pid": os.getpid()}
+        try:
+            me["backend"] = dist.get_backend() if self.use_dist else "none"
+            prop = torch.cuda.get_device_properties(self.dev)
+            me["name"] = prop.name
+            me["device_uuid"] = str(getattr(prop, "uuid", ""))
+            me["pci_bus_id"] = "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", 0),
+                                                   getattr(prop, "pci_device_id", 0))
+            ndev = me["visible_devices"] = torch.cuda.device_count()
+            me["xgmi_peers"] = sum(bool(torch.cuda.can_device_access_peer(self.dev.index, other))
+                                   for other in range(ndev) if other != self.dev.index)
+        except Exception as e:                                    # noqa: BLE001
+            me["census_error"] = f"{type(e).__name__}: {e}"
+        ranks = [me]
+        if self.use_dist:
+            try:
+                got = [None] * self.world
+                dist.all_gather_object(got, me)
+                ranks = got
+            except Exception as e:                                # noqa: BLE001  (the headline must not depend on this record)
+                me["census_error"] = f"all_gather_object: {type(e).__name__}: {e}"
+        ids = {(r["host"], r["device_uuid"] or r["pci_bus_id"] or str(r["device"])) for r in ranks}
         return {"ranks": ranks, "rccl_world": (dist.get_world_size() if self.use_dist else 1),
                 "backend": me["backend"], "distinct_devices": len(ids)}
 
