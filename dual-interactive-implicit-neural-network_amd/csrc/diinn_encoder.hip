@@ -651,7 +651,7 @@ int diinn_rdn_wino4_applies(int B, int H, int W) {
     const long long items4 = 2LL * B * (((long long)((W + 3) / 4) * ((H + 3) / 4) + 31) / 32);   // blocks of 32 consecutive tiles x 2 output halves
     const long long blocks2 = (long long)B * (((W + 1) / 2 + 7) / 8) * (((H + 1) / 2 + 3) / 4);
     const int ncu = device_cus();
-    const double r4 = 1.44 * w4_rounds(items4, ncu, true);       // (the trunk gives the kernel its workspace: a partly filled last round is split)
+    const double r4 = 1.40 * w4_rounds(items4, ncu, true);       // (the trunk gives the kernel its workspace: a partly filled last round is split)
     const double r2w = (double)((blocks2 + ncu - 1) / ncu), r2h = 0.57 * (double)((2 * blocks2 + ncu - 1) / ncu);
     return r4 < 0.97 * (r2w < r2h ? r2w : r2h);
 }
@@ -669,7 +669,7 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     const bool wino = (packed_wino_dev || packed_wino4_dev) && (long long)B * hw >= wino_min;
     // F(4x4, 3x3) (csrc/diinn_winograd4.hip): 1.78x fewer MFMAs again, in work items of 128 x 4 pixels x one output half.
     // Both kernels run in rounds of one workgroup per CU, and measured over 192 .. 512-pixel maps one F(4x4) round
-    // costs 1.44 F(2x2) rounds of whole blocks (16 x 8 pixels x both halves; a round of halves 0.57): the cheaper one
+    // costs 1.40 F(2x2) rounds of whole blocks (16 x 8 pixels x both halves; a round of halves 0.57; r04 measured 1.44, r05 1.40): the cheaper one
     // by that count runs.  DIINN_ENC_WINO4_MIN = n >= 0 replaces the rule by "from n pixels on".
     const bool wino4 = packed_wino4_dev && wino && diinn_rdn_wino4_applies(B, H, W);
     if (wino && !wino4 && !packed_wino_dev) return DIINN_ERR_INVALID_ARG;   // this map runs F(2x2): its image is needed

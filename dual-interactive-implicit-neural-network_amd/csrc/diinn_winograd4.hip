@@ -74,8 +74,9 @@ struct ConvWino4Params {
     unsigned* sk_cnt;        // [1024] words: per item arrival tickets and ready counts, zero on entry, zero on exit
     int sk_first;            // work items [0, sk_first) run whole, [sk_first, sk_first + sk_items) split
     int sk_items;
-    int sk_u;                // chunks per split workgroup: pair q (workgroups 2 q, 2 q + 1: output halves 0, 1) takes chunk-units
-                             // [q sk_u, (q + 1) sk_u) of the sk_items / 2 blocks x Cin/8 chunks
+    int sk_u;                // length of a run: pair q (workgroups 2 q, 2 q + 1: output halves 0, 1) takes units [q sk_u, (q + 1) sk_u)
+                             // of a sequence that gives each of the sk_items / 2 blocks sk_e overhead units, then its Cin/8 chunks
+    int sk_e;                // overhead units in front of a block's chunks: what a run pays in time for entering one more block
     int sk_wgs;              // split workgroups: blockIdx.x < sk_wgs (a multiple of 16)
 #ifdef W4_STAMPS
     unsigned long long* stamps;   // tools/ubench/wino4_bench.hip -DW4_STAMPS: s_memtime of workgroup 0's waves 0 and 12, [wave 2][iteration 80][4]
@@ -411,7 +412,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
                     for (int a = 0; a < 4; ++a) v[a] = f32x4{y[a][0], y[a][1], y[a][2], y[a][3]};
                 } else {
                     const int pk = sk.first_pair + k;            // the k-th workgroup pair with chunks of this block; the block
-                    const int jk = sk.blk_item - (pk * p.sk_u) / n;   // is the first (0) or second (1) one of its run
+                    const int jk = sk.blk_item - (pk * p.sk_u) / (n + p.sk_e);   // is the first (0) or second (1) one of its run
                     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                         (void*)(p.sk_slabs + (size_t)(2 * (2 * pk + hh0) + jk) * W4_SLAB_FLOATS), 0, W4_SLAB_FLOATS * 4, 0x00020000);
 #pragma unroll
@@ -472,18 +473,27 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvWino4P
         // per chunk (profiles/r05_wino4_split.txt).
         const int g = (int)(blockIdx.x & 7) * (p.sk_wgs >> 3) + (int)(blockIdx.x >> 3);
         const int pair = g >> 1, hh0 = g & 1;
-        const int units = (p.sk_items >> 1) * n;                 // chunk-units of the split blocks
-        int u0 = pair * p.sk_u;
-        const int uend = u0 + p.sk_u < units ? u0 + p.sk_u : units;
-        for (int j = 0; u0 < uend; ++j) {
-            const int it = u0 / n, c0 = u0 - it * n;
-            const int m = n - c0 < uend - u0 ? n - c0 : uend - u0;
-            const int first = (it * n) / p.sk_u, last = ((it + 1) * n - 1) / p.sk_u;   // the pairs with chunks of this block
-            const int t = (p.sk_first >> 1) + it;
-            const int b = __builtin_amdgcn_readfirstlane(t / nblk);
-            conv_wino4_body(p, lds, b, t - b * nblk, hh0, c0, m, W4Split{last - first + 1, 2 * it + hh0, 2 * g + j, first, pair, it});
-            __syncthreads();                                     // the exchange buffer is free again
-            u0 += m;
+        // A run is a stretch of a unit sequence in which every block contributes sk_e OVERHEAD units and then its chunks: a run
+        // that enters a second block pays that block's prologue, epilogue and slab hand-off, so it gets that many chunks fewer
+        // than a run that stays inside one block -- equal TIME per run, not equal chunks (the overhead units of a run's own
+        // first block are what every run pays once).
+        const int ne = n + p.sk_e;
+        const int vtotal = (p.sk_items >> 1) * ne;
+        int v0 = pair * p.sk_u;
+        const int v1 = v0 + p.sk_u < vtotal ? v0 + p.sk_u : vtotal;
+        for (int j = 0; v0 < v1;) {
+            const int it = v0 / ne;
+            const int rs = it * ne + p.sk_e, be = (it + 1) * ne;  // the block's chunks in the unit sequence
+            const int a = v0 > rs ? v0 : rs, e = v1 < be ? v1 : be;
+            if (a < e) {
+                const int first = rs / p.sk_u, last = (be - 1) / p.sk_u;   // the pairs with chunks of this block
+                const int t = (p.sk_first >> 1) + it;
+                const int b = __builtin_amdgcn_readfirstlane(t / nblk);
+                conv_wino4_body(p, lds, b, t - b * nblk, hh0, a - rs, e - a, W4Split{last - first + 1, 2 * it + hh0, 2 * g + j, first, pair, it});
+                __syncthreads();                                 // the exchange buffer is free again
+                ++j;
+            }
+            v0 = be;
         }
         return;
     }
@@ -512,40 +522,49 @@ unsigned long long* g_w4_stamps = nullptr;
 // ---- which items of a launch are split, and how (host).  Measured on 100 .. 384-pixel maps (profiles/r05_wino4_split.txt,
 // tools/ubench/wino4_bench.hip): a last round of whole items costs 10 + 1.46 n us (n chunks: prologue and epilogue, then
 // one iteration per chunk, R < N workgroups on the chip); the same items split into runs of u chunks 17.5 + 1.75 u us: one or
-// two prologues and epilogues (a run crosses an item boundary more often than not), the slab round trip, and a chunk that
+// two prologues and epilogues (a run crosses an item boundary more often than not; since the runs are balanced in TIME -- W4_SPLIT_E
+// overhead units per block entered, see the kernel -- the longest run is 10.5 + 1.75 u' with u' its units), the slab round trip, and a chunk that
 // takes longer because all N compute units are busy -- the part holds ~2.0 GHz with 256 of these workgroups resident and
 // ~2.27 GHz with 144, at equal cycles per chunk.  That is why a 192 x 192 map (0.56 of a round) gains 15-25 % from the
 // split, not 44 %: the chip is power-limited, and time follows the arithmetic done more than the workgroups in flight.
-struct W4Plan { int first, items, u, wgs; };
+struct W4Plan { int first, items, u, wgs, e; };
+constexpr int W4_SPLIT_E = 4;                                    // overhead units per block entered (prologue + epilogue + slab hand-off, in chunk times;
+                                                                 // 2 / 3 / 6 / 8 measured: 192x192 trunk 6.83 / 6.76 / 6.80 / 6.77 ms against 6.65)
 static inline double w4_whole_us(int n) { return 10.0 + 1.46 * n; }
-static inline double w4_split_us(int u) { return 17.5 + 1.75 * u; }
+static inline double w4_split_us(int u, int e) { return 17.5 - 1.75 * e + 1.75 * u; }   // u = run length in units (a run's e overhead units included)
 static W4Plan w4_plan(long long total, int n, int ncu, bool have_ws) {
-    W4Plan pl{(int)total, 0, 0, 0};
+    W4Plan pl{(int)total, 0, 0, 0, 0};
     const long long mode = knob(diinn_knobs().enc_wino4_split);           // 0 never, 1 by the cost model, 2 whenever a round is partly filled
     if (!have_ws || mode == 0 || ncu < 8) return pl;
     if (ncu > DIINN_WINO4_MAX_SPLIT_WGS) ncu = DIINN_WINO4_MAX_SPLIT_WGS;  // the slab area is sized for this many
     ncu &= ~1;                                                   // workgroup pairs (the two output halves of a block)
     const int R = (int)(total % ncu);                            // even: total is
     if (R == 0) return pl;
-    const int u = (int)(((long long)(R / 2) * n + ncu / 2 - 1) / (ncu / 2));
-    if (u >= n) return pl;                                       // a workgroup per item anyway
-    if (mode == 1 && w4_split_us(u) > w4_whole_us(n) - 1.0) return pl;
-    const int wgs = 2 * (int)(((long long)(R / 2) * n + u - 1) / u);
+    int e = W4_SPLIT_E, ne = n + e;
+    int u = (int)(((long long)(R / 2) * ne + ncu / 2 - 1) / (ncu / 2));
+    if (u <= e) {                                                // runs too short to carry a block's overhead units: plain equal runs of chunks
+        e = 0; ne = n;
+        u = (int)(((long long)(R / 2) * ne + ncu / 2 - 1) / (ncu / 2));
+    }
+    if (u >= ne) return pl;                                      // a workgroup per item anyway
+    if (mode == 1 && w4_split_us(u, e) > w4_whole_us(n) - 1.0) return pl;
+    const int wgs = 2 * (int)(((long long)(R / 2) * ne + u - 1) / u);
     pl.first = (int)(total - R);
     pl.items = R;
     pl.u = u;
+    pl.e = e;
     pl.wgs = (wgs + 15) / 16 * 16;
     return pl;
 }
 
 // the kernel's time for a map of `total` work items over the whole trunk, in rounds of whole items: the whole rounds + what a
-// last round filled to r = R / N costs once it is split, 0.26 + 0.97 r of a round (measured on 21 maps, 128 .. 208 pixels:
+// last round filled to r = R / N costs once it is split, 0.27 + 0.86 r of a round (measured on 112 .. 208-pixel maps:
 // profiles/r05_enc_trunk_times.txt); diinn_rdn_wino4_applies compares it with the F(2x2) kernel's rounds
 __attribute__((visibility("hidden"))) double w4_rounds(long long total, int ncu, bool have_ws) {
     const long long whole = total / ncu, R = total % ncu;
     if (R == 0) return (double)whole;
     const W4Plan pl = w4_plan(total, 36, ncu, have_ws);          // (would the trunk's average layer be split at all?)
-    const double last = pl.items ? 0.26 + 0.97 * (double)R / ncu : 1.0;
+    const double last = pl.items ? 0.27 + 0.86 * (double)R / ncu : 1.0;
     return (double)whole + (last < 1.0 ? last : 1.0);
 }
 
@@ -576,7 +595,7 @@ int diinn_conv_wino4_ws(void* stream, const float* in_dev, long long in_batch_st
     p.in_bs = in_batch_stride; p.out_bs = out_batch_stride; p.res_bs = res_batch_stride;
     p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0;
     const W4Plan pl = w4_plan(2 * blocks, Cin / 8, device_cus(), ws_dev != nullptr);
-    p.sk_first = pl.first; p.sk_items = pl.items; p.sk_u = pl.u; p.sk_wgs = pl.wgs;
+    p.sk_first = pl.first; p.sk_items = pl.items; p.sk_u = pl.u; p.sk_e = pl.e; p.sk_wgs = pl.wgs;
     p.sk_cnt = (unsigned*)ws_dev;
     p.sk_slabs = ws_dev ? ws_dev + 1024 : nullptr;
 #ifdef W4_STAMPS

@@ -396,7 +396,7 @@ int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* 
  * diinn_conv_wino4_ws: the same with a workspace (diinn_conv_wino4_workspace_floats() floats, 16-byte aligned; its first
  *   1024 words must be ZERO on entry and are zero again when the launch has finished).  A launch of I work items (2 per 32
  *   Winograd tiles) on N compute units runs floor(I / N) * N of them whole and, where the cost model says it pays
- *   (DIINN_ENC_WINO4_SPLIT: 0 never, 2 always), cuts the input-channel chunks of the I mod N items left into N equal runs:
+ *   (DIINN_ENC_WINO4_SPLIT: 0 never, 2 always), cuts the input-channel chunks of the I mod N items left into N runs of equal time:
  *   a workgroup that computed part of an item's channels leaves its partial outputs in the workspace and the last one to
  *   arrive adds the parts in a fixed order.  Results are deterministic and depend on (shape, N) only; they differ from
  *   diinn_conv_wino4's by a reassociation in the transformed domain (up to ~2e-5 of max|out|: the size of either one's
@@ -404,7 +404,7 @@ int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* 
  *   for nobody; word 1023 of the workspace stays 0 unless such a wait gave up.  Launches that share a
  *   workspace must be ordered (same stream).  diinn_conv_wino4 = diinn_conv_wino4_ws without a workspace (never splits).
  * diinn_conv_wino4_plan: what diinn_conv_wino4_ws would do on the current device: info[0] work items, [1] items run whole,
- *   [2] split workgroups, [3] chunks of 8 input channels per split workgroup.
+ *   [2] split workgroups, [3] units per split workgroup (chunks of 8 input channels + 4 overhead units per block entered).
  * diinn_rdn_wino4_packed_floats: floats of the 130 such weights of the trunk, in execution order.
  * diinn_rdn_forward_wino4: diinn_rdn_forward_wino with the 3x3 layers on diinn_conv_wino4 where that kernel needs fewer
  *   rounds of workgroups than diinn_conv_wino (one F(4x4) round = 1.44 F(2x2) rounds; from about 35,000 pixels on,

@@ -344,23 +344,23 @@ def test_wino4_split_plan():
     assert plan(512, 1, 256, 256) == [256, 256, 0, 0]            # exactly one round
     assert plan(512, 1, 192, 192, 0) == [144, 144, 0, 0]         # no workspace, no split
     items, whole, wgs, u = plan(512, 1, 192, 192)
-    assert (items, whole, wgs, u) == (144, 0, 256, 36)           # 72 blocks x 64 chunks over 128 pairs
+    assert (items, whole, wgs, u) == (144, 0, 256, 39)           # 72 blocks x (64 chunks + 4 overhead units) over 128 pairs
     assert plan(64, 1, 192, 192)[2] == 0                          # 8 chunks: two prologues cost more than the split saves
     items, whole, wgs, u = plan(512, 1, 384, 384)
-    assert (items, whole) == (576, 512) and wgs == 256 and u == 16
+    assert (items, whole) == (576, 512) and wgs == 256 and u == 17
     assert plan(512, 1, 320, 320)[:2] == [400, 256]
     assert lib.diinn_conv_wino4_plan(12, 1, 8, 8, 1, info) == N.ERR_INVALID_ARG
 
 
 def test_wino4_dispatch_rule(knobs):
     """diinn_rdn_wino4_applies: the F(4x4) kernel where it needs fewer rounds of workgroups (one round = 1.44 F(2x2) rounds
-    of whole blocks; a last round filled to r costs 0.26 + 0.97 r of one since round 5: it is split over the input channels);
-    never on the split-K kernel's small maps; DIINN_ENC_WINO4_MIN = n replaces the rule.  Measured on 32 shapes
-    (profiles/r05_enc_trunk_times.txt): right in 31, 4 % off at 176 x 176."""
+    of whole blocks -- r05: 1.40; a last round filled to r costs 0.27 + 0.86 r of one since round 5: it is split over the input
+    channels); never on the split-K kernel's small maps; DIINN_ENC_WINO4_MIN = n replaces the rule.  Measured on 22 + 32 shapes
+    (profiles/r05_enc_trunk_times.txt): right on all of the last table after the refit (176 x 176 moved to F(4x4))."""
     import diinn_amd._native as N
     lib = N.load()
     want = {(1, 256, 256): 1, (1, 512, 512): 1, (1, 224, 224): 1, (1, 192, 192): 1, (1, 384, 384): 1, (1, 240, 256): 1,
-            (1, 128, 128): 0, (1, 144, 144): 1, (1, 160, 160): 1, (1, 176, 176): 0, (1, 96, 100): 0, (1, 48, 48): 0, (2, 128, 130): 1,
+            (1, 128, 128): 0, (1, 144, 144): 1, (1, 160, 160): 1, (1, 176, 176): 1, (1, 112, 112): 0, (1, 96, 100): 0, (1, 48, 48): 0, (2, 128, 130): 1,
             (1, 270, 480): 1, (1, 320, 180): 1,      # work items are runs of 32 consecutive tiles: the map's width leaves none part empty
             (2, 200, 180): 1,                        # 284 work items = one round and 28 items: split, 12.2 ms (whole 15.6; F(2x2) 14.6)
             (16, 48, 48): 1,                         # the training batch's input gradient (160 items)
