@@ -321,4 +321,19 @@ def test_conv_wino4_entry_point_validates_its_arguments(lib):
     assert conv(packed=C.c_void_p(4100)) == 1                    # the weight image is read with 16-byte loads
     assert conv(b=0) == 1 and conv(h=0) == 1
     assert lib.diinn_rdn_forward_wino4(None, d, d, d, None, d, d, d, 1, 64, 64) == 1     # without the F(4x4) image
+    # the F(2x2) image may be NULL only where the map takes F(4x4): 128 x 128 runs F(2x2), so a NULL there is refused (before
+    # anything is launched)
+    assert lib.diinn_rdn_wino4_applies(1, 128, 128) == 0
+    assert lib.diinn_rdn_forward_wino4(None, d, d, None, d, d, d, d, 1, 128, 128) == 1
     assert lib.diinn_rdn_wino4_packed_floats() == lib.diinn_rdn_wino_packed_floats() // 16 * 36
+    # the workspace form: too small / misaligned workspaces (validated before the launch)
+    wsf = lib.diinn_conv_wino4_workspace_floats()
+    assert wsf == 1024 + 2 * (256 + 8) * 16384 and lib.diinn_rdn_workspace_floats(1, 8, 8) == wsf + 64 * 2240
+
+    def conv_ws(ws=d, floats=wsf, cin=64):
+        return lib.diinn_conv_wino4_ws(None, d, cin * 64 * 64, cin, d, d, None, 0, d, 64 * 64 * 64, 1, 1, 64, 64, ws, floats)
+    assert conv_ws(floats=wsf - 1) == 1 and conv_ws(ws=C.c_void_p(4100)) == 1 and conv_ws(cin=12) == 2
+    info = (C.c_int * 4)()
+    assert lib.diinn_decode_kernel_info(1, 96, 96, 0, 96, 0, 96, 0, info) == 0 and info[0] in (1, 3)
+    assert lib.diinn_decode_kernel_info(1, 96, 96, 0, 97, 0, 96, 0, info) == 1 and lib.diinn_decode_kernel_info(1, 96, 96, 0, 96, 0, 96, 9, info) == 2
+    assert lib.diinn_decode_kernel_info(1, 1024, 1024, 0, 1024, 0, 1024, 0, info) == 0 and list(info) == [1, 64, 128, 1]

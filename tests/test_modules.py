@@ -179,3 +179,33 @@ def test_set_split_bf16_switches_both_modes():
     assert net.decoder.compute == "bf16x3" and net.encoder.hip_split_bf16 is True
     net.set_split_bf16(False)
     assert net.decoder.compute == "f32" and net.encoder.hip_split_bf16 is False
+
+
+@pytest.mark.gpu
+def test_rdn_weight_images_are_built_on_demand():
+    """the derived weight images of the encoder are built only where a kernel reads them -- a map that runs
+    F(4x4,3x3) layers never builds the F(2x2) image (diinn_rdn_forward_wino4 takes NULL for it), a split-K map builds
+    neither -- and free_unused_images() drops them without changing a result."""
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    enc = M.make_rdn().to(dev).eval()
+    lib = N.load()
+    with torch.no_grad():
+        small = torch.rand(1, 3, 24, 20, device=dev)
+        a = enc(small)
+        assert enc._hip_wu2 is None and enc._hip_wu4 is None     # split-K kernel: the 85 MB permutation image only
+        big = torch.rand(1, 3, 200, 180, device=dev)
+        assert lib.diinn_rdn_wino4_applies(1, 200, 180) == 1
+        b = enc(big)
+        assert enc._hip_wu4 is not None and enc._hip_wu2 is None
+        mid = torch.rand(1, 3, 96, 100, device=dev)
+        assert lib.diinn_rdn_wino4_applies(1, 96, 100) == 0
+        c = enc(mid)
+        assert enc._hip_wu2 is not None
+        enc.free_unused_images(keep=("wino",))
+        assert enc._hip_wu4 is None and enc._hip_wu2 is not None
+        enc.free_unused_images()
+        assert enc._hip_wu2 is None
+        assert torch.equal(enc(small), a) and torch.equal(enc(big), b) and torch.equal(enc(mid), c)
