@@ -58,6 +58,22 @@ def _run_driver_command(nproc, steps=3, warmup=1, backend="gloo", timeout=1500):
     return json.loads(lines[0]), wall
 
 
+def _run_bare_command(nproc, steps=3, warmup=1, timeout=1500, extra=()):
+    """The BARE form ``python3 bench.py --gpus N --steps K --warmup W`` -- no launcher around it, WORLD_SIZE unset: bench.py
+    starts its own N ranks as a child ``torch.distributed.run`` before anything touches the GPU, relays rank 0's line and
+    exits with the child's code (the first 8-GPU lease must not depend on the launch form)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", DIINN_BENCH_ONE_DEVICE="1", DIINN_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", str(steps), "--warmup", str(warmup),
+           *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "starting the ranks as a child" in r.stderr
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]      # stdout is the ONE JSON line, nothing else
+    return json.loads(lines[0])
+
+
 def _check_census(res, nproc, backend, devices):
     """The record says who ran: N ranks, each with its device's identity, through which backend, on
     how many DISTINCT devices -- 1 on this box; N on the 8-GPU node, which is what makes that run self-verifying."""
@@ -102,6 +118,37 @@ def test_two_and_four_ranks_drivers_literal_command_default_strong_legs(nproc):
     res, wall = _run_driver_command(nproc)
     _check_default_strong_legs(res, nproc, ["tgt", "c3"])
     assert wall < 1200
+
+
+def test_bare_command_two_ranks_starts_its_own_ranks():
+    res = _run_bare_command(2)
+    _check_default_strong_legs(res, 2, ["tgt", "c3"])
+    assert len(res["ranks"]) == 2
+
+
+def test_bare_command_eight_ranks_starts_its_own_ranks():
+    """``python3 bench.py --gpus 8 --steps 3 --warmup 1`` as typed: eight ranks, one JSON line.  (The default strong legs ran
+    in the torchrun form above; here they are replaced by a small one to keep eight processes on one GPU short.)"""
+    res = _run_bare_command(8, extra=("--strong-legs", "c1", "--strong-steps", "2"))
+    _check_census(res, 8, "gloo", 1)
+    assert res["n_gpus"] == 8 and len(res["ranks"]) == 8 and res["config"]["hr"] == [8192, 1024]
+    assert res["checked"]["ok"] and res["checked"]["handoff_exact"] and res["strong"][0]["checked_ok"]
+
+
+def test_bare_command_watchdog_kills_the_child_group():
+    """The parent's watchdog ends the whole child group (launcher and ranks) and exits 124: no rank is left behind."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", DIINN_BENCH_ONE_DEVICE="1", DIINN_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c4", "--steps", "400",
+                        "--warmup", "1", "--no-check", "--no-strong", "--watchdog", "25"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 124, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    assert "killing its process group" in r.stderr or "exiting with code 124" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    import time
+    time.sleep(1.0)
+    left = subprocess.run(["pgrep", "-f", "bench.py --gpus 2 --workload c4"], capture_output=True, text=True).stdout.split()
+    assert not left, left
 
 
 def test_one_rank_torchrun_constructs_the_rccl_path():
