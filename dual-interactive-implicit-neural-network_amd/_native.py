@@ -22,9 +22,10 @@ SIN_HW_REDUCED = 2
 # default: 2-term reduction in revolutions + v_sin_f32 (max abs error 2.5e-7 for |x| <= 1e4, measured in
 # tests/test_gpu_parity.py::test_device_sine_accuracy); SIN_ACCURATE (1e-7) costs ~4 % more time
 SIN_DEFAULT = SIN_HW_REDUCED
-ABI_VERSION = 8
+ABI_VERSION = 9
 PACKED_MAGIC = 0x44493038
 P_ALGO_DIRECT, P_ALGO_WINOGRAD, P_ALGO_DIRECT_BF16, P_ALGO_DIRECT_BF16X3 = 0, 1, 2, 3
+RDN_ALGO_AUTO, RDN_ALGO_DIRECT, RDN_ALGO_WINO, RDN_ALGO_WINO4, RDN_ALGO_X3 = 0, 1, 2, 3, 4
 COMPUTE_F32 = 0
 COMPUTE_BF16 = 1
 COMPUTE_F32_QONLY = 2
@@ -91,6 +92,10 @@ SIGNATURES = {
                                    C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
                                    C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_rdn_packed_floats": (C.c_size_t, []),
+    "diinn_rdn_planes_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "diinn_rdn_forward_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "diinn_conv_wino4_ws_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _ip]),
     "diinn_rdn_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "diinn_rdn_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int]),

@@ -261,8 +261,8 @@ extern unsigned long long* g_stamps;            // diinn_misc.hip
 #endif
 
 __attribute__((visibility("hidden"))) int device_cus();                                // diinn_misc.hip
-// diinn_winograd4.hip: the F(4x4,3x3) kernel's time for `total` work items, in rounds of whole items on `ncu` compute units
-__attribute__((visibility("hidden"))) double w4_rounds(long long total, int ncu, bool have_ws);
+// diinn_winograd4.hip: the F(4x4,3x3) kernel's time for `total` work items, in rounds of whole items on the compute units it plans for (w4_cus)
+__attribute__((visibility("hidden"))) double w4_rounds(long long total, bool have_ws);
 
 static inline int hip_status(hipError_t e) {
     if (e == hipSuccess) return DIINN_OK;
@@ -301,8 +301,12 @@ __attribute__((visibility("hidden")))
 int launch_P(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,
              int B, int H, int W, int r0, int r1, int mp_total, int arith = 0,
              const RowWin* feat_win = nullptr, const RowWin* p_win = nullptr, bool derived_ok = false);
-// `arith` of launch_P: 0 fp32, 1 bf16 operands (DIINN_COMPUTE_BF16_FULL), 2 split bf16 (DIINN_COMPUTE_BF16X3)
-static inline int p_arith(int compute) { return compute == DIINN_COMPUTE_BF16_FULL ? 1 : compute == DIINN_COMPUTE_BF16X3 ? 2 : 0; }
+// `arith` of launch_P: 0 fp32, 1 bf16 operands (DIINN_COMPUTE_BF16_FULL), 2 split bf16 (DIINN_COMPUTE_BF16X3 -- and, round 6,
+// DIINN_COMPUTE_BF16: that mode's contract is "P at fp32 accuracy", which the split-bf16 P kernel holds (it is bound by the
+// fp32 path's own 1e-4 tolerance) at 0.67x the fp32 Winograd kernel's time; below DIINN_P_X3_MIN cells both fall to Winograd)
+static inline int p_arith(int compute) {
+    return compute == DIINN_COMPUTE_BF16_FULL ? 1 : (compute == DIINN_COMPUTE_BF16X3 || compute == DIINN_COMPUTE_BF16) ? 2 : 0;
+}
 // diinn_precompute_x3.hip: the hoisted conv of all 1024 channels in split-bf16 arithmetic (needs section WPX)
 __attribute__((visibility("hidden")))
 int launch_P_x3(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,

@@ -610,10 +610,17 @@ size_t diinn_rdn_packed_floats(void) {
 }
 
 size_t diinn_rdn_workspace_floats(int B, int H, int W) {
-    // [the F(4x4,3x3) kernel's split area (counters first: they are zeroed at the start of every forward)][two dense
-    // buffers 576][global fusion input 1024][64]
+    // the four one-algorithm entry points (kept for one ABI version): [the F(4x4,3x3) kernel's split area (counters first: they
+    // are zeroed at the start of every forward)][two dense buffers 576][global fusion input 1024][64]
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     return diinn_conv_wino4_workspace_floats() + (size_t)B * H * W * (2 * 576 + 1024 + 64);
+}
+
+size_t diinn_rdn_planes_floats(int algo, int B, int H, int W) {
+    // diinn_rdn_forward_ex's planes: [two dense buffers 576][global fusion input 1024][64] (+ for DIINN_RDN_ALGO_X3 the
+    // split-format copy of one dense buffer: [B][72 groups][hi, lo][H][W] x 16 bytes); the F(4x4) split area is a buffer of its own there
+    if (B <= 0 || H <= 0 || W <= 0 || algo < DIINN_RDN_ALGO_AUTO || algo > DIINN_RDN_ALGO_X3) return 0;
+    return (size_t)B * H * W * (2 * 576 + 1024 + 64 + (algo == DIINN_RDN_ALGO_X3 ? 576 : 0));
 }
 
 size_t diinn_rdn_wino_packed_floats(void) {
@@ -651,15 +658,16 @@ int diinn_rdn_wino4_applies(int B, int H, int W) {
     const long long items4 = 2LL * B * (((long long)((W + 3) / 4) * ((H + 3) / 4) + 31) / 32);   // blocks of 32 consecutive tiles x 2 output halves
     const long long blocks2 = (long long)B * (((W + 1) / 2 + 7) / 8) * (((H + 1) / 2 + 3) / 4);
     const int ncu = device_cus();
-    const double r4 = 1.40 * w4_rounds(items4, ncu, true);       // (the trunk gives the kernel its workspace: a partly filled last round is split)
+    const double r4 = 1.40 * w4_rounds(items4, true);            // (the trunk gives the kernel its workspace: a partly filled last round is split)
     const double r2w = (double)((blocks2 + ncu - 1) / ncu), r2h = 0.57 * (double)((2 * blocks2 + ncu - 1) / ncu);
     return r4 < 0.97 * (r2w < r2h ? r2w : r2h);
 }
 
+// planes: diinn_rdn_planes_floats; w4ws: the F(4x4) kernel's split area (diinn_conv_wino4_workspace_floats; NULL: no layer is split)
 static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
                             const float* packed_wino4_dev, const float* packed_x3_dev,
-                            const float* biases_dev, float* workspace_dev, float* out_dev, int B, int H, int W) {
-    if (!sfe1_dev || !packed_dev || !biases_dev || !workspace_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
+                            const float* biases_dev, float* planes, float* w4ws, float* out_dev, int B, int H, int W) {
+    if (!sfe1_dev || !packed_dev || !biases_dev || !planes || !out_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
     if (st) return st;
     const long long hw = (long long)H * W;
@@ -673,15 +681,15 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     // by that count runs.  DIINN_ENC_WINO4_MIN = n >= 0 replaces the rule by "from n pixels on".
     const bool wino4 = packed_wino4_dev && wino && diinn_rdn_wino4_applies(B, H, W);
     if (wino && !wino4 && !packed_wino_dev) return DIINN_ERR_INVALID_ARG;   // this map runs F(2x2): its image is needed
-    // the F(4x4) kernel's split area leads the workspace; its arrival counters (the first 4 KiB) are zeroed here, once per
-    // forward, whatever a caller or an aborted launch left there (a memset node: capture-safe)
-    float* const w4ws = workspace_dev;
-    const size_t w4ws_floats = diinn_conv_wino4_workspace_floats();
-    if (wino4) {
-        st = hip_status(hipMemsetAsync(w4ws, 0, 4096, (hipStream_t)stream));
+    // the F(4x4) kernel's split area leads the workspace; its arrival counters (the first 2 KiB) are zeroed here, once per
+    // forward, whatever a caller or an aborted launch left there (a memset node: capture-safe).  NOT the sticky status
+    // word behind them (word 1023 of the first 4 KiB, which the workspace's owner zeroes once when it allocates): a
+    // hand-off that gave up stays visible -- NaN features from then on -- until diinn_conv_wino4_ws_status has cleared it
+    const size_t w4ws_floats = w4ws ? diinn_conv_wino4_workspace_floats() : 0;
+    if (wino4 && w4ws) {
+        st = hip_status(hipMemsetAsync(w4ws, 0, DIINN_WINO4_COUNTER_BYTES, (hipStream_t)stream));
         if (st) return st;
     }
-    float* const planes = workspace_dev + w4ws_floats;
     float* buf[2] = {planes, planes + (size_t)B * 576 * hw};                   // dense buffers [B,576,H,W]
     float* gff_in = planes + (size_t)2 * B * 576 * hw;                           // [B,1024,H,W]
     float* tmp = gff_in + (size_t)B * 1024 * hw;                                 // [B,64,H,W]
@@ -765,32 +773,67 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     return conv(tmp, 64 * hw, 64, 9, sfe1_dev, 64 * hw, out_dev, 64 * hw, nullptr, 0, 0);
 }
 
+// ---- ONE trunk entry point (ABI v9): which kernel family the 3x3 layers may take is an argument, the images it may read are
+// the ones given.  AUTO = the fastest fp32 form the given images allow (the rules above); DIRECT / WINO / WINO4 cap the family
+// (the result of the four former entry points); X3 = split bf16 on large maps, asked for explicitly (optional arithmetic).
+int diinn_rdn_forward_ex(void* stream, int algo, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
+                         const float* packed_wino4_dev, const float* packed_x3_dev, const float* biases_dev,
+                         float* planes_dev, float* w4ws_dev, float* out_dev, int B, int H, int W) {
+    switch (algo) {
+        case DIINN_RDN_ALGO_AUTO: packed_x3_dev = nullptr; break;
+        case DIINN_RDN_ALGO_DIRECT: packed_wino_dev = packed_wino4_dev = packed_x3_dev = nullptr; break;
+        case DIINN_RDN_ALGO_WINO:
+            if (!packed_wino_dev) return DIINN_ERR_INVALID_ARG;
+            packed_wino4_dev = packed_x3_dev = nullptr;
+            break;
+        case DIINN_RDN_ALGO_WINO4:
+            // packed_wino_dev may be null when diinn_rdn_wino4_applies(B, H, W): every 3x3 layer then runs F(4x4) and the F(2x2)
+            // image is never read (a caller that only sees such maps need not build or keep it: 152 MB)
+            if (!packed_wino4_dev) return DIINN_ERR_INVALID_ARG;
+            packed_x3_dev = nullptr;
+            break;
+        case DIINN_RDN_ALGO_X3:
+            if (!packed_wino_dev || !packed_x3_dev) return DIINN_ERR_INVALID_ARG;
+            packed_wino4_dev = nullptr;
+            break;
+        default: return DIINN_ERR_INVALID_ARG;
+    }
+    if ((((size_t)planes_dev) & 15) || (((size_t)w4ws_dev) & 15)) return DIINN_ERR_INVALID_ARG;
+    return rdn_forward_impl(stream, sfe1_dev, packed_dev, packed_wino_dev, packed_wino4_dev, packed_x3_dev, biases_dev, planes_dev,
+                            w4ws_dev, out_dev, B, H, W);
+}
+
+// ---- the four one-algorithm entry points of ABI <= 8: thin wrappers, to be dropped with the next ABI number.  Their single
+// workspace is [F(4x4) split area][planes] (diinn_rdn_workspace_floats / diinn_rdn_x3_workspace_floats).
+static int rdn_forward_v8(void* stream, int algo, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
+                          const float* packed_wino4_dev, const float* packed_x3_dev, const float* biases_dev,
+                          float* workspace_dev, float* out_dev, int B, int H, int W) {
+    if (!workspace_dev) return DIINN_ERR_INVALID_ARG;
+    return diinn_rdn_forward_ex(stream, algo, sfe1_dev, packed_dev, packed_wino_dev, packed_wino4_dev, packed_x3_dev, biases_dev,
+                                workspace_dev + diinn_conv_wino4_workspace_floats(), workspace_dev, out_dev, B, H, W);
+}
+
 int diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packed_dev, const float* biases_dev,
                       float* workspace_dev, float* out_dev, int B, int H, int W) {
-    return rdn_forward_impl(stream, sfe1_dev, packed_dev, nullptr, nullptr, nullptr, biases_dev, workspace_dev, out_dev, B, H, W);
+    return rdn_forward_v8(stream, DIINN_RDN_ALGO_DIRECT, sfe1_dev, packed_dev, nullptr, nullptr, nullptr, biases_dev, workspace_dev, out_dev, B, H, W);
 }
 
 int diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
                            const float* biases_dev, float* workspace_dev, float* out_dev, int B, int H, int W) {
-    if (!packed_wino_dev) return DIINN_ERR_INVALID_ARG;
-    return rdn_forward_impl(stream, sfe1_dev, packed_dev, packed_wino_dev, nullptr, nullptr, biases_dev, workspace_dev, out_dev, B, H, W);
+    return rdn_forward_v8(stream, DIINN_RDN_ALGO_WINO, sfe1_dev, packed_dev, packed_wino_dev, nullptr, nullptr, biases_dev, workspace_dev, out_dev, B, H, W);
 }
 
 int diinn_rdn_forward_wino4(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
                             const float* packed_wino4_dev, const float* biases_dev, float* workspace_dev, float* out_dev,
                             int B, int H, int W) {
-    // packed_wino_dev may be null when diinn_rdn_wino4_applies(B, H, W): every 3x3 layer then runs F(4x4) and the F(2x2) image
-    // is never read (a caller that only sees such maps need not build or keep it: 152 MB)
-    if (!packed_wino4_dev) return DIINN_ERR_INVALID_ARG;
-    return rdn_forward_impl(stream, sfe1_dev, packed_dev, packed_wino_dev, packed_wino4_dev, nullptr, biases_dev, workspace_dev, out_dev,
-                            B, H, W);
+    return rdn_forward_v8(stream, DIINN_RDN_ALGO_WINO4, sfe1_dev, packed_dev, packed_wino_dev, packed_wino4_dev, nullptr, biases_dev, workspace_dev,
+                          out_dev, B, H, W);
 }
 
 int diinn_rdn_forward_x3(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
                          const float* packed_x3_dev, const float* biases_dev, float* workspace_dev, float* out_dev,
                          int B, int H, int W) {
-    if (!packed_wino_dev || !packed_x3_dev) return DIINN_ERR_INVALID_ARG;
-    return rdn_forward_impl(stream, sfe1_dev, packed_dev, packed_wino_dev, nullptr, packed_x3_dev, biases_dev, workspace_dev, out_dev, B, H, W);
+    return rdn_forward_v8(stream, DIINN_RDN_ALGO_X3, sfe1_dev, packed_dev, packed_wino_dev, nullptr, packed_x3_dev, biases_dev, workspace_dev, out_dev, B, H, W);
 }
 
 }  // extern "C"

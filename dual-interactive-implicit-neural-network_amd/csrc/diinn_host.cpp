@@ -34,6 +34,8 @@ const KnobDef KNOBS[] = {
     {"DIINN_ENC_WINO_HALF_MAX", &DiinnKnobs::enc_wino_half_max, -1, false},
     {"DIINN_ENC_WINO_PERSIST", &DiinnKnobs::enc_wino_persist, 256, false},
     {"DIINN_ENC_WINO4_SPLIT", &DiinnKnobs::enc_wino4_split, 1, false},
+    {"DIINN_DEBUG_NCU", &DiinnKnobs::debug_ncu, 0, false},
+    {"DIINN_ENC_WINO4_FAULT", &DiinnKnobs::enc_wino4_fault, 0, false},
 };
 }  // namespace
 

@@ -29,6 +29,8 @@ thread_local int g_last_hip_error = 0;
 // compute units of the current device, asked once per device (cost models and persistent grids: an MI355X has 256, a
 // partitioned one fewer); 256 if the runtime cannot say
 int device_cus() {
+    const long long forced = knob(diinn_knobs().debug_ncu);      // tests: a fixed count whatever the box (DIINN_DEBUG_NCU)
+    if (forced > 0) return (int)(forced < 65536 ? forced : 65536);
     static std::atomic<int> cache[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;

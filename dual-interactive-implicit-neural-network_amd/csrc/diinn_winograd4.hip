@@ -34,12 +34,28 @@
 // pixels x 32 outputs) and draws a ticket from the item's counter.  Not the last ticket: it stores the partial outputs as
 // a 64 KiB slab with write-through (sc1) stores and counts the slab ready.  The last ticket: it waits until the other parts'
 // slabs are counted ready -- workgroups that are past their arithmetic and wait for nobody themselves, so the wait is finite
-// whatever the dispatch order or residency (it is bounded all the same; giving up leaves a mark in the workspace) -- and adds
-// the parts IN PART ORDER, its own from registers (the sum does not depend on who came last), then bias, ReLU / residual and
-// the stores.  The hand-off is the guide's "sc1 stores, every storing wave drains, one lane's agent-scope atomic add; the
-// consumer polls that counter with sc1 loads, its other waves load with sc1 loads behind a workgroup barrier" row
-// (MI355X_MICROARCH.md, Workgroup dispatch ... visibility).  Counters are zero on entry and left zero (the last arriver
-// resets its item's).  A 192 x 192 map (144 items on 256 CUs) then costs 0.56 + of a round instead of a whole one.
+// whatever the dispatch order or residency -- and adds the parts IN PART ORDER, its own from registers (the sum does not
+// depend on who came last), then bias, ReLU / residual and the stores.  Counters are zero on entry and left zero (the last
+// arriver resets its item's).  A 192 x 192 map (144 items on 256 CUs) then costs 0.56 + of a round instead of a whole one.
+//
+// Why there is no acquire fence (round 6: stated, not implied).  The hand-off is row 1 of the guide's table "Hand-offs measured
+// with sc1 loads in place of the acquire" (MI355X_MICROARCH.md, Workgroup dispatch, XCD placement & inter-workgroup
+// visibility, "Valid forms", Consumer bullet conditions (1)-(4)), matched in EVERY cell:
+//   who signals     ONE lane (thread 0) of each storing workgroup, for ALL that workgroup's stores, by an agent-scope atomic
+//                   add to the item's READY counter, issued after every storing wave's `s_waitcnt vmcnt(0)` and the workgroup
+//                   barrier behind those waits (condition (3), Guideline 16 R1);
+//   how learned     an sc1 load poll of that counter (`__hip_atomic_load(relaxed, agent)` = `global_load_dword sc1`) by thread 0
+//                   of the last arriver;
+//   between         the polling wave loads only after its poll matched; the other waves load behind the workgroup barrier that
+//                   wave then joins (the __syncthreads() after the spin);
+//   memory          hipMalloc'ed workspace; one workgroup per CU (1,024 threads, 158 KiB of LDS);
+//   stores          16-byte buffer stores, all sc1 (aux 16), whole 1 KiB per wave instruction (condition (2));
+//   loads           16-byte buffer loads to registers, all sc1 (never flat_, never through LDS-DMA) (condition (1)).
+// The table is a measurement on gfx950 / ROCm 7.2, not an architectural guarantee, which is why the wait is BOUNDED and
+// why giving up is LOUD: the last arriver that runs out of spins writes NaN to every output of its item instead of a sum of
+// stale slabs, and sets the workspace's sticky STATUS word (1023), which no forward re-zeroes; from then on every split item
+// computed with that workspace is NaN too, until the host has looked (diinn_conv_wino4_ws_status) and cleared it.  The
+// library's rule elsewhere (the packed image's validity word) is the same: a loud NaN, never a plausible wrong picture.
 #include "diinn_device.h"
 
 constexpr int W4_TX = 32;                            // Winograd tiles per block: 32 = one MFMA N-tile; consecutive tiles of the row-major tile grid (128 x 4 output pixels; a block may wrap into the next tile row)
@@ -78,6 +94,8 @@ struct ConvWino4Params {
                              // of a sequence that gives each of the sk_items / 2 blocks sk_e overhead units, then its Cin/8 chunks
     int sk_e;                // overhead units in front of a block's chunks: what a run pays in time for entering one more block
     int sk_wgs;              // split workgroups: blockIdx.x < sk_wgs (a multiple of 16)
+    unsigned sk_spin_max;    // polls (with s_sleep 8 between them) before the last arriver gives up: 2^24 = seconds
+    int sk_fault;            // test only (DIINN_ENC_WINO4_FAULT): 1 = the parts never count their slab ready
 #ifdef W4_STAMPS
     unsigned long long* stamps;   // tools/ubench/wino4_bench.hip -DW4_STAMPS: s_memtime of workgroup 0's waves 0 and 12, [wave 2][iteration 80][4]
 #endif
@@ -97,7 +115,8 @@ struct ConvWino4Params {
 constexpr int W4_SLAB_FLOATS = 4 * 1024 * 4;        // a split workgroup's partial outputs: [output row 4][thread 1024] f32x4 = 64 KiB
 constexpr int W4_FLAG = 36 * 1024;                   // LDS word behind the exchange buffer: the ticket drawn by thread 0
 static_assert(W4_FLAG < W4_LDS_FLOATS, "flag word inside the LDS array");
-constexpr int W4_READY = 256, W4_TIMEOUT = 1023;     // counter words: [item] tickets, [256 + item] slabs stored, [1023] a wait gave up (stays 0)
+constexpr int W4_READY = 256, W4_STATUS = 1023;      // counter words: [item] tickets, [256 + item] slabs stored: zero on entry, zero on exit (bytes
+static_assert(2 * W4_READY * 4 == DIINN_WINO4_COUNTER_BYTES, ""); // [0, 2048): what a forward re-zeroes); [1023] STICKY status: 1 = a wait gave up in this workspace
 static_assert(DIINN_WINO4_MAX_SPLIT_WGS <= W4_READY, "one ticket and one ready word per split item");
 
 // what a workgroup knows about the item it computes a channel range of (parts == 1: the whole item, nothing below is used)
@@ -372,8 +391,11 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
             // parts IN PART ORDER, this workgroup's from its registers: whoever comes last, the same sum.
             const unsigned last_tk = (unsigned)sk.parts - 1u;
             if (threadIdx.x == 0) W4_STAMP(0, 77, 0);             // partial outputs in registers
-            if (threadIdx.x == 0)
+            if (threadIdx.x == 0) {
                 lds[W4_FLAG] = __builtin_bit_cast(float, __hip_atomic_fetch_add(p.sk_cnt + sk.item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                // the sticky status: a wait gave up in this workspace before and the host has not cleared it -> poison
+                lds[W4_FLAG + 1] = __builtin_bit_cast(float, __hip_atomic_load(p.sk_cnt + W4_STATUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
             __syncthreads();
             const unsigned tk = __builtin_bit_cast(unsigned, *(volatile float*)(lds + W4_FLAG));
             const unsigned toff = threadIdx.x * 16u;
@@ -385,7 +407,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
                 for (int a = 0; a < 4; ++a) w4_st_sc1(f32x4{y[a][0], y[a][1], y[a][2], y[a][3]}, srs, a * 16384u + toff);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (threadIdx.x == 0)
+                if (threadIdx.x == 0 && !p.sk_fault)
                     __hip_atomic_fetch_add(p.sk_cnt + W4_READY + sk.item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (threadIdx.x == 0) W4_STAMP(0, 77, 2);         // slab stored, drained and counted
                 return;
@@ -394,16 +416,18 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
                 unsigned spins = 0;
                 while (__hip_atomic_load(p.sk_cnt + W4_READY + sk.item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != last_tk) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1u << 24)) {                  // seconds: something is broken; say so and go on
-                        __hip_atomic_store(p.sk_cnt + W4_TIMEOUT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (++spins > p.sk_spin_max) {               // seconds: something is broken.  LOUD: the sticky status word
+                        __hip_atomic_store(p.sk_cnt + W4_STATUS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // and NaN outputs
+                        lds[W4_FLAG + 1] = __builtin_bit_cast(float, 1u);
                         break;
                     }
                 }
-                // everybody has arrived and stored: both counters are ready for the next launch
+                // everybody has arrived and stored (or the item is poisoned): both counters are ready for the next launch
                 __hip_atomic_store(p.sk_cnt + sk.item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(p.sk_cnt + W4_READY + sk.item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
+            const bool poisoned = __builtin_bit_cast(unsigned, *(volatile float*)(lds + W4_FLAG + 1)) != 0u;
             if (threadIdx.x == 0) W4_STAMP(0, 78, 0);             // the other parts are ready
             const int mine = sk.pair - sk.first_pair;            // this workgroup's part number
             auto part = [&](int k, f32x4 (&v)[4]) {
@@ -429,7 +453,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int x = 0; x < 4; ++x) y[a][x] = s[a][x];
+                for (int x = 0; x < 4; ++x) y[a][x] = poisoned ? __builtin_nanf("") : s[a][x];   // never a sum of slabs nobody vouched for
             if (threadIdx.x == 0) W4_STAMP(0, 78, 1);             // parts summed
         }
         const int ox = 4 * tx, oy0 = 4 * ty;
@@ -528,6 +552,14 @@ unsigned long long* g_w4_stamps = nullptr;
 // ~2.27 GHz with 144, at equal cycles per chunk.  That is why a 192 x 192 map (0.56 of a round) gains 15-25 % from the
 // split, not 44 %: the chip is power-limited, and time follows the arithmetic done more than the workgroups in flight.
 struct W4Plan { int first, items, u, wgs, e; };
+// the compute units the F(4x4) kernel plans its rounds and its split for: the device's, clipped ONCE here to the workgroups
+// the slab area holds and made even (workgroup pairs) -- w4_plan, w4_rounds and through them diinn_rdn_wino4_applies all
+// describe the split the kernel runs, also on a part with more than 256 CUs
+static int w4_cus() {
+    int ncu = device_cus();
+    if (ncu > DIINN_WINO4_MAX_SPLIT_WGS) ncu = DIINN_WINO4_MAX_SPLIT_WGS;
+    return ncu & ~1;
+}
 constexpr int W4_SPLIT_E = 4;                                    // overhead units per block entered (prologue + epilogue + slab hand-off, in chunk times;
                                                                  // 2 / 3 / 6 / 8 measured: 192x192 trunk 6.83 / 6.76 / 6.80 / 6.77 ms against 6.65)
 static inline double w4_whole_us(int n) { return 10.0 + 1.46 * n; }
@@ -536,8 +568,6 @@ static W4Plan w4_plan(long long total, int n, int ncu, bool have_ws) {
     W4Plan pl{(int)total, 0, 0, 0, 0};
     const long long mode = knob(diinn_knobs().enc_wino4_split);           // 0 never, 1 by the cost model, 2 whenever a round is partly filled
     if (!have_ws || mode == 0 || ncu < 8) return pl;
-    if (ncu > DIINN_WINO4_MAX_SPLIT_WGS) ncu = DIINN_WINO4_MAX_SPLIT_WGS;  // the slab area is sized for this many
-    ncu &= ~1;                                                   // workgroup pairs (the two output halves of a block)
     const int R = (int)(total % ncu);                            // even: total is
     if (R == 0) return pl;
     int e = W4_SPLIT_E, ne = n + e;
@@ -560,7 +590,9 @@ static W4Plan w4_plan(long long total, int n, int ncu, bool have_ws) {
 // the kernel's time for a map of `total` work items over the whole trunk, in rounds of whole items: the whole rounds + what a
 // last round filled to r = R / N costs once it is split, 0.27 + 0.86 r of a round (measured on 112 .. 208-pixel maps:
 // profiles/r05_enc_trunk_times.txt); diinn_rdn_wino4_applies compares it with the F(2x2) kernel's rounds
-__attribute__((visibility("hidden"))) double w4_rounds(long long total, int ncu, bool have_ws) {
+__attribute__((visibility("hidden"))) double w4_rounds(long long total, bool have_ws) {
+    const int ncu = w4_cus();
+    if (ncu < 2) return (double)total;
     const long long whole = total / ncu, R = total % ncu;
     if (R == 0) return (double)whole;
     const W4Plan pl = w4_plan(total, 36, ncu, have_ws);          // (would the trunk's average layer be split at all?)
@@ -594,7 +626,9 @@ int diinn_conv_wino4_ws(void* stream, const float* in_dev, long long in_batch_st
     p.in = in_dev; p.wu = packed_u_dev; p.bias = bias_dev; p.res = res_dev; p.out = out_dev;
     p.in_bs = in_batch_stride; p.out_bs = out_batch_stride; p.res_bs = res_batch_stride;
     p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0;
-    const W4Plan pl = w4_plan(2 * blocks, Cin / 8, device_cus(), ws_dev != nullptr);
+    const W4Plan pl = w4_plan(2 * blocks, Cin / 8, w4_cus(), ws_dev != nullptr);
+    p.sk_fault = knob(diinn_knobs().enc_wino4_fault) == 1 ? 1 : 0;
+    p.sk_spin_max = p.sk_fault ? (1u << 10) : (1u << 24);
     p.sk_first = pl.first; p.sk_items = pl.items; p.sk_u = pl.u; p.sk_e = pl.e; p.sk_wgs = pl.wgs;
     p.sk_cnt = (unsigned*)ws_dev;
     p.sk_slabs = ws_dev ? ws_dev + 1024 : nullptr;
@@ -604,6 +638,25 @@ int diinn_conv_wino4_ws(void* stream, const float* in_dev, long long in_batch_st
     const unsigned grid = (unsigned)pl.wgs + (unsigned)((pl.first + 7) / 8 * 8);
     hipLaunchKernelGGL(conv_wino4_kernel, dim3(grid), dim3(W4_THREADS), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
+}
+
+// the workspace's sticky status word: 1 = a last arriver gave up waiting for another part's slab in some launch that used this
+// workspace (its outputs, and those of every split item since, are NaN).  SYNCHRONISES `stream` (a 4-byte copy to the host):
+// a query for after a forward, for tests and for bench.py -- not a launch function.  clear != 0: the whole counter area
+// (4 KiB: tickets, ready counts, status) is zeroed behind the read.
+int diinn_conv_wino4_ws_status(void* stream, float* ws_dev, int clear, int* status) {
+    if (!ws_dev || !status) return DIINN_ERR_INVALID_ARG;
+    unsigned word = 0;
+    int st = hip_status(hipMemcpyAsync(&word, (const unsigned*)ws_dev + W4_STATUS, sizeof(word), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (st) return st;
+    if (clear) {
+        st = hip_status(hipMemsetAsync(ws_dev, 0, 4096, (hipStream_t)stream));
+        if (st) return st;
+    }
+    st = hip_status(hipStreamSynchronize((hipStream_t)stream));
+    if (st) return st;
+    *status = word != 0u ? 1 : 0;
+    return DIINN_OK;
 }
 
 int diinn_conv_wino4(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
@@ -617,7 +670,7 @@ int diinn_conv_wino4(void* stream, const float* in_dev, long long in_batch_strid
 int diinn_conv_wino4_plan(int Cin, int B, int H, int W, int with_workspace, int info[4]) {
     if (!info || Cin <= 0 || Cin % 8 || check_dims(B, H, W)) return DIINN_ERR_INVALID_ARG;
     const long long blocks = (((long long)((W + 3) / 4) * ((H + 3) / 4) + W4_TX - 1) / W4_TX) * B;
-    const W4Plan pl = w4_plan(2 * blocks, Cin / 8, device_cus(), with_workspace != 0);
+    const W4Plan pl = w4_plan(2 * blocks, Cin / 8, w4_cus(), with_workspace != 0);
     info[0] = (int)(2 * blocks); info[1] = pl.first; info[2] = pl.wgs; info[3] = pl.u;
     return DIINN_OK;
 }

@@ -135,7 +135,7 @@ def pack_conv_x3(weight: torch.Tensor) -> torch.Tensor:
 class RDN(nn.Module):
     _CONFIGS = {"A": (20, 6, 32), "B": (16, 8, 64)}
     # Inference (no autograd, fp32, config 'B') runs the whole encoder on the library's kernels:
-    # SFENet1 on diinn_sfe1_forward, the 147 convolutions after it through diinn_rdn_forward[_wino] -- the split-K
+    # SFENet1 on diinn_sfe1_forward, the 147 convolutions after it through diinn_rdn_forward_ex -- the split-K
     # kernel on small maps, Winograd 3x3 + streaming 1x1 kernels from 8192 pixels on.  Measured (tools/enc_trunk_time.py,
     # HIP vs MIOpen eager): 1.95 vs 7.6 ms at 48x48, 3.6 vs 7.6 at 96x96, 3.9 vs 8.1 at 128x128, 9.3 vs 20.2 at 192x192,
     # 11.8 vs 28.6 at 256x256, 28.3 vs 61.6 at 384x384, 47.0 vs 109.5 at 512x512.  The attribute caps the batch*H*W
@@ -223,45 +223,73 @@ class RDN(nn.Module):
                                      [pack_conv_x3(rdb.LFF.weight.to(device)) for rdb in self.RDBs]).to(device)
         return self._hip_x3
 
+    # the F(4x4) kernel's split area (34.6 MB: control words + partial-output slabs), ONE per (device, stream), kept across
+    # forwards: its sticky status word then remembers a hand-off that ever gave up (handoff_status()); two streams never
+    # share slabs or tickets.  Class-wide: every RDN of the process on that (device, stream) may use it (launches on one
+    # stream are ordered).
+    _w4_areas: dict = {}
+
+    @classmethod
+    def _w4_area(cls, device):
+        from . import _native
+        floats = _native.load().diinn_conv_wino4_workspace_floats()
+        if torch.cuda.is_current_stream_capturing():
+            # inside a hipGraph capture the area comes from the graph's private pool and lives with the graph (its control
+            # words are zeroed by a captured memset: a replay starts clean; a give-up is still NaN in that replay's output)
+            ws = torch.empty(floats, dtype=torch.float32, device=device)
+            ws[:1024].zero_()
+            return ws
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+        ws = cls._w4_areas.get(key)
+        if ws is None:
+            ws = torch.empty(floats, dtype=torch.float32, device=device)
+            ws[:1024].zero_()                                 # the control words, once (a forward re-zeroes only the counters)
+            cls._w4_areas[key] = ws
+        return ws
+
+    @classmethod
+    def handoff_status(cls, clear: bool = True) -> int:
+        """1 if the F(4x4) kernel's cross-workgroup hand-off has ever given up on one of this process' split areas (the
+        features computed then, and since, are NaN: the failure is loud on the device already); synchronises the streams
+        concerned.  ``clear`` re-arms the areas."""
+        import ctypes as C
+        from . import _native
+        lib = _native.load()
+        worst = 0
+        for (dev, stream), ws in list(cls._w4_areas.items()):
+            st = C.c_int(0)
+            with torch.cuda.device(ws.device):
+                _native.check(lib.diinn_conv_wino4_ws_status(C.c_void_p(stream), C.c_void_p(ws.data_ptr()), int(clear), C.byref(st)),
+                              "diinn_conv_wino4_ws_status")
+            worst = max(worst, st.value)
+        return worst
+
     def _forward_hip_trunk(self, shallow):
         import ctypes as C
         from . import _native
         lib = _native.load()
         b, _, h, w = shallow.shape
         shallow = shallow.contiguous()
-        packed, biases = self._hip_packed(shallow.device)
+        dev = shallow.device
+        packed, biases = self._hip_packed(dev)
         x3 = self.hip_winograd and self.hip_split_bf16
         w4 = self.hip_winograd and self.hip_winograd4 and not x3 and bool(lib.diinn_rdn_wino4_applies(b, h, w))
         # the F(2x2) image only where a kernel reads it (ADVICE r04: ~0.6 GB of weight copies for an 88 MB encoder otherwise)
         needs_wino = self.hip_winograd and not w4 and (x3 or b * h * w >= _native.debug_get("DIINN_ENC_WINO_MIN"))
-        packed_wino = self._hip_packed_wino(shallow.device) if needs_wino else None
-        pwp = C.c_void_p(packed_wino.data_ptr()) if packed_wino is not None else None
-        ws_floats = lib.diinn_rdn_x3_workspace_floats(b, h, w) if x3 else lib.diinn_rdn_workspace_floats(b, h, w)
-        ws = torch.empty(ws_floats, dtype=torch.float32, device=shallow.device)
+        algo = (_native.RDN_ALGO_X3 if x3 else _native.RDN_ALGO_WINO4 if w4 else _native.RDN_ALGO_WINO if needs_wino
+                else _native.RDN_ALGO_DIRECT)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+        packed_wino = self._hip_packed_wino(dev) if needs_wino else None
+        packed_w4 = self._hip_packed_wino4(dev) if w4 else None
+        packed_x3 = self._hip_packed_x3(dev) if x3 else None
+        planes = torch.empty(lib.diinn_rdn_planes_floats(algo, b, h, w), dtype=torch.float32, device=dev)
+        area = self._w4_area(dev) if w4 else None
         out = torch.empty_like(shallow)
-        with torch.cuda.device(shallow.device):
+        with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            if self.hip_winograd and self.hip_split_bf16:
-                px3 = self._hip_packed_x3(shallow.device)
-                _native.check(lib.diinn_rdn_forward_x3(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                                       pwp, C.c_void_p(px3.data_ptr()),
-                                                       C.c_void_p(biases.data_ptr()), C.c_void_p(ws.data_ptr()),
-                                                       C.c_void_p(out.data_ptr()), b, h, w), "diinn_rdn_forward_x3")
-            elif w4:
-                pw4 = self._hip_packed_wino4(shallow.device)
-                _native.check(lib.diinn_rdn_forward_wino4(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                                          pwp, C.c_void_p(pw4.data_ptr()),
-                                                          C.c_void_p(biases.data_ptr()), C.c_void_p(ws.data_ptr()),
-                                                          C.c_void_p(out.data_ptr()), b, h, w), "diinn_rdn_forward_wino4")
-            elif self.hip_winograd and packed_wino is not None:
-                _native.check(lib.diinn_rdn_forward_wino(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                                         pwp, C.c_void_p(biases.data_ptr()),
-                                                         C.c_void_p(ws.data_ptr()), C.c_void_p(out.data_ptr()), b, h, w),
-                              "diinn_rdn_forward_wino")
-            else:
-                _native.check(lib.diinn_rdn_forward(stream, C.c_void_p(shallow.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                                    C.c_void_p(biases.data_ptr()), C.c_void_p(ws.data_ptr()),
-                                                    C.c_void_p(out.data_ptr()), b, h, w), "diinn_rdn_forward")
+            _native.check(lib.diinn_rdn_forward_ex(stream, algo, ptr(shallow), ptr(packed), ptr(packed_wino), ptr(packed_w4),
+                                                   ptr(packed_x3), ptr(biases), ptr(planes), ptr(area), ptr(out), b, h, w),
+                          "diinn_rdn_forward_ex")
         return out
 
     def _sfe1_hip(self, x):

@@ -229,7 +229,7 @@ WGRAD_CONV_KSPLIT = 12     # pixel-axis splits of the hoisted conv's weight-grad
 
 
 def _conv_grads_native(feat: torch.Tensor, wx: torch.Tensor, dp: torch.Tensor, need_feat_grad: bool, want_weight: bool = True,
-                       wkey=None):
+                       wkey=None, wpins=None):
     """Gradients of P = conv3x3(feat; Wx[1024,64,3,3]) on the library's own kernels (no MIOpen in the decoder's step):
       weight:  dWx[o, (c,ky,kx)] = sum over cells of dP[o, cell] * unfold3x3(feat)[(c,ky,kx), cell] -- the plane GEMM over the
                cell axis (plane_gemm_kernel; the 576 unfolded rows padded to 640 = 5 x 128);
@@ -274,16 +274,21 @@ def _conv_grads_native(feat: torch.Tensor, wx: torch.Tensor, dp: torch.Tensor, n
             # the transposed weight in the kernel's form: repacked only when a K weight changed (an optimizer step, a
             # load_state_dict), not on every backward call.  The Winograd transforms are taken in float64 and rounded once,
             # like the encoder's: F(4x4)'s gradient error 2.5e-5 -> ~1e-5 of max|d_feat| (the fixtures' bound is 1e-4).
-            global _dgrad_pack
-            key = (form, str(dev), wkey)
-            if wkey is None or _dgrad_pack[0] != key:
+            # One entry per (kernel form, device): a multi-scale step alternates forms without evicting each other.  An entry
+            # PINS the weight tensors its key describes (as _packed_cache does): while it is cached their addresses cannot be
+            # handed to another decoder's weights with equal version counts.
+            key = (str(dev), wkey)
+            ent = _dgrad_pack.get((form, str(dev)))
+            if wkey is None or ent is None or ent[0] != key:
                 wt = wx.flip(2, 3).permute(1, 0, 2, 3).contiguous()      # [64, 1024, 3, 3]
                 pk = (M.pack_conv_wino4(wt) if form == "wino4" else M.pack_conv_wino(wt) if form == "wino" else M.pack_conv_ksplit(wt))
-                _dgrad_pack = (key, pk)
-            pk = _dgrad_pack[1]
+                ent = (key, pk, tuple(t.detach() for t in (wpins or ())))
+                if wkey is not None:
+                    _dgrad_pack[(form, str(dev))] = ent
+            pk = ent[1]
             if form == "wino4":
                 ws = _wino4_workspace(dev)                       # (a partly filled last round is split over the input channels)
-                ws[:1024].zero_()                                # the counter words, whatever an aborted launch may have left (as the trunk does)
+                ws[:512].zero_()                                 # the arrival counters, whatever an aborted launch may have left (as the trunk does; never the sticky status word)
                 _native.check(lib.diinn_conv_wino4_ws(stream, ptr(dp), cin * h * w, cin, ptr(pk), ptr(zero), None, 0, ptr(d_feat),
                                                       c * h * w, 0, b, h, w, ptr(ws), ws.numel()), "diinn_conv_wino4_ws")
             elif form == "wino":
@@ -295,17 +300,14 @@ def _conv_grads_native(feat: torch.Tensor, wx: torch.Tensor, dp: torch.Tensor, n
     return d_wx, d_feat
 
 
-_dgrad_pack: tuple = (None, None)                  # (key, the transposed hoisted-conv weight in the dgrad kernel's form)
-_wino4_ws: Dict[str, torch.Tensor] = {}
+_dgrad_pack: Dict[tuple, tuple] = {}               # (form, device) -> (key, the transposed hoisted-conv weight in that kernel's form, the pinned K weights)
 
 
 def _wino4_workspace(dev) -> torch.Tensor:
-    """diinn_conv_wino4_ws's workspace, one per device: zeroed once (the kernel leaves its counters zero); launches that
-    share it are ordered by the stream they run on -- callers on several streams of one device must not share it."""
-    ws = _wino4_ws.get(str(dev))
-    if ws is None:
-        ws = _wino4_ws[str(dev)] = torch.zeros(_native.load().diinn_conv_wino4_workspace_floats(), dtype=torch.float32, device=dev)
-    return ws
+    """diinn_conv_wino4_ws's workspace: the encoder's split area of this (device, current stream) (modules.RDN._w4_area:
+    control words zeroed once, launches on one stream are ordered, two streams never share slabs or tickets)."""
+    from . import modules as M
+    return M.RDN._w4_area(dev)
 
 
 def _conv_and_assemble(p: Dict[str, torch.Tensor], feat: torch.Tensor, dp: torch.Tensor, d_wq, d_bk,
@@ -319,7 +321,8 @@ def _conv_and_assemble(p: Dict[str, torch.Tensor], feat: torch.Tensor, dp: torch
     d_wx = d_feat = None
     if nat_w or (nat_d and need_feat_grad):
         wkey = tuple((p[f"K.{i}.0.weight"].data_ptr(), p[f"K.{i}.0.weight"]._version) for i in range(4))
-        d_wx, d_feat = _conv_grads_native(feat, wx, dp, need_feat_grad and nat_d, want_weight=nat_w, wkey=wkey)
+        d_wx, d_feat = _conv_grads_native(feat, wx, dp, need_feat_grad and nat_d, want_weight=nat_w, wkey=wkey,
+                                          wpins=tuple(p[f"K.{i}.0.weight"] for i in range(4)))
     if d_wx is None:
         d_wx = torch.nn.grad.conv2d_weight(feat, wx.shape, dp, padding=1)
     if d_feat is None and need_feat_grad:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIINN_ABI_VERSION 8
+#define DIINN_ABI_VERSION 9
 /* History of the ABI number:
  *   1  diinn_pack_weights, axis tables, diinn_precompute_P / diinn_decode_band / diinn_decode (+ _ex: compute modes)
  *   2  training (diinn_decode_train_fwd, diinn_backward_*, diinn_plane_*), LIIF / MetaSR, the encoder trunk
@@ -50,7 +50,11 @@ extern "C" {
  *   8  the validity word follows the layout (DIINN_PACKED_MAGIC "DI08": an image packed by an older library is shorter
  *      and now decodes to NaN instead of being read past its end); diinn_conv_wino4_ws / _workspace_floats / _plan (the
  *      F(4x4,3x3) layer's last round split over the input channels) and a larger diinn_rdn_workspace_floats for it;
- *      diinn_decode_kernel_info */
+ *      diinn_decode_kernel_info
+ *   9  ONE trunk entry point, diinn_rdn_forward_ex(algo, ...), with the F(4x4) split area as a buffer of its own
+ *      (diinn_rdn_planes_floats); diinn_rdn_forward / _wino / _wino4 / _x3 are wrappers of it, kept for this ABI number only;
+ *      the split hand-off fails LOUDLY (NaN outputs + a sticky status word: diinn_conv_wino4_ws_status); test-only knobs
+ *      DIINN_DEBUG_NCU, DIINN_ENC_WINO4_FAULT */
 
 /* status codes */
 #define DIINN_OK                 0
@@ -345,20 +349,41 @@ int    diinn_metasr_make_axis_tables(int n_in, int n_out, int32_t* idx, float* r
  *   + residual, written to one or two destinations (element strides in floats).  packed_w_dev holds the
  *   weight W[64][Cin][taps] as [half 2][wave 8][tap][group Cin/64][lane 64][4]:
  *   value = W[32 half + (lane&31)][wave*Cin/8 + 8 group + 2 e + (lane>>5)][tap]   (MFMA A-operand order per K-slice).
- * diinn_rdn_forward: the whole trunk as 147 launches: sfe1_dev [B,64,H,W] = SFENet1(x) (computed by the
- *   caller), packed_dev = the 147 packed weights in execution order (SFENet2; per block: 8 dense convs, LFF;
- *   GFF.0, GFF.1), biases_dev = their 147 x 64 biases, workspace_dev = diinn_rdn_workspace_floats floats
- *   (16-byte aligned; 2,240 floats per pixel + diinn_conv_wino4_workspace_floats(), which leads it and whose first 4 KiB
- *   diinn_rdn_forward_wino4 zeroes itself), out_dev [B,64,H,W]. */
+ * diinn_rdn_forward_ex: the whole trunk as 147 launches.  sfe1_dev [B,64,H,W] = SFENet1(x) (diinn_sfe1_forward, or computed by
+ *   the caller); packed_dev = the 147 packed weights in execution order (SFENet2; per block: 8 dense convs, LFF; GFF.0, GFF.1;
+ *   always read: the 1x1 layers and small maps); biases_dev = their 147 x 64 biases; out_dev [B,64,H,W].
+ *   `algo` caps the kernel family of the 3x3 layers, the images that family reads must be given (else DIINN_ERR_INVALID_ARG),
+ *   images of other families are ignored and may be NULL:
+ *     DIINN_RDN_ALGO_DIRECT  split-K direct sum everywhere (packed_dev only);
+ *     DIINN_RDN_ALGO_WINO    Winograd F(2x2,3x3) (packed_wino_dev) from B*H*W >= 8192 on, the split-K kernel below;
+ *     DIINN_RDN_ALGO_WINO4   Winograd F(4x4,3x3) (packed_wino4_dev) where that kernel needs fewer rounds of workgroups than
+ *                            F(2x2) (diinn_rdn_wino4_applies; from about 35,000 pixels on, depending on how its 2 * ceil(tiles
+ *                            / 32) work items per image fill the last round), else as WINO; packed_wino_dev may be NULL for a map
+ *                            with diinn_rdn_wino4_applies(B, H, W) == 1 (the F(2x2) image is not read then);
+ *     DIINN_RDN_ALGO_AUTO    the fastest fp32 form the given images allow (= WINO4, WINO or DIRECT by what is non-NULL);
+ *     DIINN_RDN_ALGO_X3      optional arithmetic: 3x3 and local-fusion layers in split bf16 (packed_x3_dev; packed_wino_dev too)
+ *                            from B*H*W >= 32768 on, as WINO below.
+ *   planes_dev: diinn_rdn_planes_floats(algo, B, H, W) floats, 16-byte aligned, any content (2,240 floats per pixel; X3: 2,816).
+ *   w4ws_dev: the F(4x4) kernel's split area, diinn_conv_wino4_workspace_floats() floats (34.6 MB), or NULL (no layer is then
+ *   split over its input channels: same results up to the reassociation documented at diinn_conv_wino4_ws, partly filled rounds
+ *   cost whole ones).  Its first 4 KiB are control words the OWNER zeroes once at allocation; a forward re-zeroes only the
+ *   arrival counters (DIINN_WINO4_COUNTER_BYTES), never the sticky status word (diinn_conv_wino4_ws): keep ONE such area per
+ *   (device, stream) across forwards and a hand-off that ever gave up stays visible to diinn_conv_wino4_ws_status. */
+#define DIINN_RDN_ALGO_AUTO   0
+#define DIINN_RDN_ALGO_DIRECT 1
+#define DIINN_RDN_ALGO_WINO   2
+#define DIINN_RDN_ALGO_WINO4  3
+#define DIINN_RDN_ALGO_X3     4
+size_t diinn_rdn_planes_floats(int algo, int B, int H, int W);
+int    diinn_rdn_forward_ex(void* stream, int algo, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
+                            const float* packed_wino4_dev, const float* packed_x3_dev, const float* biases_dev,
+                            float* planes_dev, float* w4ws_dev, float* out_dev, int B, int H, int W);
 int    diinn_conv_ksplit(void* stream, const float* in_dev, long long in_batch_stride, int Cin, int taps,
                         const float* packed_w_dev, const float* bias_dev,
                         const float* res_dev, long long res_batch_stride,
                         float* out0_dev, long long out0_batch_stride, float* out1_dev, long long out1_batch_stride,
                         int relu, int B, int H, int W);
 size_t diinn_rdn_packed_floats(void);
-size_t diinn_rdn_workspace_floats(int B, int H, int W);
-int    diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packed_dev, const float* biases_dev,
-                         float* workspace_dev, float* out_dev, int B, int H, int W);
 
 /* Winograd F(2x2, 3x3) for the trunk's 3x3 convolutions (csrc/diinn_winograd.hip): 2.25x fewer MFMAs than the direct
  * sum, fp32, results equal up to reassociation (~1e-6 relative).
@@ -367,14 +392,11 @@ int    diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packe
  *   as [row i 4][chunk Cin/8][col j 4][half 2][lane 64][4]:
  *   value = s_j U[32 half + (lane&31)][8 chunk + 2 e + (lane>>5)][i][j], s_2 = -1, else 1   (16 * 64 * Cin floats;
  *   bias_dev 16-byte aligned).
- * diinn_rdn_wino_packed_floats: floats of the 130 transformed 3x3 weights of the trunk, in execution order.
- * diinn_rdn_forward_wino: diinn_rdn_forward with the 3x3 layers on diinn_conv_wino where that is the faster kernel
- *   (B*H*W >= 8192) and on the split-K kernel otherwise; packed_dev and
- *   biases_dev as for diinn_rdn_forward (the 1x1 layers and small maps read them), packed_wino_dev = the transformed
- *   3x3 weights. */
+ * diinn_rdn_wino_packed_floats: floats of the 130 transformed 3x3 weights of the trunk, in execution order
+ *   (diinn_rdn_forward_ex's packed_wino_dev). */
 /* diinn_sfe1_forward: SFENet1 (rdn.py:96): 3x3 zero-padded convolution n_colors = Cin (1..4) -> 64 on the image itself,
  *   x_dev [B,Cin,H,W], w_dev [64,Cin,3,3] and bias_dev [64] in the reference's own layout, out_dev [B,64,H,W] = the
- *   sfe1_dev argument of diinn_rdn_forward[_wino]: with it the whole encoder runs through this library. */
+ *   sfe1_dev argument of diinn_rdn_forward_ex: with it the whole encoder runs through this library. */
 int    diinn_sfe1_forward(void* stream, const float* x_dev, int Cin, const float* w_dev, const float* bias_dev,
                           float* out_dev, int B, int H, int W);
 int    diinn_conv_wino(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
@@ -382,8 +404,6 @@ int    diinn_conv_wino(void* stream, const float* in_dev, long long in_batch_str
                       const float* res_dev, long long res_batch_stride,
                       float* out_dev, long long out_batch_stride, int relu, int B, int H, int W);
 size_t diinn_rdn_wino_packed_floats(void);
-int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
-                              const float* biases_dev, float* workspace_dev, float* out_dev, int B, int H, int W);
 
 /* Winograd F(4x4, 3x3) for the same layers on larger maps (csrc/diinn_winograd4.hip): 36 multiplies per (input, output)
  * pair and 4x4 output block, 1.78x fewer MFMAs than F(2x2, 3x3); fp32, transformed weights computed in float64 and
@@ -393,24 +413,29 @@ int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* 
  * diinn_conv_wino4: as diinn_conv_wino.  packed_u_dev holds U = G W G^T (6x6 per pair, G of F(4x4,3x3): Lavin & Gray,
  *   points 0, +-1, +-2, inf) as [wave 12][half 2][chunk Cin/8][q 3][lane 64][4]:
  *   value = U[32 half + (lane&31)][8 chunk + 2 e + (lane>>5)][i][j] with 6 i + j = 3 wave + q     (36 * 64 * Cin floats).
- * diinn_conv_wino4_ws: the same with a workspace (diinn_conv_wino4_workspace_floats() floats, 16-byte aligned; its first
- *   1024 words must be ZERO on entry and are zero again when the launch has finished).  A launch of I work items (2 per 32
+ * diinn_conv_wino4_ws: the same with a workspace (diinn_conv_wino4_workspace_floats() floats, 16-byte aligned).  Its first
+ *   4 KiB are control words: the OWNER zeroes them once when it allocates the workspace; words [0, 512)
+ *   (DIINN_WINO4_COUNTER_BYTES: arrival tickets and ready counts) are zero on entry and zero again when a launch has finished,
+ *   and may be re-zeroed before a launch; word 1023 is the STICKY STATUS (below) and must not be re-zeroed by launch paths.  A launch of I work items (2 per 32
  *   Winograd tiles) on N compute units runs floor(I / N) * N of them whole and, where the cost model says it pays
  *   (DIINN_ENC_WINO4_SPLIT: 0 never, 2 always), cuts the input-channel chunks of the I mod N items left into N runs of equal time:
  *   a workgroup that computed part of an item's channels leaves its partial outputs in the workspace and the last one to
  *   arrive adds the parts in a fixed order.  Results are deterministic and depend on (shape, N) only; they differ from
  *   diinn_conv_wino4's by a reassociation in the transformed domain (up to ~2e-5 of max|out|: the size of either one's
  *   distance to the exact convolution).  The last arriver of an item waits -- bounded -- for the other parts' stores, which wait
- *   for nobody; word 1023 of the workspace stays 0 unless such a wait gave up.  Launches that share a
- *   workspace must be ordered (same stream).  diinn_conv_wino4 = diinn_conv_wino4_ws without a workspace (never splits).
+ *   for nobody.  If such a wait ever gives up (a broken device or hand-off; never observed), the failure is LOUD: every output
+ *   of that item is NaN, the status word is set, and every split item of every later launch on this workspace is NaN too until
+ *   the host has cleared the status -- the library's rule (cf. the packed image's validity word): a NaN, never a plausible
+ *   wrong picture.  Launches that share a workspace must be ordered (same stream).  diinn_conv_wino4 = diinn_conv_wino4_ws
+ *   without a workspace (never splits).
+ * diinn_conv_wino4_ws_status: *status = 1 if a wait has given up on this workspace since it was last cleared (else 0);
+ *   clear != 0 zeroes the 4 KiB of control words behind the read.  NOT a launch function: it copies 4 bytes to the host and
+ *   SYNCHRONISES `stream` (call it after a forward where a host check is wanted: tests, bench.py, RDN.handoff_status()).
  * diinn_conv_wino4_plan: what diinn_conv_wino4_ws would do on the current device: info[0] work items, [1] items run whole,
  *   [2] split workgroups, [3] units per split workgroup (chunks of 8 input channels + 4 overhead units per block entered).
- * diinn_rdn_wino4_packed_floats: floats of the 130 such weights of the trunk, in execution order.
- * diinn_rdn_forward_wino4: diinn_rdn_forward_wino with the 3x3 layers on diinn_conv_wino4 where that kernel needs fewer
- *   rounds of workgroups than diinn_conv_wino (one F(4x4) round = 1.44 F(2x2) rounds; from about 35,000 pixels on,
- *   depending on how its 2 * ceil(tiles / 32) work items per image fill the last round; DIINN_ENC_WINO4_MIN = n: from n pixels on); other
- *   maps run exactly as diinn_rdn_forward_wino.  packed_wino_dev may be NULL for a map with diinn_rdn_wino4_applies(B, H, W)
- *   == 1 (the F(2x2) image is not read then); for any other map a NULL is DIINN_ERR_INVALID_ARG. */
+ * diinn_rdn_wino4_packed_floats: floats of the 130 such weights of the trunk, in execution order (diinn_rdn_forward_ex's
+ *   packed_wino4_dev).  diinn_rdn_wino4_applies: 1 if the trunk takes diinn_conv_wino4 for this map on the current device (one
+ *   F(4x4) round = 1.40 F(2x2) rounds; DIINN_ENC_WINO4_MIN = n: from n pixels on), else the F(4x4) image is not read. */
 int    diinn_conv_wino4(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
                         const float* packed_u_dev, const float* bias_dev,
                         const float* res_dev, long long res_batch_stride,
@@ -422,12 +447,11 @@ int    diinn_conv_wino4_ws(void* stream, const float* in_dev, long long in_batch
                            float* out_dev, long long out_batch_stride, int relu, int B, int H, int W,
                            float* ws_dev, size_t ws_floats);
 int    diinn_conv_wino4_plan(int Cin, int B, int H, int W, int with_workspace, int info[4]);
+int    diinn_conv_wino4_ws_status(void* stream, float* ws_dev, int clear, int* status);
 #define DIINN_WINO4_MAX_SPLIT_WGS 256   /* split workgroups of a launch (one per compute unit of an MI355X) */
+#define DIINN_WINO4_COUNTER_BYTES 2048  /* the workspace's arrival counters (what a forward may re-zero); the status word is word 1023 */
 size_t diinn_rdn_wino4_packed_floats(void);
-int    diinn_rdn_wino4_applies(int B, int H, int W);   /* 1 if diinn_rdn_forward_wino4 takes diinn_conv_wino4 for this map (else the F(4x4) image is not read) */
-int    diinn_rdn_forward_wino4(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
-                               const float* packed_wino4_dev, const float* biases_dev, float* workspace_dev, float* out_dev,
-                               int B, int H, int W);
+int    diinn_rdn_wino4_applies(int B, int H, int W);
 
 /* Split-bf16 arithmetic for the trunk's 3x3 convolutions (csrc/diinn_conv_x3.hip; optional, large maps): the direct sum
  * on v_mfma_f32_32x32x16_bf16 with every operand as hi + lo bf16 parts (hi = bf16(v), lo = bf16(v - hi)), a product as
@@ -438,17 +462,26 @@ int    diinn_rdn_forward_wino4(void* stream, const float* sfe1_dev, const float*
  *   value = part(W[32 mt + (lane&31)][16 group + 8 (lane>>5) + j][tap / 3][tap % 3])   (9 * 64 * Cin floats).
  * diinn_rdn_x3_packed_floats: floats of the 130 such weights of the trunk in execution order, followed by the 16 local-fusion
  *   1x1 weights (64 x 576 each) in the same format with one tap: [group 36][M-tile 2][hi, lo][lane 64][8 bf16].
- * diinn_rdn_x3_workspace_floats: floats of diinn_rdn_forward_x3's workspace (diinn_rdn_workspace_floats + one dense
- *   buffer in the split format the dense blocks' 3x3 layers exchange: [B][72 groups of 8 channels][hi, lo][H][W] x 16 B).
- * diinn_rdn_forward_x3: diinn_rdn_forward_wino with the 3x3 layers and the local-fusion 1x1 layers in this arithmetic (inside
- *   the trunk they exchange their activations already split, through the workspace's last buffer) from B*H*W >= 32768 pixels on
- *   (DIINN_ENC_X3_MIN); smaller maps run exactly as diinn_rdn_forward_wino. */
+ * DIINN_RDN_ALGO_X3 (diinn_rdn_forward_ex): inside the trunk these layers exchange their activations already split, through the
+ *   planes' last buffer ([B][72 groups of 8 channels][hi, lo][H][W] x 16 B), from B*H*W >= 32768 pixels on (DIINN_ENC_X3_MIN). */
 int    diinn_conv3x3_x3(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
                         const float* packed_x3_dev, const float* bias_dev,
                         const float* res_dev, long long res_batch_stride,
                         float* out_dev, long long out_batch_stride, int relu, int B, int H, int W);
 size_t diinn_rdn_x3_packed_floats(void);
+
+/* DEPRECATED, kept for this ABI number only: the one-algorithm trunk entry points of ABI <= 8 = diinn_rdn_forward_ex with algo
+ * DIRECT / WINO / WINO4 / X3 and ONE workspace laid out [F(4x4) split area][planes] (diinn_rdn_workspace_floats = the split
+ * area + 2,240 floats per pixel; diinn_rdn_x3_workspace_floats: + 576 per pixel); its first 4 KiB zeroed once by the caller. */
+size_t diinn_rdn_workspace_floats(int B, int H, int W);
 size_t diinn_rdn_x3_workspace_floats(int B, int H, int W);
+int    diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packed_dev, const float* biases_dev,
+                         float* workspace_dev, float* out_dev, int B, int H, int W);
+int    diinn_rdn_forward_wino(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
+                              const float* biases_dev, float* workspace_dev, float* out_dev, int B, int H, int W);
+int    diinn_rdn_forward_wino4(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
+                               const float* packed_wino4_dev, const float* biases_dev, float* workspace_dev, float* out_dev,
+                               int B, int H, int W);
 int    diinn_rdn_forward_x3(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
                             const float* packed_x3_dev, const float* biases_dev, float* workspace_dev, float* out_dev,
                             int B, int H, int W);
@@ -473,10 +506,14 @@ int diinn_p_launch_info(int B, int H, int W, int r0, int r1, int compute, int* a
 
 /* ---- diagnostic overrides (tests, A/B timing; never needed in production) -------------------------------------
  * The launch functions pick kernel variants by launch size; each choice can be forced.  The knobs are named like the
- * environment variables that seed them -- DIINN_F32_KERNEL, DIINN_BF16_KERNEL, DIINN_X3_KERNEL, DIINN_PBF16_KERNEL, DIINN_P_KERNEL, DIINN_P_X3_MIN, DIINN_ENC_X3_MIN, DIINN_ENC_X3_ROWS,
- * DIINN_P_WINO_MIN, DIINN_ENC_S1_MIN_BLOCKS, DIINN_ENC_NO_STREAM1X1, DIINN_ENC_LAT_MAX_TILES,
- * DIINN_ENC_WINO_MIN, DIINN_ENC_WINO_HALF_MAX, DIINN_ENC_WINO_PERSIST (csrc/diinn_knobs.h lists values and
- * defaults).  The environment is read ONCE, at the first launch or the first call of either function; afterwards
+ * environment variables that seed them (csrc/diinn_knobs.h lists values and defaults):
+ *   thresholds a deployment may tune -- DIINN_P_X3_MIN, DIINN_P_WINO_MIN, DIINN_ENC_WINO_MIN, DIINN_ENC_WINO4_MIN,
+ *     DIINN_ENC_X3_MIN, DIINN_ENC_WINO4_SPLIT;
+ *   TEST / A-B ONLY (force a kernel variant that the launch cost models would not take, or inject a fault; results stay
+ *     within the documented equivalences) -- DIINN_F32_KERNEL, DIINN_BF16_KERNEL, DIINN_X3_KERNEL, DIINN_PBF16_KERNEL,
+ *     DIINN_P_KERNEL, DIINN_ENC_X3_ROWS, DIINN_ENC_S1_MIN_BLOCKS, DIINN_ENC_NO_STREAM1X1, DIINN_ENC_LAT_MAX_TILES,
+ *     DIINN_ENC_WINO_HALF_MAX, DIINN_ENC_WINO_PERSIST, DIINN_DEBUG_NCU (the compute-unit count cost models, split plans and persistent grids assume),
+ *     DIINN_ENC_WINO4_FAULT (1: the split hand-off's give-up path on demand: NaN outputs + sticky status).  The environment is read ONCE, at the first launch or the first call of either function; afterwards
  * only diinn_debug_set changes a knob (process-wide, atomic stores: safe against concurrent launches, which see
  * either the old or the new value).  Unknown name -> DIINN_ERR_INVALID_ARG.  This is the library's only mutable
  * global state. */

@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.diinn_abi_version() == 8
+    assert lib.diinn_abi_version() == 9
     assert lib.diinn_status_string(0) == b"ok"
     assert b"invalid" in lib.diinn_status_string(1)
 
@@ -333,6 +333,25 @@ def test_conv_wino4_entry_point_validates_its_arguments(lib):
     def conv_ws(ws=d, floats=wsf, cin=64):
         return lib.diinn_conv_wino4_ws(None, d, cin * 64 * 64, cin, d, d, None, 0, d, 64 * 64 * 64, 1, 1, 64, 64, ws, floats)
     assert conv_ws(floats=wsf - 1) == 1 and conv_ws(ws=C.c_void_p(4100)) == 1 and conv_ws(cin=12) == 2
+    # the ONE trunk entry point (ABI v9): algo caps the kernel family; the images that family reads must be given, others
+    # may be NULL; planes / split area must be 16-byte aligned; the split area may be NULL (nothing is split then)
+    A = {"auto": 0, "direct": 1, "wino": 2, "wino4": 3, "x3": 4}
+
+    def ex(algo, packed=d, wino=d, wino4=d, x3=d, planes=d, area=d, sfe1=d, biases=d, out=d, b=1, h=64, w=64):
+        return lib.diinn_rdn_forward_ex(None, A[algo], sfe1, packed, wino, wino4, x3, biases, planes, area, out, b, h, w)
+    for algo in A:
+        assert ex(algo, sfe1=None) == 1 and ex(algo, packed=None) == 1 and ex(algo, biases=None) == 1 and ex(algo, out=None) == 1
+        assert ex(algo, planes=None) == 1 and ex(algo, planes=C.c_void_p(4100)) == 1 and ex(algo, area=C.c_void_p(4100)) == 1
+        assert ex(algo, b=0) == 1 and ex(algo, h=0) == 1
+    assert ex("wino", wino=None) == 1 and ex("wino4", wino4=None) == 1 and ex("x3", x3=None) == 1 and ex("x3", wino=None) == 1
+    assert ex("wino4", wino=None, h=128, w=128) == 1             # 128 x 128 runs F(2x2): its image is needed (as the v8 wrapper)
+    assert lib.diinn_rdn_forward_ex(None, 5, d, d, d, d, d, d, d, d, d, 1, 64, 64) == 1 and \
+        lib.diinn_rdn_forward_ex(None, -1, d, d, d, d, d, d, d, d, d, 1, 64, 64) == 1
+    assert lib.diinn_rdn_planes_floats(A["wino4"], 1, 8, 8) == 64 * 2240 and lib.diinn_rdn_planes_floats(A["x3"], 2, 8, 8) == 128 * 2816
+    assert lib.diinn_rdn_planes_floats(7, 1, 8, 8) == 0 and lib.diinn_rdn_planes_floats(0, 0, 8, 8) == 0
+    assert lib.diinn_rdn_x3_workspace_floats(1, 8, 8) == wsf + 64 * 2816   # the deprecated wrappers' single workspace
+    st = C.c_int(0)
+    assert lib.diinn_conv_wino4_ws_status(None, None, 0, C.byref(st)) == 1 and lib.diinn_conv_wino4_ws_status(None, d, 0, None) == 1
     info = (C.c_int * 4)()
     assert lib.diinn_decode_kernel_info(1, 96, 96, 0, 96, 0, 96, 0, info) == 0 and info[0] in (1, 3)
     assert lib.diinn_decode_kernel_info(1, 96, 96, 0, 97, 0, 96, 0, info) == 1 and lib.diinn_decode_kernel_info(1, 96, 96, 0, 96, 0, 96, 9, info) == 2

@@ -272,13 +272,95 @@ def test_conv_wino4_split_last_round(knobs):
         assert float((outs[0] - whole).abs().max()) <= 3e-5 * scale, (cin, h, w)   # two F(4x4) evaluations, each ~1e-5 from the truth
         if info[2]:
             assert not torch.equal(outs[0], whole), (cin, h, w)   # the split form did run
-        assert int(ws[:1024].view(torch.int32).abs().sum()) == 0, (cin, h, w)
+        assert int(ws[:1024].view(torch.int32).abs().sum()) == 0, (cin, h, w)   # counters back at zero, status word never set
     assert nsplit >= 7
     # argument checks of the workspace form: too small a workspace, a misaligned one
     assert lib.diinn_conv_wino4_ws(stream, ptr(x), cin * h * w, cin, ptr(packed), ptr(bias), None, 0, ptr(off), 64 * h * w, 0, b, h, w,
                                    ptr(ws), wsf - 1) == N.ERR_INVALID_ARG
     assert lib.diinn_conv_wino4_ws(stream, ptr(x), cin * h * w, cin, ptr(packed), ptr(bias), None, 0, ptr(off), 64 * h * w, 0, b, h, w,
                                    C.c_void_p(ws.data_ptr() + 4), wsf) == N.ERR_INVALID_ARG
+
+
+@pytest.mark.gpu
+def test_conv_wino4_split_handoff_gives_up_loudly(knobs):
+    """VERDICT r05 item 3 / ADVICE r05: a last arriver that runs out of patience must not sum whatever is in the slabs.  With
+    DIINN_ENC_WINO4_FAULT = 1 the split parts store their slabs but never count them ready (and the wait is short): every output
+    of every split item is NaN -- never a plausible number --, items that ran whole are untouched, the workspace's STICKY status
+    word is set, a later launch on the same workspace without the fault is poisoned as well (a forward's counter reset does
+    not clear the word), and diinn_conv_wino4_ws_status reports and clears it; after that the workspace computes again,
+    bit-identical to a fresh one."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    gen = torch.Generator(device=dev).manual_seed(23)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
+    wsf = lib.diinn_conv_wino4_workspace_floats()
+    ws, fresh = torch.zeros(wsf, device=dev), torch.zeros(wsf, device=dev)
+    info = (C.c_int * 4)()
+    st = C.c_int(-1)
+    knobs("DIINN_ENC_WINO4_SPLIT", 2)
+    for (b, cin, h, w) in [(1, 256, 192, 192), (1, 512, 320, 324)]:      # less than a round; a whole round + a remainder
+        x = torch.randn((b, cin, h, w), device=dev, generator=gen)
+        wt = torch.randn((64, cin, 3, 3), device=dev, generator=gen) / (cin * 9) ** 0.5
+        bias = torch.randn(64, device=dev, generator=gen)
+        packed = M.pack_conv_wino4(wt).to(dev)
+
+        def run(workspace):
+            out = torch.zeros((b, 64, h, w), device=dev)
+            assert lib.diinn_conv_wino4_ws(stream, ptr(x), cin * h * w, cin, ptr(packed), ptr(bias), None, 0, ptr(out), 64 * h * w,
+                                           1, b, h, w, ptr(workspace), wsf) == 0
+            return out
+        good = run(fresh)
+        assert lib.diinn_conv_wino4_plan(cin, b, h, w, 1, info) == 0 and info[2] > 0
+        whole_items = info[1]
+        assert lib.diinn_conv_wino4_ws_status(stream, ptr(ws), 0, C.byref(st)) == 0 and st.value == 0
+        knobs("DIINN_ENC_WINO4_FAULT", 1)
+        bad = run(ws)
+        knobs("DIINN_ENC_WINO4_FAULT", 0)
+        torch.cuda.synchronize()
+        nan = torch.isnan(bad)
+        assert bool(nan.any())
+        assert bool(torch.equal(bad[~nan], good[~nan]))           # what is not NaN is RIGHT (the whole items), never a stale sum
+        # the NaN region is exactly the split items: work items are (block of 128 x 4 pixels in tile order, output half)
+        frac = float(nan.float().mean())
+        assert abs(frac - (1.0 - whole_items / info[0])) < 0.02, (frac, whole_items, info[0])
+        assert int(ws[:512].view(torch.int32).abs().sum()) == 0   # counters were reset even so
+        # sticky: the next launch (no fault any more; counters re-zeroed as a forward does) is poisoned too
+        ws[:512].zero_()
+        again = run(ws)
+        assert bool(torch.isnan(again).any()) and bool(torch.equal(torch.isnan(again), nan))
+        assert lib.diinn_conv_wino4_ws_status(stream, ptr(ws), 1, C.byref(st)) == 0 and st.value == 1
+        assert lib.diinn_conv_wino4_ws_status(stream, ptr(ws), 0, C.byref(st)) == 0 and st.value == 0
+        assert bool(torch.equal(run(ws), good))                   # cleared: computes again, bit for bit
+    assert lib.diinn_conv_wino4_ws_status(stream, None, 0, C.byref(st)) == N.ERR_INVALID_ARG
+    assert lib.diinn_conv_wino4_ws_status(stream, ptr(ws), 0, None) == N.ERR_INVALID_ARG
+
+
+@pytest.mark.gpu
+def test_rdn_handoff_status_is_sticky_across_forwards(knobs):
+    """The module keeps ONE split area per (device, stream) across forwards: a give-up in one forward (forced) turns that
+    forward's features into NaN, stays visible to RDN.handoff_status() after a SECOND forward (whose counter reset must not
+    clear it, and whose features are NaN as well), and clearing re-arms the area."""
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    net = M.make_rdn().to(dev).eval()
+    x = torch.rand(1, 3, 200, 180, device=dev)
+    M.RDN.handoff_status(clear=True)
+    with torch.no_grad():
+        good = net(x)
+        assert bool(torch.isfinite(good).all()) and M.RDN.handoff_status(clear=False) == 0
+        knobs("DIINN_ENC_WINO4_FAULT", 1)
+        bad = net(x)
+        knobs("DIINN_ENC_WINO4_FAULT", 0)
+        assert bool(torch.isnan(bad).any())
+        still = net(x)                                            # no fault now, same area: poisoned until somebody looked
+        assert bool(torch.isnan(still).any())
+        assert M.RDN.handoff_status(clear=True) == 1 and M.RDN.handoff_status(clear=False) == 0
+        assert bool(torch.equal(net(x), good))
 
 
 @pytest.mark.gpu
@@ -329,14 +411,16 @@ def test_conv_wino4_split_handoff_under_load_and_changing_inputs(knobs):
         assert int(ws[:1024].view(torch.int32).abs().sum()) == 0, (cin, h, w)
 
 
-def test_wino4_split_plan():
-    """diinn_conv_wino4_plan (host only; no device: 256 compute units assumed): whole rounds stay whole, the remainder is cut into
+def test_wino4_split_plan(knobs):
+    """diinn_conv_wino4_plan (host only; the compute-unit count fixed at an MI355X's 256 through DIINN_DEBUG_NCU, so the numbers
+    below hold on any box: a partitioned part, a 304-CU one, no device at all): whole rounds stay whole, the remainder is cut into
     equal runs over pairs of workgroups (the two output halves of a block side by side), never for a full last round, never
     without a workspace; the cost model leaves thin layers of a half-filled round whole."""
     import ctypes as C
     import diinn_amd._native as N
     lib = N.load()
     info = (C.c_int * 4)()
+    knobs("DIINN_DEBUG_NCU", 256)
 
     def plan(cin, b, h, w, ws=1):
         assert lib.diinn_conv_wino4_plan(cin, b, h, w, ws, info) == 0
@@ -350,6 +434,14 @@ def test_wino4_split_plan():
     assert (items, whole) == (576, 512) and wgs == 256 and u == 17
     assert plan(512, 1, 320, 320)[:2] == [400, 256]
     assert lib.diinn_conv_wino4_plan(12, 1, 8, 8, 1, info) == N.ERR_INVALID_ARG
+    # a part with more compute units than the slab area has workgroup slots (304: an MI300X): plan, rounds and dispatch rule
+    # all describe the split of the CLIPPED count -- 576 items = 2 rounds of 256 + 64, not 1 of 304 + 272
+    knobs("DIINN_DEBUG_NCU", 304)
+    items, whole, wgs, u = plan(512, 1, 384, 384)
+    assert (items, whole) == (576, 512) and 0 < wgs <= 256
+    knobs("DIINN_DEBUG_NCU", 64)                                  # a partitioned part: rounds of 64
+    items, whole, wgs, u = plan(512, 1, 192, 200)
+    assert items == 150 and whole == 128 and 0 < wgs <= 64
 
 
 def test_wino4_dispatch_rule(knobs):
@@ -359,6 +451,7 @@ def test_wino4_dispatch_rule(knobs):
     (profiles/r05_enc_trunk_times.txt): right on all of the last table after the refit (176 x 176 moved to F(4x4))."""
     import diinn_amd._native as N
     lib = N.load()
+    knobs("DIINN_DEBUG_NCU", 256)                                 # the table below is an MI355X's
     want = {(1, 256, 256): 1, (1, 512, 512): 1, (1, 224, 224): 1, (1, 192, 192): 1, (1, 384, 384): 1, (1, 240, 256): 1,
             (1, 128, 128): 0, (1, 144, 144): 1, (1, 160, 160): 1, (1, 176, 176): 1, (1, 112, 112): 0, (1, 96, 100): 0, (1, 48, 48): 0, (2, 128, 130): 1,
             (1, 270, 480): 1, (1, 320, 180): 1,      # work items are runs of 32 consecutive tiles: the map's width leaves none part empty
