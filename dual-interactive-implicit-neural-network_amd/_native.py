@@ -82,6 +82,7 @@ SIGNATURES = {
     "diinn_decode_kernel_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
     "diinn_debug_set": (C.c_int, [C.c_char_p, C.c_longlong]),
     "diinn_debug_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_longlong)]),
+    "diinn_debug_clock_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint]),
     "diinn_metasr_packed_floats": (C.c_size_t, []),
     "diinn_metasr_pack_weights": (C.c_int, [_f, _f, _f, _f, _f]),
     "diinn_metasr_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

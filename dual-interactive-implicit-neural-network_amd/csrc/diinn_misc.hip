@@ -24,6 +24,27 @@ __global__ void axis_tables_kernel(Axis a, int n_out, int32_t* idx, float* rel) 
     if (rel) rel[j] = r;
 }
 
+// ---------------------------------------------------------------------------------
+// clock probe (diagnosis; tools/clock_trace.py): ONE wave that runs beside whatever else the chip is doing and samples the
+// SHADER clock the part holds: per sample, the s_memtime ticks (shader cycles) that passed while s_memrealtime (the constant
+// 100 MHz counter) advanced by `ticks` -- MI355X_MICROARCH.md, DVFS give-back item 6: clock = d(memtime) / d(memrealtime) x
+// 100 MHz.  The wave sleeps between looks; it writes only its own sample buffer.
+// ---------------------------------------------------------------------------------
+__global__ void clock_probe_kernel(unsigned long long* out, int n, unsigned ticks) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < n; ++i) {
+        unsigned long long r0, r1, c0, c1;
+        asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0), "=s"(c0)::"memory");
+        do {
+            __builtin_amdgcn_s_sleep(64);
+            asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1), "=s"(c1)::"memory");
+        } while (r1 - r0 < ticks);
+        out[3 * i] = c1 - c0;
+        out[3 * i + 1] = r1 - r0;
+        out[3 * i + 2] = r0;
+    }
+}
+
 thread_local int g_last_hip_error = 0;
 
 // compute units of the current device, asked once per device (cost models and persistent grids: an MI355X has 256, a
@@ -49,6 +70,12 @@ extern "C" int diinn_debug_set_stamp_buffer(void* dev_ptr) { g_stamps = (unsigne
 extern "C" {
 
 int diinn_last_hip_error(void) { return g_last_hip_error; }
+
+int diinn_debug_clock_probe(void* stream, unsigned long long* samples_dev, int n, unsigned realtime_ticks) {
+    if (!samples_dev || n <= 0 || realtime_ticks == 0) return DIINN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, samples_dev, n, realtime_ticks);
+    return hip_status(hipGetLastError());
+}
 
 int diinn_make_axis_tables_device(void* stream, int n_in, int n_out, int small_output,
                                   int32_t* idx_dev, float* rel_dev) {

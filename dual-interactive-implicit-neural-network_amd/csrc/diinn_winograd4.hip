@@ -109,8 +109,18 @@ struct ConvWino4Params {
             p.stamps[((role) * 80 + (it)) * 4 + (i)] = t_;                                           \
         }                                                                                            \
     } while (0)
+// the same instant on the constant 100 MHz counter (slot 79): shader clock over a phase = d(s_memtime) / d(s_memrealtime) x 100 MHz
+#define W4_STAMP_RT(i)                                                                               \
+    do {                                                                                             \
+        if (blockIdx.x == 0 && lane == 0) {                                                          \
+            unsigned long long t_;                                                                   \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+            p.stamps[(0 * 80 + 79) * 4 + (i)] = t_;                                                  \
+        }                                                                                            \
+    } while (0)
 #else
 #define W4_STAMP(role, it, i) do {} while (0)
+#define W4_STAMP_RT(i) do {} while (0)
 #endif
 constexpr int W4_SLAB_FLOATS = 4 * 1024 * 4;        // a split workgroup's partial outputs: [output row 4][thread 1024] f32x4 = 64 KiB
 constexpr int W4_FLAG = 36 * 1024;                   // LDS word behind the exchange buffer: the ticket drawn by thread 0
@@ -317,6 +327,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         for (int q = 0; q < 3; ++q) Bf[0][q] = f32x4{bsrc[q * 256], bsrc[q * 256 + 64], bsrc[q * 256 + 128], bsrc[q * 256 + 192]};
 
         if (mw == 0) W4_STAMP(0, 76, 1);                          // prologue done
+        if (mw == 0) W4_STAMP_RT(1);
         int slot1 = 1;                                           // ring slot of chunk c + 1
         // One iteration = one chunk: per position its four MFMAs, behind them the request of the position's weights of
         // chunk c + 2 into the registers just used and the read of its B operands of chunk c + 1; one barrier.  The
@@ -358,6 +369,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
         __builtin_amdgcn_s_barrier();
 
         if (mw == 0) W4_STAMP(0, 76, 2);                          // loop done
+        if (mw == 0) W4_STAMP_RT(2);
         // the 36 positions meet through LDS: [pos][accumulator register 16][lane]
 #pragma unroll
         for (int q = 0; q < 3; ++q)

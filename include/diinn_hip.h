@@ -519,6 +519,10 @@ int diinn_p_launch_info(int B, int H, int W, int r0, int r1, int compute, int* a
  * global state. */
 int diinn_debug_set(const char* name, long long value);
 int diinn_debug_get(const char* name, long long* value);
+/* Diagnosis only (tools/clock_trace.py): enqueue ONE wave that takes n samples of the shader clock beside whatever else runs on
+ * the device -- samples_dev[3 i] = s_memtime ticks (shader cycles) that passed while s_memrealtime (100 MHz) advanced by
+ * samples_dev[3 i + 1] >= realtime_ticks, [3 i + 2] = the sample's start on the realtime counter.  clock = [3i] / [3i+1] x 100 MHz. */
+int diinn_debug_clock_probe(void* stream, unsigned long long* samples_dev, int n, unsigned realtime_ticks);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@
 #include "wino4_r04_ablate.hip"
 #else
 #include "../../dual-interactive-implicit-neural-network_amd/csrc/diinn_winograd4.hip"
-int device_cus() { int n = 256; hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, 0); return n; }
+int device_cus() { int n = 256; hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, 0); if (getenv("W4_NCU")) n = atoi(getenv("W4_NCU")); return n; }
 #endif
 thread_local int g_last_hip_error = 0;
 #include <cstdio>
@@ -153,6 +153,9 @@ int main(int argc, char** argv) {
                "slab store + drain + count %lld | last arriver: wait %lld, sum %lld, final stores (from sum) %lld\n",
                f[1] - f[0], f[2] - f[1], (long long)(g7[0] - f[2]), (long long)(g7[1] - g7[0]), (long long)(g7[2] - g7[1]),
                (long long)(g8[0] - g7[1]), (long long)(g8[1] - g8[0]), (long long)(f[3] - g8[1]));
+        const unsigned long long* rt = &st[(0 * 80 + 79) * 4];
+        printf("  shader clock over workgroup 0's loop (last launch): %llu cycles / %llu ticks of the 100 MHz counter = %.3f GHz\n",
+               f[2] - f[1], rt[2] - rt[1], (double)(f[2] - f[1]) / (double)(rt[2] - rt[1]) * 0.1);
     }
 #endif
     return 0;
