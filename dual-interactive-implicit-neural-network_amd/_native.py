@@ -24,6 +24,7 @@ SIN_HW_REDUCED = 2
 SIN_DEFAULT = SIN_HW_REDUCED
 ABI_VERSION = 9
 PACKED_MAGIC = 0x44493038
+PACKED_MAGIC_WPU = 0x44495750          # a training image: permutation sections + section 13 (WPU) filled on the device
 P_ALGO_DIRECT, P_ALGO_WINOGRAD, P_ALGO_DIRECT_BF16, P_ALGO_DIRECT_BF16X3 = 0, 1, 2, 3
 RDN_ALGO_AUTO, RDN_ALGO_DIRECT, RDN_ALGO_WINO, RDN_ALGO_WINO4, RDN_ALGO_X3 = 0, 1, 2, 3, 4
 COMPUTE_F32 = 0
@@ -55,6 +56,8 @@ SIGNATURES = {
     "diinn_lr_rows_for_band": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip]),
     "diinn_precompute_P": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "diinn_precompute_P_wpu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_precompute_P_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_decode_band": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -135,6 +138,9 @@ SIGNATURES = {
                                      C.c_longlong, C.c_int]),
     "diinn_backward_cell_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "diinn_backward_cell_sum_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "diinn_unfold_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_training_plane_floats": (C.c_longlong, [C.c_longlong, C.c_int]),
     "diinn_decode_train_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -314,7 +314,7 @@ int launch_P_x3(void* stream, const float* feat_dev, const float* packed_dev, fl
 // diinn_precompute_wino.hip: the fp32 hoisted conv of all 1024 channels as Winograd F(2x2,3x3) (needs section WPU)
 __attribute__((visibility("hidden")))
 int launch_P_wino(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,
-                  int B, int H, int W, int r0, int r1, RowWin fw, RowWin pw);
+                  int B, int H, int W, int r0, int r1, RowWin fw, RowWin pw, bool wpu_only_ok = false);
 // diinn_bf16.hip: the bf16 decode of HR rows [p.y0, p.y1) (grid of the one-tile kernel: gx, gy, gz)
 __attribute__((visibility("hidden")))
 int launch_decode_bf16(void* stream, const DecodeParams& p, int gx, int gy, int gz, int sin_mode);

@@ -36,6 +36,7 @@ const KnobDef KNOBS[] = {
     {"DIINN_ENC_WINO4_SPLIT", &DiinnKnobs::enc_wino4_split, 1, false},
     {"DIINN_DEBUG_NCU", &DiinnKnobs::debug_ncu, 0, false},
     {"DIINN_ENC_WINO4_FAULT", &DiinnKnobs::enc_wino4_fault, 0, false},
+    {"DIINN_TRAIN_SPLIT_HEAD", &DiinnKnobs::train_split_head, 0, false},
 };
 }  // namespace
 

@@ -557,6 +557,17 @@ int diinn_precompute_P(void* stream, const float* feat_dev, const float* packed_
     return launch_P(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, 16);
 }
 
+int diinn_precompute_P_wpu(void* stream, const float* feat_dev, const float* packed_dev,
+                           float* P_dev, int B, int H, int W, int r0, int r1) {
+    // the fp32 Winograd form on an image whose validity word is DIINN_PACKED_MAGIC or DIINN_PACKED_MAGIC_WPU (a training image
+    // whose WPU section the caller has filled on the device); any other word: NaN into every P value
+    if (!feat_dev || !packed_dev || !P_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (r0 < 0 || r1 > H || r0 >= r1) return DIINN_ERR_INVALID_ARG;
+    return launch_P_wino(stream, feat_dev, packed_dev, P_dev, B, H, W, r0, r1, RowWin{0, H}, RowWin{0, H}, true);
+}
+
 int diinn_precompute_P_ex(void* stream, const float* feat_dev, const float* packed_dev,
                           float* P_dev, int B, int H, int W, int r0, int r1, int compute) {
     if (!compute_ok(compute))

@@ -33,6 +33,7 @@ struct PWinoParams {
     int msplit;          // the 32 M-tiles are divided over `msplit` workgroups per block (small maps: fills the chip)
     int stream_stores;
     int warm_l2;         // touch the Winograd weight section first (maps whose P image has flushed it out of the L2s)
+    int wpu_only_ok;     // the validity word may also be DIINN_PACKED_MAGIC_WPU (a training image: permutation sections + WPU only)
 };
 
 constexpr int PWN_TX = 8, PWN_TY = 4;
@@ -119,7 +120,8 @@ __device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, flo
         pdst[k] = in ? p.P + (((size_t)b * p.Prows + (oy - p.Prow0)) * p.W + ox) * PCH + 4 * chunk : nullptr;
     }
     const float* __restrict__ bk = p.Wt + OFF_BK + 4 * chunk;
-    const unsigned nanm = derived_nan_mask(p.Wt);              // section WPU missing -> NaN into every P value
+    unsigned nanm = derived_nan_mask(p.Wt);                    // section WPU missing -> NaN into every P value
+    if (p.wpu_only_ok && __builtin_bit_cast(unsigned, p.Wt[OFF_BL + 3]) == DIINN_PACKED_MAGIC_WPU) nanm = 0u;
 
     // ---- main loop
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -294,8 +296,9 @@ __global__ __launch_bounds__(256, 1) void precompute_P_wino_kernel(const PWinoPa
 
 // Winograd form of launch_P for the fp32 hoisted convolution of all 1024 channels (diinn_precompute.hip decides when)
 int launch_P_wino(void* stream, const float* feat_dev, const float* packed_dev, float* P_dev,
-                  int B, int H, int W, int r0, int r1, RowWin fw, RowWin pw) {
+                  int B, int H, int W, int r0, int r1, RowWin fw, RowWin pw, bool wpu_only_ok) {
     PWinoParams p;
+    p.wpu_only_ok = wpu_only_ok ? 1 : 0;
     p.feat = feat_dev; p.Wt = packed_dev; p.P = P_dev;
     p.B = B; p.H = H; p.W = W; p.r0 = r0; p.r1 = r1;
     p.Frow0 = fw.row0; p.Frows = fw.rows; p.Prow0 = pw.row0; p.Prows = pw.rows;

@@ -65,6 +65,12 @@ __global__ __launch_bounds__(256) void bwd_head_kernel(const BwdParams p) {
     }
 }
 
+// HEAD (round 6; layer 3 only): the wave computes its own B operand -- g_q,3 = L^T g_out and the gates of layer 3 from the saved
+// k_3, s_3 -- in place of bwd_head_kernel, which wrote G_3 and q_3 (1.8 GB at B = 16, 192 x 192) only for this kernel to read G_3
+// back (1.2 GB): the loads that fetched G_3's groups fetch (k_3, s_3) instead, a group is turned into (g_a,3 ; g_s,3) right before
+// its first MFMAs and stored from there (G_3 and q_3 are still needed: the weight-gradient GEMM, the cell sums, dL).  Same
+// formulas in the same order as bwd_head_kernel: bit-identical planes.
+template <bool HEAD>
 __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -89,13 +95,48 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
     // hide behind its own arithmetic instead of in front of it.
     constexpr int BLD = 8;
     float ga[128], gs[128];
+    // HEAD: the saved planes of THIS layer (k in ga, s in gs until head_group turns them into the gate gradients)
+    const __amdgpu_buffer_rsrc_t act_li = tile_rsrc(p.acts + (size_t)li * agroup, tile, ACT_ROWS);
+    const __amdgpu_buffer_rsrc_t outG_li = tile_rsrc(p.G + (size_t)li * agroup, tile, ACT_ROWS);
+    const __amdgpu_buffer_rsrc_t outQ_li = tile_rsrc(p.Q + (size_t)li * qgroup, tile, HID);
     auto load_group = [&](int kg) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int kk = 4 * kg + e;
             const unsigned so = (unsigned)(32 * (kk >> 4) + (kk & 3) + 8 * ((kk & 15) >> 2)) * PLANE_ROW_BYTES;
-            ga[kk] = ld_act(inG, voff, so);
-            gs[kk] = ld_act(inG, voff, so + HID * PLANE_ROW_BYTES);
+            ga[kk] = ld_act(HEAD ? act_li : inG, voff, so);
+            gs[kk] = ld_act(HEAD ? act_li : inG, voff, so + HID * PLANE_ROW_BYTES);
+        }
+    };
+    float go0 = 0.0f, go1 = 0.0f, go2 = 0.0f;                    // HEAD: d loss / d out of this lane's pixel
+    if constexpr (HEAD) {
+        const long long pix = tile * PLANE_TILE + j;
+        if (valid) {
+            go0 = p.gout[pix];
+            go1 = p.gout[(size_t)p.npix + pix];
+            go2 = p.gout[2 * (size_t)p.npix + pix];
+        }
+    }
+    // HEAD: (k, s) of group kg -> (g_a, g_s), stored with q (bwd_head_kernel's arithmetic, term for term)
+    auto head_group = [&](int kg) {
+        const float* __restrict__ L = p.Wt + OFF_L;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int kk = 4 * kg + e;
+            const int c0 = 32 * (kk >> 4) + (kk & 3) + 8 * ((kk & 15) >> 2);      // channel of lane-half 0; half 1: + 4
+            const unsigned so = (unsigned)c0 * PLANE_ROW_BYTES;
+            const float l0 = h ? L[c0 + 4] : L[c0], l1 = h ? L[HID + c0 + 4] : L[HID + c0], l2 = h ? L[2 * HID + c0 + 4] : L[2 * HID + c0];
+            float g = l0 * go0;
+            g = __builtin_fmaf(l1, go1, g);
+            g = __builtin_fmaf(l2, go2, g);
+            const float kv = ga[kk], sv = gs[kk];
+            float sn, cs;
+            dsincos(sv, sn, cs);
+            ga[kk] = kv > 0.0f ? g * sn : 0.0f;
+            gs[kk] = g * kv * cs;
+            st_act(outG_li, voff, so, ga[kk]);
+            st_act(outG_li, voff, so + HID * PLANE_ROW_BYTES, gs[kk]);
+            st_act(outQ_li, voff, so, kv * sn);
         }
     };
 #pragma unroll
@@ -135,6 +176,9 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
             const int s = m * WL_KG + kg;
             const f32x4 wk = rk[s % PF];
             const f32x4 wq = rq[s % PF];
+            if constexpr (HEAD) {
+                if (m == 0) head_group(kg);                       // (its loads went out BLD groups = 64 MFMAs ago)
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 ak = MFMA32(wk[e], ga[4 * kg + e], ak);
@@ -178,9 +222,18 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
 // NCHW [B][1024][H][W], channel = 256 i + ch: the layout the 3x3 convolution's weight/input
 // gradients are taken in.  HBM-bound (reads the g_a rows of G once).
 // ---------------------------------------------------------------------------------
+// Round 6: one thread per (cell, plane) with the cells of an image FLATTENED over the threads (a 48-wide map left a quarter of
+// a 64-lane row idle), and a cell's row segment fetched as ONE 16- or 8-byte load where it is 4 or 2 pixels wide and aligned
+// (the integer scales x4 / x2 of the reference's training batches; the rows of a cell are independent loads in flight at
+// once) -- 16 dependent 4-byte loads per thread before: 1.00 -> ~0.6 ms at B = 16, 48 x 48 -> 192 x 192 (2.4 GB read once).
+// The summation order is unchanged (left to right inside a row, rows top to bottom): bit-identical results.
+// dP_tiled (optional): the same values as a tiled plane group [ceil(B H W / 32)][1024][32] over the CELL axis -- the A operand
+// of the hoisted conv's weight-gradient GEMM (diinn_plane_gemm_nt), written here instead of by a transposing copy.
+// ---------------------------------------------------------------------------------
 struct CellSumParams {
     const float* G;          // tiled [4][ntiles][512][32]; rows 0..255 (g_a) are summed
     float* dP;               // [B][1024][H][W]
+    float* dP_tiled;         // optional: [ceil(B*H*W / 32)][1024][32]
     const int* seg_h;        // [H+1] first HR row of every LR row (seg_h[H] = Hu)
     const int* seg_w;        // [W+1]
     int B, H, W, Hu, Wu;
@@ -188,26 +241,86 @@ struct CellSumParams {
 };
 
 __global__ __launch_bounds__(256) void cell_sum_kernel(const CellSumParams p) {
-    const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int hb = (p.H + 3) / 4;
-    const int b = blockIdx.y / hb;
-    const int cy = (blockIdx.y - b * hb) * 4 + (threadIdx.x >> 6);
-    if (cx >= p.W || cy >= p.H) return;
+    const int cell = blockIdx.x * 256 + threadIdx.x;                 // cy * W + cx
+    if (cell >= p.H * p.W) return;
+    const int b = blockIdx.y;
+    const int cy = cell / p.W, cx = cell - cy * p.W;
     const int plane = blockIdx.z;                                    // 256 i + ch
     const float* __restrict__ src = p.G + ((size_t)(plane >> 8) * p.ntiles * ACT_ROWS + (plane & 255)) * PLANE_TILE;
     const int y0 = p.seg_h[cy], y1 = p.seg_h[cy + 1];
     const int x0 = p.seg_w[cx], x1 = p.seg_w[cx + 1];
+    const int wd = x1 - x0;
+    auto at = [&](long long pix) { return src + (size_t)(pix >> 5) * (ACT_ROWS * PLANE_TILE) + (size_t)(pix & 31); };
     float acc = 0.0f;
-    for (int y = y0; y < y1; ++y) {
-        const long long rowpix = ((long long)b * p.Hu + y) * p.Wu;
-        float r = 0.0f;
-        for (int x = x0; x < x1; ++x) {
-            const long long pix = rowpix + x;
-            r += src[(size_t)(pix >> 5) * (ACT_ROWS * PLANE_TILE) + (size_t)(pix & 31)];
+    // (Wu % 4 == 0 and x0 % 4 == 0: the segment's first pixel is a multiple of 4 in the flattened index, so the 4 pixels lie in
+    // one 32-pixel tile row, 16-byte aligned; likewise for 2)
+    if (wd == 4 && ((p.Wu | x0) & 3) == 0) {
+        for (int y = y0; y < y1; y += 4) {                       // up to four rows in flight
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (y + k < y1) v[k] = *(const f32x4*)at(((long long)b * p.Hu + y + k) * p.Wu + x0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (y + k < y1) acc += ((v[k][0] + v[k][1]) + v[k][2]) + v[k][3];
         }
-        acc += r;
+    } else if (wd == 2 && ((p.Wu | x0) & 1) == 0) {
+        for (int y = y0; y < y1; y += 4) {
+            f32x2 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (y + k < y1) v[k] = *(const f32x2*)at(((long long)b * p.Hu + y + k) * p.Wu + x0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (y + k < y1) acc += v[k][0] + v[k][1];
+        }
+    } else {
+        for (int y = y0; y < y1; ++y) {
+            const long long rowpix = ((long long)b * p.Hu + y) * p.Wu;
+            float r = 0.0f;
+            for (int x = x0; x < x1; ++x) r += *at(rowpix + x);
+            acc += r;
+        }
     }
     p.dP[(((size_t)b * PCH + plane) * p.H + cy) * p.W + cx] = acc;
+    if (p.dP_tiled) {
+        const long long n = (long long)b * p.H * p.W + cell;
+        p.dP_tiled[((size_t)(n >> 5) * PCH + plane) * PLANE_TILE + (size_t)(n & 31)] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// unfold_tiled_kernel (training backward, weight gradient of the hoisted 3x3 conv): the reference's F.unfold(feat, 3, padding=1)
+// (diinn.py:168; row = c * 9 + ky * 3 + kx) written directly as a tiled plane group over the CELL axis,
+// [ceil(B H W / 32)][rows][32] with rows >= 576 (the rows past 576 zero: diinn_plane_gemm_nt wants M % 128 == 0) -- the B
+// operand of dWx^T = unfold . dP^T.  A gather of 9.4 MB into 94 MB: one thread per element, 128-byte store runs.
+// ---------------------------------------------------------------------------------
+struct UnfoldTiledParams {
+    const float* feat;       // [B][64][H][W]
+    float* out;              // [ceil(B*H*W / 32)][rows][32]
+    int B, H, W, rows;
+};
+
+__global__ __launch_bounds__(256) void unfold_tiled_kernel(const UnfoldTiledParams p) {
+    const long long tile = blockIdx.x;
+    const int lane = threadIdx.x & 31;
+    const long long n = tile * PLANE_TILE + lane;                    // flattened cell (b, cy, cx)
+    const long long cells = (long long)p.B * p.H * p.W;
+    const bool in = n < cells;
+    const int hw = p.H * p.W;
+    const int b = in ? (int)(n / hw) : 0;
+    const int c0 = in ? (int)(n - (long long)b * hw) : 0;
+    const int cy = c0 / p.W, cx = c0 - cy * p.W;
+    float* __restrict__ dst = p.out + (size_t)tile * p.rows * PLANE_TILE + lane;
+    for (int row = (int)(threadIdx.x >> 5) + 8 * (int)blockIdx.y; row < p.rows; row += 8 * (int)gridDim.y) {
+        float v = 0.0f;
+        if (in && row < C_IN * 9) {
+            const int c = row / 9, tap = row - 9 * c;
+            const int y = cy + tap / 3 - 1, x = cx + tap % 3 - 1;
+            if (y >= 0 && y < p.H && x >= 0 && x < p.W) v = p.feat[(((size_t)b * C_IN + c) * p.H + y) * p.W + x];
+        }
+        dst[(size_t)row * PLANE_TILE] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -352,36 +465,63 @@ struct RowDotParams {
     int a_rows, M, tiles_per_split;
 };
 
+// Round 6: a lane owns one 16-byte piece of one row -- lane = (row r of 8, piece q of 8) -- so a wave instruction reads 8 rows x
+// 128 B = 1 KiB CONTIGUOUS of the tile (one thread per row read 64 different lines per instruction, 16 bytes of each, and leaned
+// on the L1 to keep them until its 8th load: ~3 TB/s).  A wave takes 8-row groups wave, wave + 4, ...; each lane keeps the partial
+// dot products of its 4 pixels against the 4 columns for every group it owns (M / 32 groups: 16 for M = 512) and the 8 lanes of
+// a row meet once at the end (3 butterfly steps).  Sums over a row's pixels are taken in another order than before (per piece,
+// then across pieces): results differ from the round-5 kernel by fp32 reassociation only (the test bounds it against float64).
 __global__ __launch_bounds__(256) void plane_rowdot_kernel(const RowDotParams p) {
     const long long ntiles = (p.npix + PLANE_TILE - 1) / PLANE_TILE;
     const long long t0 = (long long)blockIdx.x * p.tiles_per_split;
     long long t1 = t0 + p.tiles_per_split;
     if (t1 > ntiles) t1 = ntiles;
-    for (int row = threadIdx.x; row < p.M; row += 256) {
-        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
-        for (long long t = t0; t < t1; ++t) {
-            const f32x4* __restrict__ a = (const f32x4*)(p.A + ((size_t)t * p.a_rows + row) * PLANE_TILE);
-            const f32x4* __restrict__ s = (const f32x4*)(p.S + (size_t)t * 4 * PLANE_TILE);
-            const int left = (int)(p.npix - t * PLANE_TILE < PLANE_TILE ? p.npix - t * PLANE_TILE : PLANE_TILE);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane >> 3, q = lane & 7;
+    constexpr int MAXG = 16;                                     // row groups per wave: M <= 4 waves x 16 groups x 8 rows = 512
+    const int groups = p.M / 8;                                  // M % 8 == 0 (launch check)
+    f32x4 c[MAXG];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                f32x4 av = a[q];
+    for (int g = 0; g < MAXG; ++g) c[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (long long t = t0; t < t1; ++t) {
+        const float* __restrict__ a = p.A + (size_t)t * p.a_rows * PLANE_TILE;
+        const f32x4* __restrict__ s = (const f32x4*)(p.S + (size_t)t * 4 * PLANE_TILE);
+        const int left = (int)(p.npix - t * PLANE_TILE < PLANE_TILE ? p.npix - t * PLANE_TILE : PLANE_TILE);
+        const f32x4 s0 = s[q], s1 = s[8 + q], s2 = s[16 + q], s3 = s[24 + q];
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            const int row = 8 * (wave + 4 * g) + r;
+            if (wave + 4 * g < groups) {
+                f32x4 av = *(const f32x4*)(a + (size_t)row * PLANE_TILE + 4 * q);
                 if (left < PLANE_TILE) {                          // ragged last tile: padding was never written
 #pragma unroll
                     for (int e = 0; e < 4; ++e) av[e] = 4 * q + e < left ? av[e] : 0.0f;
                 }
-                const f32x4 s0 = s[q], s1 = s[8 + q], s2 = s[16 + q], s3 = s[24 + q];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    c0 = __builtin_fmaf(av[e], s0[e], c0);
-                    c1 = __builtin_fmaf(av[e], s1[e], c1);
-                    c2 = __builtin_fmaf(av[e], s2[e], c2);
-                    c3 = __builtin_fmaf(av[e], s3[e], c3);
+                    c[g][0] = __builtin_fmaf(av[e], s0[e], c[g][0]);
+                    c[g][1] = __builtin_fmaf(av[e], s1[e], c[g][1]);
+                    c[g][2] = __builtin_fmaf(av[e], s2[e], c[g][2]);
+                    c[g][3] = __builtin_fmaf(av[e], s3[e], c[g][3]);
                 }
             }
         }
-        float* __restrict__ dst = p.part + ((size_t)blockIdx.x * p.M + row) * 4;
-        dst[0] = c0; dst[1] = c1; dst[2] = c2; dst[3] = c3;
+    }
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        if (wave + 4 * g >= groups) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = c[g][k];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            c[g][k] = v;
+        }
+        if (q == 0) {
+            const int row = 8 * (wave + 4 * g) + r;
+            *(f32x4*)(p.part + ((size_t)blockIdx.x * p.M + row) * 4) = c[g];
+        }
     }
 }
 
@@ -400,14 +540,20 @@ int diinn_backward_data(void* stream, const float* gout_planes_dev, const float*
     BwdParams p;
     p.Wt = packed_dev; p.acts = acts_dev; p.gout = gout_planes_dev; p.G = G_dev; p.Q = Q_dev;
     p.npix = npix; p.ntiles = (npix + PLANE_TILE - 1) / PLANE_TILE; p.layer = 0;
-    hipLaunchKernelGGL(bwd_head_kernel, dim3((unsigned)((npix + 255) / 256), HID / 16), dim3(256), 0,
-                       (hipStream_t)stream, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_status(e);
+    // DIINN_TRAIN_SPLIT_HEAD = 1 (test / A-B only): bwd_head_kernel as a launch of its own, as before round 6
+    const bool split_head = knob(diinn_knobs().train_split_head) != 0;
+    hipError_t e;
+    if (split_head) {
+        hipLaunchKernelGGL(bwd_head_kernel, dim3((unsigned)((npix + 255) / 256), HID / 16), dim3(256), 0,
+                           (hipStream_t)stream, p);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_status(e);
+    }
     const unsigned blocks = (unsigned)((p.ntiles + 3) / 4);
     for (int layer = 3; layer >= 1; --layer) {
         p.layer = layer;
-        hipLaunchKernelGGL(bwd_layer_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+        if (layer == 3 && !split_head) hipLaunchKernelGGL(bwd_layer_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(bwd_layer_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
         e = hipGetLastError();
         if (e != hipSuccess) return hip_status(e);
     }
@@ -449,6 +595,8 @@ int diinn_plane_rowdot(void* stream, const float* A_dev, int a_rows, const float
     if (!A_dev || !S_dev || !part_dev || M <= 0 || M > a_rows || splits <= 0) return DIINN_ERR_INVALID_ARG;
     const int stp = check_npix(npix);
     if (stp) return stp;
+    if (M % 8 || M > 512) return DIINN_ERR_UNSUPPORTED;          // 8-row groups, at most 16 per wave
+    if ((((size_t)A_dev) & 15) || (((size_t)S_dev) & 15) || (((size_t)part_dev) & 15)) return DIINN_ERR_INVALID_ARG;
     RowDotParams p;
     p.A = A_dev; p.S = S_dev; p.part = part_dev; p.npix = npix; p.a_rows = a_rows; p.M = M;
     const long long ntiles = (npix + PLANE_TILE - 1) / PLANE_TILE;
@@ -457,8 +605,8 @@ int diinn_plane_rowdot(void* stream, const float* A_dev, int a_rows, const float
     return hip_status(hipGetLastError());
 }
 
-int diinn_backward_cell_sum(void* stream, const float* G_dev, const int32_t* seg_h_dev, const int32_t* seg_w_dev,
-                            float* dP_dev, int B, int H, int W, int Hu, int Wu) {
+int diinn_backward_cell_sum_ex(void* stream, const float* G_dev, const int32_t* seg_h_dev, const int32_t* seg_w_dev,
+                               float* dP_dev, float* dP_tiled_dev, int B, int H, int W, int Hu, int Wu) {
     if (!G_dev || !seg_h_dev || !seg_w_dev || !dP_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
     if (st) return st;
@@ -466,9 +614,27 @@ int diinn_backward_cell_sum(void* stream, const float* G_dev, const int32_t* seg
     const long long npix = (long long)B * Hu * Wu;
     st = check_npix(npix);
     if (st) return st;
-    if ((long long)((H + 3) / 4) * B > 65535) return DIINN_ERR_TOO_LARGE;
-    CellSumParams p{G_dev, dP_dev, seg_h_dev, seg_w_dev, B, H, W, Hu, Wu, (npix + PLANE_TILE - 1) / PLANE_TILE};
-    hipLaunchKernelGGL(cell_sum_kernel, dim3((W + 63) / 64, ((H + 3) / 4) * B, PCH), dim3(256), 0, (hipStream_t)stream, p);
+    if (B > 65535 || (long long)H * W > 2147483000LL) return DIINN_ERR_TOO_LARGE;
+    if ((((size_t)G_dev) & 15)) return DIINN_ERR_INVALID_ARG;
+    CellSumParams p{G_dev, dP_dev, dP_tiled_dev, seg_h_dev, seg_w_dev, B, H, W, Hu, Wu, (npix + PLANE_TILE - 1) / PLANE_TILE};
+    hipLaunchKernelGGL(cell_sum_kernel, dim3((unsigned)(((long long)H * W + 255) / 256), (unsigned)B, PCH), dim3(256), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+int diinn_backward_cell_sum(void* stream, const float* G_dev, const int32_t* seg_h_dev, const int32_t* seg_w_dev,
+                            float* dP_dev, int B, int H, int W, int Hu, int Wu) {
+    return diinn_backward_cell_sum_ex(stream, G_dev, seg_h_dev, seg_w_dev, dP_dev, nullptr, B, H, W, Hu, Wu);
+}
+
+int diinn_unfold_tiled(void* stream, const float* feat_dev, float* out_tiled_dev, int rows, int B, int H, int W) {
+    if (!feat_dev || !out_tiled_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (rows < C_IN * 9 || rows > 65535) return DIINN_ERR_INVALID_ARG;
+    const long long tiles = ((long long)B * H * W + PLANE_TILE - 1) / PLANE_TILE;
+    if (tiles > 2147483000LL) return DIINN_ERR_TOO_LARGE;
+    UnfoldTiledParams p{feat_dev, out_tiled_dev, B, H, W, rows};
+    hipLaunchKernelGGL(unfold_tiled_kernel, dim3((unsigned)tiles, 4), dim3(256), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
 

@@ -57,7 +57,7 @@ PARAM_SHAPES: Dict[str, Tuple[int, ...]] = {
 # (0.19 ms against MIOpen's 0.39); the weight gradient as unfold + plane GEMM costs 0.5 ms MORE than MIOpen's implicit GEMM
 # (im2col and two layout copies of 85-151 MB around a 0.42 ms GEMM), so it is available, not the default.
 NATIVE_CONV_DGRAD = True
-NATIVE_CONV_WGRAD = False
+NATIVE_CONV_WGRAD = True
 WGRAD_KSPLIT = 64          # pixel-axis splits of the weight-gradient GEMM: 4 output blocks x 64 = one workgroup per CU
 ROWDOT_SPLITS = 1024       # workgroups of the skinny products (HBM-bound)
 
@@ -120,6 +120,41 @@ def pack_on_device(params: Sequence[torch.Tensor]) -> torch.Tensor:
     return packed
 
 
+TRAIN_P_WINOGRAD = True    # the training forward's hoisted conv on the fp32 Winograd kernel (0.21 against 0.48 ms at B = 16, 48 x 48)
+_WPU_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+_section_cache: Dict[int, Tuple[int, int]] = {}
+
+
+def _section(i: int) -> Tuple[int, int]:
+    if i not in _section_cache:
+        off, size = C.c_size_t(), C.c_size_t()
+        _native.check(_native.load().diinn_packed_section(i, C.byref(off), C.byref(size)), "diinn_packed_section")
+        _section_cache[i] = (off.value, size.value)
+    return _section_cache[i]
+
+
+def _fill_wpu(packed: torch.Tensor, params: Sequence[torch.Tensor]) -> None:
+    """Section 13 (WPU) of a gathered image, on the device: U = G Wx G^T per (output, input) pair in float64 in the host
+    packer's own operation order (csrc/diinn_host.cpp: (G g) first, then (.) G^T, sums left to right), rounded once, column 2
+    negated, laid out [mt 32][row i 4][sg 8][col j 4][lane 64][e 4] -- bit-identical to diinn_pack_weights' section -- and
+    the validity word DIINN_PACKED_MAGIC_WPU ("this training image holds WPU and nothing else derived")."""
+    p = dict(zip(PARAM_NAMES, params))
+    wx = torch.cat([p["K.0.0.weight"].detach().reshape(HIDDEN, UNFOLD)]
+                   + [p[f"K.{i}.0.weight"].detach().reshape(HIDDEN, HIDDEN + UNFOLD)[:, HIDDEN:] for i in (1, 2, 3)], 0)
+    w = wx.reshape(4 * HIDDEN, IN_CHANNELS, 3, 3).to(torch.float64)
+    g = torch.tensor(_WPU_G, dtype=torch.float64, device=w.device)
+    gi = [g[:, a].view(1, 1, 4, 1) for a in range(3)]
+    t = gi[0] * w[:, :, 0:1, :] + gi[1] * w[:, :, 1:2, :] + gi[2] * w[:, :, 2:3, :]          # [O, C, i 4, b 3]
+    gj = [g[:, b].view(1, 1, 1, 4) for b in range(3)]
+    u = t[..., 0:1] * gj[0] + t[..., 1:2] * gj[1] + t[..., 2:3] * gj[2]                      # [O, C, i 4, j 4]
+    u[..., 2] = -u[..., 2]
+    u = u.to(torch.float32).reshape(32, 32, 8, 4, 2, 4, 4)                                   # [mt, m, sg, e, h, i, j]
+    off, size = _section(13)
+    packed[off:off + size] = u.permute(0, 5, 2, 6, 4, 1, 3).reshape(-1)                      # [mt, i, sg, j, h, m, e]
+    word = _section(6)[0] + 3
+    packed[word:word + 1].view(torch.int32).fill_(_native.PACKED_MAGIC_WPU)
+
+
 def _pack_on_device(params: Sequence[torch.Tensor]) -> torch.Tensor:
     dev = params[0].device
     key = str(dev)
@@ -128,7 +163,10 @@ def _pack_on_device(params: Sequence[torch.Tensor]) -> torch.Tensor:
         idx = pack_gather_index().to(dev)
         _gather_index_dev[key] = idx
     flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in params] + [torch.zeros(1, device=dev)])
-    return flat.index_select(0, idx)
+    packed = flat.index_select(0, idx)
+    if TRAIN_P_WINOGRAD:
+        _fill_wpu(packed, params)
+    return packed
 
 
 # ---------------------------------------------------------------------------
@@ -229,7 +267,7 @@ WGRAD_CONV_KSPLIT = 12     # pixel-axis splits of the hoisted conv's weight-grad
 
 
 def _conv_grads_native(feat: torch.Tensor, wx: torch.Tensor, dp: torch.Tensor, need_feat_grad: bool, want_weight: bool = True,
-                       wkey=None, wpins=None):
+                       wkey=None, wpins=None, a_t: Optional[torch.Tensor] = None):
     """Gradients of P = conv3x3(feat; Wx[1024,64,3,3]) on the library's own kernels (no MIOpen in the decoder's step):
       weight:  dWx[o, (c,ky,kx)] = sum over cells of dP[o, cell] * unfold3x3(feat)[(c,ky,kx), cell] -- the plane GEMM over the
                cell axis (plane_gemm_kernel; the 576 unfolded rows padded to 640 = 5 x 128);
@@ -244,16 +282,14 @@ def _conv_grads_native(feat: torch.Tensor, wx: torch.Tensor, dp: torch.Tensor, n
     dp = dp.contiguous()
     d_wx = None
     if want_weight:
-        unf = F.unfold(feat, 3, padding=1)                       # [B, 576, H*W], rows (c, ky, kx): the reference's unfold order
-        if (h * w) % PLANE_TILE == 0:                            # one copy each straight into the tiled layout [tile][row][32]
-            tpi = h * w // PLANE_TILE
-            b_t = torch.empty((b * tpi, 640, PLANE_TILE), dtype=torch.float32, device=dev)
-            b_t[:, UNFOLD:] = 0
-            b_t.view(b, tpi, 640, PLANE_TILE)[:, :, :UNFOLD] = unf.view(b, UNFOLD, tpi, PLANE_TILE).permute(0, 2, 1, 3)
-            a_t = dp.view(b, 4 * HIDDEN, tpi, PLANE_TILE).permute(0, 2, 1, 3).contiguous().view(b * tpi, 4 * HIDDEN, PLANE_TILE)
-        else:
-            unf = unf.permute(1, 0, 2).reshape(UNFOLD, n)
-            b_t = tile_planes(torch.cat([unf, unf.new_zeros((640 - UNFOLD, n))], 0))
+        # both operands as tiled plane groups over the CELL axis: dP from cell_sum_kernel itself (``a_t``: no transposing copy),
+        # the reference's unfold (rows (c, ky, kx), diinn.py:168) from unfold_tiled_kernel (rows 576..639 zero)
+        tiles = (n + PLANE_TILE - 1) // PLANE_TILE
+        b_t = torch.empty((tiles, 640, PLANE_TILE), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _native.check(lib.diinn_unfold_tiled(C.c_void_p(torch.cuda.current_stream().cuda_stream), ptr(feat.contiguous()), ptr(b_t),
+                                                 640, b, h, w), "diinn_unfold_tiled")
+        if a_t is None:
             a_t = tile_planes(dp.permute(1, 0, 2, 3).reshape(4 * HIDDEN, n))
         # the product is taken transposed, dWx^T [640 x 1024] = unfold . dP^T: with 1024 = 4 x 256 columns it runs on the kernel's
         # 128 x 256 block form (113 TFLOP/s; the 128 x 128 form the 640 columns of dWx would need: 70)
@@ -311,7 +347,8 @@ def _wino4_workspace(dev) -> torch.Tensor:
 
 
 def _conv_and_assemble(p: Dict[str, torch.Tensor], feat: torch.Tensor, dp: torch.Tensor, d_wq, d_bk,
-                       grads: Dict[str, torch.Tensor], need_feat_grad: bool, native: bool = False) -> Optional[torch.Tensor]:
+                       grads: Dict[str, torch.Tensor], need_feat_grad: bool, native: bool = False,
+                       a_t: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """P = conv3x3(feat; Wx[1024,64,3,3]) + bK: weight / input gradients of that one convolution (``native``: the
     library's kernels, else torch.nn.grad = MIOpen on the GPU), then the K.i gradients in the reference's [256, 256+576] layout."""
     wx = torch.cat([p["K.0.0.weight"].reshape(HIDDEN, UNFOLD)]
@@ -322,7 +359,7 @@ def _conv_and_assemble(p: Dict[str, torch.Tensor], feat: torch.Tensor, dp: torch
     if nat_w or (nat_d and need_feat_grad):
         wkey = tuple((p[f"K.{i}.0.weight"].data_ptr(), p[f"K.{i}.0.weight"]._version) for i in range(4))
         d_wx, d_feat = _conv_grads_native(feat, wx, dp, need_feat_grad and nat_d, want_weight=nat_w, wkey=wkey,
-                                          wpins=tuple(p[f"K.{i}.0.weight"] for i in range(4)))
+                                          wpins=tuple(p[f"K.{i}.0.weight"] for i in range(4)), a_t=a_t)
     if d_wx is None:
         d_wx = torch.nn.grad.conv2d_weight(feat, wx.shape, dp, padding=1)
     if d_feat is None and need_feat_grad:
@@ -415,6 +452,13 @@ def backward_fused(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tensor, p
     part0 = torch.empty((rsplit, 2 * HIDDEN, 4), dtype=torch.float32, device=dev)
     partl = torch.empty((rsplit, HIDDEN, 4), dtype=torch.float32, device=dev)
     dp = torch.empty((b, 4 * HIDDEN, h, w), dtype=torch.float32, device=dev)
+    # the hoisted conv's weight gradient on the library's own GEMM wants dP tiled over the cell axis as well: cell_sum_kernel
+    # writes it (a ragged last tile's padding must be zero: the GEMM reads whole tiles)
+    cells = b * h * w
+    a_t = None
+    if NATIVE_CONV_WGRAD:
+        a_t = (torch.empty if cells % PLANE_TILE == 0 else torch.zeros)(((cells + PLANE_TILE - 1) // PLANE_TILE, 4 * HIDDEN, PLANE_TILE),
+                                                                        dtype=torch.float32, device=dev)
     ptr = lambda x: C.c_void_p(x.data_ptr())                      # noqa: E731
     with torch.cuda.device(dev):
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -428,8 +472,8 @@ def backward_fused(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tensor, p
                       "diinn_plane_rowdot")
         _native.check(lib.diinn_plane_rowdot(stream, ptr(q[3]), HIDDEN, ptr(gout_t), ptr(partl), HIDDEN, n, rsplit),
                       "diinn_plane_rowdot")
-        _native.check(lib.diinn_backward_cell_sum(stream, ptr(g), ptr(seg_h), ptr(seg_w), ptr(dp), b, h, w, hu, wu),
-                      "diinn_backward_cell_sum")
+        _native.check(lib.diinn_backward_cell_sum_ex(stream, ptr(g), ptr(seg_h), ptr(seg_w), ptr(dp), ptr(a_t) if a_t is not None else None,
+                                                     b, h, w, hu, wu), "diinn_backward_cell_sum_ex")
     grads: Dict[str, torch.Tensor] = {}
     dl = partl.sum(0)                                             # [256, 4]: q_3 . (g_out ; 0)^T
     grads["last_layer.weight"] = dl[:, :3].t().reshape(3, HIDDEN, 1, 1)
@@ -447,7 +491,7 @@ def backward_fused(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tensor, p
     d_bk[0] = d0[:HIDDEN, 3]
     grads["Q.0.0.weight"] = d0[HIDDEN:, :3].reshape(HIDDEN, 3, 1, 1)
     grads["Q.0.0.bias"] = d0[HIDDEN:, 3]
-    d_feat = _conv_and_assemble(p, feat, dp, d_wq, d_bk, grads, need_feat_grad, native=(NATIVE_CONV_WGRAD, NATIVE_CONV_DGRAD))
+    d_feat = _conv_and_assemble(p, feat, dp, d_wq, d_bk, grads, need_feat_grad, native=(NATIVE_CONV_WGRAD, NATIVE_CONV_DGRAD), a_t=a_t)
     return d_feat, [grads[name] for name in PARAM_NAMES]
 
 
@@ -478,8 +522,11 @@ class DecodeMode3Function(torch.autograd.Function):
         out = torch.empty((b, 3, hu, wu), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            _native.check(lib.diinn_precompute_P(stream, C.c_void_p(feat_c.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                                 C.c_void_p(workspace.data_ptr()), b, h, w, 0, h), "diinn_precompute_P")
+            # the hoisted conv: the Winograd kernel when the image carries its section (DIINN_PACKED_MAGIC_WPU: _fill_wpu), else
+            # the direct kernel, which reads permutation sections only
+            p_fn = lib.diinn_precompute_P_wpu if TRAIN_P_WINOGRAD else lib.diinn_precompute_P
+            _native.check(p_fn(stream, C.c_void_p(feat_c.data_ptr()), C.c_void_p(packed.data_ptr()),
+                               C.c_void_p(workspace.data_ptr()), b, h, w, 0, h), "diinn_precompute_P")
             _native.check(lib.diinn_decode_train_fwd(stream, C.c_void_p(workspace.data_ptr()),
                                                      C.c_void_p(packed.data_ptr()), C.c_void_p(out.data_ptr()),
                                                      C.c_void_p(acts.data_ptr()), b, h, w, hu, wu, int(sin_mode)),

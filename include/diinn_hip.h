@@ -144,6 +144,10 @@ size_t diinn_packed_weight_floats(void);
  * diinn_decode*, in every compute mode) writes NaN into ALL of its outputs when the word is missing -- a loud
  * wrong answer instead of a silent one (tests/test_gpu_parity.py::test_image_without_derived_sections_is_refused). */
 #define DIINN_PACKED_MAGIC 0x44493038u   /* "DI08": changes whenever the packed layout does (sections, sizes) */
+/* A TRAINING image (the permutation sections gathered on the device, derived sections absent) may carry this word instead once
+ * its section 13 (WPU, the hoisted conv in Winograd form) has been filled on the device as well: diinn_precompute_P_wpu accepts
+ * it; every other entry point that reads a derived section still answers NaN. */
+#define DIINN_PACKED_MAGIC_WPU 0x44495750u   /* "DIWP" */
 int    diinn_packed_section(int section, size_t* offset_floats, size_t* size_floats);
 int    diinn_pack_weights(const float* K0w, const float* K0b,
                           const float* const Kw[3], const float* const Kb[3],
@@ -192,6 +196,10 @@ int diinn_precompute_P(void* stream, const float* feat_dev, const float* packed_
  * packed image); every other mode is the fp32 conv above. */
 int diinn_precompute_P_ex(void* stream, const float* feat_dev, const float* packed_dev,
                           float* P_dev, int B, int H, int W, int r0, int r1, int compute);
+/* The fp32 Winograd form of P for an image whose validity word is DIINN_PACKED_MAGIC or DIINN_PACKED_MAGIC_WPU (the training
+ * forward: 0.21 against the direct kernel's 0.48 ms at B = 16, 48 x 48); any other word: NaN into every P value. */
+int diinn_precompute_P_wpu(void* stream, const float* feat_dev, const float* packed_dev,
+                           float* P_dev, int B, int H, int W, int r0, int r1);
 int diinn_decode_band(void* stream, const float* P_dev, const float* packed_dev,
                       float* out_dev, int B, int H, int W, int Hu, int Wu,
                       int y0, int y1, int sin_mode);
@@ -284,7 +292,8 @@ int diinn_decode_train_fwd(void* stream, const float* P_dev, const float* packed
  * From these every parameter gradient is a GEMM over the pixel axis (the two functions below):
  *   d[Wq_i ; Qw_i] = G_i q_{i-1}^T,  dL = g_out q_3^T,  (dbK_0 ; dQ0, dbQ0) = G_0 (syn, 1)^T,
  *   dP_i[cell] = sum of g_a,i (diinn_backward_cell_sum).
- * Enqueues 4 kernels on `stream`; no allocation, no synchronisation. */
+ * Enqueues 3 kernels on `stream` (the head's gates are computed inside layer 3's kernel since round 6); no allocation, no
+ * synchronisation. */
 int diinn_backward_data(void* stream, const float* gout_planes_dev, const float* acts_dev,
                         const float* packed_dev, float* G_dev, float* Q_dev, long long npix);
 
@@ -310,6 +319,14 @@ int diinn_plane_rowdot(void* stream, const float* A_dev, int a_rows, const float
  * the index tables are monotone, so a cell's pixels form a rectangle.  Deterministic (no atomics). */
 int diinn_backward_cell_sum(void* stream, const float* G_dev, const int32_t* seg_h_dev, const int32_t* seg_w_dev,
                             float* dP_dev, int B, int H, int W, int Hu, int Wu);
+/* _ex: additionally (dP_tiled_dev non-NULL) the same sums as a tiled plane group over the CELL axis, [ceil(B H W / 32)][1024][32]:
+ * the A operand of the hoisted conv's weight-gradient GEMM, dWx^T [576(+64) x 1024] = unfold . dP^T (diinn_plane_gemm_nt), whose
+ * B operand diinn_unfold_tiled writes: the reference's F.unfold(feat, 3, padding=1) (diinn.py:168; row = c * 9 + ky * 3 + kx) as a
+ * tiled group [ceil(B H W / 32)][rows][32], rows >= 576, the rows past 576 zero.  With these two the decoder's training step has
+ * no library convolution left (sr_module.py:127-137). */
+int diinn_backward_cell_sum_ex(void* stream, const float* G_dev, const int32_t* seg_h_dev, const int32_t* seg_w_dev,
+                               float* dP_dev, float* dP_tiled_dev, int B, int H, int W, int Hu, int Wu);
+int diinn_unfold_tiled(void* stream, const float* feat_dev, float* out_tiled_dev, int rows, int B, int H, int W);
 
 /* ---- LIIF comparison decoder ------------------------
  * Replaces: LIIF.query_rgb + batched_predict + reshape_pred (liif.py:59-127,129-146), constructor
@@ -512,7 +529,7 @@ int diinn_p_launch_info(int B, int H, int W, int r0, int r1, int compute, int* a
  *   TEST / A-B ONLY (force a kernel variant that the launch cost models would not take, or inject a fault; results stay
  *     within the documented equivalences) -- DIINN_F32_KERNEL, DIINN_BF16_KERNEL, DIINN_X3_KERNEL, DIINN_PBF16_KERNEL,
  *     DIINN_P_KERNEL, DIINN_ENC_X3_ROWS, DIINN_ENC_S1_MIN_BLOCKS, DIINN_ENC_NO_STREAM1X1, DIINN_ENC_LAT_MAX_TILES,
- *     DIINN_ENC_WINO_HALF_MAX, DIINN_ENC_WINO_PERSIST, DIINN_DEBUG_NCU (the compute-unit count cost models, split plans and persistent grids assume),
+ *     DIINN_ENC_WINO_HALF_MAX, DIINN_ENC_WINO_PERSIST, DIINN_TRAIN_SPLIT_HEAD, DIINN_DEBUG_NCU (the compute-unit count cost models, split plans and persistent grids assume),
  *     DIINN_ENC_WINO4_FAULT (1: the split hand-off's give-up path on demand: NaN outputs + sticky status).  The environment is read ONCE, at the first launch or the first call of either function; afterwards
  * only diinn_debug_set changes a knob (process-wide, atomic stores: safe against concurrent launches, which see
  * either the old or the new value).  Unknown name -> DIINN_ERR_INVALID_ARG.  This is the library's only mutable

@@ -227,7 +227,31 @@ def test_fused_backward_equals_formula_backward_on_gpu():
         packed = T.pack_on_device(params)
         # the permutation sections agree with the host packer; the pad word behind bL is the validity word of the
         # derived sections (the magic on the host, 0 in a gathered image)
-        assert torch.equal(packed[: 986_627].cpu(), D.pack_state_dict(sd)[: 986_627]) and packed[986_627].item() == 0.0
+        host = D.pack_state_dict(sd)
+        assert torch.equal(packed[: 986_627].cpu(), host[: 986_627])
+        # ... "DIWP" on the device image, whose WPU section (13: the hoisted conv in Winograd form, filled on the device in
+        # float64 in the host packer's operation order) is bit-identical to the host packer's; every other derived section zero
+        assert packed[986_627:986_628].view(torch.int32).item() == N.PACKED_MAGIC_WPU
+        o13, z13 = T._section(13)
+        assert torch.equal(packed[o13:o13 + z13].cpu(), host[o13:o13 + z13])
+        for sec in (7, 9, 10, 11, 12, 14, 15, 16):
+            o, z = T._section(sec)
+            assert not bool(packed[o:o + z].any())
+        # P from the training image on the Winograd kernel == P from the inference image, bit for bit; an inference decode
+        # from the training image is refused (NaN): only diinn_precompute_P_wpu accepts the WPU-only word
+        ptr_ = lambda x: C.c_void_p(x.data_ptr())                 # noqa: E731
+        st0 = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        p_a, p_b = torch.empty((b, h, w, 1024), device=dev), torch.empty((b, h, w, 1024), device=dev)
+        hostd = host.to(dev)
+        N.check(lib.diinn_precompute_P_wpu(st0, ptr_(feat), ptr_(packed), ptr_(p_a), b, h, w, 0, h), "P_wpu")
+        N.check(lib.diinn_precompute_P_ex(st0, ptr_(feat), ptr_(hostd), ptr_(p_b), b, h, w, 0, h, 0), "P_ex")
+        assert torch.equal(p_a, p_b)
+        N.check(lib.diinn_precompute_P_ex(st0, ptr_(feat), ptr_(packed), ptr_(p_b), b, h, w, 0, h, 0), "P_ex")
+        assert bool(torch.isnan(p_b).all())
+        blank = packed.clone()
+        blank[986_627] = 0.0
+        N.check(lib.diinn_precompute_P_wpu(st0, ptr_(feat), ptr_(blank), ptr_(p_b), b, h, w, 0, h), "P_wpu")
+        assert bool(torch.isnan(p_b).all())
         out, acts_t = _train_forward(lib, N, packed, feat, b, h, w, hu, wu, dev, fill=0.0)
         acts = T.untile_planes(acts_t, n).view(4, 2, 256, n)
         # planes
@@ -239,6 +263,20 @@ def test_fused_backward_equals_formula_backward_on_gpu():
                                         C.c_void_p(packed.data_ptr()), C.c_void_p(g_t.data_ptr()),
                                         C.c_void_p(q_t.data_ptr()), n), "bwd")
         torch.cuda.synchronize()
+        # round 6: the head's gates are computed inside layer 3's kernel; bwd_head_kernel as a launch of its own
+        # (DIINN_TRAIN_SPLIT_HEAD = 1) leaves bit-identical planes, padding included
+        g_s = torch.full((4, t, 512, 32), float("nan"), device=dev)
+        q_s = torch.full((4, t, 256, 32), float("nan"), device=dev)
+        N.debug_set("DIINN_TRAIN_SPLIT_HEAD", 1)
+        try:
+            N.check(lib.diinn_backward_data(stream, C.c_void_p(gp.data_ptr()), C.c_void_p(acts_t.data_ptr()),
+                                            C.c_void_p(packed.data_ptr()), C.c_void_p(g_s.data_ptr()),
+                                            C.c_void_p(q_s.data_ptr()), n), "bwd")
+        finally:
+            N.debug_set("DIINN_TRAIN_SPLIT_HEAD", 0)
+        torch.cuda.synchronize()
+        same = lambda x, y: bool(((x == y) | (torch.isnan(x) & torch.isnan(y))).all())   # noqa: E731
+        assert same(g_t, g_s) and same(q_t, q_s), (b, h, w)
         g = T.untile_planes(g_t, n).view(4, 2, 256, n)
         q = T.untile_planes(q_t, n)
         assert torch.isfinite(g).all() and torch.isfinite(q).all()
@@ -269,6 +307,50 @@ def test_fused_backward_equals_formula_backward_on_gpu():
     assert lib.diinn_backward_data(None, C.c_void_p(gp.data_ptr()), C.c_void_p(acts_t.data_ptr()),
                                    C.c_void_p(packed.data_ptr()), C.c_void_p(g_t.data_ptr()),
                                    C.c_void_p(q_t.data_ptr()), 0) == N.ERR_INVALID_ARG
+
+
+@pytest.mark.gpu
+def test_cell_sum_and_unfold_kernels():
+    """cell_sum_kernel (round 6: one 16- / 8-byte load per cell row at the integer scales x4 / x2, scalar loads elsewhere) against
+    the one-hot-GEMM statement of the same sums (training._cell_sum) -- x4, x2, x3, non-integer, down-scaling, Wu % 4 != 0, batches
+    -- with its optional tiled copy (the A operand of the hoisted conv's weight-gradient GEMM) equal to tile_planes of the NCHW
+    result; unfold_tiled_kernel equal to the reference's F.unfold(feat, 3, padding=1), tiled, rows 576.. zero."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.training as T
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    gen = torch.Generator(device=dev).manual_seed(11)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda x: C.c_void_p(x.data_ptr())                      # noqa: E731
+    for (b, h, w, hu, wu) in [(2, 12, 12, 48, 48), (1, 9, 10, 18, 20), (2, 8, 8, 24, 24), (1, 7, 5, 23, 18), (1, 16, 12, 8, 6),
+                              (3, 6, 6, 24, 26), (1, 48, 48, 192, 192)]:
+        n = b * hu * wu
+        t = (n + 31) // 32
+        g_t = torch.randn((4, t, 512, 32), device=dev, generator=gen)
+        geo = T._geometry(b, h, w, hu, wu, dev)
+        idx_h, _, idx_w, _, _ = T.coordinate_tensors(h, w, hu, wu, dev)
+        dp = torch.full((b, 1024, h, w), float("nan"), device=dev)
+        cells = b * h * w
+        tc = (cells + 31) // 32
+        dp_t = torch.zeros((tc, 1024, 32), device=dev)
+        N.check(lib.diinn_backward_cell_sum_ex(stream, ptr(g_t), ptr(geo["seg_h"]), ptr(geo["seg_w"]), ptr(dp), ptr(dp_t), b, h, w, hu, wu), "cell_sum")
+        dp2 = torch.full((b, 1024, h, w), float("nan"), device=dev)
+        N.check(lib.diinn_backward_cell_sum(stream, ptr(g_t), ptr(geo["seg_h"]), ptr(geo["seg_w"]), ptr(dp2), b, h, w, hu, wu), "cell_sum")
+        torch.cuda.synchronize()
+        assert torch.equal(dp, dp2)
+        ga = T.untile_planes(g_t, n)[:, :256].reshape(1024, n)                       # g_a rows of the four layers
+        ref = T._cell_sum(ga.double(), b, hu, wu, h, w, idx_h, idx_w)
+        assert float((dp.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), (b, h, w, hu, wu)
+        assert torch.equal(dp_t, T.tile_planes(dp.permute(1, 0, 2, 3).reshape(1024, cells)))
+        feat = torch.randn((b, 64, h, w), device=dev, generator=gen)
+        u_t = torch.full((tc, 640, 32), float("nan"), device=dev)
+        N.check(lib.diinn_unfold_tiled(stream, ptr(feat), ptr(u_t), 640, b, h, w), "unfold")
+        unf = torch.nn.functional.unfold(feat, 3, padding=1).permute(1, 0, 2).reshape(576, cells)
+        assert torch.equal(u_t, T.tile_planes(torch.cat([unf, unf.new_zeros((64, cells))], 0)))
+    assert lib.diinn_unfold_tiled(stream, ptr(feat), ptr(u_t), 100, b, h, w) == N.ERR_INVALID_ARG
+    assert lib.diinn_unfold_tiled(stream, None, ptr(u_t), 640, b, h, w) == N.ERR_INVALID_ARG
+    assert lib.diinn_backward_cell_sum_ex(stream, ptr(g_t), ptr(geo["seg_h"]), ptr(geo["seg_w"]), None, None, b, h, w, hu, wu) == N.ERR_INVALID_ARG
 
 
 @pytest.mark.gpu
