@@ -138,6 +138,7 @@ SIGNATURES = {
                                      C.c_longlong, C.c_int]),
     "diinn_backward_cell_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "diinn_sum_parts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong]),
     "diinn_backward_cell_sum_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_unfold_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),

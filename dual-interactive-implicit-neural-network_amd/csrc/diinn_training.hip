@@ -134,9 +134,16 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
             dsincos(sv, sn, cs);
             ga[kk] = kv > 0.0f ? g * sn : 0.0f;
             gs[kk] = g * kv * cs;
+            st_act(outQ_li, voff, so, kv * sn);                  // q_3 leaves now; (g_a,3 ; g_s,3) stay in registers as the B operand
+        }                                                         // and are stored later, one k-group per 8 MFMAs of M-tiles 1..4
+    };
+    auto head_store_group = [&](int kg) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int kk = 4 * kg + e;
+            const unsigned so = (unsigned)(32 * (kk >> 4) + (kk & 3) + 8 * ((kk & 15) >> 2)) * PLANE_ROW_BYTES;
             st_act(outG_li, voff, so, ga[kk]);
             st_act(outG_li, voff, so + HID * PLANE_ROW_BYTES, gs[kk]);
-            st_act(outQ_li, voff, so, kv * sn);
         }
     };
 #pragma unroll
@@ -178,7 +185,8 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
             const f32x4 wq = rq[s % PF];
             if constexpr (HEAD) {
                 if (m == 0) head_group(kg);                       // (its loads went out BLD groups = 64 MFMAs ago)
-            }
+                if (m == 1) head_store_group(kg);                 // 8 stores behind 8 MFMAs (in M-tile 0 they would sit beside the
+            }                                                     // group's 8 loads, ~76 VALU instructions and 4 q_3 stores)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 ak = MFMA32(wk[e], ga[4 * kg + e], ak);
@@ -378,55 +386,58 @@ __global__ __launch_bounds__(256, 1) void plane_gemm_kernel(const PlaneGemmParam
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     float rs[2] = {0.0f, 0.0f};
 
-    f32x4 fa[2][2][4], fb[2][NB][4];                              // [buffer][panel][t]: 4 pixels each
-    auto load = [&](int buf, int t) {
+    // Round 6: ONE tile of operands in registers (96), refilled piece by piece.  The round-5 form held two whole tiles (192
+    // registers beside 128 accumulators): hipcc staged the second tile through AGPRs -- 715 v_accvgpr_read / _write per 256 MFMAs
+    // -- and SLP-packed the row sums into v_pk_add_f32 behind v_movs: 3 VALU instructions per MFMA on a chip whose fp32 MFMA
+    // and VALU share one pipe (PMC: SQ_INSTS_VALU 9.4e7 against SQ_INSTS_MFMA 3.1e7).  Now a quarter tile (8 pixels: the 16-byte
+    // piece q of every row) is reloaded for the NEXT tile as soon as its 32 MFMAs have been issued, i.e. three quarters
+    // (96 MFMAs, ~6,000 cycles) ahead of its use, and the row sums are taken only by the waves that store them.
+    f32x4 fa[2][4], fb[NB][4];                                    // [panel][q]: 4 pixels each
+    const bool sums = p.with_rowsum && n0 == 0;                  // wave-uniform
+    auto load_q = [&](int q, int t) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int a = 0; a < 2; ++a)
+            fa[a][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                ra, (int)voff, (int)(t * a_pitch + a * MFMA_ROWS + 32u * q), 0));
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-                fa[buf][a][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    ra, (int)voff, (int)(t * a_pitch + a * MFMA_ROWS + 32u * q), 0));
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-                fb[buf][b][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    rb, (int)voff, (int)(t * b_pitch + b * MFMA_ROWS + 32u * q), 0));
-        }
+        for (int b = 0; b < NB; ++b)
+            fb[b][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rb, (int)voff, (int)(t * b_pitch + b * MFMA_ROWS + 32u * q), 0));
     };
-    auto compute = [&](int buf, int t) {
+    auto compute_q = [&](int q, int t) {
         const long long pix0 = (t0 + t) * PLANE_TILE;
         if (pix0 + PLANE_TILE > p.npix) {                        // ragged last tile: its padding was never written
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int e = 0; e < 4; ++e) {
+                const bool in = pix0 + 8 * q + 4 * h + e < p.npix;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool in = pix0 + 8 * q + 4 * h + e < p.npix;
+                for (int a = 0; a < 2; ++a) fa[a][q][e] = in ? fa[a][q][e] : 0.0f;
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) fa[buf][a][q][e] = in ? fa[buf][a][q][e] : 0.0f;
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) fb[buf][b][q][e] = in ? fb[buf][b][q][e] : 0.0f;
-                }
+                for (int b = 0; b < NB; ++b) fb[b][q][e] = in ? fb[b][q][e] : 0.0f;
+            }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
+                for (int b = 0; b < NB; ++b) acc[a][b] = MFMA32(fa[a][q][e], fb[b][q][e], acc[a][b]);
+        if (sums) {
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) acc[a][b] = MFMA32(fa[buf][a][q][e], fb[buf][b][q][e], acc[a][b]);
-                    rs[a] += fa[buf][a][q][e];
-                }
-            }
+            for (int a = 0; a < 2; ++a) rs[a] += (fa[a][q][0] + fa[a][q][1]) + (fa[a][q][2] + fa[a][q][3]);
+        }
     };
 
     if (nt > 0) {
-        load(0, 0);
-        for (int t = 0; t < nt; t += 2) {
-            if (t + 1 < nt) load(1, t + 1);
-            compute(0, t);
-            if (t + 1 < nt) {
-                if (t + 2 < nt) load(0, t + 2);
-                compute(1, t + 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load_q(q, 0);
+        for (int t = 0; t < nt; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                compute_q(q, t);
+                __builtin_amdgcn_sched_barrier(0);               // the refill goes out HERE: behind the MFMAs that read these registers,
+                if (t + 1 < nt) load_q(q, t + 1);                // not hoisted in front of them into a second set
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -442,6 +453,146 @@ __global__ __launch_bounds__(256, 1) void plane_gemm_kernel(const PlaneGemmParam
                 dst[(size_t)row * p.ldc + n0 + 32 * b + j] = acc[a][b][r];
             }
     if (p.with_rowsum && n0 == 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float v = rs[a] + __shfl_xor(rs[a], 32);
+            if (h == 0) dst[(size_t)(m0 + 32 * a + j) * p.ldc + p.Nc] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// plane_gemm_lds_kernel (round 6; the 128 x 256 block form): the same product with the operands staged through LDS.
+// What bounded plane_gemm_kernel<4> at 0.72 of the fp32 peak (PMC: MfmaUtil 76 % at 2.26 GHz) was how its operands arrive: every
+// wave fetched its own 64 x 32 and 128 x 32 panels with loads that touch 32 different 128-byte lines per instruction, 32 bytes
+// of each (an MFMA fragment is a COLUMN of the row-major panel), twice per workgroup (two waves share every panel), held in 192
+// registers beside the 128 accumulators (3 VALU instructions per MFMA of AGPR staging); with the loads re-ordered to hold one
+// tile (no AGPR staging: 0.6 VALU per MFMA) the time did not move -- the four loads of a line were then 32 MFMAs apart and
+// the 32 KiB L1 did not keep it.  Here a tile's 384 rows x 128 B (48 KiB) are copied ONCE per workgroup, as 48 fully
+// coalesced 1 KiB LDS-DMA pieces (12 per wave, no registers), two stages; the column reads are ds_read_b128.  The deposit of
+// an LDS-DMA is lane-linear, so the bank swizzle is applied on the SOURCE side: lane (row r of 8, position p of 8) of a piece
+// fetches 16-byte chunk p ^ r of its row, i.e. chunk c of row rr sits at position c ^ (rr & 7) -- a column read then spreads
+// over 8 positions (2-way conflicts instead of 32-way).  One barrier per tile: [own pieces landed: vmcnt(0)] -> barrier (every
+// wave's pieces landed, every wave done with the other stage) -> request the next tile into the other stage -> 128 MFMAs.
+// ---------------------------------------------------------------------------------
+constexpr int PG_STAGE_FLOATS = (128 + 256) * PLANE_TILE;        // 12,288 floats = 48 KiB
+
+__global__ __launch_bounds__(256, 1) void plane_gemm_lds_kernel(const PlaneGemmParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * PG_STAGE_FLOATS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int nblk = p.Nc / 256;
+    const int mb = blockIdx.x / nblk, nb = blockIdx.x % nblk;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int m0 = mb * 128 + wm * 64, n0 = nb * 256 + wn * 128;
+    const int ks = blockIdx.y;
+    const long long ntiles = (p.npix + PLANE_TILE - 1) / PLANE_TILE;
+    const long long t0 = (long long)ks * p.tiles_per_split;
+    long long t1 = t0 + p.tiles_per_split;
+    if (t1 > ntiles) t1 = ntiles;
+    const int nt = t1 > t0 ? (int)(t1 - t0) : 0;
+
+    const unsigned a_pitch = (unsigned)p.a_rows * PLANE_ROW_BYTES, b_pitch = (unsigned)p.b_rows * PLANE_ROW_BYTES;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.A + ((size_t)t0 * p.a_rows + p.a_row0 + mb * 128) * PLANE_TILE), 0, (int)(nt * a_pitch), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.Bm + ((size_t)t0 * p.b_rows + p.b_row0 + nb * 256) * PLANE_TILE), 0, (int)(nt * b_pitch), 0x00020000);
+    // piece i (0..47) of a stage = rows 8 i .. 8 i + 7 of the sequence [A rows 0..127][B rows 0..255]; its lane (r, pos) fetches
+    // chunk pos ^ r of row 8 i + r: the same per-lane offset for every piece
+    const unsigned dma_off = (unsigned)(lane >> 3) * PLANE_ROW_BYTES + (unsigned)(((lane & 7) ^ (lane >> 3)) * 16);
+    auto dma_piece = [&](int st, int t, int k) {                 // this wave's k-th piece (0..11) of tile t into stage st
+        float* dst = lds + st * PG_STAGE_FLOATS;
+        const int i = wave * 12 + k;                              // wave-uniform: wave 0 and a third of wave 1 copy A, the rest B
+        if (i < 16)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(dst + i * 256), 16, (int)dma_off,
+                                                     (int)((unsigned)t * a_pitch + (unsigned)i * 1024u), 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(dst + i * 256), 16, (int)dma_off,
+                                                     (int)((unsigned)t * b_pitch + (unsigned)(i - 16) * 1024u), 0, 0);
+    };
+    auto dma = [&](int st, int t) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) dma_piece(st, t, k);
+    };
+    // fragment (panel rows 32 P .. 32 P + 31, k-piece q) of lane (j, h): chunk 2 q + h of row 32 P + j
+    int cq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cq[q] = j * PLANE_TILE + (((2 * q + h) ^ (j & 7)) * 4);
+    const float* __restrict__ abase = lds + (2 * wm) * 32 * PLANE_TILE;
+    const float* __restrict__ bbase = lds + (128 + 4 * wn * 32) * PLANE_TILE;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float rs[2] = {0.0f, 0.0f};
+    const bool sums = p.with_rowsum && n0 == 0;                  // wave-uniform
+
+    if (nt > 0) dma(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        const int st = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of tile t have landed
+        __syncthreads();                                         // ... everybody's have; and everybody is done with the other stage
+        const bool more = t + 1 < nt;
+        const bool ragged = (t0 + t) * PLANE_TILE + PLANE_TILE > p.npix;   // the last tile's padding was never written
+        const long long pix0 = (t0 + t) * PLANE_TILE;
+        f32x4 fa[2][2], fb[2][4];                                 // [q parity][panel]
+        auto frag = [&](int par, int q) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fa[par][a] = *(const f32x4*)(abase + st * PG_STAGE_FLOATS + a * 32 * PLANE_TILE + cq[q]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fb[par][b] = *(const f32x4*)(bbase + st * PG_STAGE_FLOATS + b * 32 * PLANE_TILE + cq[q]);
+        };
+        frag(0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int par = q & 1;
+            if (q + 1 < 4) frag(par ^ 1, q + 1);                  // the next piece's reads go out in front of this piece's MFMAs
+            if (ragged) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = pix0 + 8 * q + 4 * h + e < p.npix;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) fa[par][a][e] = in ? fa[par][a][e] : 0.0f;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) fb[par][b][e] = in ? fb[par][b][e] : 0.0f;
+                }
+            }
+            // the next tile's 12 pieces go out ONE AT A TIME, each behind 8 MFMAs: an LDS-DMA instruction holds its wave's
+            // issue for ~60-100 cycles -- free behind a 64-cycle fp32 MFMA, 12 of them back to back cost 11 MFMA slots per tile
+            // (measured: all twelve in front of the tile's MFMAs 1.376 ms, none 1.232; profiles/r06_train.txt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = MFMA32(fa[par][a][e], fb[par][b][e], acc[a][b]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && 4 * q + e < 12) dma_piece(st ^ 1, t + 1, 4 * q + e);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (sums) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) rs[a] += (fa[par][a][0] + fa[par][a][1]) + (fa[par][a][2] + fa[par][a][3]);
+            }
+        }
+    }
+
+    float* __restrict__ dst = p.part + (size_t)ks * p.M * p.ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                dst[(size_t)row * p.ldc + n0 + 32 * b + j] = acc[a][b][r];
+            }
+    if (sums) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const float v = rs[a] + __shfl_xor(rs[a], 32);
@@ -525,7 +676,37 @@ __global__ __launch_bounds__(256) void plane_rowdot_kernel(const RowDotParams p)
     }
 }
 
+// ---------------------------------------------------------------------------------
+// sum_parts_kernel: out[i] = part[0][i] + part[1][i] + ... (slices in order: deterministic), the add of the split-K partial
+// products the GEMM / rowdot launches leave.  101 MB at B = 16, 192 x 192 (3 x 64 slices of 512 x 257): HBM-bound, 16 bytes per
+// lane (torch.sum over the slice axis of the same buffer: 137 us; this: ~30).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;                      // f32x4 index inside a slice
+    if (i >= n4) return;
+    const f32x4* __restrict__ src = (const f32x4*)part + (size_t)blockIdx.y * nparts * n4 + i;
+    f32x4 s = src[0];
+    int k = 1;
+    for (; k + 4 <= nparts; k += 4) {                            // four slices in flight
+        const f32x4 a = src[(size_t)k * n4], b = src[(size_t)(k + 1) * n4], c = src[(size_t)(k + 2) * n4], d = src[(size_t)(k + 3) * n4];
+        s = (((s + a) + b) + c) + d;
+    }
+    for (; k < nparts; ++k) s += src[(size_t)k * n4];
+    ((f32x4*)out)[(size_t)blockIdx.y * n4 + i] = s;
+}
+
 extern "C" {
+
+int diinn_sum_parts(void* stream, const float* part_dev, float* out_dev, int groups, int nparts, long long n) {
+    // part_dev [groups][nparts][n] -> out_dev [groups][n]; n % 4 == 0, 16-byte aligned buffers
+    if (!part_dev || !out_dev || groups <= 0 || groups > 65535 || nparts <= 0 || n <= 0) return DIINN_ERR_INVALID_ARG;
+    if ((n & 3) || (((size_t)part_dev) & 15) || (((size_t)out_dev) & 15)) return DIINN_ERR_INVALID_ARG;
+    const long long n4 = n / 4;
+    if ((n4 + 255) / 256 > 2147483000LL) return DIINN_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n4 + 255) / 256), (unsigned)groups), dim3(256), 0, (hipStream_t)stream,
+                       part_dev, out_dev, nparts, n4);
+    return hip_status(hipGetLastError());
+}
 
 long long diinn_training_plane_floats(long long npix, int rows) {
     if (npix <= 0 || rows <= 0 || npix > DIINN_TRAIN_MAX_PIXELS) return -1;
@@ -583,7 +764,10 @@ int diinn_plane_gemm_nt(void* stream, const float* A_dev, int a_rows, int a_row0
 #ifndef PLANE_GEMM_NB
 #define PLANE_GEMM_NB 4
 #endif
-    if (PLANE_GEMM_NB == 4 && Nc % 256 == 0)
+    const bool a16 = ((((size_t)A_dev) | ((size_t)B_dev)) & 15) == 0;
+    if (PLANE_GEMM_NB == 4 && Nc % 256 == 0 && a16 && knob(diinn_knobs().train_gemm_regs) == 0)
+        hipLaunchKernelGGL(plane_gemm_lds_kernel, dim3((M / 128) * (Nc / 256), ksplit), dim3(256), 0, (hipStream_t)stream, p);
+    else if (PLANE_GEMM_NB == 4 && Nc % 256 == 0)
         hipLaunchKernelGGL(plane_gemm_kernel<4>, dim3((M / 128) * (Nc / 256), ksplit), dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(plane_gemm_kernel<2>, dim3((M / 128) * (Nc / 128), ksplit), dim3(256), 0, (hipStream_t)stream, p);

@@ -82,6 +82,18 @@ def pack_conv_ksplit(weight: torch.Tensor) -> torch.Tensor:
     return w.permute(0, 2, 6, 3, 5, 1, 4).reshape(-1)                               # [half, wave, tap, g, h, i, e]
 
 
+def _winograd_weight(weight: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """U = G W G^T per (output, input) pair, [O, C, 3, 3] -> [O, C, R, R], in ``g``'s dtype as plain broadcast products and sums
+    (left to right, (G W) first: the host packer's order for the decoder's hoisted conv) -- not an einsum, which would run a
+    library GEMM per call (the training step re-packs the input gradient's weight whenever a parameter changed)."""
+    w = weight.detach().to(g.dtype)
+    r = g.shape[0]
+    gi = [g[:, a].view(1, 1, r, 1) for a in range(3)]
+    t = gi[0] * w[:, :, 0:1, :] + gi[1] * w[:, :, 1:2, :] + gi[2] * w[:, :, 2:3, :]          # [O, C, R, 3]
+    gj = [g[:, b].view(1, 1, 1, r) for b in range(3)]
+    return t[..., 0:1] * gj[0] + t[..., 1:2] * gj[1] + t[..., 2:3] * gj[2]                   # [O, C, R, R]
+
+
 def pack_conv_wino(weight: torch.Tensor, dtype: torch.dtype = torch.float64) -> torch.Tensor:
     """3x3 conv weight [64, Cin, 3, 3] (Cin % 8 == 0) -> the Winograd F(2x2, 3x3) image ``diinn_conv_wino`` reads
     (include/diinn_hip.h): U = G W G^T per (output, input) pair, computed in float64 and rounded once, laid out
@@ -92,7 +104,7 @@ def pack_conv_wino(weight: torch.Tensor, dtype: torch.dtype = torch.float64) -> 
         raise ValueError(f"unsupported convolution shape {tuple(weight.shape)}")
     g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=dtype,
                      device=weight.device)                       # on the weight's device: 1.4 s for the trunk on the CPU, ms on the GPU
-    u = torch.einsum("ia,ocab,jb->ocij", g, weight.detach().to(dtype), g).to(torch.float32)
+    u = _winograd_weight(weight, g).to(torch.float32)
     u[..., 2] = -u[..., 2]                                      # the kernel's input transform produces column 2 negated
     u = u.reshape(2, 32, cin // 8, 4, 2, 4, 4)                  # [half, m, chunk, e, h, i, j]
     return u.permute(5, 2, 6, 0, 4, 1, 3).reshape(-1)           # [i, chunk, j, half, h, m, e]
@@ -110,7 +122,7 @@ def pack_conv_wino4(weight: torch.Tensor, dtype: torch.dtype = torch.float64) ->
     if co != 64 or cin % 8 or (kh, kw) != (3, 3):
         raise ValueError(f"unsupported convolution shape {tuple(weight.shape)}")
     g = torch.tensor(_WINO4_G, dtype=dtype, device=weight.device)
-    u = torch.einsum("ia,ocab,jb->ocij", g, weight.detach().to(dtype), g).to(torch.float32)
+    u = _winograd_weight(weight, g).to(torch.float32)
     u = u.reshape(2, 32, cin // 8, 4, 2, 12, 3)                 # [half, m, chunk, e, h, wave, q]
     return u.permute(5, 0, 2, 6, 4, 1, 3).reshape(-1)           # [wave, half, chunk, q, h, m, e]
 

@@ -24,6 +24,7 @@ gather through a permutation index derived once from the host packer (``pack_gat
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -58,6 +59,7 @@ PARAM_SHAPES: Dict[str, Tuple[int, ...]] = {
 # (im2col and two layout copies of 85-151 MB around a 0.42 ms GEMM), so it is available, not the default.
 NATIVE_CONV_DGRAD = True
 NATIVE_CONV_WGRAD = True
+NATIVE_SUM_PARTS = os.environ.get("DIINN_TRAIN_TORCH_SUM") != "1"       # (A/B: torch.sum over the slice axis instead of sum_parts_kernel)
 WGRAD_KSPLIT = 64          # pixel-axis splits of the weight-gradient GEMM: 4 output blocks x 64 = one workgroup per CU
 ROWDOT_SPLITS = 1024       # workgroups of the skinny products (HBM-bound)
 
@@ -301,7 +303,7 @@ def _conv_grads_native(feat: torch.Tensor, wx: torch.Tensor, dp: torch.Tensor, n
         if want_weight:
             _native.check(lib.diinn_plane_gemm_nt(stream, ptr(b_t), 640, 0, ptr(a_t), 4 * HIDDEN, 0, ptr(part), 640, 4 * HIDDEN, n, ks, 0),
                           "diinn_plane_gemm_nt")
-            d_wx = part.sum(0)[:UNFOLD].t()
+            d_wx = _sum_parts(part.view(1, ks, -1)).view(640, 4 * HIDDEN)[:UNFOLD].t()
         if need_feat_grad:
             d_feat = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
             zero = torch.zeros(64, dtype=torch.float32, device=dev)
@@ -420,6 +422,20 @@ def _geometry(b: int, h: int, w: int, hu: int, wu: int, dev) -> dict:
     return geo
 
 
+def _sum_parts(part: torch.Tensor) -> torch.Tensor:
+    """[groups, nparts, n] -> [groups, n]: the split partials of a GEMM / rowdot launch added in slice order (sum_parts_kernel)."""
+    groups, nparts, n = part.shape
+    # (a thread of sum_parts_kernel walks all the slices of its 4 columns: short rows with many slices -- the rowdot partials, 1,024
+    # slices of 1,024 .. 2,048 floats -- would be one or two workgroups in a 1,024-step chain: those stay on torch.sum, 12-25 us)
+    if n % 4 or n < 32768 or not part.is_contiguous() or not NATIVE_SUM_PARTS:
+        return part.sum(1)
+    out = torch.empty((groups, n), dtype=torch.float32, device=part.device)
+    with torch.cuda.device(part.device):
+        _native.check(_native.load().diinn_sum_parts(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(part.data_ptr()),
+                                                     C.c_void_p(out.data_ptr()), groups, nparts, n), "diinn_sum_parts")
+    return out
+
+
 def backward_fused(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tensor, params: Sequence[torch.Tensor],
                    packed: torch.Tensor, size: Sequence[int],
                    need_feat_grad: bool = True) -> Tuple[Optional[torch.Tensor], List[torch.Tensor]]:
@@ -475,10 +491,10 @@ def backward_fused(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tensor, p
         _native.check(lib.diinn_backward_cell_sum_ex(stream, ptr(g), ptr(seg_h), ptr(seg_w), ptr(dp), ptr(a_t) if a_t is not None else None,
                                                      b, h, w, hu, wu), "diinn_backward_cell_sum_ex")
     grads: Dict[str, torch.Tensor] = {}
-    dl = partl.sum(0)                                             # [256, 4]: q_3 . (g_out ; 0)^T
+    dl = _sum_parts(partl.view(1, rsplit, -1)).view(HIDDEN, 4)    # [256, 4]: q_3 . (g_out ; 0)^T
     grads["last_layer.weight"] = dl[:, :3].t().reshape(3, HIDDEN, 1, 1)
     grads["last_layer.bias"] = gp.sum(1)
-    dws = part.sum(1)                                             # [3, 512, 257]: [dWq_i ; dQw_i | bias sums]
+    dws = _sum_parts(part.view(3, ksplit, -1)).view(3, 2 * HIDDEN, HIDDEN + 1)   # [3, 512, 257]: [dWq_i ; dQw_i | bias sums]
     d_wq: List[Optional[torch.Tensor]] = [None] * 4
     d_bk: List[Optional[torch.Tensor]] = [None] * 4
     for i in (3, 2, 1):
@@ -487,7 +503,7 @@ def backward_fused(gout: torch.Tensor, feat: torch.Tensor, acts: torch.Tensor, p
         d_bk[i] = dw[:HIDDEN, HIDDEN]
         grads[f"Q.{i}.0.weight"] = dw[HIDDEN:, :HIDDEN].reshape(HIDDEN, HIDDEN, 1, 1)
         grads[f"Q.{i}.0.bias"] = dw[HIDDEN:, HIDDEN]
-    d0 = part0.sum(0)                                             # [512, 4]: (g_a,0 ; g_s,0) . (rel_h, rel_w, ratio, 1)^T
+    d0 = _sum_parts(part0.view(1, rsplit, -1)).view(2 * HIDDEN, 4)   # [512, 4]: (g_a,0 ; g_s,0) . (rel_h, rel_w, ratio, 1)^T
     d_bk[0] = d0[:HIDDEN, 3]
     grads["Q.0.0.weight"] = d0[HIDDEN:, :3].reshape(HIDDEN, 3, 1, 1)
     grads["Q.0.0.bias"] = d0[HIDDEN:, 3]
