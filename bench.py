@@ -713,10 +713,46 @@ def whole_model_leg(device, steps=5, warmup=2, lr=256, scale=4):
     leg = {"workload": f"DIINN.forward: RDN encoder + implicit decoder, {lr}x{lr} LR x{scale} ({size[0]}x{size[1]}), B = 1, random-init weights",
            "steps": steps, "warmup": warmup, "forward_ms": round(fwd, 3), "encoder_ms": round(enc, 3), "decoder_ms": round(dec, 3),
            "finite": bool(torch.isfinite(out).all()),
+           "handoff_gave_up": int(M.RDN.handoff_status(clear=False)),     # the F(4x4) split hand-off's sticky status (0: never gave up)
            "encoder_3x3_layers": ("Winograd F(4x4,3x3)" if net.encoder.hip_winograd4 and N.load().diinn_rdn_wino4_applies(1, lr, lr)
                                   else "Winograd F(2x2,3x3)" if lr * lr >= 8192 else "direct, split-K"),
            "note": "parity of this path: tests/test_modules.py (reference DIINN fixture), tests/test_encoder_trunk.py (the real reference's encoder)"}
     del net, x, feat, out
+    torch.cuda.empty_cache()
+    return leg
+
+
+def training_leg(device, steps=5, warmup=2, b=16, lr=48, scale=4):
+    """Informational, never part of `value`: one training step of the DECODER (reference: sr_module.py:127-137 calls
+    forward with grad and bsize=None) at the reference's training geometry (configs/default.yaml: batch 16, 48 x 48 LR patches, scales
+    2-4): forward with saved planes + backward, every kernel the library's own (no library convolution or GEMM), in ms."""
+    import diinn_amd.decoder as D
+    import diinn_amd.synth as synth
+    dec = D.ImplicitDecoder(mode=3, init_q=False)
+    dec.load_state_dict({k: torch.from_numpy(v) for k, v in synth.decoder_state_dict(123).items()})
+    dec = dec.to(device).train()
+    feat = torch.from_numpy(synth.encoder_features(123, b, lr, lr)).to(device).requires_grad_(True)
+    hu = wu = lr * scale
+    r = torch.randn(b, 3, hu, wu, device=device)
+
+    def step():
+        dec.zero_grad(set_to_none=True)
+        feat.grad = None
+        (dec(feat, [hu, wu]) * r).sum().backward()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(device)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    ok = bool(torch.isfinite(feat.grad).all()) and all(bool(torch.isfinite(p.grad).all()) for p in dec.parameters())
+    leg = {"workload": f"decoder training step (forward with saved planes + backward), B = {b}, {lr}x{lr} LR x{scale} ({hu}x{wu}): "
+                       f"{b * hu * wu} HR pixels", "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3),
+           "mpix_s": round(b * hu * wu / ms / 1e3, 2), "finite_grads": ok,
+           "note": "gradient parity: tests/test_training.py (fixtures from the real reference's autograd); kernel times: profiles/r06_train_kernel_stats.csv"}
+    del dec, feat, r
     torch.cuda.empty_cache()
     return leg
 
@@ -802,6 +838,7 @@ def main():
             # the reference's own timing protocol (runtime_test.py: a 48 x 48 crop) at x2 and x4: encoder-bound
             whole["small_inputs"] = [whole_model_leg(job.dev, steps=20, warmup=5, lr=48, scale=2),
                                      whole_model_leg(job.dev, steps=20, warmup=5, lr=48, scale=4)]
+            whole["training_step"] = training_leg(job.dev)
         except Exception as e:                                   # informational leg: report, do not lose the line
             whole = {"error": f"{type(e).__name__}: {e}"}
 

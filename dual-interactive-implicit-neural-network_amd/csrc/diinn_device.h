@@ -194,6 +194,15 @@ __device__ __forceinline__ f32x4 ld_piece(__amdgpu_buffer_rsrc_t rsrc, int lane_
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, WSTREAM_AUX));
 }
 constexpr int PIECE_BYTES = (int)(WL_PIECE * sizeof(float));
+// L2 warm-up touch: one dword per lane from (descriptor base + voff), deposited by LDS-DMA into a dead 256-byte LDS area of the wave.
+// There is NO destination register, so a late arrival has nothing to overwrite.  (Rounds 2-5 issued these loads from inline asm into
+// registers: the compiler takes an asm output for written AT the statement and is free to copy it out and reuse the register while
+// the load is still in flight.  It did, once an unrelated edit of round 6 changed precompute_P_wino_kernel's allocation -- the fourth
+// load's destination became the patch loads' offset register: P came out wrong and different from run to run on maps that warm up.
+// cdna_hip_programming.md 5.7: what hipcc does not do for an asm statement.)
+__device__ __forceinline__ void l2_touch(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, float* sink_wave) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)sink_wave, 4, (int)voff, 0, 0, 0);
+}
 constexpr int WG_TILES_X = 2, WG_TILES_Y = 2;   // 4 waves -> 16x8 HR pixels per workgroup
 
 // KPART = false (decoder modes 1 and 2, diinn.py:116-131): the modulation chain k_i depends on the LR

@@ -47,21 +47,22 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
     // P through every L2, so the 2.25 MiB weight image is gone; all waves of an XCD then walk it in lock-step and
     // the whole first round of workgroups advances at HBM-latency pace (67 % MFMA utilisation at c2 against 80 % warm).
     // Every workgroup touches a slice of the image first so the fills run while the feature tile is staged.  The
-    // loaded values are dead; their registers stay reserved until the staging loop's waits have drained them.
-    float warm[4];
+    // loaded values are dead: they go to a dead LDS area by LDS-DMA (round 6: l2_touch, diinn_device.h, says why not to registers).
+    __shared__ float warm_sink[4][64];
     {
         const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
         const unsigned wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         const unsigned per_xcd = (nwg + 7) / 8, slot = wg >> 3;      // workgroups are dealt to the 8 XCDs round-robin
         constexpr unsigned LINES = (unsigned)(SZ_WP * sizeof(float) / 128);   // 128-byte lines of the WP image
         const unsigned share = (LINES + per_xcd - 1) / per_xcd;       // lines this workgroup touches (at most 1024)
-        const char* wpb = (const char*)(p.Wt + OFF_WP);
+        const __amdgpu_buffer_rsrc_t wpb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Wt + OFF_WP), 0, (int)(SZ_WP * sizeof(float)), 0x00020000);
+        float* sink = warm_sink[__builtin_amdgcn_readfirstlane(wave)];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned k = threadIdx.x + 256 * i;
             unsigned line = slot * share + k;
             line = (k < share && line < LINES) ? line : 0;            // surplus lanes re-touch line 0
-            asm volatile("global_load_dword %0, %1, off" : "=v"(warm[i]) : "v"(wpb + (size_t)line * 128) : "memory");
+            l2_touch(wpb, line * 128u, sink);
         }
     }
 
@@ -87,7 +88,6 @@ __global__ __launch_bounds__(256, 2) void precompute_P_kernel(const PParams p) {
         const float v = fb[((size_t)c * p.Frows + yc) * p.W + xc];
         tile[idx] = ok ? v : 0.0f;
     }
-    asm volatile("s_waitcnt vmcnt(0)" :: "v"(warm[0]), "v"(warm[1]), "v"(warm[2]), "v"(warm[3]) : "memory");
     __syncthreads();
 
     const int x = x0 + j, y = y0 + wave;

@@ -45,8 +45,7 @@ constexpr int PWN_MT_BYTES = 4 * 8 * 4 * PIECE_BYTES;            // bytes of WPU
 #define PWN_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <bool EDGE>
-__device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, float* __restrict__ zs, int b, int tx0, int ty0, int mt0, int mtn,
-                                                       const float (&warm)[4]) {
+__device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, float* __restrict__ zs, int b, int tx0, int ty0, int mt0, int mtn) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = row i of the transformed tile
     const int h = lane >> 5, m = lane & 31;
@@ -102,7 +101,6 @@ __device__ __forceinline__ void precompute_P_wino_body(const PWinoParams& p, flo
         }
     }
 
-    asm volatile("" :: "v"(warm[0]), "v"(warm[1]), "v"(warm[2]), "v"(warm[3]));   // the warm-up loads are older than the patch rows just waited for
     // ---- output side: wave = output row pr of the 2x2 block and tile half th; store group k, lane L: cell n = 8k + (L >> 3)
     // of the wave's 32 cells (tile 16 th + (n >> 1), column q = n & 1), chunk c = L & 7 (channels 4c .. 4c+3 of the M-tile)
     const int pr = wave & 1, th = wave >> 1;
@@ -265,20 +263,22 @@ __global__ __launch_bounds__(256, 1) void precompute_P_wino_kernel(const PWinoPa
     // round touches its share of the section's 128-byte lines first; the values are dead.  In the c2 step: 0.325 ->
     // 0.293 ms (same box, A/B); c5: neutral; on maps whose whole working set stays in the L2s (c1: +1.6 us on 26) it is
     // pure overhead, so the host switches it on from 8,192 cells (a P image of 32 MiB = the eight L2s) on.
-    float warm[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // (round 6: the touches are LDS-DMA loads into a dead LDS area -- l2_touch, diinn_device.h, says why not registers)
+    __shared__ float warm_sink[4][64];
     {
         const unsigned slot = blockIdx.x >> 3;                   // this workgroup's index inside its XCD
         const unsigned first = (unsigned)per_xcd < 32u ? (unsigned)per_xcd : 32u;   // workgroups of an XCD's first round (one per CU)
         constexpr unsigned LINES = (unsigned)(SZ_WPU * sizeof(float) / 128);
         const unsigned share = (LINES + first - 1) / first;      // <= 1024 once 32 workgroups share the section
         if (p.warm_l2 && slot < first) {
-            const char* wpu = (const char*)(p.Wt + OFF_WPU);
+            const __amdgpu_buffer_rsrc_t wpu = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Wt + OFF_WPU), 0, (int)(SZ_WPU * sizeof(float)), 0x00020000);
+            float* sink = warm_sink[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned k = threadIdx.x + 256 * i;
                 unsigned line = slot * share + k;
                 line = (k < share && line < LINES) ? line : 0;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(warm[i]) : "v"(wpu + (size_t)line * 128) : "memory");
+                l2_touch(wpu, line * 128u, sink);
             }
         }
     }
@@ -290,8 +290,8 @@ __global__ __launch_bounds__(256, 1) void precompute_P_wino_kernel(const PWinoPa
     const int by = __builtin_amdgcn_readfirstlane(t / p.bx_n), bx = t - by * p.bx_n;
     const int tx0 = bx * PWN_TX, ty0 = p.ty_first + by * PWN_TY;
     const bool edge = tx0 == 0 || 2 * (tx0 + PWN_TX - 1) + 2 >= p.W;
-    if (edge) precompute_P_wino_body<true>(p, zs, b, tx0, ty0, mt0, mtn, warm);
-    else      precompute_P_wino_body<false>(p, zs, b, tx0, ty0, mt0, mtn, warm);
+    if (edge) precompute_P_wino_body<true>(p, zs, b, tx0, ty0, mt0, mtn);
+    else      precompute_P_wino_body<false>(p, zs, b, tx0, ty0, mt0, mtn);
 }
 
 // Winograd form of launch_P for the fp32 hoisted convolution of all 1024 channels (diinn_precompute.hip decides when)

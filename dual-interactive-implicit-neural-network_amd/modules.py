@@ -240,6 +240,7 @@ class RDN(nn.Module):
     # share slabs or tickets.  Class-wide: every RDN of the process on that (device, stream) may use it (launches on one
     # stream are ordered).
     _w4_areas: dict = {}
+    _W4_AREAS_MAX = 16
 
     @classmethod
     def _w4_area(cls, device):
@@ -254,6 +255,8 @@ class RDN(nn.Module):
         key = (str(device), torch.cuda.current_stream(device).cuda_stream)
         ws = cls._w4_areas.get(key)
         if ws is None:
+            while len(cls._w4_areas) >= cls._W4_AREAS_MAX:       # streams come and go: the oldest area goes with them
+                cls._w4_areas.pop(next(iter(cls._w4_areas)))
             ws = torch.empty(floats, dtype=torch.float32, device=device)
             ws[:1024].zero_()                                 # the control words, once (a forward re-zeroes only the counters)
             cls._w4_areas[key] = ws

@@ -123,14 +123,25 @@ def encoder_features(seed: int, b: int, h: int, w: int, tag: str = "feat") -> np
     return normalish(seed, f"{tag}:{b}x{h}x{w}", (b, IN_CHANNELS, h, w))
 
 
-def state_dict_for(shapes, seed: int = 123, prefix: str = "", gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+def layer_gain(gain_seed: int, layer: str) -> float:
+    """A per-LAYER gain 2^u, u ~ U(-0.6, 1.0) (0.66 .. 2.0), keyed by (gain_seed, layer name): a trained network has gains of its
+    own in every layer, a uniformly scaled default init has not (round 6 fixtures: tests/golden/make_golden_r6.py)."""
+    u = float(uniform(gain_seed, "layer_gain:" + layer, (1,), 0.8)[0]) + 0.2
+    return float(2.0 ** u)
+
+
+def state_dict_for(shapes, seed: int = 123, prefix: str = "", gain: float = 1.0,
+                   layer_gain_seed=None) -> "OrderedDict[str, np.ndarray]":
     """Synthetic tensors for any conv-style module given ``{name: shape}`` (names ending in
-    ``.weight``/``.bias``): U(+-gain/sqrt(fan_in)) with fan_in taken from the sibling weight."""
+    ``.weight``/``.bias``): U(+-gain/sqrt(fan_in)) with fan_in taken from the sibling weight; ``layer_gain_seed``: every
+    layer's weight and bias additionally scaled by ``layer_gain(layer_gain_seed, layer)``."""
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     for name, shape in shapes.items():
         shape = tuple(int(x) for x in shape)
-        wname = name.rsplit(".", 1)[0] + ".weight"
+        layer = name.rsplit(".", 1)[0]
+        wname = layer + ".weight"
         wshape = tuple(int(x) for x in shapes.get(wname, shape))
         fan_in = int(np.prod(wshape[1:])) if len(wshape) > 1 else 1
-        out[name] = uniform(seed, prefix + name, shape, gain / math.sqrt(max(fan_in, 1)))
+        g = gain * (layer_gain(layer_gain_seed, prefix + layer) if layer_gain_seed is not None else 1.0)
+        out[name] = uniform(seed, prefix + name, shape, g / math.sqrt(max(fan_in, 1)))
     return out

@@ -163,6 +163,7 @@ def test_one_rank_torchrun_constructs_the_rccl_path():
     assert whole["finite"] and 0 < whole["decoder_ms"] < whole["forward_ms"] and 0 < whole["encoder_ms"] < whole["forward_ms"]
     assert [leg["workload"].split(",")[1].strip() for leg in whole["small_inputs"]] == ["48x48 LR x2 (96x96)", "48x48 LR x4 (192x192)"]
     assert all(leg["finite"] and leg["forward_ms"] > 0 for leg in whole["small_inputs"])
+    assert whole["handoff_gave_up"] == 0 and whole["training_step"]["finite_grads"] and 0 < whole["training_step"]["ms_per_step"] < 100
     assert res["roofline"]["kernel"] == "decode_kernel"          # c2: the throughput kernel (the library's own answer)
     legs = {(leg["name"], leg["compute"]): leg for leg in res["side_legs"]}
     assert legs[("c1", "f32")]["kernel"] == "decode_coop16_kernel" and legs[("c5", "bf16")]["checked"]["ok"]

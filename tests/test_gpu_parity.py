@@ -926,10 +926,11 @@ def test_nonfinite_weights_propagate_like_the_reference(dev):
 
 
 def test_image_without_derived_sections_is_refused(dev):
-    """the gather-packed image of a training step has empty derived sections (WPU, WLR, BQR, Q0R, WLB, WPB)
-    and a zero validity word.  The inference entry points read those sections; handed such an image they answer NaN
-    everywhere instead of decoding with empty weights (the launch functions cannot look into device memory).  The
-    entry points of the training path accept the same image."""
+    """the gather-packed image of a training step has empty derived sections (WLR, BQR, Q0R, WLB, WPB, ...) and
+    no DIINN_PACKED_MAGIC: its validity word is zero, or -- round 6, once its Winograd section 13 has been derived on the device
+    for the training forward's P -- DIINN_PACKED_MAGIC_WPU, which only diinn_precompute_P_wpu accepts.  The inference entry
+    points read the other derived sections; handed such an image they answer NaN everywhere instead of decoding with empty
+    weights (the launch functions cannot look into device memory).  The entry points of the training path accept the same image."""
     import ctypes as C
     import diinn_amd._native as N
     import diinn_amd.decoder as D
@@ -942,7 +943,7 @@ def test_image_without_derived_sections_is_refused(dev):
     off, size = C.c_size_t(), C.c_size_t()
     N.check(lib.diinn_packed_section(6, C.byref(off), C.byref(size)), "section")
     word = off.value + 3
-    assert gathered[word].item() == 0.0
+    assert gathered[word:word + 1].view(torch.int32).item() == (N.PACKED_MAGIC_WPU if T.TRAIN_P_WINOGRAD else 0)
     assert host[word:word + 1].view(torch.int32).item() == N.PACKED_MAGIC
     feat = torch.from_numpy(synth.encoder_features(5, 1, 24, 20)).to(dev)
     good = D.decode_features(feat, host, (79, 66))
@@ -967,3 +968,17 @@ def test_image_without_derived_sections_is_refused(dev):
                                    C.c_void_p(Pg.data_ptr()), 1, 24, 20, 0, 24), "P")
     torch.cuda.synchronize()
     assert bool(torch.isfinite(P).all()) and torch.equal(P, Pg)
+    # ... and the Winograd entry point of the training forward takes either image, bit-identically (the device-derived section 13
+    # equals the host packer's); an image with neither word: NaN
+    Pw, Pwh = torch.empty_like(P), torch.empty_like(P)
+    N.check(lib.diinn_precompute_P_wpu(stream, C.c_void_p(feat.data_ptr()), C.c_void_p(gathered.data_ptr()),
+                                       C.c_void_p(Pw.data_ptr()), 1, 24, 20, 0, 24), "P_wpu")
+    N.check(lib.diinn_precompute_P_wpu(stream, C.c_void_p(feat.data_ptr()), C.c_void_p(host.data_ptr()),
+                                       C.c_void_p(Pwh.data_ptr()), 1, 24, 20, 0, 24), "P_wpu")
+    blank = gathered.clone()
+    blank[word] = 0.0
+    N.check(lib.diinn_precompute_P_wpu(stream, C.c_void_p(feat.data_ptr()), C.c_void_p(blank.data_ptr()),
+                                       C.c_void_p(Pg.data_ptr()), 1, 24, 20, 0, 24), "P_wpu")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(Pw).all()) and torch.equal(Pw, Pwh) and bool(torch.isnan(Pg).all())
+    assert float((Pw - P).abs().max()) <= 1e-5 * max(1.0, float(P.abs().max()))      # Winograd vs direct: reassociation
