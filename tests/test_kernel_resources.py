@@ -107,3 +107,32 @@ def test_no_shipped_kernel_uses_scratch_and_occupancy_is_as_designed(tmp_path):
             bad.append(f"{k['.name']}: occupancy {occupancy(k)} waves/SIMD < designed {need} "
                        f"({k['.vgpr_count']} registers, {k['.group_segment_fixed_size']} B LDS)")
     assert not bad, "\n".join(bad)
+
+
+def test_no_inline_asm_statement_has_an_asynchronous_output():
+    """Source gate (round 6): an asm statement whose OUTPUT operand is written by an asynchronous instruction -- a vector / scalar
+    memory load or an LDS read -- is a latent corruption: hipcc takes the output for written at the statement and may copy it out
+    and reuse the register while the load is in flight (cdna_hip_programming.md 5.7).  The P kernels' L2 warm-up touches were such
+    statements for four rounds and went wrong the day an unrelated edit changed the register allocation.  Loads
+    belong in builtins the compiler counts in vmcnt / lgkmcnt; the one exception is a statement that waits for its own result
+    inside the statement (the s_memtime / s_memrealtime stamps: "... s_waitcnt lgkmcnt(0)")."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    srcs = sorted(glob.glob(os.path.join(root, "dual-interactive-implicit-neural-network_amd", "csrc", "*")))
+    assert len(srcs) >= 15
+    asynchronous = re.compile(r"\b(global_load|buffer_load|flat_load|scratch_load|ds_read|ds_load|s_load|s_buffer_load|s_memtime|s_memrealtime|global_atomic|buffer_atomic)")
+    bad = []
+    for path in srcs:
+        text = open(path).read()
+        for m in re.finditer(r"asm\s+volatile\s*\((.*?)\)\s*;", text, flags=re.S):
+            stmt = m.group(1)
+            parts = stmt.split(":")
+            code = parts[0]
+            outputs = parts[1].strip() if len(parts) > 1 else ""
+            if not outputs or not asynchronous.search(code):
+                continue
+            if re.search(r"s_mem(real)?time", code) and "s_waitcnt lgkmcnt(0)" in code and not re.search(r"(global|buffer|flat|ds)_", code):
+                continue                                         # waits for its own result inside the statement
+            bad.append((os.path.basename(path), text[:m.start()].count("\n") + 1, " ".join(code.split())[:80]))
+    assert not bad, bad

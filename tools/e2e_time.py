@@ -41,7 +41,7 @@ for lr, s in ((48, 2), (128, 4), (256, 4), (512, 4)):
         te33 = t_ms(lambda: net(x, (lr * s, lr * s), 30000))
         enc.hip_split_bf16 = False
         net.decoder.compute = "f32"
-    print(f"LR {lr}x{lr} x{s}: encoder HIP trunk {t_hip:.2f} ms ({43.9e6*lr*lr/t_hip/1e9:.1f} TFLOP/s) | MIOpen {t_mi:.2f} ms; "
+    print(f"LR {lr}x{lr} x{s}: encoder HIP trunk {t_hip:.2f} ms ({43.9e6*lr*lr/t_hip/1e9:.1f} direct-conv-equivalent TFLOP/s: a speed figure -- the Winograd layers issue 4/9 or 1/4 of these FLOPs) | MIOpen {t_mi:.2f} ms; "
           f"decoder {td:.2f} ms; whole model eager {te:.2f} ms, hipGraph {tg:.2f} ms; "
           f"with the split-bf16 decoder: decoder {td3:.2f} ms, whole model {te3:.2f} ms; "
           f"with split-bf16 3x3 encoder layers too: encoder {t_hip3:.2f} ms, whole model {te33:.2f} ms", flush=True)
