@@ -149,7 +149,10 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
 #pragma unroll
     for (int kg = 0; kg < BLD; ++kg) load_group(kg);
 
-    constexpr int PF = DECODE_PREFETCH;
+#ifndef BWD_PREFETCH
+#define BWD_PREFETCH DECODE_PREFETCH
+#endif
+    constexpr int PF = BWD_PREFETCH;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);   // reads past the end return 0
     const int lane_off = lane * 16;
