@@ -16,7 +16,7 @@
 //                         <KPART=false>: decoder modes 1/2 (with cell_chain_kernel);
 //                         <SAVE>: training forward, also writes k_i, s_i as tiled planes
 //   decode_bf16_kernel, decode_bf16x2_kernel : bf16 operands in layers 1..3 (optional paths)
-//   bwd_head_kernel, bwd_layer_kernel, plane_gemm_kernel, plane_rowdot_kernel, cell_sum_kernel :
+//   bwd_layer_kernel (+ bwd_head_kernel), plane_gemm_lds_kernel, plane_rowdot_kernel, cell_sum_kernel :
 //                         backward pass of the decoder (training)
 //   liif_kernel; unfold_cells_kernel + metasr_kernel : the LIIF and MetaSR comparison decoders
 //   axis_tables_kernel, sin_kernel : the device coordinate / sine code, exposed for tests.

@@ -37,7 +37,6 @@ const KnobDef KNOBS[] = {
     {"DIINN_DEBUG_NCU", &DiinnKnobs::debug_ncu, 0, false},
     {"DIINN_ENC_WINO4_FAULT", &DiinnKnobs::enc_wino4_fault, 0, false},
     {"DIINN_TRAIN_SPLIT_HEAD", &DiinnKnobs::train_split_head, 0, false},
-    {"DIINN_TRAIN_GEMM_REGS", &DiinnKnobs::train_gemm_regs, 0, false},
 };
 }  // namespace
 

@@ -15,7 +15,7 @@
 //                    (the rows are read in accumulator order, so no shuffle is needed), streams the
 //                    transposed weights (WLT section) exactly like the forward kernel streams WL, and
 //                    its epilogue applies the gates of layer i-1 and writes G_{i-1} and q_{i-1}.
-// plane_gemm_kernel / plane_rowdot_kernel : the parameter gradients, GEMMs over the pixel axis of the
+// plane_gemm_lds_kernel / plane_rowdot_kernel : the parameter gradients, GEMMs over the pixel axis of the
 //                    planes written here (dW_i = G_i q_{i-1}^T ...).
 // All planes are tiled (see PLANE_TILE above): acts, G [4][ntiles][512][32]; Q [4][ntiles][256][32].
 // ---------------------------------------------------------------------------------
@@ -149,10 +149,7 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
 #pragma unroll
     for (int kg = 0; kg < BLD; ++kg) load_group(kg);
 
-#ifndef BWD_PREFETCH
-#define BWD_PREFETCH DECODE_PREFETCH
-#endif
-    constexpr int PF = BWD_PREFETCH;
+    constexpr int PF = DECODE_PREFETCH;                          // (a ring of 8 or 16 steps: no change, 14.65-14.76 ms -- round 6)
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.Wt, 0, (int)(PACKED_FLOATS * sizeof(float)), 0x00020000);   // reads past the end return 0
     const int lane_off = lane * 16;
@@ -335,16 +332,15 @@ __global__ __launch_bounds__(256) void unfold_tiled_kernel(const UnfoldTiledPara
 }
 
 // ---------------------------------------------------------------------------------
-// plane_gemm_kernel (training backward, weight gradients): C[M x Nc] = A[M x npix] . B[Nc x npix]^T, A and B
-// being rows [a_row0, a_row0+M) / [b_row0, b_row0+Nc) of tiled plane groups, i.e. a GEMM whose reduction
-// axis is the pixel axis.  Split-K: workgroup (block, ks) reduces the plane tiles of chunk ks for a
-// 128 x 256 output block and writes its partial product to part[ks]; the caller adds the ksplit
-// partials (fixed order, no atomics).  4 waves = 2 (M) x 2 (N), wave tile 64 x 128 = 2 x 4 MFMA tiles
-// (128 accumulator registers).  Operand fragments go global -> registers directly: with tiled planes a
-// 32-row x 32-pixel MFMA panel is one contiguous 4 KiB block; lane (row = l&31, half = l>>5) reads
-// 16 bytes of its row per load, four loads cover the row's whole 128-byte line.  The MFMA k-pair
-// (pixel e, pixel 4+e) is the same for A and B, and the sum over pixels does not care about the order.
-// Optional extra column Nc: row sums of A (bias gradients).
+// plane GEMM (training backward, weight gradients): C[M x Nc] = A[M x npix] . B[Nc x npix]^T, A and B being rows
+// [a_row0, a_row0+M) / [b_row0, b_row0+Nc) of tiled plane groups, i.e. a GEMM whose reduction axis is the pixel axis.
+// Split-K: workgroup (block, ks) reduces the plane tiles of chunk ks for a 128 x 256 output block and writes its partial
+// product to part[ks]; the caller adds the ksplit partials (sum_parts_kernel: fixed order, no atomics).  4 waves = 2 (M) x 2 (N),
+// wave tile 64 x 128 = 2 x 4 MFMA tiles (128 accumulator registers).  With tiled planes a 32-row x 32-pixel MFMA panel is one
+// contiguous 4 KiB block; the MFMA k-pair (pixel e, pixel 4+e) is the same for A and B, and the sum over pixels does not care
+// about the order.  Optional extra column Nc: row sums of A (bias gradients).
+// (Rounds 1-5 streamed the operands global -> registers per wave, plane_gemm_kernel<NB>: 110 TFLOP/s; deleted in round 6 for
+// the LDS-staged kernel below -- profiles/r06_train.txt has the comparison and the timing ablations.)
 // ---------------------------------------------------------------------------------
 struct PlaneGemmParams {
     const float* A;          // tiled group, a_rows rows per tile; rows [a_row0, a_row0 + M) are used
@@ -355,118 +351,9 @@ struct PlaneGemmParams {
     int M, Nc, ldc, tiles_per_split, with_rowsum;
 };
 
-template <int NB>
-__global__ __launch_bounds__(256, 1) void plane_gemm_kernel(const PlaneGemmParams p) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = lane >> 5, j = lane & 31;
-    constexpr int WGN = 2 * NB * 32;                          // output columns per workgroup
-    const int nblk = p.Nc / WGN;
-    const int m0 = (blockIdx.x / nblk) * 128 + (wave & 1) * 64;
-    const int n0 = (blockIdx.x % nblk) * WGN + (wave >> 1) * (NB * 32);
-    const int ks = blockIdx.y;
-    const long long ntiles = (p.npix + PLANE_TILE - 1) / PLANE_TILE;
-    const long long t0 = (long long)ks * p.tiles_per_split;
-    long long t1 = t0 + p.tiles_per_split;
-    if (t1 > ntiles) t1 = ntiles;
-    const int nt = t1 > t0 ? (int)(t1 - t0) : 0;                 // tiles this workgroup reduces
-
-    // descriptors start at this split's first tile (offsets inside a split stay far below 4 GiB)
-    const unsigned a_pitch = (unsigned)p.a_rows * PLANE_ROW_BYTES, b_pitch = (unsigned)p.b_rows * PLANE_ROW_BYTES;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.A + ((size_t)t0 * p.a_rows + p.a_row0 + m0) * PLANE_TILE), 0, (int)(nt * a_pitch), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.Bm + ((size_t)t0 * p.b_rows + p.b_row0 + n0) * PLANE_TILE), 0, (int)(nt * b_pitch), 0x00020000);
-    const unsigned voff = (unsigned)j * PLANE_ROW_BYTES + 16u * h;
-    constexpr unsigned MFMA_ROWS = 32u * PLANE_ROW_BYTES;        // one 32-row MFMA panel: 4 KiB
-
-    f32x16 acc[2][NB];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    float rs[2] = {0.0f, 0.0f};
-
-    // Round 6: ONE tile of operands in registers (96), refilled piece by piece.  The round-5 form held two whole tiles (192
-    // registers beside 128 accumulators): hipcc staged the second tile through AGPRs -- 715 v_accvgpr_read / _write per 256 MFMAs
-    // -- and SLP-packed the row sums into v_pk_add_f32 behind v_movs: 3 VALU instructions per MFMA on a chip whose fp32 MFMA
-    // and VALU share one pipe (PMC: SQ_INSTS_VALU 9.4e7 against SQ_INSTS_MFMA 3.1e7).  Now a quarter tile (8 pixels: the 16-byte
-    // piece q of every row) is reloaded for the NEXT tile as soon as its 32 MFMAs have been issued, i.e. three quarters
-    // (96 MFMAs, ~6,000 cycles) ahead of its use, and the row sums are taken only by the waves that store them.
-    f32x4 fa[2][4], fb[NB][4];                                    // [panel][q]: 4 pixels each
-    const bool sums = p.with_rowsum && n0 == 0;                  // wave-uniform
-    auto load_q = [&](int q, int t) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-            fa[a][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                ra, (int)voff, (int)(t * a_pitch + a * MFMA_ROWS + 32u * q), 0));
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-            fb[b][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                rb, (int)voff, (int)(t * b_pitch + b * MFMA_ROWS + 32u * q), 0));
-    };
-    auto compute_q = [&](int q, int t) {
-        const long long pix0 = (t0 + t) * PLANE_TILE;
-        if (pix0 + PLANE_TILE > p.npix) {                        // ragged last tile: its padding was never written
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool in = pix0 + 8 * q + 4 * h + e < p.npix;
-#pragma unroll
-                for (int a = 0; a < 2; ++a) fa[a][q][e] = in ? fa[a][q][e] : 0.0f;
-#pragma unroll
-                for (int b = 0; b < NB; ++b) fb[b][q][e] = in ? fb[b][q][e] : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < NB; ++b) acc[a][b] = MFMA32(fa[a][q][e], fb[b][q][e], acc[a][b]);
-        if (sums) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a) rs[a] += (fa[a][q][0] + fa[a][q][1]) + (fa[a][q][2] + fa[a][q][3]);
-        }
-    };
-
-    if (nt > 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) load_q(q, 0);
-        for (int t = 0; t < nt; ++t) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                compute_q(q, t);
-                __builtin_amdgcn_sched_barrier(0);               // the refill goes out HERE: behind the MFMAs that read these registers,
-                if (t + 1 < nt) load_q(q, t + 1);                // not hoisted in front of them into a second set
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-
-    float* __restrict__ dst = p.part + (size_t)ks * p.M * p.ldc;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
-                dst[(size_t)row * p.ldc + n0 + 32 * b + j] = acc[a][b][r];
-            }
-    if (p.with_rowsum && n0 == 0) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const float v = rs[a] + __shfl_xor(rs[a], 32);
-            if (h == 0) dst[(size_t)(m0 + 32 * a + j) * p.ldc + p.Nc] = v;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------
-// plane_gemm_lds_kernel (round 6; the 128 x 256 block form): the same product with the operands staged through LDS.
-// What bounded plane_gemm_kernel<4> at 0.72 of the fp32 peak (PMC: MfmaUtil 76 % at 2.26 GHz) was how its operands arrive: every
+// plane_gemm_lds_kernel: the product above with the operands staged through LDS.
+// What bounded the register-streaming kernel at 0.72 of the fp32 peak (PMC: MfmaUtil 76 % at 2.26 GHz) was how its operands arrive: every
 // wave fetched its own 64 x 32 and 128 x 32 panels with loads that touch 32 different 128-byte lines per instruction, 32 bytes
 // of each (an MFMA fragment is a COLUMN of the row-major panel), twice per workgroup (two waves share every panel), held in 192
 // registers beside the 128 accumulators (3 VALU instructions per MFMA of AGPR staging); with the loads re-ordered to hold one
@@ -609,7 +496,7 @@ __global__ __launch_bounds__(256, 1) void plane_gemm_lds_kernel(const PlaneGemmP
 // with A rows of a tiled group (M = 256 or 512) and S a tiled 4-row group.  Used for
 //   layer 0: (g_a,0 ; g_s,0) . (rel_h, rel_w, ratio, 1)^T  -> dbK_0, dQ0, dbQ0          (diinn.py:133-134,165-167)
 //   head   : q_3 . (g_out0, g_out1, g_out2, 0)^T            -> d last_layer.weight      (diinn.py:138)
-// HBM-bound (reads A once); split over the tiles like plane_gemm_kernel, partials added by the caller.
+// HBM-bound (reads A once); split over the tiles like the plane GEMM, partials added by the caller.
 // ---------------------------------------------------------------------------------
 struct RowDotParams {
     const float* A;          // tiled, a_rows per tile, rows [0, M)
@@ -751,7 +638,8 @@ int diinn_plane_gemm_nt(void* stream, const float* A_dev, int a_rows, int a_row0
         return DIINN_ERR_INVALID_ARG;
     const int stp = check_npix(npix);
     if (stp) return stp;
-    if (M % 128 || Nc % 128) return DIINN_ERR_UNSUPPORTED;
+    if (M % 128 || Nc % 256) return DIINN_ERR_UNSUPPORTED;
+    if ((((size_t)A_dev) | ((size_t)B_dev)) & 15) return DIINN_ERR_INVALID_ARG;          // the tiles are copied in 16-byte pieces
     if (ksplit > 65535) return DIINN_ERR_TOO_LARGE;
     PlaneGemmParams p;
     p.A = A_dev; p.Bm = B_dev; p.part = part_dev; p.npix = npix;
@@ -764,16 +652,7 @@ int diinn_plane_gemm_nt(void* stream, const float* A_dev, int a_rows, int a_row0
     // offsets inside one split are 32-bit: tiles_per_split * rows * 128 bytes must stay below 2 GiB
     if (per * (long long)(a_rows > b_rows ? a_rows : b_rows) * PLANE_ROW_BYTES >= 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;
     p.tiles_per_split = (int)per;
-#ifndef PLANE_GEMM_NB
-#define PLANE_GEMM_NB 4
-#endif
-    const bool a16 = ((((size_t)A_dev) | ((size_t)B_dev)) & 15) == 0;
-    if (PLANE_GEMM_NB == 4 && Nc % 256 == 0 && a16 && knob(diinn_knobs().train_gemm_regs) == 0)
-        hipLaunchKernelGGL(plane_gemm_lds_kernel, dim3((M / 128) * (Nc / 256), ksplit), dim3(256), 0, (hipStream_t)stream, p);
-    else if (PLANE_GEMM_NB == 4 && Nc % 256 == 0)
-        hipLaunchKernelGGL(plane_gemm_kernel<4>, dim3((M / 128) * (Nc / 256), ksplit), dim3(256), 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(plane_gemm_kernel<2>, dim3((M / 128) * (Nc / 128), ksplit), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(plane_gemm_lds_kernel, dim3((M / 128) * (Nc / 256), ksplit), dim3(256), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
 

@@ -11,7 +11,7 @@ records ~30 ATen ops per call on the materialised [B,576,Hu,Wu] tensor.  Here:
             g_q[i-1] = Wq_i^T g_a + Qw_i^T g_s) runs on bwd_head_kernel + 3 x bwd_layer_kernel (C ABI
             ``diinn_backward_data``), which leave the gate gradients G_i and the activations q_i as
             tiled planes; every parameter gradient is then one GEMM over the pixel axis per layer
-            (plane_gemm_kernel, split-K, no atomics), two skinny products (plane_rowdot_kernel), a
+            (plane_gemm_lds_kernel, split-K, no atomics), two skinny products (plane_rowdot_kernel), a
             per-cell segment sum (cell_sum_kernel) and the 3x3 conv's input/weight gradients (MIOpen
             through torch.nn.grad).
             ``backward_from_saved`` states the same gradients in device-agnostic tensor algebra; it
@@ -272,7 +272,7 @@ def _conv_grads_native(feat: torch.Tensor, wx: torch.Tensor, dp: torch.Tensor, n
                        wkey=None, wpins=None, a_t: Optional[torch.Tensor] = None):
     """Gradients of P = conv3x3(feat; Wx[1024,64,3,3]) on the library's own kernels (no MIOpen in the decoder's step):
       weight:  dWx[o, (c,ky,kx)] = sum over cells of dP[o, cell] * unfold3x3(feat)[(c,ky,kx), cell] -- the plane GEMM over the
-               cell axis (plane_gemm_kernel; the 576 unfolded rows padded to 640 = 5 x 128);
+               cell axis (plane_gemm_lds_kernel; the 576 unfolded rows padded to 640 = 5 x 128);
       input :  d_feat = conv3x3(dP; Wx transposed and flipped) -- a 64-output 3x3 convolution over 1024 planes, i.e. the
                encoder's convolution kernels (Winograd F(4x4) / F(2x2) / split-K by the same rule as the trunk)."""
     from . import modules as M                                   # (pack functions; imported late: modules imports the decoder)

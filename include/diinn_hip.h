@@ -532,7 +532,7 @@ int diinn_p_launch_info(int B, int H, int W, int r0, int r1, int compute, int* a
  *   TEST / A-B ONLY (force a kernel variant that the launch cost models would not take, or inject a fault; results stay
  *     within the documented equivalences) -- DIINN_F32_KERNEL, DIINN_BF16_KERNEL, DIINN_X3_KERNEL, DIINN_PBF16_KERNEL,
  *     DIINN_P_KERNEL, DIINN_ENC_X3_ROWS, DIINN_ENC_S1_MIN_BLOCKS, DIINN_ENC_NO_STREAM1X1, DIINN_ENC_LAT_MAX_TILES,
- *     DIINN_ENC_WINO_HALF_MAX, DIINN_ENC_WINO_PERSIST, DIINN_TRAIN_SPLIT_HEAD, DIINN_TRAIN_GEMM_REGS, DIINN_DEBUG_NCU (the compute-unit count cost models, split plans and persistent grids assume),
+ *     DIINN_ENC_WINO_HALF_MAX, DIINN_ENC_WINO_PERSIST, DIINN_TRAIN_SPLIT_HEAD, DIINN_DEBUG_NCU (the compute-unit count cost models, split plans and persistent grids assume),
  *     DIINN_ENC_WINO4_FAULT (1: the split hand-off's give-up path on demand: NaN outputs + sticky status).  The environment is read ONCE, at the first launch or the first call of either function; afterwards
  * only diinn_debug_set changes a knob (process-wide, atomic stores: safe against concurrent launches, which see
  * either the old or the new value).  Unknown name -> DIINN_ERR_INVALID_ARG.  This is the library's only mutable

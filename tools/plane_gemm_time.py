@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time plane_gemm_kernel (C ABI diinn_plane_gemm_nt) against torch.matmul on the same planes.
+"""Time plane_gemm_lds_kernel (C ABI diinn_plane_gemm_nt) against torch.matmul on the same planes.
 usage: plane_gemm_time.py [npix] [M] [Nc] [ksplit]"""
 import ctypes as C
 import os
