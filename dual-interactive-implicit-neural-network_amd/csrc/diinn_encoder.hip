@@ -666,7 +666,8 @@ int diinn_rdn_wino4_applies(int B, int H, int W) {
 // planes: diinn_rdn_planes_floats; w4ws: the F(4x4) kernel's split area (diinn_conv_wino4_workspace_floats; NULL: no layer is split)
 static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
                             const float* packed_wino4_dev, const float* packed_x3_dev,
-                            const float* biases_dev, float* planes, float* w4ws, float* out_dev, int B, int H, int W) {
+                            const float* biases_dev, float* planes, float* w4ws, float* out_dev, int B, int H, int W,
+                            bool zero_status = false) {
     if (!sfe1_dev || !packed_dev || !biases_dev || !planes || !out_dev) return DIINN_ERR_INVALID_ARG;
     int st = check_dims(B, H, W);
     if (st) return st;
@@ -687,7 +688,7 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     // hand-off that gave up stays visible -- NaN features from then on -- until diinn_conv_wino4_ws_status has cleared it
     const size_t w4ws_floats = w4ws ? diinn_conv_wino4_workspace_floats() : 0;
     if (wino4 && w4ws) {
-        st = hip_status(hipMemsetAsync(w4ws, 0, DIINN_WINO4_COUNTER_BYTES, (hipStream_t)stream));
+        st = hip_status(hipMemsetAsync(w4ws, 0, zero_status ? 4096 : DIINN_WINO4_COUNTER_BYTES, (hipStream_t)stream));
         if (st) return st;
     }
     float* buf[2] = {planes, planes + (size_t)B * 576 * hw};                   // dense buffers [B,576,H,W]
@@ -776,9 +777,9 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
 // ---- ONE trunk entry point (ABI v9): which kernel family the 3x3 layers may take is an argument, the images it may read are
 // the ones given.  AUTO = the fastest fp32 form the given images allow (the rules above); DIRECT / WINO / WINO4 cap the family
 // (the result of the four former entry points); X3 = split bf16 on large maps, asked for explicitly (optional arithmetic).
-int diinn_rdn_forward_ex(void* stream, int algo, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
-                         const float* packed_wino4_dev, const float* packed_x3_dev, const float* biases_dev,
-                         float* planes_dev, float* w4ws_dev, float* out_dev, int B, int H, int W) {
+static int rdn_forward_algo(void* stream, int algo, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
+                            const float* packed_wino4_dev, const float* packed_x3_dev, const float* biases_dev,
+                            float* planes_dev, float* w4ws_dev, float* out_dev, int B, int H, int W, bool zero_status) {
     switch (algo) {
         case DIINN_RDN_ALGO_AUTO: packed_x3_dev = nullptr; break;
         case DIINN_RDN_ALGO_DIRECT: packed_wino_dev = packed_wino4_dev = packed_x3_dev = nullptr; break;
@@ -800,7 +801,14 @@ int diinn_rdn_forward_ex(void* stream, int algo, const float* sfe1_dev, const fl
     }
     if ((((size_t)planes_dev) & 15) || (((size_t)w4ws_dev) & 15)) return DIINN_ERR_INVALID_ARG;
     return rdn_forward_impl(stream, sfe1_dev, packed_dev, packed_wino_dev, packed_wino4_dev, packed_x3_dev, biases_dev, planes_dev,
-                            w4ws_dev, out_dev, B, H, W);
+                            w4ws_dev, out_dev, B, H, W, zero_status);
+}
+
+int diinn_rdn_forward_ex(void* stream, int algo, const float* sfe1_dev, const float* packed_dev, const float* packed_wino_dev,
+                         const float* packed_wino4_dev, const float* packed_x3_dev, const float* biases_dev,
+                         float* planes_dev, float* w4ws_dev, float* out_dev, int B, int H, int W) {
+    return rdn_forward_algo(stream, algo, sfe1_dev, packed_dev, packed_wino_dev, packed_wino4_dev, packed_x3_dev, biases_dev, planes_dev,
+                            w4ws_dev, out_dev, B, H, W, false);
 }
 
 // ---- the four one-algorithm entry points of ABI <= 8: thin wrappers, to be dropped with the next ABI number.  Their single
@@ -809,8 +817,10 @@ static int rdn_forward_v8(void* stream, int algo, const float* sfe1_dev, const f
                           const float* packed_wino4_dev, const float* packed_x3_dev, const float* biases_dev,
                           float* workspace_dev, float* out_dev, int B, int H, int W) {
     if (!workspace_dev) return DIINN_ERR_INVALID_ARG;
-    return diinn_rdn_forward_ex(stream, algo, sfe1_dev, packed_dev, packed_wino_dev, packed_wino4_dev, packed_x3_dev, biases_dev,
-                                workspace_dev + diinn_conv_wino4_workspace_floats(), workspace_dev, out_dev, B, H, W);
+    // ABI <= 8 promised "the first 4 KiB are zeroed by the forward itself" (callers hand in uninitialised workspaces): all control
+    // words, the status word included -- so these entry points have no sticky status (a give-up is still NaN in that forward's output)
+    return rdn_forward_algo(stream, algo, sfe1_dev, packed_dev, packed_wino_dev, packed_wino4_dev, packed_x3_dev, biases_dev,
+                            workspace_dev + diinn_conv_wino4_workspace_floats(), workspace_dev, out_dev, B, H, W, true);
 }
 
 int diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packed_dev, const float* biases_dev,

@@ -492,7 +492,9 @@ size_t diinn_rdn_x3_packed_floats(void);
 
 /* DEPRECATED, kept for this ABI number only: the one-algorithm trunk entry points of ABI <= 8 = diinn_rdn_forward_ex with algo
  * DIRECT / WINO / WINO4 / X3 and ONE workspace laid out [F(4x4) split area][planes] (diinn_rdn_workspace_floats = the split
- * area + 2,240 floats per pixel; diinn_rdn_x3_workspace_floats: + 576 per pixel); its first 4 KiB zeroed once by the caller. */
+ * area + 2,240 floats per pixel; diinn_rdn_x3_workspace_floats: + 576 per pixel), any content: as before v9 these entry points zero
+ * the area's 4 KiB of control words themselves at every forward (so they keep no sticky status: a hand-off that gives up is NaN in
+ * that forward's output only). */
 size_t diinn_rdn_workspace_floats(int B, int H, int W);
 size_t diinn_rdn_x3_workspace_floats(int B, int H, int W);
 int    diinn_rdn_forward(void* stream, const float* sfe1_dev, const float* packed_dev, const float* biases_dev,

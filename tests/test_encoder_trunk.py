@@ -364,6 +364,42 @@ def test_rdn_handoff_status_is_sticky_across_forwards(knobs):
 
 
 @pytest.mark.gpu
+def test_deprecated_trunk_entry_points_take_an_uninitialised_workspace():
+    """The one-algorithm entry points of ABI <= 8 (wrappers of diinn_rdn_forward_ex since v9) promised to zero the split area's
+    control words themselves: a workspace full of garbage (every word 0xFFFFFFFF: a set status word, full counters) must give the
+    features of the module's own forward, bit for bit, on a map whose F(4x4) layers split their last round; likewise the F(2x2)
+    and direct wrappers."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    torch.manual_seed(9)
+    enc = M.make_rdn().to(dev).eval()
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for (b, h, w) in [(1, 200, 180), (1, 100, 120), (1, 40, 44)]:
+        x = torch.rand(b, 3, h, w, device=dev)
+        with torch.no_grad():
+            want = enc(x)
+            sfe1 = enc._sfe1_hip(x)
+        packed, biases = enc._hip_packed(dev)
+        ws = torch.full((lib.diinn_rdn_workspace_floats(b, h, w),), float("nan"), device=dev)
+        ws.view(torch.int32).fill_(-1)
+        out = torch.empty_like(want)
+        if lib.diinn_rdn_wino4_applies(b, h, w):
+            st = lib.diinn_rdn_forward_wino4(stream, ptr(sfe1), ptr(packed), None, ptr(enc._hip_packed_wino4(dev)), ptr(biases), ptr(ws), ptr(out), b, h, w)
+        elif b * h * w >= 8192:
+            st = lib.diinn_rdn_forward_wino(stream, ptr(sfe1), ptr(packed), ptr(enc._hip_packed_wino(dev)), ptr(biases), ptr(ws), ptr(out), b, h, w)
+        else:
+            st = lib.diinn_rdn_forward(stream, ptr(sfe1), ptr(packed), ptr(biases), ptr(ws), ptr(out), b, h, w)
+        assert st == 0
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(out).all()) and torch.equal(out, want), (b, h, w)
+    assert M.RDN.handoff_status(clear=False) == 0
+
+
+@pytest.mark.gpu
 def test_conv_wino4_split_handoff_under_load_and_changing_inputs(knobs):
     """The slab hand-off of the split form, screened the way the guide asks (cdna_hip_programming.md, Guideline 16: "test every
     hand-off under UNEVEN load ... checking every word"): the SAME workspace serves launches on ALTERNATING inputs -- a part
