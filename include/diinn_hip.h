@@ -32,29 +32,10 @@ extern "C" {
 #endif
 
 #define DIINN_ABI_VERSION 9
-/* History of the ABI number:
- *   1  diinn_pack_weights, axis tables, diinn_precompute_P / diinn_decode_band / diinn_decode (+ _ex: compute modes)
- *   2  training (diinn_decode_train_fwd, diinn_backward_*, diinn_plane_*), LIIF / MetaSR, the encoder trunk
- *      (diinn_conv_ksplit, diinn_rdn_forward); packed image sections 8 (WLT) and 9 (WPB)
- *   3  row-window entry points (diinn_window_rows, *_win): band-sized buffers for the multi-GPU row-band split
- *   4  Winograd encoder (diinn_conv_wino, diinn_rdn_forward_wino); packed sections 10-12 (BQR, Q0R, WLR: the
- *      synthesis branch in revolutions)
- *   5  diinn_sfe1_forward; packed section 13 (WPU: the hoisted 3x3 conv in Winograd form)
- *   6  the packed image carries a validity word for its derived sections (DIINN_PACKED_MAGIC, below);
- *      diinn_p_launch_info; diinn_debug_set / diinn_debug_get;
- *      bf16 kernel choice taken from the full image, not the band; DIINN_COMPUTE_BF16X3 and packed sections 14-15 (DIINN_P_ALGO_DIRECT_BF16X3);
- *      split-bf16 encoder layers (diinn_conv3x3_x3, diinn_rdn_forward_x3)
- *   7  tiles: diinn_decode_tile_win (HR column range + output strides; the row-band entry points are wrappers of it);
- *      packed section 16 (WL16) and the 16-pixel fp32 latency kernel for the smallest launches (DIINN_F32_KERNEL = 3);
- *      Winograd F(4x4,3x3) encoder layers (diinn_conv_wino4, diinn_rdn_forward_wino4)
- *   8  the validity word follows the layout (DIINN_PACKED_MAGIC "DI08": an image packed by an older library is shorter
- *      and now decodes to NaN instead of being read past its end); diinn_conv_wino4_ws / _workspace_floats / _plan (the
- *      F(4x4,3x3) layer's last round split over the input channels) and a larger diinn_rdn_workspace_floats for it;
- *      diinn_decode_kernel_info
- *   9  ONE trunk entry point, diinn_rdn_forward_ex(algo, ...), with the F(4x4) split area as a buffer of its own
- *      (diinn_rdn_planes_floats); diinn_rdn_forward / _wino / _wino4 / _x3 are wrappers of it, kept for this ABI number only;
- *      the split hand-off fails LOUDLY (NaN outputs + a sticky status word: diinn_conv_wino4_ws_status); test-only knobs
- *      DIINN_DEBUG_NCU, DIINN_ENC_WINO4_FAULT */
+/* What each ABI number added: INTEGRATION.md, "ABI history".  v9 (this header): ONE trunk entry point (diinn_rdn_forward_ex; the four
+ * one-algorithm entry points are wrappers kept for this number only), the F(4x4) split hand-off fails loudly (sticky status word,
+ * diinn_conv_wino4_ws_status), the training step's own kernels for the hoisted conv's weight gradient and its Winograd forward
+ * (diinn_backward_cell_sum_ex, diinn_unfold_tiled, diinn_sum_parts, diinn_precompute_P_wpu). */
 
 /* status codes */
 #define DIINN_OK                 0
