@@ -223,8 +223,14 @@ constexpr int WG_TILES_X = 2, WG_TILES_Y = 2;   // 4 waves -> 16x8 HR pixels per
 constexpr int PLANE_TILE = 32;
 constexpr int ACT_ROWS = 2 * HID;                               // rows 0..255: k_i (or g_a,i); 256..511: s_i (or g_s,i)
 constexpr unsigned PLANE_ROW_BYTES = PLANE_TILE * sizeof(float);   // 128
+// (aux 2 = nt: the training planes -- 4.8 GB forward, 1.8 GB per backward layer at B = 16, 192 x 192 -- are read back by LATER kernels
+// only after all of them are written and do not fit any cache: streaming stores leave the L2 to the weight stream.  Round 6, one box,
+// A/B: training forward 4.09 -> 3.98 ms, backward chain 4.92 -> 4.85, step 14.65 -> 14.55; write-through (sc1) instead: +0.25 ms.)
+#ifndef ST_ACT_AUX
+#define ST_ACT_AUX 2
+#endif
 __device__ __forceinline__ void st_act(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, (int)soff, ST_ACT_AUX);
 }
 // Workgroups are dealt round-robin over the 8 XCDs in launch order (x fastest): blocks b and b + 8 share an L2.  This
 // gives every XCD a contiguous run of the launch's blocks instead, so that neighbouring blocks -- which at non-integer
