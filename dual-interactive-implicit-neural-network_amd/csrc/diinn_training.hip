@@ -19,6 +19,24 @@
 //                    planes written here (dW_i = G_i q_{i-1}^T ...).
 // All planes are tiled (see PLANE_TILE above): acts, G [4][ntiles][512][32]; Q [4][ntiles][256][32].
 // ---------------------------------------------------------------------------------
+// Cache policy of the training planes (round 6, A/B in ABBA order on one box: step 14.44 -> 14.31 ms): they are written once and read once
+// or twice by LATER kernels, gigabytes at a time -- streaming (nt) loads in bwd_layer_kernel, plane_rowdot_kernel and cell_sum_kernel
+// like the nt stores of st_act leave the L2 to the weight stream.  (nt on the plane GEMM's LDS-DMA pieces as well: no further change.)
+#ifndef PLANE_LD_AUX
+#define PLANE_LD_AUX 2
+#endif
+#ifndef PG_A_AUX
+#define PG_A_AUX 0
+#endif
+#ifndef PG_B_AUX
+#define PG_B_AUX 0
+#endif
+#ifndef STREAM_LD_NT
+#define STREAM_LD_NT 1
+#endif
+__device__ __forceinline__ float ld_plane(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, PLANE_LD_AUX));
+}
 struct BwdParams {
     const float* Wt;         // packed image
     const float* acts;       // k_i (rows 0..255), s_i (rows 256..511)
@@ -104,8 +122,8 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
         for (int e = 0; e < 4; ++e) {
             const int kk = 4 * kg + e;
             const unsigned so = (unsigned)(32 * (kk >> 4) + (kk & 3) + 8 * ((kk & 15) >> 2)) * PLANE_ROW_BYTES;
-            ga[kk] = ld_act(HEAD ? act_li : inG, voff, so);
-            gs[kk] = ld_act(HEAD ? act_li : inG, voff, so + HID * PLANE_ROW_BYTES);
+            ga[kk] = ld_plane(HEAD ? act_li : inG, voff, so);
+            gs[kk] = ld_plane(HEAD ? act_li : inG, voff, so + HID * PLANE_ROW_BYTES);
         }
     };
     float go0 = 0.0f, go1 = 0.0f, go2 = 0.0f;                    // HEAD: d loss / d out of this lane's pixel
@@ -199,8 +217,8 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned so = (unsigned)(32 * (m - 1) + (r & 3) + 8 * (r >> 2)) * PLANE_ROW_BYTES;
-                    kt[r] = ld_act(act, voff, so);
-                    st[r] = ld_act(act, voff, so + HID * PLANE_ROW_BYTES);
+                    kt[r] = ld_plane(act, voff, so);
+                    st[r] = ld_plane(act, voff, so + HID * PLANE_ROW_BYTES);
                 }
             }
             if (m > 0 && kg >= 8 && kg < 24) {                    // one epilogue element of tile m-1 every 8 MFMAs
@@ -214,8 +232,8 @@ __global__ __launch_bounds__(256, 1) void bwd_layer_kernel(const BwdParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const unsigned so = (unsigned)(32 * 7 + (r & 3) + 8 * (r >> 2)) * PLANE_ROW_BYTES;
-        kt[r] = ld_act(act, voff, so);
-        st[r] = ld_act(act, voff, so + HID * PLANE_ROW_BYTES);
+        kt[r] = ld_plane(act, voff, so);
+        st[r] = ld_plane(act, voff, so + HID * PLANE_ROW_BYTES);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) gate_store(7, r, pg[r], kt[r], st[r]);
@@ -267,7 +285,8 @@ __global__ __launch_bounds__(256) void cell_sum_kernel(const CellSumParams p) {
             f32x4 v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (y + k < y1) v[k] = *(const f32x4*)at(((long long)b * p.Hu + y + k) * p.Wu + x0);
+                if (y + k < y1) v[k] = STREAM_LD_NT ? __builtin_nontemporal_load((const f32x4*)at(((long long)b * p.Hu + y + k) * p.Wu + x0))
+                                                      : *(const f32x4*)at(((long long)b * p.Hu + y + k) * p.Wu + x0);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (y + k < y1) acc += ((v[k][0] + v[k][1]) + v[k][2]) + v[k][3];
@@ -396,10 +415,10 @@ __global__ __launch_bounds__(256, 1) void plane_gemm_lds_kernel(const PlaneGemmP
         const int i = wave * 12 + k;                              // wave-uniform: wave 0 and a third of wave 1 copy A, the rest B
         if (i < 16)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(dst + i * 256), 16, (int)dma_off,
-                                                     (int)((unsigned)t * a_pitch + (unsigned)i * 1024u), 0, 0);
+                                                     (int)((unsigned)t * a_pitch + (unsigned)i * 1024u), 0, PG_A_AUX);
         else
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(dst + i * 256), 16, (int)dma_off,
-                                                     (int)((unsigned)t * b_pitch + (unsigned)(i - 16) * 1024u), 0, 0);
+                                                     (int)((unsigned)t * b_pitch + (unsigned)(i - 16) * 1024u), 0, PG_B_AUX);
     };
     auto dma = [&](int st, int t) {
 #pragma unroll
@@ -533,7 +552,8 @@ __global__ __launch_bounds__(256) void plane_rowdot_kernel(const RowDotParams p)
         for (int g = 0; g < MAXG; ++g) {
             const int row = 8 * (wave + 4 * g) + r;
             if (wave + 4 * g < groups) {
-                f32x4 av = *(const f32x4*)(a + (size_t)row * PLANE_TILE + 4 * q);
+                f32x4 av = STREAM_LD_NT ? __builtin_nontemporal_load((const f32x4*)(a + (size_t)row * PLANE_TILE + 4 * q))
+                                        : *(const f32x4*)(a + (size_t)row * PLANE_TILE + 4 * q);
                 if (left < PLANE_TILE) {                          // ragged last tile: padding was never written
 #pragma unroll
                     for (int e = 0; e < 4; ++e) av[e] = 4 * q + e < left ? av[e] : 0.0f;
@@ -567,22 +587,35 @@ __global__ __launch_bounds__(256) void plane_rowdot_kernel(const RowDotParams p)
 }
 
 // ---------------------------------------------------------------------------------
-// sum_parts_kernel: out[i] = part[0][i] + part[1][i] + ... (slices in order: deterministic), the add of the split-K partial
-// products the GEMM / rowdot launches leave.  101 MB at B = 16, 192 x 192 (3 x 64 slices of 512 x 257): HBM-bound, 16 bytes per
-// lane (torch.sum over the slice axis of the same buffer: 137 us; this: ~30).
+// sum_parts_kernel: out[i] = sum over the slices of part[k][i] in a FIXED order (deterministic), the add of the split partial
+// products the GEMM / rowdot launches leave: 101 MB of GEMM partials at B = 16, 192 x 192 (3 x 64 slices of 512 x 257) and the
+// rowdot partials (1,024 slices of 1,024 .. 2,048 floats; torch.sum over their slice axis: 137 us).
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, long long n4) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;                      // f32x4 index inside a slice
-    if (i >= n4) return;
-    const f32x4* __restrict__ src = (const f32x4*)part + (size_t)blockIdx.y * nparts * n4 + i;
-    f32x4 s = src[0];
-    int k = 1;
-    for (; k + 4 <= nparts; k += 4) {                            // four slices in flight
-        const f32x4 a = src[(size_t)k * n4], b = src[(size_t)(k + 1) * n4], c = src[(size_t)(k + 2) * n4], d = src[(size_t)(k + 3) * n4];
-        s = (((s + a) + b) + c) + d;
+    // a workgroup = 32 column quads x 8 slice groups: thread (quad, g) adds slices g, g + 8, ... in order, the 8 group sums meet in LDS
+    // and are added in group order -- a fixed order whatever the launch, and enough threads for SHORT rows with MANY slices too (the
+    // rowdot partials: 1,024 slices of 1,024 .. 2,048 floats, which one thread per column walked as a 1,024-step chain)
+    __shared__ f32x4 red[8][32];
+    const int cq = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long long i = (long long)blockIdx.x * 32 + cq;             // f32x4 index inside a slice
+    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (i < n4) {
+        const f32x4* __restrict__ src = (const f32x4*)part + (size_t)blockIdx.y * nparts * n4 + i;
+        int k = g;
+        for (; k + 24 < nparts; k += 32) {                       // four slices in flight
+            const f32x4 a = src[(size_t)k * n4], b = src[(size_t)(k + 8) * n4], c = src[(size_t)(k + 16) * n4], d = src[(size_t)(k + 24) * n4];
+            s = (((s + a) + b) + c) + d;
+        }
+        for (; k < nparts; k += 8) s += src[(size_t)k * n4];
     }
-    for (; k < nparts; ++k) s += src[(size_t)k * n4];
-    ((f32x4*)out)[(size_t)blockIdx.y * n4 + i] = s;
+    red[g][cq] = s;
+    __syncthreads();
+    if (g == 0 && i < n4) {
+        f32x4 t = red[0][cq];
+#pragma unroll
+        for (int gg = 1; gg < 8; ++gg) t += red[gg][cq];
+        ((f32x4*)out)[(size_t)blockIdx.y * n4 + i] = t;
+    }
 }
 
 extern "C" {
@@ -592,8 +625,8 @@ int diinn_sum_parts(void* stream, const float* part_dev, float* out_dev, int gro
     if (!part_dev || !out_dev || groups <= 0 || groups > 65535 || nparts <= 0 || n <= 0) return DIINN_ERR_INVALID_ARG;
     if ((n & 3) || (((size_t)part_dev) & 15) || (((size_t)out_dev) & 15)) return DIINN_ERR_INVALID_ARG;
     const long long n4 = n / 4;
-    if ((n4 + 255) / 256 > 2147483000LL) return DIINN_ERR_TOO_LARGE;
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n4 + 255) / 256), (unsigned)groups), dim3(256), 0, (hipStream_t)stream,
+    if ((n4 + 31) / 32 > 2147483000LL) return DIINN_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n4 + 31) / 32), (unsigned)groups), dim3(256), 0, (hipStream_t)stream,
                        part_dev, out_dev, nparts, n4);
     return hip_status(hipGetLastError());
 }

@@ -425,9 +425,7 @@ def _geometry(b: int, h: int, w: int, hu: int, wu: int, dev) -> dict:
 def _sum_parts(part: torch.Tensor) -> torch.Tensor:
     """[groups, nparts, n] -> [groups, n]: the split partials of a GEMM / rowdot launch added in slice order (sum_parts_kernel)."""
     groups, nparts, n = part.shape
-    # (a thread of sum_parts_kernel walks all the slices of its 4 columns: short rows with many slices -- the rowdot partials, 1,024
-    # slices of 1,024 .. 2,048 floats -- would be one or two workgroups in a 1,024-step chain: those stay on torch.sum, 12-25 us)
-    if n % 4 or n < 32768 or not part.is_contiguous() or not NATIVE_SUM_PARTS:
+    if n % 4 or not part.is_contiguous() or not NATIVE_SUM_PARTS:
         return part.sum(1)
     out = torch.empty((groups, n), dtype=torch.float32, device=part.device)
     with torch.cuda.device(part.device):
