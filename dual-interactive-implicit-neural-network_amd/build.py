@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 
 # one gfx950 translation unit per kernel family (shared definitions: diinn_device.h) + the host-only half of the ABI
 HIP_SOURCES = ["diinn_decode.hip", "diinn_precompute.hip", "diinn_precompute_wino.hip", "diinn_precompute_x3.hip", "diinn_bf16.hip", "diinn_bf16x3.hip", "diinn_training.hip",
-               "diinn_baselines.hip", "diinn_encoder.hip", "diinn_winograd.hip", "diinn_winograd4.hip", "diinn_conv_x3.hip", "diinn_misc.hip"]
+               "diinn_baselines.hip", "diinn_encoder.hip", "diinn_winograd.hip", "diinn_winograd4.hip", "diinn_conv_x3.hip", "diinn_conv_t16.hip", "diinn_misc.hip"]
 HOST_SOURCES = ["diinn_host.cpp"]
 SOURCES = HIP_SOURCES + HOST_SOURCES
 # (build.py itself counts as a header: it holds the compiler flags of every translation unit)

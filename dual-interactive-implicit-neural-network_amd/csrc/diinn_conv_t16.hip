@@ -1,0 +1,239 @@
+// diinn_conv_t16.hip -- the 3x3 convolutions of the RDN trunk on SMALL maps (gfx950; round 6).
+// (part of libdiinn_hip.so; shared definitions in diinn_device.h)
+//
+// Reference: src/models/components/rdn.py:9-35,90-105 on the reference's own timing protocol (runtime_test.py:13,31-33,59-62: a
+// 1 x 3 x 48 x 48 crop).  What bounds a small map's layer (profiles/r05_small_map_analysis.txt, r06_small_map_s16.txt): the
+// split-K kernel gives a 48 x 48 map 144 workgroups of (32 pixels, 32 outputs, all of Cin) = 9.4 MFLOP each at Cin 512, a layer
+// costs one such workgroup's MFMA time on its CU, and 112 of the 256 CUs idle.  Finer units only help if a CU does not re-fetch
+// the weights per unit (a CU takes in 46-70 GB/s from its L2).
+//
+// This kernel: the map is cut into STRIPS 16 pixels wide (one N-tile of v_mfma_f32_16x16x4_f32 per row) and the outputs into
+// quarters of 16; a workgroup owns ONE output quarter and 1 .. 3 consecutive rows of one strip -- 64 workgroups per quarter on
+// a 256-CU part, a strip's rows dealt evenly to its workgroups (48 x 48: 3 strips x 48 rows over 64 = 2 or 3 rows each: 7.1 MFLOP
+// on the busiest CU instead of 9.4) -- and streams its quarter's weights ONCE, each group of 16 input channels used for all of
+// the workgroup's rows, whose halo rows it stages once (3 rows: 5 halo rows for 3 tiles).  8 waves split the reduction (wave w
+// takes the groups w, w + 8, ...).  Direct fp32 sum: the reference's arithmetic up to the order of the sum.
+//   * a step = one group: 16 channels x (rows + 2) halo rows x 24 columns (x0 - 4 .. x0 + 19, whole 16-byte pieces: W % 4 == 0)
+//     by wave-private LDS-DMA into one of two stages (channel pitch 32 (rows + 2) - 16 floats = 16 banks mod 32, so the two
+//     channels a 32-lane group of a ds_read_b32 touches fall on disjoint banks; the padding pieces and everything outside the
+//     map are out-of-range lanes, which deposit zero), and the group's 9 KiB of weights into registers; 36 MFMAs per row.
+//   * a step waits for ITS stage and weights with vmcnt(0) -- nothing younger is in flight then -- issues the next step's
+//     loads, and computes: the loads have a whole step (36 .. 108 MFMAs) to arrive (MI355X_MICROARCH.md, Two waves per SIMD,
+//     item 7: LDS-DMA data is ordered for the issuing wave's own ds_reads by its vmcnt).
+//   * the 8 partial sums meet ONCE in LDS at the end (over the stages, behind a barrier); bias, ReLU / residual, 64-byte runs.
+#include "diinn_device.h"
+
+constexpr int T16_WAVES = 8, T16_MAXR = 3;
+constexpr int T16_GROUP = 16;                                  // input channels per step / weight run
+constexpr int T16_STAGE = T16_GROUP * (32 * (T16_MAXR + 2) - 16);   // 2,304 floats = 9 KiB: the largest stage (3 rows)
+constexpr int T16_LDS_FLOATS = T16_WAVES * 2 * T16_STAGE;      // 147,456 bytes
+static_assert(T16_LDS_FLOATS * 4 <= 160 * 1024 && T16_WAVES * T16_MAXR * 4 * 64 <= T16_LDS_FLOATS, "LDS budget");
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+struct ConvT16Params {
+    const float* in;         // input channel planes: in + b*in_bs + c*H*W
+    const float* w;          // the split-K kernel's image (diinn_conv_ksplit, 9 taps)
+    const float* bias;       // [64]
+    const float* res;        // optional residual [B,64,H,W] (batch stride res_bs), added after bias (no ReLU with it)
+    float* out;              // out + b*out_bs + co*H*W
+    long long in_bs, out_bs, res_bs;
+    int Cin, B, H, W, relu;
+    int slots;               // workgroups per output quarter, dealt to the B * ceil(W / 16) strips (t16_share)
+};
+
+// the share of slot `slot` (of `slots`) in a map of `strips` strips of H rows: strip k has slots / strips (+ 1 for the first
+// slots % strips) workgroups, which cut its rows evenly
+struct T16Share { int strip, y0, rows; };
+__host__ __device__ inline T16Share t16_share(int slot, int slots, int strips, int H) {
+    const int base = slots / strips, extra = slots - base * strips;
+    int k, j, n;
+    if (slot < extra * (base + 1)) { n = base + 1; k = slot / n; j = slot - k * n; }
+    else { n = base; const int s2 = slot - extra * (base + 1); k = extra + s2 / n; j = s2 - (s2 / n) * n; }
+    const int y0 = (int)((long long)j * H / n), y1 = (int)((long long)(j + 1) * H / n);
+    return T16Share{k, y0, y1 - y0};
+}
+
+template <int NR>
+__device__ __forceinline__ void conv_t16_body(const ConvT16Params& p, float* __restrict__ lds, int quarter, int b, int y0, int x0) {
+    constexpr int R = NR + 2, CP = 32 * R - 16, PPC = CP / 4, NDMA = 2 * R - 1, STAGE = T16_GROUP * CP;
+    static_assert(NDMA * 64 == T16_GROUP * PPC && STAGE <= T16_STAGE, "stage geometry");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t plane = (size_t)p.H * p.W;
+    const unsigned plane_b = (unsigned)(plane * sizeof(float));
+    const int G = p.Cin / T16_GROUP;
+    const int my = wave < G ? (G - wave + T16_WAVES - 1) / T16_WAVES : 0;        // this wave's groups: wave, wave + 8, ...
+    constexpr unsigned OUTSIDE = 0x80000000u;
+
+    f32x4 acc[NR];                                               // row ti: D[out 4 (lane >> 4) + r][column lane & 15]
+#pragma unroll
+    for (int ti = 0; ti < NR; ++ti) acc[ti] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    if (my > 0) {
+        float* __restrict__ ring = lds + wave * 2 * T16_STAGE;
+        // piece i * 64 + lane of a stage: channel ch, halo row hr, piece pc of the row -- or one of the channel's padding pieces
+        unsigned voff[NDMA];
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int pi = i * 64 + lane;
+            const int ch = pi / PPC, rem = pi - ch * PPC;
+            const int hr = rem / 6, pc = rem - hr * 6;
+            const int y = y0 - 1 + hr, x = x0 - 4 + 4 * pc;
+            voff[i] = (rem < 6 * R && y >= 0 && y < p.H && x >= 0 && x < p.W) ? (unsigned)ch * plane_b + (unsigned)(y * p.W + x) * 4u : OUTSIDE;
+        }
+        const float* in_b = p.in + (size_t)b * p.in_bs;
+        auto dma_rsrc = [&](int gi) {
+            return __builtin_amdgcn_make_buffer_rsrc((void*)(in_b + (size_t)T16_GROUP * (wave + T16_WAVES * gi) * plane), 0,
+                                                     (int)((unsigned)T16_GROUP * plane_b), 0x00020000);
+        };
+        auto dma_piece = [&](auto PAR_, const __amdgpu_buffer_rsrc_t irs, int i) {
+            constexpr int PAR = decltype(PAR_)::value;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (__attribute__((address_space(3))) void*)(ring + PAR * T16_STAGE + i * 256), 16, (int)voff[i], 0, 0, 0);
+        };
+        // the weights come from the split-K kernel's image ([half 2][wave 8][tap 9][run Cin/64][h 2][i 32][4]: the 16 bytes at
+        // (half, wave w, tap, run g, h, i) hold W[32 half + i][8 (w Cin/64 + g) + 2 e + h][tap], e = 0 .. 3), so the trunk keeps ONE
+        // direct-sum image: lane (k = lane >> 4, m = lane & 15) takes output 16 quarter + m and, of the group's 16 channels,
+        // the run of 8 number k >> 1 at h = k & 1 -- k-step e multiplies the group's channels 8 (k >> 1) + 2 e + (k & 1)
+        const int runs = p.Cin / 64;
+        const unsigned inv_runs = (65536u + runs - 1) / runs;     // r / runs = (r * inv_runs) >> 16 for r < 128
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Cin * (64 * 9 * 4), 0x00020000);
+        const int wlane = (quarter >> 1) * (8 * 9 * runs * 1024) + ((lane >> 4) & 1) * 512 + (16 * (quarter & 1) + (lane & 15)) * 16;
+        f32x4 wr[2][9];
+        auto woff = [&](int gi) {
+            const unsigned r8 = 2u * (wave + T16_WAVES * gi) + (lane >> 5);
+            const unsigned w8 = (r8 * inv_runs) >> 16, g = r8 - w8 * runs;
+            return wlane + (int)((w8 * 9 * runs + g) * 1024);
+        };
+        // B operand of (row ti, k-step e, tap (ky, kx)): the lane's channel of the k-step, halo row ti + ky, column (lane & 15) + kx - 1
+        const float* __restrict__ bbase = ring + (8 * (lane >> 5) + ((lane >> 4) & 1)) * CP + (lane & 15) + 3;
+        {
+            const int off = woff(0);
+            const __amdgpu_buffer_rsrc_t irs = dma_rsrc(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) wr[0][tap] = ld_piece(wrs, off, tap * runs * 1024);
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) dma_piece(IC<0>{}, irs, i);
+        }
+        auto do_group = [&](auto PAR_, int gi) {
+            constexpr int PAR = decltype(PAR_)::value;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this group's stage has landed (and its weights): nothing younger is in flight
+            // The next group's loads (after the last group its own again, read by nobody) go out BETWEEN the MFMAs, one or two per
+            // (k-step, halo row): a VMEM instruction holds its wave's issue for 60 - 100 cycles, and the two waves of a SIMD reach a
+            // step's start together.  They fill the stage group gi - 1 was read from (its reads fed MFMAs already issued).
+            const int gn = gi + 1 < my ? gi + 1 : gi;
+            const int off = woff(gn);
+            const __amdgpu_buffer_rsrc_t irs = dma_rsrc(gn);
+            const float* __restrict__ bs = bbase + PAR * T16_STAGE;
+            constexpr int NL = 9 + NDMA, NJ = 4 * R;
+            float bq[2][3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) bq[0][kx] = bs[kx];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {                        // j = (k-step s, halo row hr)
+                const int s = j / R, hr = j % R;
+                if (j + 1 < NJ) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) bq[(j + 1) & 1][kx] = bs[((j + 1) / R) * 2 * CP + ((j + 1) % R) * 24 + kx];
+                }
+#pragma unroll
+                for (int l = j * NL / NJ; l < (j + 1) * NL / NJ; ++l) {
+                    if (l < 9) wr[PAR ^ 1][l] = ld_piece(wrs, off, l * runs * 1024);
+                    else dma_piece(IC<PAR ^ 1>{}, irs, l - 9);
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ti = 0; ti < NR; ++ti)
+                        if (hr - ti >= 0 && hr - ti < 3) acc[ti] = MFMA16(wr[PAR][3 * (hr - ti) + kx][s], bq[j & 1][kx], acc[ti]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        int gi = 0;
+        for (; gi + 1 < my; gi += 2) {
+            do_group(IC<0>{}, gi);
+            do_group(IC<1>{}, gi + 1);
+        }
+        if (gi < my) do_group(IC<0>{}, gi);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the surplus loads have landed: nothing arrives in this LDS later
+    }
+    // ---- the 8 partial sums of every row meet in LDS, over the stages once every wave has left them
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < NR; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[((wave * T16_MAXR + ti) * 4 + r) * 64 + lane] = acc[ti][r];
+    __syncthreads();
+    const int v = (int)threadIdx.x & 255, r = v >> 6, l = v & 63;
+    const int co = 16 * quarter + 4 * (l >> 4) + r;
+    const float bias = p.bias[co];
+    const int x = x0 + (l & 15);
+    for (int ti = (int)threadIdx.x >> 8; ti < NR; ti += 2) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w8 = 0; w8 < T16_WAVES; ++w8) s += lds[((w8 * T16_MAXR + ti) * 4 + r) * 64 + l];
+        s += bias;
+        if (p.relu) s = relu0(s);
+        if (x < p.W) {
+            const size_t o = (size_t)co * plane + (size_t)(y0 + ti) * p.W + x;
+            if (p.res) s += p.res[(size_t)b * p.res_bs + o];
+            p.out[(size_t)b * p.out_bs + o] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void conv_t16_kernel(const ConvT16Params p) {
+    __shared__ __attribute__((aligned(16))) float lds[T16_LDS_FLOATS];
+    const int quarter = (int)blockIdx.x & 3, slot = (int)blockIdx.x >> 2;
+    const int tiles_x = (p.W + 15) >> 4;
+    const T16Share sh = t16_share(slot, p.slots, p.B * tiles_x, p.H);
+    const int b = sh.strip / tiles_x, x0 = 16 * (sh.strip - b * tiles_x);
+    if (sh.rows == 1) conv_t16_body<1>(p, lds, quarter, b, sh.y0, x0);
+    else if (sh.rows == 2) conv_t16_body<2>(p, lds, quarter, b, sh.y0, x0);
+    else if (sh.rows == 3) conv_t16_body<3>(p, lds, quarter, b, sh.y0, x0);       // (0 rows: more workgroups than rows; more than 3: refused at launch)
+}
+
+// workgroups per output quarter for a map of `strips` strips of H rows (0: not a map for this kernel)
+static int t16_slots(long long strips, int H) {
+    const long long per_quarter = device_cus() / 4 > 0 ? device_cus() / 4 : 1;
+    const long long slots = strips * H < per_quarter ? strips * H : per_quarter;
+    if (slots < strips) return 0;                                // a strip would be left without a workgroup
+    return (H + (slots / strips) - 1) / (slots / strips) <= T16_MAXR ? (int)slots : 0;
+}
+
+static int t16_slots(long long tiles) {
+    const int per_quarter = device_cus() / 4 > 0 ? device_cus() / 4 : 1;
+    return (int)(tiles < per_quarter ? tiles : per_quarter);
+}
+
+extern "C" {
+
+int diinn_conv_t16_applies(int B, int H, int W) {
+    // the small-map kernel's maps: whole 16-byte pieces per row, at most T16_MAXR rows per workgroup, and fewer split-K units
+    // (tiles of 8 x 4 pixels x 2 output halves) than compute units -- where that kernel leaves CUs idle
+    if (B <= 0 || H <= 0 || W <= 0 || (W & 3) || knob(diinn_knobs().enc_no_t16) != 0) return 0;
+    if ((long long)B * H * W >= knob(diinn_knobs().enc_wino_min)) return 0;
+    if (t16_slots((long long)B * ((W + 15) / 16), H) == 0) return 0;
+    const long long ks_units = 2LL * B * ((W + 7) / 8) * ((H + 3) / 4);
+    return ks_units < device_cus();
+}
+
+int diinn_conv_t16(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
+                   const float* packed_w_dev, const float* bias_dev, const float* res_dev, long long res_batch_stride,
+                   float* out_dev, long long out_batch_stride, int relu, int B, int H, int W) {
+    if (!in_dev || !packed_w_dev || !bias_dev || !out_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (Cin <= 0 || Cin % 64 || (W & 3)) return DIINN_ERR_UNSUPPORTED;
+    if ((((size_t)in_dev) & 15) || (((size_t)packed_w_dev) & 15) || (in_batch_stride & 3)) return DIINN_ERR_INVALID_ARG;
+    const int slots = t16_slots((long long)B * ((W + 15) / 16), H);
+    if (slots == 0) return DIINN_ERR_UNSUPPORTED;                // a map for the other kernels
+    if ((long long)H * W * 4 * T16_GROUP > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;
+    ConvT16Params p;
+    p.in = in_dev; p.w = packed_w_dev; p.bias = bias_dev; p.res = res_dev; p.out = out_dev;
+    p.in_bs = in_batch_stride; p.out_bs = out_batch_stride; p.res_bs = res_batch_stride;
+    p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0; p.slots = slots;
+    hipLaunchKernelGGL(conv_t16_kernel, dim3((unsigned)(4 * slots)), dim3(512), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+}  // extern "C"

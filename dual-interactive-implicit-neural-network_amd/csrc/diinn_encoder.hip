@@ -698,6 +698,9 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     // per CU on (measured per trunk, x3 vs Winograd: 160x160 7.8 vs 6.2 ms, 192x192 7.2 vs 9.3, 224x224 7.5 vs 11.4, 256x256 8.6 vs 11.8,
     // 384x384 20.8 vs 28.0, 512x512 32.9 vs 46.5)
     const bool x3 = packed_x3_dev && (long long)B * hw >= knob(diinn_knobs().enc_x3_min);
+    // small maps (csrc/diinn_conv_t16.hip): the direct sum in units of (1 .. 3 rows x 16 pixels, 16 outputs) where the split-K
+    // kernel's units leave compute units idle; the same weight image (per trunk: 48x48 1.95 -> 1.85 ms, 40x40 1.92 -> 1.44, 32x32 1.87 -> 1.05)
+    const bool t16 = !wino && !x3 && diinn_conv_t16_applies(B, H, W) != 0;
     const float* w = packed_dev;
     const float* wu = packed_wino_dev;
     const float* wu4 = packed_wino4_dev;
@@ -711,6 +714,8 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
             ? diinn_conv_wino4_ws(stream, in, in_bs, cin, wu4, bias, res, res_bs, o0, o0_bs, relu, B, H, W, w4ws, w4ws_floats)
             : (wino && taps == 9 && !o1)
             ? diinn_conv_wino(stream, in, in_bs, cin, wu, bias, res, res_bs, o0, o0_bs, relu, B, H, W)
+            : (t16 && taps == 9 && !o1)
+            ? diinn_conv_t16(stream, in, in_bs, cin, w, bias, res, res_bs, o0, o0_bs, relu, B, H, W)
             : diinn_conv_ksplit(stream, in, in_bs, cin, taps, w, bias, res, res_bs, o0, o0_bs, o1, o1_bs, relu, B, H, W);
         w += (size_t)64 * cin * taps;
         if (taps == 9 && wu) wu += (size_t)64 * cin * 16;

@@ -37,6 +37,7 @@ const KnobDef KNOBS[] = {
     {"DIINN_DEBUG_NCU", &DiinnKnobs::debug_ncu, 0, false},
     {"DIINN_ENC_WINO4_FAULT", &DiinnKnobs::enc_wino4_fault, 0, false},
     {"DIINN_TRAIN_SPLIT_HEAD", &DiinnKnobs::train_split_head, 0, false},
+    {"DIINN_ENC_NO_T16", &DiinnKnobs::enc_no_t16, 0, false},
 };
 }  // namespace
 

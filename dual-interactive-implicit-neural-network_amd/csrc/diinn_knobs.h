@@ -27,6 +27,7 @@ struct DiinnKnobs {
     std::atomic<long long> debug_ncu;           // DIINN_DEBUG_NCU (TEST ONLY; default 0: ask the device): the compute-unit count the launch cost models, the F(4x4) rounds / split plan and the persistent grids assume (any value is correct, only differently fast)
     std::atomic<long long> train_split_head;    // DIINN_TRAIN_SPLIT_HEAD (TEST / A-B ONLY; default 0): 1 = the backward pass runs bwd_head_kernel as its own launch instead of inside layer 3's bwd_layer_kernel (bit-identical planes)
     std::atomic<long long> enc_wino4_fault;     // DIINN_ENC_WINO4_FAULT (TEST ONLY; default 0): 1 = split parts never count their slab ready and the last arriver's wait is short: the give-up path (NaN outputs, sticky status) on demand
+    std::atomic<long long> enc_no_t16;          // DIINN_ENC_NO_T16 (TEST / A-B ONLY; default 0): 1 = small maps keep the split-K 3x3 kernel instead of the 1 x 16-pixel tile kernel (diinn_conv_t16.hip)
     std::atomic<long long> enc_wino4_split;     // DIINN_ENC_WINO4_SPLIT: F(4x4,3x3) kernel, split of the last round over the input channels: 0 never, 1 by the cost model (default), 2 whenever a round is partly filled
 };
 

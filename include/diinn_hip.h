@@ -471,6 +471,21 @@ int    diinn_conv3x3_x3(void* stream, const float* in_dev, long long in_batch_st
                         float* out_dev, long long out_batch_stride, int relu, int B, int H, int W);
 size_t diinn_rdn_x3_packed_floats(void);
 
+/* Small maps (csrc/diinn_conv_t16.hip; the reference's own timing protocol, runtime_test.py:13: a 48 x 48 crop): the same
+ * 3x3 layers as a direct fp32 sum (v_mfma_f32_16x16x4_f32) over strips 16 pixels wide and output quarters of 16 -- a
+ * workgroup owns one quarter and 1 .. 3 consecutive rows of a strip and streams its quarter's weights once -- so that all
+ * compute units work where the split-K kernel's (32 pixels x 32 outputs) units number fewer than the compute units.
+ * diinn_conv_t16: addressing, epilogue and packed_w_dev as diinn_conv_ksplit with taps = 9 (it reads the SAME image) and one
+ *   destination; W % 4 == 0, Cin % 64 == 0, and a map whose strips' rows can be dealt at most 3 to a workgroup
+ *   (DIINN_ERR_UNSUPPORTED otherwise).  diinn_conv_t16_applies: 1 if the trunk gives this map's 3x3 layers to this kernel on
+ *   the current device (a map below the Winograd kernels', with fewer split-K units than compute units; DIINN_ENC_NO_T16 = 1:
+ *   never).  Results differ from diinn_conv_ksplit's by the order of the fp32 sum only. */
+int    diinn_conv_t16(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
+                      const float* packed_w_dev, const float* bias_dev,
+                      const float* res_dev, long long res_batch_stride,
+                      float* out_dev, long long out_batch_stride, int relu, int B, int H, int W);
+int    diinn_conv_t16_applies(int B, int H, int W);
+
 /* DEPRECATED, kept for this ABI number only: the one-algorithm trunk entry points of ABI <= 8 = diinn_rdn_forward_ex with algo
  * DIRECT / WINO / WINO4 / X3 and ONE workspace laid out [F(4x4) split area][planes] (diinn_rdn_workspace_floats = the split
  * area + 2,240 floats per pixel; diinn_rdn_x3_workspace_floats: + 576 per pixel), any content: as before v9 these entry points zero

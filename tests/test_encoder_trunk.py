@@ -646,6 +646,111 @@ def test_conv_ksplit_kernel_matches_torch():
 
 
 @pytest.mark.gpu
+def test_conv_t16_kernel_matches_fp64_conv(knobs):
+    """diinn_conv_t16 (small maps: strips of 16 pixels x output quarters, 1..3 rows per workgroup, the split-K kernel's weight
+    image): ReLU / residual, strided channel-plane views, batches, partly filled strips, single-row maps, every rows-per-
+    workgroup form (compute-unit counts forced through DIINN_DEBUG_NCU), against the float64 convolution; repeatable bit for bit;
+    and the maps it refuses."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    gen = torch.Generator(device=dev).manual_seed(5)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
+    cases = [(0, 1, 64, 48, 48, 1, 0), (0, 1, 512, 48, 48, 0, 1), (0, 2, 320, 12, 20, 1, 0), (0, 1, 192, 32, 32, 1, 0),
+             (0, 1, 128, 40, 40, 0, 0), (0, 1, 448, 16, 16, 1, 0), (0, 4, 256, 24, 24, 1, 1), (0, 1, 64, 1, 4, 0, 0),
+             (0, 1, 576, 20, 24, 1, 0), (0, 1, 128, 7, 100, 0, 1),
+             # 32 / 128 compute units: 8 / 32 workgroups per output quarter = 3, 2 and 1 rows each on these maps
+             (32, 1, 256, 24, 16, 1, 0), (32, 1, 128, 16, 16, 0, 1), (128, 2, 192, 30, 12, 1, 0), (128, 1, 64, 64, 8, 0, 0)]
+    for (ncu, b, cin, h, w, relu, use_res) in cases:
+        knobs("DIINN_DEBUG_NCU", ncu)
+        total = cin + 64
+        buf = torch.randn((b, total, h, w), device=dev, generator=gen)          # input = first cin planes of a larger buffer
+        wt = torch.randn((64, cin, 3, 3), device=dev, generator=gen) / (cin * 9) ** 0.5
+        bias = torch.randn(64, device=dev, generator=gen)
+        res = torch.randn((b, 64, h, w), device=dev, generator=gen) if use_res else None
+        out = torch.full((b, 96, h, w), float("nan"), device=dev)
+        packed = M.pack_conv_ksplit(wt).to(dev)
+
+        def run():
+            return lib.diinn_conv_t16(stream, ptr(buf), total * h * w, cin, ptr(packed), ptr(bias), ptr(res) if use_res else None,
+                                      64 * h * w, ptr(out[:, 32:]), 96 * h * w, relu, b, h, w)
+        assert run() == 0, (ncu, b, cin, h, w)
+        torch.cuda.synchronize()
+        ref = F.conv2d(buf[:, :cin].double(), wt.double(), bias.double(), padding=1)
+        if relu:
+            ref = torch.relu(ref)
+        if use_res:
+            ref = ref + res.double()
+        err = float((out[:, 32:].double() - ref).abs().max())
+        assert err <= 2e-6 * max(1.0, float(ref.abs().max())), (ncu, b, cin, h, w, err)
+        assert torch.isnan(out[:, :32]).all()                    # nothing outside the destination planes
+        first = out.clone()
+        for _ in range(5):
+            out.fill_(float("nan"))
+            assert run() == 0
+            assert torch.equal(out[:, 32:], first[:, 32:])
+    knobs("DIINN_DEBUG_NCU", 0)
+    # refused: rows not made of whole 16-byte pieces, channels not in runs of 64, more than 3 rows per workgroup
+    small = torch.zeros(1, 128, 64, 64, device=dev)
+    o = torch.zeros(1, 64, 64, 64, device=dev)
+    for (cin, h, w) in [(64, 8, 6), (96, 8, 8), (64, 64, 64)]:
+        assert lib.diinn_conv_t16(stream, ptr(small), 128 * h * w, cin, ptr(packed), ptr(bias), None, 0, ptr(o), 64 * h * w, 0, 1, h, w) == N.ERR_UNSUPPORTED
+
+
+def test_conv_t16_dispatch_rule(knobs):
+    """diinn_conv_t16_applies: the maps whose 3x3 layers the trunk gives to the small-map kernel (no device needed: the
+    compute-unit count is forced)."""
+    import diinn_amd._native as N
+    lib = N.load()
+    knobs("DIINN_DEBUG_NCU", 256)
+    assert lib.diinn_conv_t16_applies(1, 48, 48) == 1           # 144 split-K units on 256 CUs; 3 strips x 48 rows over 64 = 2 or 3 rows
+    assert lib.diinn_conv_t16_applies(1, 32, 32) == 1
+    assert lib.diinn_conv_t16_applies(1, 40, 40) == 1
+    assert lib.diinn_conv_t16_applies(4, 24, 24) == 1
+    assert lib.diinn_conv_t16_applies(1, 1, 4) == 1
+    assert lib.diinn_conv_t16_applies(1, 64, 64) == 0           # 256 split-K units: every CU has one; 4 rows per workgroup here
+    assert lib.diinn_conv_t16_applies(1, 48, 50) == 0           # rows of whole 16-byte pieces only
+    assert lib.diinn_conv_t16_applies(1, 128, 128) == 0         # a Winograd map
+    assert lib.diinn_conv_t16_applies(0, 48, 48) == 0
+    knobs("DIINN_DEBUG_NCU", 64)                                 # a partition of 64 CUs: 16 workgroups per quarter
+    assert lib.diinn_conv_t16_applies(1, 48, 48) == 0 and lib.diinn_conv_t16_applies(1, 16, 16) == 1
+    knobs("DIINN_DEBUG_NCU", 256)
+    knobs("DIINN_ENC_NO_T16", 1)
+    assert lib.diinn_conv_t16_applies(1, 48, 48) == 0
+
+
+@pytest.mark.gpu
+def test_rdn_trunk_small_map_kernel_against_the_split_k_kernel(knobs):
+    """The trunk on maps the small-map kernel takes (48 x 48: the reference's timing protocol, runtime_test.py:13) equals the
+    trunk with that kernel switched off (DIINN_ENC_NO_T16: split-K everywhere) up to the order of the fp32 sums, and MIOpen."""
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    enc = M.make_rdn()
+    shapes = {k: list(v.shape) for k, v in enc.state_dict().items()}
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_for(shapes, 31, "enc.").items()})
+    enc = enc.to(dev).eval()
+    for (b, h, w) in [(1, 48, 48), (1, 32, 32), (2, 24, 40), (1, 17, 52)]:
+        assert N.load().diinn_conv_t16_applies(b, h, w) == 1
+        x = torch.from_numpy(synth.uniform(9, f"img:{b}x{h}x{w}", (b, 3, h, w), 0.5) + np.float32(0.5)).to(dev)
+        with torch.no_grad():
+            got = enc(x)
+            knobs("DIINN_ENC_NO_T16", 1)
+            ks = enc(x)
+            knobs("DIINN_ENC_NO_T16", 0)
+            enc.hip_trunk_max_pixels = None
+            ref = enc(x)
+            enc.hip_trunk_max_pixels = M.RDN.hip_trunk_max_pixels
+        scale = max(1.0, float(ref.abs().max()))
+        assert not torch.equal(got, ks)                          # (another kernel did run)
+        assert float((got - ks).abs().max()) <= 5e-6 * scale, (b, h, w)
+        assert float((got - ref).abs().max()) <= 2e-5 * scale, (b, h, w)
+
+
+@pytest.mark.gpu
 def test_rdn_hip_trunk_matches_miopen():
     """RDN.forward with the HIP trunk (small maps, no grad) against the same module on PyTorch-ROCm/MIOpen."""
     import diinn_amd.modules as M

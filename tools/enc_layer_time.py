@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer timing of diinn_conv_ksplit on one MI355X: every (Cin, taps) shape of the RDN trunk at a given map size,
 each launched alone in a loop -- shows which layers of the encoder sit furthest below the fp32 MFMA roof.
-usage: enc_layer_time.py [SIZE=256] [--wino | --wino4] [--relu]"""
+usage: enc_layer_time.py [SIZE=256] [--wino | --wino4 | --t16] [--relu]   (--t16: the small-map kernel, each shape checked against F.conv2d)"""
 import ctypes as C
 import os
 import sys
@@ -20,6 +20,7 @@ def main():
     lr = int(args[0]) if args else 256
     wino4 = "--wino4" in sys.argv                              # 3x3 layers on diinn_conv_wino4 (F(4x4,3x3))
     wino = "--wino" in sys.argv or wino4                                # 3x3 layers on diinn_conv_wino (% of peak = direct-conv flops / time)
+    t16 = "--t16" in sys.argv                                  # 3x3 layers on diinn_conv_t16 (small maps)
     dev = torch.device("cuda:0")
     lib = _native.load()
     hw = lr * lr
@@ -37,6 +38,11 @@ def main():
         out = buf[:, 1024:]
 
         def run():
+            if t16 and taps == 9:
+                _native.check(lib.diinn_conv_t16(stream, C.c_void_p(buf.data_ptr()), (1024 + 64) * hw, cin,
+                                                 C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), None, 0,
+                                                 C.c_void_p(out.data_ptr()), (1024 + 64) * hw, 1, 1, lr, lr), "conv")
+                return
             if wino and taps == 9:
                 _native.check((lib.diinn_conv_wino4 if wino4 else lib.diinn_conv_wino)(stream, C.c_void_p(buf.data_ptr()), (1024 + 64) * hw, cin,
                                                   C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), None, 0,
@@ -56,6 +62,10 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
+        if t16 and taps == 9:
+            want = torch.relu(torch.nn.functional.conv2d(buf[:, :cin].double(), wt.to(dev).double(), padding=1))
+            err = float((out.double() - want).abs().max() / want.abs().max())
+            assert err < 2e-6, f"Cin {cin}: relative error {err:.2e}"
         fl = 2.0 * 64 * cin * taps * hw
         total += ms * count
         print(f"Cin {cin:5d} taps {taps}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s  {100*fl/ms/1e-3/PEAK:5.1f} %  x{count} = {ms*count:6.3f} ms", flush=True)
