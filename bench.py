@@ -715,7 +715,9 @@ def whole_model_leg(device, steps=5, warmup=2, lr=256, scale=4):
            "finite": bool(torch.isfinite(out).all()),
            "handoff_gave_up": int(M.RDN.handoff_status(clear=False)),     # the F(4x4) split hand-off's sticky status (0: never gave up)
            "encoder_3x3_layers": ("Winograd F(4x4,3x3)" if net.encoder.hip_winograd4 and N.load().diinn_rdn_wino4_applies(1, lr, lr)
-                                  else "Winograd F(2x2,3x3)" if lr * lr >= 8192 else "direct, split-K"),
+                                  else "Winograd F(2x2,3x3)" if lr * lr >= 8192
+                                  else "direct, strips of 16 pixels x 16 outputs (conv_t16_kernel)" if N.load().diinn_conv_t16_applies(1, lr, lr)
+                                  else "direct, split-K"),
            "note": "parity of this path: tests/test_modules.py (reference DIINN fixture), tests/test_encoder_trunk.py (the real reference's encoder)"}
     del net, x, feat, out
     torch.cuda.empty_cache()

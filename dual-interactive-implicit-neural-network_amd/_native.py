@@ -113,6 +113,9 @@ SIGNATURES = {
     "diinn_conv_t16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_conv_t16_applies": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "diinn_conv1x1_t16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
+                                   C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_rdn_x3_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "diinn_rdn_forward_x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_int, C.c_int]),

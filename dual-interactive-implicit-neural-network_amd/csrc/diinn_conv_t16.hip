@@ -17,10 +17,14 @@
 //     by wave-private LDS-DMA into one of two stages (channel pitch 32 (rows + 2) - 16 floats = 16 banks mod 32, so the two
 //     channels a 32-lane group of a ds_read_b32 touches fall on disjoint banks; the padding pieces and everything outside the
 //     map are out-of-range lanes, which deposit zero), and the group's 9 KiB of weights into registers; 36 MFMAs per row.
-//   * a step waits for ITS stage and weights with vmcnt(0) -- nothing younger is in flight then -- issues the next step's
-//     loads, and computes: the loads have a whole step (36 .. 108 MFMAs) to arrive (MI355X_MICROARCH.md, Two waves per SIMD,
-//     item 7: LDS-DMA data is ordered for the issuing wave's own ds_reads by its vmcnt).
+//   * a step waits for ITS stage and weights with vmcnt(0) -- nothing younger is in flight then -- and computes, the next
+//     step's loads going out between its MFMAs (MI355X_MICROARCH.md, Two waves per SIMD, item 7: LDS-DMA data is ordered for
+//     the issuing wave's own ds_reads by its vmcnt).
+//   * the weights are read from the SPLIT-K kernel's image (diinn_conv_ksplit: modules.pack_conv_ksplit): no second direct-sum
+//     image, no change to diinn_rdn_forward_ex; the lane mapping is at the loads below.
 //   * the 8 partial sums meet ONCE in LDS at the end (over the stages, behind a barrier); bias, ReLU / residual, 64-byte runs.
+// Measured (profiles/r06_small_map_t16.txt): per trunk 48 x 48 1.95 -> 1.65 ms (with the 1x1 sibling below), 32 x 32 1.87 -> 1.00,
+// 24 x 24 1.92 -> 0.95; per layer 6.0 + 1.9 us per 64 input channels at 48 x 48 (split-K: 6.1 + 2.33).
 #include "diinn_device.h"
 
 constexpr int T16_WAVES = 8, T16_MAXR = 3;
@@ -29,6 +33,15 @@ constexpr int T16_STAGE = T16_GROUP * (32 * (T16_MAXR + 2) - 16);   // 2,304 flo
 constexpr int T16_LDS_FLOATS = T16_WAVES * 2 * T16_STAGE;      // 147,456 bytes
 static_assert(T16_LDS_FLOATS * 4 <= 160 * 1024 && T16_WAVES * T16_MAXR * 4 * 64 <= T16_LDS_FLOATS, "LDS budget");
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#ifndef T16_W_AUX
+#define T16_W_AUX 0          // cache policy of the weight loads / the LDS-DMA pieces (2 = nt; A/B builds: profiles/r06_small_map_t16.txt)
+#endif
+#ifndef T16_DMA_AUX
+#define T16_DMA_AUX 0
+#endif
+__device__ __forceinline__ f32x4 t16_ld_w(__amdgpu_buffer_rsrc_t rsrc, int lane_off, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, T16_W_AUX));
+}
 
 struct ConvT16Params {
     const float* in;         // input channel planes: in + b*in_bs + c*H*W
@@ -36,7 +49,8 @@ struct ConvT16Params {
     const float* bias;       // [64]
     const float* res;        // optional residual [B,64,H,W] (batch stride res_bs), added after bias (no ReLU with it)
     float* out;              // out + b*out_bs + co*H*W
-    long long in_bs, out_bs, res_bs;
+    float* out1;             // 1x1 kernel only: optional second destination (batch stride out1_bs)
+    long long in_bs, out_bs, out1_bs, res_bs;
     int Cin, B, H, W, relu;
     int slots;               // workgroups per output quarter, dealt to the B * ceil(W / 16) strips (t16_share)
 };
@@ -65,22 +79,17 @@ __device__ __forceinline__ void conv_t16_body(const ConvT16Params& p, float* __r
     const int my = wave < G ? (G - wave + T16_WAVES - 1) / T16_WAVES : 0;        // this wave's groups: wave, wave + 8, ...
     constexpr unsigned OUTSIDE = 0x80000000u;
 
+    // the epilogue's thread: output co of column x; its bias is asked for now, not behind the last barrier
+    const int ev = (int)threadIdx.x & 255, er = ev >> 6, el = ev & 63;
+    const int co = 16 * quarter + 4 * (el >> 4) + er;
+    const float bias = p.bias[co];
     f32x4 acc[NR];                                               // row ti: D[out 4 (lane >> 4) + r][column lane & 15]
 #pragma unroll
     for (int ti = 0; ti < NR; ++ti) acc[ti] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     if (my > 0) {
         float* __restrict__ ring = lds + wave * 2 * T16_STAGE;
-        // piece i * 64 + lane of a stage: channel ch, halo row hr, piece pc of the row -- or one of the channel's padding pieces
         unsigned voff[NDMA];
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-            const int pi = i * 64 + lane;
-            const int ch = pi / PPC, rem = pi - ch * PPC;
-            const int hr = rem / 6, pc = rem - hr * 6;
-            const int y = y0 - 1 + hr, x = x0 - 4 + 4 * pc;
-            voff[i] = (rem < 6 * R && y >= 0 && y < p.H && x >= 0 && x < p.W) ? (unsigned)ch * plane_b + (unsigned)(y * p.W + x) * 4u : OUTSIDE;
-        }
         const float* in_b = p.in + (size_t)b * p.in_bs;
         auto dma_rsrc = [&](int gi) {
             return __builtin_amdgcn_make_buffer_rsrc((void*)(in_b + (size_t)T16_GROUP * (wave + T16_WAVES * gi) * plane), 0,
@@ -88,7 +97,7 @@ __device__ __forceinline__ void conv_t16_body(const ConvT16Params& p, float* __r
         };
         auto dma_piece = [&](auto PAR_, const __amdgpu_buffer_rsrc_t irs, int i) {
             constexpr int PAR = decltype(PAR_)::value;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (__attribute__((address_space(3))) void*)(ring + PAR * T16_STAGE + i * 256), 16, (int)voff[i], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (__attribute__((address_space(3))) void*)(ring + PAR * T16_STAGE + i * 256), 16, (int)voff[i], 0, 0, T16_DMA_AUX);
         };
         // the weights come from the split-K kernel's image ([half 2][wave 8][tap 9][run Cin/64][h 2][i 32][4]: the 16 bytes at
         // (half, wave w, tap, run g, h, i) hold W[32 half + i][8 (w Cin/64 + g) + 2 e + h][tap], e = 0 .. 3), so the trunk keeps ONE
@@ -107,10 +116,22 @@ __device__ __forceinline__ void conv_t16_body(const ConvT16Params& p, float* __r
         // B operand of (row ti, k-step e, tap (ky, kx)): the lane's channel of the k-step, halo row ti + ky, column (lane & 15) + kx - 1
         const float* __restrict__ bbase = ring + (8 * (lane >> 5) + ((lane >> 4) & 1)) * CP + (lane & 15) + 3;
         {
-            const int off = woff(0);
-            const __amdgpu_buffer_rsrc_t irs = dma_rsrc(0);
+            const int off = woff(0);                             // the first weights are on their way while the stage's addresses are worked out
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) wr[0][tap] = ld_piece(wrs, off, tap * runs * 1024);
+            for (int tap = 0; tap < 9; ++tap) wr[0][tap] = t16_ld_w(wrs, off, tap * runs * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // piece i * 64 + lane of a stage: channel ch, halo row hr, piece pc of the row -- or one of the channel's padding pieces
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int pi = i * 64 + lane;
+            const int ch = pi / PPC, rem = pi - ch * PPC;
+            const int hr = rem / 6, pc = rem - hr * 6;
+            const int y = y0 - 1 + hr, x = x0 - 4 + 4 * pc;
+            voff[i] = (rem < 6 * R && y >= 0 && y < p.H && x >= 0 && x < p.W) ? (unsigned)ch * plane_b + (unsigned)(y * p.W + x) * 4u : OUTSIDE;
+        }
+        {
+            const __amdgpu_buffer_rsrc_t irs = dma_rsrc(0);
 #pragma unroll
             for (int i = 0; i < NDMA; ++i) dma_piece(IC<0>{}, irs, i);
         }
@@ -119,7 +140,8 @@ __device__ __forceinline__ void conv_t16_body(const ConvT16Params& p, float* __r
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this group's stage has landed (and its weights): nothing younger is in flight
             // The next group's loads (after the last group its own again, read by nobody) go out BETWEEN the MFMAs, one or two per
             // (k-step, halo row): a VMEM instruction holds its wave's issue for 60 - 100 cycles, and the two waves of a SIMD reach a
-            // step's start together.  They fill the stage group gi - 1 was read from (its reads fed MFMAs already issued).
+            // step's start together (spread over the first 3 / 5 / 7 tenths of the step instead of all of it: the same time).
+            // They fill the stage group gi - 1 was read from (its reads fed MFMAs already issued).
             const int gn = gi + 1 < my ? gi + 1 : gi;
             const int off = woff(gn);
             const __amdgpu_buffer_rsrc_t irs = dma_rsrc(gn);
@@ -137,7 +159,7 @@ __device__ __forceinline__ void conv_t16_body(const ConvT16Params& p, float* __r
                 }
 #pragma unroll
                 for (int l = j * NL / NJ; l < (j + 1) * NL / NJ; ++l) {
-                    if (l < 9) wr[PAR ^ 1][l] = ld_piece(wrs, off, l * runs * 1024);
+                    if (l < 9) wr[PAR ^ 1][l] = t16_ld_w(wrs, off, l * runs * 1024);
                     else dma_piece(IC<PAR ^ 1>{}, irs, l - 9);
                 }
 #pragma unroll
@@ -163,9 +185,7 @@ __device__ __forceinline__ void conv_t16_body(const ConvT16Params& p, float* __r
 #pragma unroll
         for (int r = 0; r < 4; ++r) lds[((wave * T16_MAXR + ti) * 4 + r) * 64 + lane] = acc[ti][r];
     __syncthreads();
-    const int v = (int)threadIdx.x & 255, r = v >> 6, l = v & 63;
-    const int co = 16 * quarter + 4 * (l >> 4) + r;
-    const float bias = p.bias[co];
+    const int r = er, l = el;
     const int x = x0 + (l & 15);
     for (int ti = (int)threadIdx.x >> 8; ti < NR; ti += 2) {
         float s = 0.0f;
@@ -190,6 +210,119 @@ __global__ __launch_bounds__(512, 2) void conv_t16_kernel(const ConvT16Params p)
     if (sh.rows == 1) conv_t16_body<1>(p, lds, quarter, b, sh.y0, x0);
     else if (sh.rows == 2) conv_t16_body<2>(p, lds, quarter, b, sh.y0, x0);
     else if (sh.rows == 3) conv_t16_body<3>(p, lds, quarter, b, sh.y0, x0);       // (0 rows: more workgroups than rows; more than 3: refused at launch)
+}
+
+// ---- the local-fusion layers (1x1, Cin = 576; rdn.py:34) on the same maps: the same units, 4 MFMAs per row and group -- a
+// latency problem, not an arithmetic one (170 MFLOP per layer at 48 x 48).  EVERY load of the workgroup goes out at once: a wave's
+// <= 5 groups of 16 channels have a stage each (16 channels x rows x 16 columns by LDS-DMA, channel pitch 16 / 48 / 48 floats =
+// 16 banks mod 32) and a 1 KiB weight run each in registers; bias and residual are asked for before that; one wait, <= 60 MFMAs,
+// the reduction through LDS, two destinations.  The split-K kernel's 1x1 form stages a chunk, multiplies, stages the next.
+constexpr int T16_1X1_MAXG = 5;                                // groups per wave: Cin <= 640
+static_assert(T16_1X1_MAXG * T16_GROUP * 48 <= 2 * T16_STAGE, "the 1x1 stages fit the wave's share of the LDS");
+
+template <int NR>
+__device__ __forceinline__ void conv1x1_t16_body(const ConvT16Params& p, float* __restrict__ lds, int quarter, int b, int y0, int x0) {
+    constexpr int CP = NR == 1 ? 16 : 48, PPC = CP / 4, NDMA = T16_GROUP * PPC / 64, STAGE = T16_GROUP * CP;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t plane = (size_t)p.H * p.W;
+    const unsigned plane_b = (unsigned)(plane * sizeof(float));
+    const int G = p.Cin / T16_GROUP;
+    const int my = wave < G ? (G - wave + T16_WAVES - 1) / T16_WAVES : 0;        // this wave's groups: wave, wave + 8, ... (<= T16_1X1_MAXG)
+    constexpr unsigned OUTSIDE = 0x80000000u;
+    // the epilogue's thread: output co of column x, rows y0 + rsel (+ 2): bias and residual are on their way before anything else
+    const int ev = (int)threadIdx.x & 255, er = ev >> 6, el = ev & 63, rsel = (int)threadIdx.x >> 8;
+    const int co = 16 * quarter + 4 * (el >> 4) + er;
+    const int x = x0 + (el & 15);
+    const float bias = p.bias[co];
+    float resv[2] = {0.0f, 0.0f};
+    if (p.res && x < p.W) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (rsel + 2 * u < NR) resv[u] = p.res[(size_t)b * p.res_bs + (size_t)co * plane + (size_t)(y0 + rsel + 2 * u) * p.W + x];
+    }
+    f32x4 acc[NR];
+#pragma unroll
+    for (int ti = 0; ti < NR; ++ti) acc[ti] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (my > 0) {
+        float* __restrict__ ring = lds + wave * 2 * T16_STAGE;
+        const int runs = p.Cin / 64;
+        const unsigned inv_runs = (65536u + runs - 1) / runs;     // r / runs = (r * inv_runs) >> 16 for r < 128
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Cin * (64 * 4), 0x00020000);
+        // the split-K kernel's 1x1 image: [half 2][wave 8][run Cin/64][h 2][i 32][4] (conv_t16_body's lane mapping, one tap)
+        const int wlane = (quarter >> 1) * (8 * runs * 1024) + ((lane >> 4) & 1) * 512 + (16 * (quarter & 1) + (lane & 15)) * 16;
+        f32x4 wr[T16_1X1_MAXG];
+#pragma unroll
+        for (int gi = 0; gi < T16_1X1_MAXG; ++gi)
+            if (gi < my) {
+                const unsigned r8 = 2u * (wave + T16_WAVES * gi) + (lane >> 5);
+                const unsigned w8 = (r8 * inv_runs) >> 16, g = r8 - w8 * runs;
+                wr[gi] = t16_ld_w(wrs, wlane + (int)((w8 * runs + g) * 1024), 0);
+            }
+        // piece i * 64 + lane of a stage: channel ch, row, piece pc of the row's 16 columns -- or padding
+        unsigned voff[NDMA];
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int pi = i * 64 + lane;
+            const int ch = pi / PPC, rem = pi - ch * PPC;
+            const int row = rem >> 2, xx = x0 + 4 * (rem & 3);
+            voff[i] = (row < NR && xx < p.W) ? (unsigned)ch * plane_b + (unsigned)((y0 + row) * p.W + xx) * 4u : OUTSIDE;
+        }
+        const float* in_b = p.in + (size_t)b * p.in_bs;
+#pragma unroll
+        for (int gi = 0; gi < T16_1X1_MAXG; ++gi)
+            if (gi < my) {
+                const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(in_b + (size_t)T16_GROUP * (wave + T16_WAVES * gi) * plane), 0, (int)((unsigned)T16_GROUP * plane_b), 0x00020000);
+#pragma unroll
+                for (int i = 0; i < NDMA; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (__attribute__((address_space(3))) void*)(ring + gi * STAGE + i * 256), 16, (int)voff[i], 0, 0, T16_DMA_AUX);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every stage has landed
+        const float* __restrict__ bbase = ring + (8 * (lane >> 5) + ((lane >> 4) & 1)) * CP + (lane & 15);
+#pragma unroll
+        for (int gi = 0; gi < T16_1X1_MAXG; ++gi)
+            if (gi < my) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int ti = 0; ti < NR; ++ti) acc[ti] = MFMA16(wr[gi][e], bbase[gi * STAGE + e * 2 * CP + ti * 16], acc[ti]);
+            }
+    }
+    __syncthreads();                                             // the sums meet over the stages once every wave has left them
+#pragma unroll
+    for (int ti = 0; ti < NR; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[((wave * T16_MAXR + ti) * 4 + r) * 64 + lane] = acc[ti][r];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int ti = rsel + 2 * u;
+        if (ti < NR) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w8 = 0; w8 < T16_WAVES; ++w8) s += lds[((w8 * T16_MAXR + ti) * 4 + er) * 64 + el];
+            s += bias;
+            if (p.relu) s = relu0(s);
+            s += resv[u];
+            if (x < p.W) {
+                const size_t o = (size_t)co * plane + (size_t)(y0 + ti) * p.W + x;
+                p.out[(size_t)b * p.out_bs + o] = s;
+                if (p.out1) p.out1[(size_t)b * p.out1_bs + o] = s;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void conv1x1_t16_kernel(const ConvT16Params p) {
+    __shared__ __attribute__((aligned(16))) float lds[T16_LDS_FLOATS];
+    const int quarter = (int)blockIdx.x & 3, slot = (int)blockIdx.x >> 2;
+    const int tiles_x = (p.W + 15) >> 4;
+    const T16Share sh = t16_share(slot, p.slots, p.B * tiles_x, p.H);
+    const int b = sh.strip / tiles_x, x0 = 16 * (sh.strip - b * tiles_x);
+    if (sh.rows == 1) conv1x1_t16_body<1>(p, lds, quarter, b, sh.y0, x0);
+    else if (sh.rows == 2) conv1x1_t16_body<2>(p, lds, quarter, b, sh.y0, x0);
+    else if (sh.rows == 3) conv1x1_t16_body<3>(p, lds, quarter, b, sh.y0, x0);
 }
 
 // workgroups per output quarter for a map of `strips` strips of H rows (0: not a map for this kernel)
@@ -231,8 +364,29 @@ int diinn_conv_t16(void* stream, const float* in_dev, long long in_batch_stride,
     ConvT16Params p;
     p.in = in_dev; p.w = packed_w_dev; p.bias = bias_dev; p.res = res_dev; p.out = out_dev;
     p.in_bs = in_batch_stride; p.out_bs = out_batch_stride; p.res_bs = res_batch_stride;
+    p.out1 = nullptr; p.out1_bs = 0;
     p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0; p.slots = slots;
     hipLaunchKernelGGL(conv_t16_kernel, dim3((unsigned)(4 * slots)), dim3(512), 0, (hipStream_t)stream, p);
+    return hip_status(hipGetLastError());
+}
+
+int diinn_conv1x1_t16(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
+                      const float* packed_w_dev, const float* bias_dev, const float* res_dev, long long res_batch_stride,
+                      float* out0_dev, long long out0_batch_stride, float* out1_dev, long long out1_batch_stride,
+                      int relu, int B, int H, int W) {
+    if (!in_dev || !packed_w_dev || !bias_dev || !out0_dev) return DIINN_ERR_INVALID_ARG;
+    int st = check_dims(B, H, W);
+    if (st) return st;
+    if (Cin <= 0 || Cin % 64 || Cin > T16_1X1_MAXG * T16_WAVES * T16_GROUP || (W & 3)) return DIINN_ERR_UNSUPPORTED;
+    if ((((size_t)in_dev) & 15) || (((size_t)packed_w_dev) & 15) || (in_batch_stride & 3)) return DIINN_ERR_INVALID_ARG;
+    const int slots = t16_slots((long long)B * ((W + 15) / 16), H);
+    if (slots == 0) return DIINN_ERR_UNSUPPORTED;                // a map for the other kernels
+    if ((long long)H * W * 4 * T16_GROUP > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;
+    ConvT16Params p;
+    p.in = in_dev; p.w = packed_w_dev; p.bias = bias_dev; p.res = res_dev; p.out = out0_dev; p.out1 = out1_dev;
+    p.in_bs = in_batch_stride; p.out_bs = out0_batch_stride; p.out1_bs = out1_batch_stride; p.res_bs = res_batch_stride;
+    p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0; p.slots = slots;
+    hipLaunchKernelGGL(conv1x1_t16_kernel, dim3((unsigned)(4 * slots)), dim3(512), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
 

@@ -716,6 +716,8 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
             ? diinn_conv_wino(stream, in, in_bs, cin, wu, bias, res, res_bs, o0, o0_bs, relu, B, H, W)
             : (t16 && taps == 9 && !o1)
             ? diinn_conv_t16(stream, in, in_bs, cin, w, bias, res, res_bs, o0, o0_bs, relu, B, H, W)
+            : (t16 && taps == 1 && cin <= 640)
+            ? diinn_conv1x1_t16(stream, in, in_bs, cin, w, bias, res, res_bs, o0, o0_bs, o1, o1_bs, relu, B, H, W)
             : diinn_conv_ksplit(stream, in, in_bs, cin, taps, w, bias, res, res_bs, o0, o0_bs, o1, o1_bs, relu, B, H, W);
         w += (size_t)64 * cin * taps;
         if (taps == 9 && wu) wu += (size_t)64 * cin * 16;

@@ -35,7 +35,7 @@ extern "C" {
 /* What each ABI number added: INTEGRATION.md, "ABI history".  v9 (this header): ONE trunk entry point (diinn_rdn_forward_ex; the four
  * one-algorithm entry points are wrappers kept for this number only), the F(4x4) split hand-off fails loudly (sticky status word,
  * diinn_conv_wino4_ws_status), the training step's own kernels for the hoisted conv's weight gradient and its Winograd forward
- * (diinn_backward_cell_sum_ex, diinn_unfold_tiled, diinn_sum_parts, diinn_precompute_P_wpu). */
+ * (diinn_backward_cell_sum_ex, diinn_unfold_tiled, diinn_sum_parts, diinn_precompute_P_wpu), the small-map kernels (diinn_conv_t16, diinn_conv1x1_t16). */
 
 /* status codes */
 #define DIINN_OK                 0
@@ -355,7 +355,8 @@ int    diinn_metasr_make_axis_tables(int n_in, int n_out, int32_t* idx, float* r
  *   always read: the 1x1 layers and small maps); biases_dev = their 147 x 64 biases; out_dev [B,64,H,W].
  *   `algo` caps the kernel family of the 3x3 layers, the images that family reads must be given (else DIINN_ERR_INVALID_ARG),
  *   images of other families are ignored and may be NULL:
- *     DIINN_RDN_ALGO_DIRECT  split-K direct sum everywhere (packed_dev only);
+ *     DIINN_RDN_ALGO_DIRECT  direct sum everywhere (packed_dev only): the split-K kernel, and on small maps with fewer of its units than
+ *                            compute units the strip kernel on the same image (diinn_conv_t16_applies);
  *     DIINN_RDN_ALGO_WINO    Winograd F(2x2,3x3) (packed_wino_dev) from B*H*W >= 8192 on, the split-K kernel below;
  *     DIINN_RDN_ALGO_WINO4   Winograd F(4x4,3x3) (packed_wino4_dev) where that kernel needs fewer rounds of workgroups than
  *                            F(2x2) (diinn_rdn_wino4_applies; from about 35,000 pixels on, depending on how its 2 * ceil(tiles
@@ -485,6 +486,16 @@ int    diinn_conv_t16(void* stream, const float* in_dev, long long in_batch_stri
                       const float* res_dev, long long res_batch_stride,
                       float* out_dev, long long out_batch_stride, int relu, int B, int H, int W);
 int    diinn_conv_t16_applies(int B, int H, int W);
+/* diinn_conv1x1_t16: the local-fusion layers (1x1; rdn.py:34) on the same maps and units: addressing, epilogue (bias, ReLU,
+ *   residual, two destinations) and packed_w_dev as diinn_conv_ksplit with taps = 1; W % 4 == 0, Cin % 64 == 0, Cin <= 640
+ *   (every load of a workgroup is in flight at once: five groups of 16 channels per wave), else DIINN_ERR_UNSUPPORTED.  The
+ *   trunk gives it the 16 fusion layers of a map with diinn_conv_t16_applies == 1 (the 1024-channel global fusion keeps
+ *   diinn_conv_ksplit). */
+int    diinn_conv1x1_t16(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
+                         const float* packed_w_dev, const float* bias_dev,
+                         const float* res_dev, long long res_batch_stride,
+                         float* out0_dev, long long out0_batch_stride, float* out1_dev, long long out1_batch_stride,
+                         int relu, int B, int H, int W);
 
 /* DEPRECATED, kept for this ABI number only: the one-algorithm trunk entry points of ABI <= 8 = diinn_rdn_forward_ex with algo
  * DIRECT / WINO / WINO4 / X3 and ONE workspace laid out [F(4x4) split area][planes] (diinn_rdn_workspace_floats = the split
@@ -530,7 +541,7 @@ int diinn_p_launch_info(int B, int H, int W, int r0, int r1, int compute, int* a
  *   TEST / A-B ONLY (force a kernel variant that the launch cost models would not take, or inject a fault; results stay
  *     within the documented equivalences) -- DIINN_F32_KERNEL, DIINN_BF16_KERNEL, DIINN_X3_KERNEL, DIINN_PBF16_KERNEL,
  *     DIINN_P_KERNEL, DIINN_ENC_X3_ROWS, DIINN_ENC_S1_MIN_BLOCKS, DIINN_ENC_NO_STREAM1X1, DIINN_ENC_LAT_MAX_TILES,
- *     DIINN_ENC_WINO_HALF_MAX, DIINN_ENC_WINO_PERSIST, DIINN_TRAIN_SPLIT_HEAD, DIINN_DEBUG_NCU (the compute-unit count cost models, split plans and persistent grids assume),
+ *     DIINN_ENC_WINO_HALF_MAX, DIINN_ENC_WINO_PERSIST, DIINN_ENC_NO_T16 (1: small maps keep the split-K 3x3 kernel), DIINN_TRAIN_SPLIT_HEAD, DIINN_DEBUG_NCU (the compute-unit count cost models, split plans and persistent grids assume),
  *     DIINN_ENC_WINO4_FAULT (1: the split hand-off's give-up path on demand: NaN outputs + sticky status).  The environment is read ONCE, at the first launch or the first call of either function; afterwards
  * only diinn_debug_set changes a knob (process-wide, atomic stores: safe against concurrent launches, which see
  * either the old or the new value).  Unknown name -> DIINN_ERR_INVALID_ARG.  This is the library's only mutable

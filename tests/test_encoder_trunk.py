@@ -700,6 +700,59 @@ def test_conv_t16_kernel_matches_fp64_conv(knobs):
         assert lib.diinn_conv_t16(stream, ptr(small), 128 * h * w, cin, ptr(packed), ptr(bias), None, 0, ptr(o), 64 * h * w, 0, 1, h, w) == N.ERR_UNSUPPORTED
 
 
+@pytest.mark.gpu
+def test_conv1x1_t16_kernel_matches_fp64_conv(knobs):
+    """diinn_conv1x1_t16 (the local-fusion layers on small maps; the split-K kernel's 1x1 image): residual, ReLU, two
+    destinations, batches, partly filled strips, 1 / 2 / 3 rows per workgroup, against the float64 convolution; repeatable
+    bit for bit; and what it refuses."""
+    import ctypes as C
+    import diinn_amd._native as N
+    import diinn_amd.modules as M
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    gen = torch.Generator(device=dev).manual_seed(6)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())                    # noqa: E731
+    cases = [(0, 1, 576, 48, 48, 0, 1, 1), (0, 1, 576, 32, 32, 0, 1, 1), (0, 2, 576, 24, 40, 0, 1, 1), (0, 1, 64, 17, 52, 1, 0, 0),
+             (0, 1, 640, 1, 4, 0, 0, 1), (0, 4, 320, 24, 24, 1, 1, 0), (32, 1, 576, 24, 16, 0, 1, 1), (32, 1, 128, 16, 16, 1, 0, 1),
+             (128, 2, 192, 30, 12, 0, 1, 0)]
+    for (ncu, b, cin, h, w, relu, use_res, two) in cases:
+        knobs("DIINN_DEBUG_NCU", ncu)
+        total = cin + 64
+        buf = torch.randn((b, total, h, w), device=dev, generator=gen)
+        wt = torch.randn((64, cin, 1, 1), device=dev, generator=gen) / cin ** 0.5
+        bias = torch.randn(64, device=dev, generator=gen)
+        res = torch.randn((b, 64, h, w), device=dev, generator=gen) if use_res else None
+        out0 = torch.full((b, 64, h, w), float("nan"), device=dev)
+        out1 = torch.full((b, 96, h, w), float("nan"), device=dev) if two else None
+        packed = M.pack_conv_ksplit(wt).to(dev)
+
+        def run():
+            return lib.diinn_conv1x1_t16(stream, ptr(buf), total * h * w, cin, ptr(packed), ptr(bias), ptr(res) if use_res else None,
+                                         64 * h * w, ptr(out0), 64 * h * w, ptr(out1[:, 32:]) if two else None, 96 * h * w, relu, b, h, w)
+        assert run() == 0, (ncu, b, cin, h, w)
+        torch.cuda.synchronize()
+        ref = F.conv2d(buf[:, :cin].double(), wt.double(), bias.double())
+        if relu:
+            ref = torch.relu(ref)
+        if use_res:
+            ref = ref + res.double()
+        err = float((out0.double() - ref).abs().max())
+        assert err <= 2e-6 * max(1.0, float(ref.abs().max())), (ncu, b, cin, h, w, err)
+        if two:
+            assert torch.equal(out1[:, 32:], out0) and torch.isnan(out1[:, :32]).all()
+        first = out0.clone()
+        for _ in range(5):
+            out0.fill_(float("nan"))
+            assert run() == 0
+            assert torch.equal(out0, first)
+    knobs("DIINN_DEBUG_NCU", 0)
+    z = torch.zeros(1, 1088, 8, 8, device=dev)
+    o = torch.zeros(1, 64, 64, 64, device=dev)
+    for (cin, h, w) in [(1024, 8, 8), (96, 8, 8), (64, 8, 6), (64, 64, 64)]:   # too many channels for one wave's stages, ...
+        assert lib.diinn_conv1x1_t16(stream, ptr(z), 1088 * h * w, cin, ptr(packed), ptr(bias), None, 0, ptr(o), 64 * h * w, None, 0, 0, 1, h, w) == N.ERR_UNSUPPORTED
+
+
 def test_conv_t16_dispatch_rule(knobs):
     """diinn_conv_t16_applies: the maps whose 3x3 layers the trunk gives to the small-map kernel (no device needed: the
     compute-unit count is forced)."""
