@@ -799,6 +799,10 @@ def test_rdn_trunk_small_map_kernel_against_the_split_k_kernel(knobs):
             enc.hip_trunk_max_pixels = M.RDN.hip_trunk_max_pixels
         scale = max(1.0, float(ref.abs().max()))
         assert not torch.equal(got, ks)                          # (another kernel did run)
+        if (b, h, w) == (1, 48, 48):
+            with torch.no_grad():
+                for _ in range(90):                              # back-to-back forwards repeat bit for bit
+                    assert torch.equal(enc(x), got)
         assert float((got - ks).abs().max()) <= 5e-6 * scale, (b, h, w)
         assert float((got - ref).abs().max()) <= 2e-5 * scale, (b, h, w)
 
