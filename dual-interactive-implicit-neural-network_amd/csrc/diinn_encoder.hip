@@ -700,7 +700,8 @@ static int rdn_forward_impl(void* stream, const float* sfe1_dev, const float* pa
     const bool x3 = packed_x3_dev && (long long)B * hw >= knob(diinn_knobs().enc_x3_min);
     // small maps (csrc/diinn_conv_t16.hip): the direct sum in units of (1 .. 3 rows x 16 pixels, 16 outputs) where the split-K
     // kernel's units leave compute units idle; the same weight image (per trunk: 48x48 1.95 -> 1.85 ms, 40x40 1.92 -> 1.44, 32x32 1.87 -> 1.05)
-    const bool t16 = !wino && !x3 && diinn_conv_t16_applies(B, H, W) != 0;
+    const bool t16 = !wino && !x3 && diinn_conv_t16_applies(B, H, W) != 0 &&
+                     ((((size_t)sfe1_dev) | ((size_t)planes) | ((size_t)packed_dev)) & 15) == 0;   // (its 16-byte LDS-DMA pieces; else the split-K kernel, as before)
     const float* w = packed_dev;
     const float* wu = packed_wino_dev;
     const float* wu4 = packed_wino4_dev;

@@ -803,6 +803,21 @@ def test_rdn_trunk_small_map_kernel_against_the_split_k_kernel(knobs):
             with torch.no_grad():
                 for _ in range(90):                              # back-to-back forwards repeat bit for bit
                     assert torch.equal(enc(x), got)
+            # shallow features that are not 16-byte aligned (the strip kernel stages 16-byte pieces): the split-K kernel, as before
+            import ctypes as C
+            lib = N.load()
+            ptr = lambda t: C.c_void_p(t.data_ptr())            # noqa: E731
+            with torch.no_grad():
+                sfe1 = enc._sfe1_hip(x)
+            shifted = torch.empty(sfe1.numel() + 1, device=dev)[1:].view_as(sfe1).copy_(sfe1)
+            assert shifted.data_ptr() % 16 == 4
+            packed, biases = enc._hip_packed(dev)
+            planes = torch.empty(lib.diinn_rdn_planes_floats(N.RDN_ALGO_DIRECT, b, h, w), device=dev)
+            out = torch.empty_like(sfe1)
+            assert lib.diinn_rdn_forward_ex(C.c_void_p(torch.cuda.current_stream().cuda_stream), N.RDN_ALGO_DIRECT, ptr(shifted), ptr(packed),
+                                            None, None, None, ptr(biases), ptr(planes), None, ptr(out), b, h, w) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(out, ks)
         assert float((got - ks).abs().max()) <= 5e-6 * scale, (b, h, w)
         assert float((got - ref).abs().max()) <= 2e-5 * scale, (b, h, w)
 
