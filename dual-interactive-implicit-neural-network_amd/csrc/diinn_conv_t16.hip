@@ -53,7 +53,20 @@ struct ConvT16Params {
     long long in_bs, out_bs, out1_bs, res_bs;
     int Cin, B, H, W, relu;
     int slots;               // workgroups per output quarter, dealt to the B * ceil(W / 16) strips (t16_share)
+#ifdef T16_STAMPS
+    unsigned long long* stamps;   // tools/ubench/t16_bench.hip -DT16_STAMPS: s_memrealtime (100 MHz) per (workgroup, wave, point 0..7)
+#endif
 };
+#ifdef T16_STAMPS
+#define T16_STAMP(i)                                                                                             \
+    do {                                                                                                         \
+        unsigned long long t_;                                                                                   \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
+        if (lane == 0) p.stamps[((size_t)blockIdx.x * T16_WAVES + wave) * 8 + (i)] = t_;                         \
+    } while (0)
+#else
+#define T16_STAMP(i) do {} while (0)
+#endif
 
 // the share of slot `slot` (of `slots`) in a map of `strips` strips of H rows: strip k has slots / strips (+ 1 for the first
 // slots % strips) workgroups, which cut its rows evenly
@@ -83,6 +96,14 @@ __device__ __forceinline__ void conv_t16_body(const ConvT16Params& p, float* __r
     const int ev = (int)threadIdx.x & 255, er = ev >> 6, el = ev & 63;
     const int co = 16 * quarter + 4 * (el >> 4) + er;
     const float bias = p.bias[co];
+    T16_STAMP(0);                                                // body entered
+#ifdef T16_STAMPS
+    {
+        unsigned hw_;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+        if (lane == 0) p.stamps[((size_t)blockIdx.x * T16_WAVES + wave) * 8 + 7] = hw_;     // which SIMD / CU the wave sits on
+    }
+#endif
     f32x4 acc[NR];                                               // row ti: D[out 4 (lane >> 4) + r][column lane & 15]
 #pragma unroll
     for (int ti = 0; ti < NR; ++ti) acc[ti] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -138,6 +159,7 @@ __device__ __forceinline__ void conv_t16_body(const ConvT16Params& p, float* __r
         auto do_group = [&](auto PAR_, int gi) {
             constexpr int PAR = decltype(PAR_)::value;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this group's stage has landed (and its weights): nothing younger is in flight
+            if (gi == 0) T16_STAMP(1);                           // the first group's loads have landed
             // The next group's loads (after the last group its own again, read by nobody) go out BETWEEN the MFMAs, one or two per
             // (k-step, halo row): a VMEM instruction holds its wave's issue for 60 - 100 cycles, and the two waves of a SIMD reach a
             // step's start together (spread over the first 3 / 5 / 7 tenths of the step instead of all of it: the same time).
@@ -176,10 +198,13 @@ __device__ __forceinline__ void conv_t16_body(const ConvT16Params& p, float* __r
             do_group(IC<1>{}, gi + 1);
         }
         if (gi < my) do_group(IC<0>{}, gi);
+        T16_STAMP(2);                                            // the last MFMA has been issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the surplus loads have landed: nothing arrives in this LDS later
+        T16_STAMP(3);
     }
     // ---- the 8 partial sums of every row meet in LDS, over the stages once every wave has left them
     __syncthreads();
+    T16_STAMP(4);                                                // every wave of the workgroup is here
 #pragma unroll
     for (int ti = 0; ti < NR; ++ti)
 #pragma unroll
@@ -199,6 +224,11 @@ __device__ __forceinline__ void conv_t16_body(const ConvT16Params& p, float* __r
             p.out[(size_t)b * p.out_bs + o] = s;
         }
     }
+    T16_STAMP(5);                                                // stores issued
+#ifdef T16_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    T16_STAMP(6);                                                // stores acknowledged
+#endif
 }
 
 __global__ __launch_bounds__(512, 2) void conv_t16_kernel(const ConvT16Params p) {
@@ -325,17 +355,20 @@ __global__ __launch_bounds__(512, 2) void conv1x1_t16_kernel(const ConvT16Params
     else if (sh.rows == 3) conv1x1_t16_body<3>(p, lds, quarter, b, sh.y0, x0);
 }
 
+#ifdef T16_STAMPS
+static unsigned long long* g_t16_stamps = nullptr;               // set by tools/ubench/t16_bench.hip before each launch
+#endif
 // workgroups per output quarter for a map of `strips` strips of H rows (0: not a map for this kernel)
 static int t16_slots(long long strips, int H) {
     const long long per_quarter = device_cus() / 4 > 0 ? device_cus() / 4 : 1;
-    const long long slots = strips * H < per_quarter ? strips * H : per_quarter;
-    if (slots < strips) return 0;                                // a strip would be left without a workgroup
-    return (H + (slots / strips) - 1) / (slots / strips) <= T16_MAXR ? (int)slots : 0;
-}
-
-static int t16_slots(long long tiles) {
-    const int per_quarter = device_cus() / 4 > 0 ? device_cus() / 4 : 1;
-    return (int)(tiles < per_quarter ? tiles : per_quarter);
+    long long per_strip = per_quarter / strips;                  // workgroups a strip can have
+    if (per_strip < 1) return 0;                                 // a strip would be left without a workgroup
+    if (per_strip > H) per_strip = H;
+    const long long rows = (H + per_strip - 1) / per_strip;      // the busiest workgroup's rows: the layer's time
+    if (rows > T16_MAXR) return 0;
+    // no more workgroups than that load asks for (48 x 48: 3 strips x 16 workgroups of exactly 3 rows = 192 of 256 CUs, not 3 x 21 of 2
+    // or 3 rows): the busiest workgroup is the layer either way (measured: 1.651 / 1.649 against 1.655 / 1.633 ms per trunk), the idle CUs draw less
+    return (int)(strips * ((H + rows - 1) / rows));
 }
 
 extern "C" {
@@ -366,6 +399,9 @@ int diinn_conv_t16(void* stream, const float* in_dev, long long in_batch_stride,
     p.in_bs = in_batch_stride; p.out_bs = out_batch_stride; p.res_bs = res_batch_stride;
     p.out1 = nullptr; p.out1_bs = 0;
     p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0; p.slots = slots;
+#ifdef T16_STAMPS
+    p.stamps = g_t16_stamps;
+#endif
     hipLaunchKernelGGL(conv_t16_kernel, dim3((unsigned)(4 * slots)), dim3(512), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
@@ -386,6 +422,9 @@ int diinn_conv1x1_t16(void* stream, const float* in_dev, long long in_batch_stri
     p.in = in_dev; p.w = packed_w_dev; p.bias = bias_dev; p.res = res_dev; p.out = out0_dev; p.out1 = out1_dev;
     p.in_bs = in_batch_stride; p.out_bs = out0_batch_stride; p.out1_bs = out1_batch_stride; p.res_bs = res_batch_stride;
     p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0; p.slots = slots;
+#ifdef T16_STAMPS
+    p.stamps = nullptr;
+#endif
     hipLaunchKernelGGL(conv1x1_t16_kernel, dim3((unsigned)(4 * slots)), dim3(512), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
