@@ -52,7 +52,10 @@ struct ConvT16Params {
     float* out1;             // 1x1 kernel only: optional second destination (batch stride out1_bs)
     long long in_bs, out_bs, out1_bs, res_bs;
     int Cin, B, H, W, relu;
-    int slots;               // workgroups per output quarter, dealt to the B * ceil(W / 16) strips (t16_share)
+    // the partition, worked out once on the host (t16_plan): a strip has `per_strip` workgroups of `rows` rows (the last one what is
+    // left); divisions by per_strip, tiles_x and Cin / 64 as multiplications (x / d == (x * m) >> 32 for x, d < 65536, m = 2^32 / d + 1)
+    int per_strip, rows, tiles_x;
+    unsigned m_per_strip, m_tiles_x, inv_runs;
 #ifdef T16_STAMPS
     unsigned long long* stamps;   // tools/ubench/t16_bench.hip -DT16_STAMPS: s_memrealtime (100 MHz) per (workgroup, wave, point 0..7)
 #endif
@@ -68,16 +71,14 @@ struct ConvT16Params {
 #define T16_STAMP(i) do {} while (0)
 #endif
 
-// the share of slot `slot` (of `slots`) in a map of `strips` strips of H rows: strip k has slots / strips (+ 1 for the first
-// slots % strips) workgroups, which cut its rows evenly
-struct T16Share { int strip, y0, rows; };
-__host__ __device__ inline T16Share t16_share(int slot, int slots, int strips, int H) {
-    const int base = slots / strips, extra = slots - base * strips;
-    int k, j, n;
-    if (slot < extra * (base + 1)) { n = base + 1; k = slot / n; j = slot - k * n; }
-    else { n = base; const int s2 = slot - extra * (base + 1); k = extra + s2 / n; j = s2 - (s2 / n) * n; }
-    const int y0 = (int)((long long)j * H / n), y1 = (int)((long long)(j + 1) * H / n);
-    return T16Share{k, y0, y1 - y0};
+// workgroup (quarter, slot) of the launch: strip slot / per_strip (image b, columns x0 .. x0 + 15), rows y0 .. y0 + rows - 1
+struct T16Share { int b, x0, y0, rows; };
+__device__ __forceinline__ T16Share t16_share(const ConvT16Params& p, int slot) {
+    // (m = 2^32 / d + 1 does not fit 32 bits for d = 1)
+    const int strip = p.per_strip == 1 ? slot : (int)(((unsigned long long)(unsigned)slot * p.m_per_strip) >> 32), j = slot - strip * p.per_strip;
+    const int b = p.tiles_x == 1 ? strip : (int)(((unsigned long long)(unsigned)strip * p.m_tiles_x) >> 32);
+    const int y0 = j * p.rows, left = p.H - y0;
+    return T16Share{b, 16 * (strip - b * p.tiles_x), y0, left < p.rows ? left : p.rows};
 }
 
 template <int NR>
@@ -89,7 +90,7 @@ __device__ __forceinline__ void conv_t16_body(const ConvT16Params& p, float* __r
     const size_t plane = (size_t)p.H * p.W;
     const unsigned plane_b = (unsigned)(plane * sizeof(float));
     const int G = p.Cin / T16_GROUP;
-    const int my = wave < G ? (G - wave + T16_WAVES - 1) / T16_WAVES : 0;        // this wave's groups: wave, wave + 8, ...
+    const int my = wave < G ? (G - wave + T16_WAVES - 1) >> 3 : 0;        // this wave's groups: wave, wave + 8, ...
     constexpr unsigned OUTSIDE = 0x80000000u;
 
     // the epilogue's thread: output co of column x; its bias is asked for now, not behind the last barrier
@@ -125,7 +126,7 @@ __device__ __forceinline__ void conv_t16_body(const ConvT16Params& p, float* __r
         // direct-sum image: lane (k = lane >> 4, m = lane & 15) takes output 16 quarter + m and, of the group's 16 channels,
         // the run of 8 number k >> 1 at h = k & 1 -- k-step e multiplies the group's channels 8 (k >> 1) + 2 e + (k & 1)
         const int runs = p.Cin / 64;
-        const unsigned inv_runs = (65536u + runs - 1) / runs;     // r / runs = (r * inv_runs) >> 16 for r < 128
+        const unsigned inv_runs = p.inv_runs;                     // r / runs = (r * inv_runs) >> 16 for r < 128
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Cin * (64 * 9 * 4), 0x00020000);
         const int wlane = (quarter >> 1) * (8 * 9 * runs * 1024) + ((lane >> 4) & 1) * 512 + (16 * (quarter & 1) + (lane & 15)) * 16;
         f32x4 wr[2][9];
@@ -234,12 +235,10 @@ __device__ __forceinline__ void conv_t16_body(const ConvT16Params& p, float* __r
 __global__ __launch_bounds__(512, 2) void conv_t16_kernel(const ConvT16Params p) {
     __shared__ __attribute__((aligned(16))) float lds[T16_LDS_FLOATS];
     const int quarter = (int)blockIdx.x & 3, slot = (int)blockIdx.x >> 2;
-    const int tiles_x = (p.W + 15) >> 4;
-    const T16Share sh = t16_share(slot, p.slots, p.B * tiles_x, p.H);
-    const int b = sh.strip / tiles_x, x0 = 16 * (sh.strip - b * tiles_x);
-    if (sh.rows == 1) conv_t16_body<1>(p, lds, quarter, b, sh.y0, x0);
-    else if (sh.rows == 2) conv_t16_body<2>(p, lds, quarter, b, sh.y0, x0);
-    else if (sh.rows == 3) conv_t16_body<3>(p, lds, quarter, b, sh.y0, x0);       // (0 rows: more workgroups than rows; more than 3: refused at launch)
+    const T16Share sh = t16_share(p, slot);
+    if (sh.rows == 1) conv_t16_body<1>(p, lds, quarter, sh.b, sh.y0, sh.x0);
+    else if (sh.rows == 2) conv_t16_body<2>(p, lds, quarter, sh.b, sh.y0, sh.x0);
+    else if (sh.rows == 3) conv_t16_body<3>(p, lds, quarter, sh.b, sh.y0, sh.x0);  // (more than 3: refused at launch)
 }
 
 // ---- the local-fusion layers (1x1, Cin = 576; rdn.py:34) on the same maps: the same units, 4 MFMAs per row and group -- a
@@ -258,7 +257,7 @@ __device__ __forceinline__ void conv1x1_t16_body(const ConvT16Params& p, float* 
     const size_t plane = (size_t)p.H * p.W;
     const unsigned plane_b = (unsigned)(plane * sizeof(float));
     const int G = p.Cin / T16_GROUP;
-    const int my = wave < G ? (G - wave + T16_WAVES - 1) / T16_WAVES : 0;        // this wave's groups: wave, wave + 8, ... (<= T16_1X1_MAXG)
+    const int my = wave < G ? (G - wave + T16_WAVES - 1) >> 3 : 0;        // this wave's groups: wave, wave + 8, ... (<= T16_1X1_MAXG)
     constexpr unsigned OUTSIDE = 0x80000000u;
     // the epilogue's thread: output co of column x, rows y0 + rsel (+ 2): bias and residual are on their way before anything else
     const int ev = (int)threadIdx.x & 255, er = ev >> 6, el = ev & 63, rsel = (int)threadIdx.x >> 8;
@@ -277,7 +276,7 @@ __device__ __forceinline__ void conv1x1_t16_body(const ConvT16Params& p, float* 
     if (my > 0) {
         float* __restrict__ ring = lds + wave * 2 * T16_STAGE;
         const int runs = p.Cin / 64;
-        const unsigned inv_runs = (65536u + runs - 1) / runs;     // r / runs = (r * inv_runs) >> 16 for r < 128
+        const unsigned inv_runs = p.inv_runs;                     // r / runs = (r * inv_runs) >> 16 for r < 128
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Cin * (64 * 4), 0x00020000);
         // the split-K kernel's 1x1 image: [half 2][wave 8][run Cin/64][h 2][i 32][4] (conv_t16_body's lane mapping, one tap)
         const int wlane = (quarter >> 1) * (8 * runs * 1024) + ((lane >> 4) & 1) * 512 + (16 * (quarter & 1) + (lane & 15)) * 16;
@@ -347,28 +346,33 @@ __device__ __forceinline__ void conv1x1_t16_body(const ConvT16Params& p, float* 
 __global__ __launch_bounds__(512, 2) void conv1x1_t16_kernel(const ConvT16Params p) {
     __shared__ __attribute__((aligned(16))) float lds[T16_LDS_FLOATS];
     const int quarter = (int)blockIdx.x & 3, slot = (int)blockIdx.x >> 2;
-    const int tiles_x = (p.W + 15) >> 4;
-    const T16Share sh = t16_share(slot, p.slots, p.B * tiles_x, p.H);
-    const int b = sh.strip / tiles_x, x0 = 16 * (sh.strip - b * tiles_x);
-    if (sh.rows == 1) conv1x1_t16_body<1>(p, lds, quarter, b, sh.y0, x0);
-    else if (sh.rows == 2) conv1x1_t16_body<2>(p, lds, quarter, b, sh.y0, x0);
-    else if (sh.rows == 3) conv1x1_t16_body<3>(p, lds, quarter, b, sh.y0, x0);
+    const T16Share sh = t16_share(p, slot);
+    if (sh.rows == 1) conv1x1_t16_body<1>(p, lds, quarter, sh.b, sh.y0, sh.x0);
+    else if (sh.rows == 2) conv1x1_t16_body<2>(p, lds, quarter, sh.b, sh.y0, sh.x0);
+    else if (sh.rows == 3) conv1x1_t16_body<3>(p, lds, quarter, sh.b, sh.y0, sh.x0);
 }
 
 #ifdef T16_STAMPS
 static unsigned long long* g_t16_stamps = nullptr;               // set by tools/ubench/t16_bench.hip before each launch
 #endif
-// workgroups per output quarter for a map of `strips` strips of H rows (0: not a map for this kernel)
-static int t16_slots(long long strips, int H) {
+// the launch's partition for a map of `strips` strips of H rows (workgroups per output quarter; 0: not a map for this kernel)
+static int t16_plan(long long strips, int H, int W, int Cin, ConvT16Params* p) {
     const long long per_quarter = device_cus() / 4 > 0 ? device_cus() / 4 : 1;
     long long per_strip = per_quarter / strips;                  // workgroups a strip can have
-    if (per_strip < 1) return 0;                                 // a strip would be left without a workgroup
+    if (per_strip < 1 || strips > 65535) return 0;               // a strip would be left without a workgroup
     if (per_strip > H) per_strip = H;
     const long long rows = (H + per_strip - 1) / per_strip;      // the busiest workgroup's rows: the layer's time
     if (rows > T16_MAXR) return 0;
     // no more workgroups than that load asks for (48 x 48: 3 strips x 16 workgroups of exactly 3 rows = 192 of 256 CUs, not 3 x 21 of 2
     // or 3 rows): the busiest workgroup is the layer either way (measured: 1.651 / 1.649 against 1.655 / 1.633 ms per trunk), the idle CUs draw less
-    return (int)(strips * ((H + rows - 1) / rows));
+    per_strip = (H + rows - 1) / rows;
+    if (p) {
+        p->per_strip = (int)per_strip; p->rows = (int)rows; p->tiles_x = (W + 15) / 16;
+        p->m_per_strip = (unsigned)((1ull << 32) / (unsigned long long)per_strip + 1);
+        p->m_tiles_x = (unsigned)((1ull << 32) / (unsigned long long)p->tiles_x + 1);
+        p->inv_runs = Cin >= 64 ? (65536u + (unsigned)(Cin / 64) - 1) / (unsigned)(Cin / 64) : 0;
+    }
+    return (int)(strips * per_strip);
 }
 
 extern "C" {
@@ -378,7 +382,7 @@ int diinn_conv_t16_applies(int B, int H, int W) {
     // (tiles of 8 x 4 pixels x 2 output halves) than compute units -- where that kernel leaves CUs idle
     if (B <= 0 || H <= 0 || W <= 0 || (W & 3) || knob(diinn_knobs().enc_no_t16) != 0) return 0;
     if ((long long)B * H * W >= knob(diinn_knobs().enc_wino_min)) return 0;
-    if (t16_slots((long long)B * ((W + 15) / 16), H) == 0) return 0;
+    if (t16_plan((long long)B * ((W + 15) / 16), H, W, 0, nullptr) == 0) return 0;
     const long long ks_units = 2LL * B * ((W + 7) / 8) * ((H + 3) / 4);
     return ks_units < device_cus();
 }
@@ -391,14 +395,14 @@ int diinn_conv_t16(void* stream, const float* in_dev, long long in_batch_stride,
     if (st) return st;
     if (Cin <= 0 || Cin % 64 || (W & 3)) return DIINN_ERR_UNSUPPORTED;
     if ((((size_t)in_dev) & 15) || (((size_t)packed_w_dev) & 15) || (in_batch_stride & 3)) return DIINN_ERR_INVALID_ARG;
-    const int slots = t16_slots((long long)B * ((W + 15) / 16), H);
+    ConvT16Params p;
+    const int slots = t16_plan((long long)B * ((W + 15) / 16), H, W, Cin, &p);
     if (slots == 0) return DIINN_ERR_UNSUPPORTED;                // a map for the other kernels
     if ((long long)H * W * 4 * T16_GROUP > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;
-    ConvT16Params p;
     p.in = in_dev; p.w = packed_w_dev; p.bias = bias_dev; p.res = res_dev; p.out = out_dev;
     p.in_bs = in_batch_stride; p.out_bs = out_batch_stride; p.res_bs = res_batch_stride;
     p.out1 = nullptr; p.out1_bs = 0;
-    p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0; p.slots = slots;
+    p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0;
 #ifdef T16_STAMPS
     p.stamps = g_t16_stamps;
 #endif
@@ -415,13 +419,13 @@ int diinn_conv1x1_t16(void* stream, const float* in_dev, long long in_batch_stri
     if (st) return st;
     if (Cin <= 0 || Cin % 64 || Cin > T16_1X1_MAXG * T16_WAVES * T16_GROUP || (W & 3)) return DIINN_ERR_UNSUPPORTED;
     if ((((size_t)in_dev) & 15) || (((size_t)packed_w_dev) & 15) || (in_batch_stride & 3)) return DIINN_ERR_INVALID_ARG;
-    const int slots = t16_slots((long long)B * ((W + 15) / 16), H);
+    ConvT16Params p;
+    const int slots = t16_plan((long long)B * ((W + 15) / 16), H, W, Cin, &p);
     if (slots == 0) return DIINN_ERR_UNSUPPORTED;                // a map for the other kernels
     if ((long long)H * W * 4 * T16_GROUP > 0x7FFFFFFFLL) return DIINN_ERR_TOO_LARGE;
-    ConvT16Params p;
     p.in = in_dev; p.w = packed_w_dev; p.bias = bias_dev; p.res = res_dev; p.out = out0_dev; p.out1 = out1_dev;
     p.in_bs = in_batch_stride; p.out_bs = out0_batch_stride; p.out1_bs = out1_batch_stride; p.res_bs = res_batch_stride;
-    p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0; p.slots = slots;
+    p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0;
 #ifdef T16_STAMPS
     p.stamps = nullptr;
 #endif
