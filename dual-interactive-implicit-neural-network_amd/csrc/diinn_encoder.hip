@@ -37,10 +37,15 @@ struct ConvKsplitParams {
     float* out1;             // optional destination 1
     long long in_bs, out0_bs, out1_bs, res_bs;
     int Cin, B, H, W, relu;
+    // set by the launch: divisions of the workgroup's tile number as multiplications (x / d == (x * m) >> 32 for x, d < 2^16 with
+    // m = 2^32 / d + 1; 0: divide) -- an integer division in a kernel's preamble costs every launch ~0.2 us before its first load
+    unsigned m_per_image, m_tiles_x;
 #ifdef DIINN_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/stamp_report_enc.py)
 #endif
 };
+__device__ __forceinline__ int div_m(int x, int d, unsigned m) { return m ? (int)(((unsigned long long)(unsigned)x * m) >> 32) : x / d; }
+static unsigned magic_m(long long d, long long x_max) { return (d > 1 && d < 65536 && x_max < 65536) ? (unsigned)((1ull << 32) / (unsigned long long)d + 1) : 0u; }
 
 // NH = 1: a workgroup computes one 32-output half (blockIdx.y) -- twice the workgroups, for maps with few tiles.
 // NH = 2: both halves from the same staged features (half the staging and half the LDS reads per MFMA), for maps
@@ -74,9 +79,9 @@ __device__ __forceinline__ void conv_ksplit_body(const ConvKsplitParams& p) {
     }
 #endif
     STAMP(0);
-    const int b = t / (tiles_x * tiles_y);
+    const int b = div_m(t, tiles_x * tiles_y, p.m_per_image);
     t -= b * tiles_x * tiles_y;
-    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int ty = div_m(t, tiles_x, p.m_tiles_x), tx = t - ty * tiles_x;
     const int half = NH == 1 ? (int)blockIdx.y : 0;
     const int y0 = ty * CS_TH, x0 = tx * CS_TW;
     const int cw = p.Cin / CS_WAVES;                             // channels reduced by this wave
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const ConvKsplit
     const int per_xcd = gridDim.x >> 3;                          // every XCD a contiguous run of blocks
     int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (t >= p.B * blocks_per) return;
-    const int b = __builtin_amdgcn_readfirstlane(t / blocks_per);
+    const int b = __builtin_amdgcn_readfirstlane(div_m(t, blocks_per, p.m_per_image));
     const int blk = t - b * blocks_per;
     const int g8 = p.Cin / 64;                                   // pieces per part of the packed weight
     const int n = 2 * g8;                                        // chunks of 8 channels this wave reduces (two parts)
@@ -548,8 +553,12 @@ static int launch_conv_ksplit(void* stream, const ConvKsplitParams& p_in, int ta
     const bool no_stream = knob(diinn_knobs().enc_no_stream1x1) != 0;   // A/B switches for tools/
     const int lat_max = (int)knob(diinn_knobs().enc_lat_max_tiles);
     const bool lat = tiles <= lat_max;                           // <= 2 workgroups per CU: about one wave per SIMD
+    const long long tiles_x = (p.W + CS_TW - 1) / CS_TW, per_image = tiles_x * ((p.H + CS_TH - 1) / CS_TH);
+    p.m_per_image = magic_m(per_image, (long long)grid.x);
+    p.m_tiles_x = magic_m(tiles_x, per_image);
     if (taps == 1 && !no_stream && conv1x1_stream_ok(p)) {
-        const long long blocks = (long long)p.B * (((long long)p.H * p.W + S1_PIX - 1) / S1_PIX);
+        const long long blocks_per = ((long long)p.H * p.W + S1_PIX - 1) / S1_PIX, blocks = (long long)p.B * blocks_per;
+        p.m_per_image = magic_m(blocks_per, (blocks + 7) / 8 * 8);
         hipLaunchKernelGGL(conv1x1_stream_kernel, dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, p);
     } else if (taps == 9) {
         if (both) hipLaunchKernelGGL(conv_ksplit_kernel_3x3<2>, grid, dim3(512), 0, (hipStream_t)stream, p);
