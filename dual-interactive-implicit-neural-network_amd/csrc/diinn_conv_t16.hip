@@ -23,8 +23,9 @@
 //   * the weights are read from the SPLIT-K kernel's image (diinn_conv_ksplit: modules.pack_conv_ksplit): no second direct-sum
 //     image, no change to diinn_rdn_forward_ex; the lane mapping is at the loads below.
 //   * the 8 partial sums meet ONCE in LDS at the end (over the stages, behind a barrier); bias, ReLU / residual, 64-byte runs.
-// Measured (profiles/r06_small_map_t16.txt): per trunk 48 x 48 1.95 -> 1.65 ms (with the 1x1 sibling below), 32 x 32 1.87 -> 1.00,
-// 24 x 24 1.92 -> 0.95; per layer 6.0 + 1.9 us per 64 input channels at 48 x 48 (split-K: 6.1 + 2.33).
+// Measured (profiles/r06_small_map_t16.txt): per trunk 48 x 48 1.95 -> 1.57 ms (with the 1x1 sibling below), 32 x 32 1.87 -> 0.95,
+// 24 x 24 1.92 -> 0.87; per layer 5.7 + 1.9 us per 64 input channels at 48 x 48 (split-K: 6.1 + 2.33).  The workgroup's share of the map
+// arrives as multipliers from the host (t16_plan): six integer divisions in the preamble cost every launch ~0.4 us.
 #include "diinn_device.h"
 
 constexpr int T16_WAVES = 8, T16_MAXR = 3;
