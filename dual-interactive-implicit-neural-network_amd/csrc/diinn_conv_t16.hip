@@ -8,9 +8,9 @@
 // the weights per unit (a CU takes in 46-70 GB/s from its L2).
 //
 // This kernel: the map is cut into STRIPS 16 pixels wide (one N-tile of v_mfma_f32_16x16x4_f32 per row) and the outputs into
-// quarters of 16; a workgroup owns ONE output quarter and 1 .. 3 consecutive rows of one strip -- 64 workgroups per quarter on
-// a 256-CU part, a strip's rows dealt evenly to its workgroups (48 x 48: 3 strips x 48 rows over 64 = 2 or 3 rows each: 7.1 MFLOP
-// on the busiest CU instead of 9.4) -- and streams its quarter's weights ONCE, each group of 16 input channels used for all of
+// quarters of 16; a workgroup owns ONE output quarter and 1 .. 3 consecutive rows of one strip -- up to 64 workgroups per quarter
+// on a 256-CU part, as many per strip as the busiest one's rows ask for (t16_plan; 48 x 48: 3 strips x 16 workgroups of 3 rows =
+// 7.1 MFLOP on the busiest CU instead of 9.4) -- and streams its quarter's weights ONCE, each group of 16 input channels used for all of
 // the workgroup's rows, whose halo rows it stages once (3 rows: 5 halo rows for 3 tiles).  8 waves split the reduction (wave w
 // takes the groups w, w + 8, ...).  Direct fp32 sum: the reference's arithmetic up to the order of the sum.
 //   * a step = one group: 16 channels x (rows + 2) halo rows x 24 columns (x0 - 4 .. x0 + 19, whole 16-byte pieces: W % 4 == 0)
