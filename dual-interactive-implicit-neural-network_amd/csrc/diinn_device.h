@@ -291,6 +291,10 @@ static inline bool compute_ok(int compute) {
            compute == DIINN_COMPUTE_BF16_FULL || compute == DIINN_COMPUTE_BF16X3;
 }
 
+// x / d as a multiplication, for the tile arithmetic in kernel preambles (an integer division there is ~40 dependent instructions,
+// ~0.1 us in front of a launch's first load): m = 2^32 / d + 1 is exact for 0 <= x < 65536, 1 < d < 65536; m == 0: divide.
+__device__ __forceinline__ int div_m(int x, int d, unsigned m) { return m ? (int)(((unsigned long long)(unsigned)x * m) >> 32) : x / d; }
+static inline unsigned magic_m(long long d, long long x_max) { return (d > 1 && d < 65536 && x_max < 65536) ? (unsigned)((1ull << 32) / (unsigned long long)d + 1) : 0u; }
 static inline int check_dims(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return DIINN_ERR_INVALID_ARG;
     if ((double)B * H * W * PCH >= 9.0e18 || B > 65535 || H > 65535) return DIINN_ERR_TOO_LARGE;

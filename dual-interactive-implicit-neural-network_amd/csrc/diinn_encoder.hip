@@ -44,8 +44,6 @@ struct ConvKsplitParams {
     unsigned long long* stamps;   // diagnostic build only (tools/stamp_report_enc.py)
 #endif
 };
-__device__ __forceinline__ int div_m(int x, int d, unsigned m) { return m ? (int)(((unsigned long long)(unsigned)x * m) >> 32) : x / d; }
-static unsigned magic_m(long long d, long long x_max) { return (d > 1 && d < 65536 && x_max < 65536) ? (unsigned)((1ull << 32) / (unsigned long long)d + 1) : 0u; }
 
 // NH = 1: a workgroup computes one 32-output half (blockIdx.y) -- twice the workgroups, for maps with few tiles.
 // NH = 2: both halves from the same staged features (half the staging and half the LDS reads per MFMA), for maps

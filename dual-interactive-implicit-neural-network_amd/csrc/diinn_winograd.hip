@@ -43,6 +43,7 @@ struct ConvWinoParams {
     float* out;              // out + b*out_bs + co*H*W
     long long in_bs, out_bs, res_bs;
     int Cin, B, H, W, relu;
+    unsigned m_per_image, m_bx_n;   // block / blocks-per-image and block / blocks-per-row as multiplications (div_m; 0: divide)
 #ifdef DIINN_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/stamp_report_enc.py)
 #endif
@@ -305,9 +306,9 @@ __device__ __forceinline__ void conv_wino_entry(const ConvWinoParams& p, float* 
         }
         // (integer division runs on the vector unit: pin the results back into scalar registers, or every descriptor
         // derived from them is treated as divergent and each load becomes a waterfall loop)
-        const int b = __builtin_amdgcn_readfirstlane(t / (bx_n * by_n));
+        const int b = __builtin_amdgcn_readfirstlane(div_m(t, bx_n * by_n, p.m_per_image));
         t -= b * bx_n * by_n;
-        const int by = __builtin_amdgcn_readfirstlane(t / bx_n), bx = t - by * bx_n;
+        const int by = __builtin_amdgcn_readfirstlane(div_m(t, bx_n, p.m_bx_n)), bx = t - by * bx_n;
         const int tx0 = bx * WN_TX, ty0 = by * WN_TY;
         const bool edge = tx0 == 0 || 2 * (tx0 + WN_TX - 1) + 2 >= p.W;
         if (edge) conv_wino_body<true, NH>(p, zs, b, tx0, ty0, hh0);
@@ -344,6 +345,11 @@ int diinn_conv_wino(void* stream, const float* in_dev, long long in_batch_stride
     p.in = in_dev; p.wu = packed_u_dev; p.bias = bias_dev; p.res = res_dev; p.out = out_dev;
     p.in_bs = in_batch_stride; p.out_bs = out_batch_stride; p.res_bs = res_batch_stride;
     p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0;
+    {
+        const long long bx_n = ((W + 1) / 2 + WN_TX - 1) / WN_TX, per_image = bx_n * (((H + 1) / 2 + WN_TY - 1) / WN_TY);
+        p.m_per_image = magic_m(per_image, blocks);
+        p.m_bx_n = magic_m(bx_n, per_image);
+    }
 #ifdef DIINN_STAMPS
     p.stamps = g_stamps;
 #endif

@@ -85,6 +85,7 @@ struct ConvWino4Params {
     float* out;              // out + b*out_bs + co*H*W
     long long in_bs, out_bs, res_bs;
     int Cin, B, H, W, relu;
+    unsigned m_tiles_x, m_nblk;   // tile / tiles_x and item / blocks-per-image as multiplications (div_m; 0: divide)
     // split of the last round over the input channels (0 items: none)
     float* sk_slabs;         // [2 sk_wgs][4][1024][4]: a split workgroup's partial outputs of its first / second item
     unsigned* sk_cnt;        // [1024] words: per item arrival tickets and ready counts, zero on entry, zero on exit
@@ -170,7 +171,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvWino4Params& p, float*
     // on in the next one: no work item is left part empty by the map's width); tiles past the last one load zeros and store nothing
     const int tiles_x = (p.W + 3) / 4, tiles_n = tiles_x * ((p.H + 3) / 4);
     auto tile_xy = [&](int tile, int& tx, int& ty) {
-        ty = tile / tiles_x;
+        ty = div_m(tile, tiles_x, p.m_tiles_x);
         tx = tile - ty * tiles_x;
         return tile < tiles_n;
     };
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvWino4P
             if (a < e) {
                 const int first = rs / p.sk_u, last = (be - 1) / p.sk_u;   // the pairs with chunks of this block
                 const int t = (p.sk_first >> 1) + it;
-                const int b = __builtin_amdgcn_readfirstlane(t / nblk);
+                const int b = __builtin_amdgcn_readfirstlane(div_m(t, nblk, p.m_nblk));
                 conv_wino4_body(p, lds, b, t - b * nblk, hh0, a - rs, e - a, W4Split{last - first + 1, 2 * it + hh0, 2 * g + j, first, pair, it});
                 __syncthreads();                                 // the exchange buffer is free again
                 ++j;
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(const ConvWino4P
         if (t >= total) break;
         const int hh0 = t & 1;
         t >>= 1;
-        const int b = __builtin_amdgcn_readfirstlane(t / nblk);
+        const int b = __builtin_amdgcn_readfirstlane(div_m(t, nblk, p.m_nblk));
         conv_wino4_body(p, lds, b, t - b * nblk, hh0, 0, n, W4Split{1, 0, 0, 0, 0, 0});
         __syncthreads();                                         // the exchange buffer is free again
     }
@@ -638,6 +639,11 @@ int diinn_conv_wino4_ws(void* stream, const float* in_dev, long long in_batch_st
     p.in = in_dev; p.wu = packed_u_dev; p.bias = bias_dev; p.res = res_dev; p.out = out_dev;
     p.in_bs = in_batch_stride; p.out_bs = out_batch_stride; p.res_bs = res_batch_stride;
     p.Cin = Cin; p.B = B; p.H = H; p.W = W; p.relu = relu ? 1 : 0;
+    {
+        const long long tiles_x = (W + 3) / 4, nblk = (tiles_x * ((H + 3) / 4) + W4_TX - 1) / W4_TX;
+        p.m_tiles_x = magic_m(tiles_x, nblk * W4_TX);            // tile numbers run up to a block's last (possibly past the map's)
+        p.m_nblk = magic_m(nblk, blocks);
+    }
     const W4Plan pl = w4_plan(2 * blocks, Cin / 8, w4_cus(), ws_dev != nullptr);
     p.sk_fault = knob(diinn_knobs().enc_wino4_fault) == 1 ? 1 : 0;
     p.sk_spin_max = p.sk_fault ? (1u << 10) : (1u << 24);
