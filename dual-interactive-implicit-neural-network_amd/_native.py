@@ -113,6 +113,7 @@ SIGNATURES = {
     "diinn_conv_t16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int]),
     "diinn_conv_t16_applies": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "diinn_conv_t16_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "diinn_conv1x1_t16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
                                    C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -388,6 +388,14 @@ int diinn_conv_t16_applies(int B, int H, int W) {
     return ks_units < device_cus();
 }
 
+int diinn_conv_t16_plan(int B, int H, int W, int info[4]) {
+    if (!info || check_dims(B, H, W)) return DIINN_ERR_INVALID_ARG;
+    ConvT16Params p;
+    const int slots = t16_plan((long long)B * ((W + 15) / 16), H, W, 64, &p);
+    info[0] = slots; info[1] = slots ? p.per_strip : 0; info[2] = slots ? p.rows : 0; info[3] = B * ((W + 15) / 16);
+    return DIINN_OK;
+}
+
 int diinn_conv_t16(void* stream, const float* in_dev, long long in_batch_stride, int Cin,
                    const float* packed_w_dev, const float* bias_dev, const float* res_dev, long long res_batch_stride,
                    float* out_dev, long long out_batch_stride, int relu, int B, int H, int W) {

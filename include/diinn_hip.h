@@ -486,6 +486,10 @@ int    diinn_conv_t16(void* stream, const float* in_dev, long long in_batch_stri
                       const float* res_dev, long long res_batch_stride,
                       float* out_dev, long long out_batch_stride, int relu, int B, int H, int W);
 int    diinn_conv_t16_applies(int B, int H, int W);
+/* diinn_conv_t16_plan: the partition a launch on this map would use on the current device: info[0] workgroups per output quarter
+ *   (0: the kernel does not take this map), [1] workgroups per strip, [2] rows of each (the strip's last one: what is left),
+ *   [3] strips = B * ceil(W / 16).  Workgroup s of a quarter owns strip s / info[1], rows (s % info[1]) * info[2] onwards. */
+int    diinn_conv_t16_plan(int B, int H, int W, int info[4]);
 /* diinn_conv1x1_t16: the local-fusion layers (1x1; rdn.py:34) on the same maps and units: addressing, epilogue (bias, ReLU,
  *   residual, two destinations) and packed_w_dev as diinn_conv_ksplit with taps = 1; W % 4 == 0, Cin % 64 == 0, Cin <= 640
  *   (every load of a workgroup is in flight at once: five groups of 16 channels per wave), else DIINN_ERR_UNSUPPORTED.  The

@@ -775,6 +775,44 @@ def test_conv_t16_dispatch_rule(knobs):
     assert lib.diinn_conv_t16_applies(1, 48, 48) == 0
 
 
+def test_conv_t16_partition_covers_every_row_once(knobs):
+    """diinn_conv_t16_plan: on every map the kernel takes, the workgroups of a quarter cover every row of every strip exactly
+    once with at most 3 rows each and no more workgroups than a quarter of the compute units; and the multiplier form of the
+    kernel's divisions (x / d == (x * (2^32 / d + 1)) >> 32) is exact on its whole range."""
+    import ctypes as C
+    import diinn_amd._native as N
+    lib = N.load()
+    info = (C.c_int * 4)()
+    taken = 0
+    for ncu in (256, 304, 128, 64, 20):
+        knobs("DIINN_DEBUG_NCU", ncu)
+        for b in (1, 2, 3, 5):
+            for h in (1, 2, 7, 16, 17, 24, 31, 40, 48, 49, 63, 64, 96, 200):
+                for w in (4, 12, 16, 20, 48, 52, 64, 100):
+                    assert lib.diinn_conv_t16_plan(b, h, w, info) == 0
+                    slots, per_strip, rows, strips = info[0], info[1], info[2], info[3]
+                    assert strips == b * ((w + 15) // 16)
+                    if lib.diinn_conv_t16_applies(b, h, w):
+                        assert slots > 0
+                    if slots == 0:
+                        continue
+                    taken += 1
+                    assert slots == strips * per_strip and slots <= max(1, ncu // 4) and 1 <= rows <= 3
+                    cover = np.zeros((strips, h), dtype=np.int32)
+                    for s in range(slots):
+                        strip, j = divmod(s, per_strip)
+                        y0 = j * rows
+                        n = min(rows, h - y0)
+                        assert n >= 1                            # no workgroup without rows
+                        cover[strip, y0:y0 + n] += 1
+                    assert (cover == 1).all(), (ncu, b, h, w)
+    assert taken > 100
+    x = np.arange(65536, dtype=np.uint64)
+    for d in list(range(2, 300)) + [511, 512, 513, 1000, 4095, 4096, 21845, 32768, 65535]:
+        m = np.uint64((1 << 32) // d + 1)
+        assert np.array_equal((x * m) >> np.uint64(32), x // np.uint64(d)), d
+
+
 @pytest.mark.gpu
 def test_rdn_trunk_small_map_kernel_against_the_split_k_kernel(knobs):
     """The trunk on maps the small-map kernel takes (48 x 48: the reference's timing protocol, runtime_test.py:13) equals the
